@@ -1,0 +1,434 @@
+"""ctypes binding of libaar.so -- the C ABI declared in include/aar.h.
+
+This is test / benchmark plumbing: the product is the C-ABI library (HIP kernels for gfx950) and the C++
+MultiCamMapper mirror in automatic-ar_amd/host/.  Nothing here computes; every numeric call lands in a
+HIP kernel and raises AarError(AAR_ERR_NO_DEVICE) on a machine without a GPU -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libaar.so")
+
+AAR_OK = 0
+AAR_ERR_INVALID, AAR_ERR_NO_DEVICE, AAR_ERR_HIP, AAR_ERR_UNSUPPORTED = -1, -2, -3, -4
+AAR_ERR_NUMERIC, AAR_ERR_IO, AAR_ERR_COMM = -5, -6, -7
+RES_F32, RES_F64 = 0, 1
+COMM_ID_BYTES = 128
+
+# every symbol include/aar.h declares (tests/test_capi_symbols.py checks the header against this list and the .so)
+SYMBOLS = [
+    "aar_last_error", "aar_dataset_free", "aar_dataset_full_len", "aar_synth_default", "aar_synth_generate",
+    "aar_solution_read", "aar_solution_write", "aar_solution_write_yaml", "aar_detections_write",
+    "aar_rodrigues_vec2mat", "aar_rodrigues_mat2vec", "aar_plan_shards", "aar_comm_make_id", "aar_comm_create",
+    "aar_comm_destroy", "aar_problem_desc_from_dataset", "aar_problem_create", "aar_problem_destroy",
+    "aar_problem_full_len", "aar_problem_num_vars", "aar_problem_local_obs", "aar_eval_residuals",
+    "aar_eval_normal_equations", "aar_eval_damped_step", "aar_lm_default_params", "aar_lm_init", "aar_lm_step",
+    "aar_lm_get_solution", "aar_lm_solve", "aar_get_stage_times", "aar_reproj_stats", "aar_device_count",
+    "aar_device_synchronize",
+]
+
+
+class AarError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("aar error %d: %s" % (code, msg))
+        self.code = code
+
+
+class CDataset(C.Structure):
+    _fields_ = [
+        ("num_cams", C.c_int32), ("num_markers", C.c_int32), ("num_frames", C.c_int32),
+        ("root_cam", C.c_int32), ("root_marker", C.c_int32),
+        ("cam_ids", C.POINTER(C.c_int32)), ("marker_ids", C.POINTER(C.c_int32)), ("frame_ids", C.POINTER(C.c_int32)),
+        ("image_sizes", C.POINTER(C.c_int32)), ("cam_mats", C.POINTER(C.c_double)), ("dist_coeffs", C.POINTER(C.c_double)),
+        ("marker_size", C.c_double), ("num_obs", C.c_int64),
+        ("obs_frame", C.POINTER(C.c_int32)), ("obs_cam", C.POINTER(C.c_int32)), ("obs_marker", C.POINTER(C.c_int32)),
+        ("obs_uv", C.POINTER(C.c_float)), ("x_full", C.POINTER(C.c_double)), ("x_truth", C.POINTER(C.c_double)),
+        ("optimize_cam_poses", C.c_int32), ("optimize_marker_poses", C.c_int32),
+        ("optimize_object_poses", C.c_int32), ("optimize_cam_intrinsics", C.c_int32),
+    ]
+
+
+class CSynthDesc(C.Structure):
+    _fields_ = [
+        ("num_cams", C.c_int32), ("num_markers", C.c_int32), ("num_frames", C.c_int32), ("seed", C.c_uint64),
+        ("marker_size", C.c_double), ("noise_px", C.c_double), ("init_rot_sigma", C.c_double),
+        ("init_trans_sigma", C.c_double), ("init_scale", C.c_double),
+    ]
+
+
+class CProblemDesc(C.Structure):
+    _fields_ = [
+        ("num_cams", C.c_int32), ("num_markers", C.c_int32), ("num_frames", C.c_int32),
+        ("root_cam", C.c_int32), ("root_marker", C.c_int32),
+        ("cam_mats", C.POINTER(C.c_double)), ("marker_size", C.c_double), ("num_obs", C.c_int64),
+        ("obs_frame", C.POINTER(C.c_int32)), ("obs_cam", C.POINTER(C.c_int32)), ("obs_marker", C.POINTER(C.c_int32)),
+        ("obs_uv", C.POINTER(C.c_float)),
+        ("optimize_cam_poses", C.c_int32), ("optimize_marker_poses", C.c_int32), ("optimize_object_poses", C.c_int32),
+        ("residual_mode", C.c_int32), ("device_id", C.c_int32), ("comm", C.c_void_p),
+    ]
+
+
+class CLmParams(C.Structure):
+    _fields_ = [
+        ("max_iters", C.c_int32), ("min_error", C.c_double), ("min_step_error_diff", C.c_double),
+        ("min_average_step_error_diff", C.c_double), ("tau", C.c_double), ("verbose", C.c_int32),
+    ]
+
+
+class CLmIter(C.Structure):
+    _fields_ = [("err", C.c_double), ("mu", C.c_double), ("gain", C.c_double), ("delta_norm", C.c_double),
+                ("accepted", C.c_int32), ("tries", C.c_int32)]
+
+
+class CLmReport(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32), ("stop_code", C.c_int32), ("initial_err", C.c_double), ("final_err", C.c_double),
+        ("final_mu", C.c_double), ("solve_seconds", C.c_double), ("trial_points", C.c_int64),
+        ("trace", C.POINTER(CLmIter)), ("trace_cap", C.c_int32),
+    ]
+
+
+class CStageTimes(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("unpack", "jacobian_normal_eq", "schur", "chol", "backsub", "residual",
+                                          "control", "allreduce", "total")] + [("launches", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libaar.so (built by __graft_entry__.build() / `make -C automatic-ar_amd`).  Fails loudly when missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libaar.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.aar_last_error.restype = C.c_char_p
+    L.aar_dataset_full_len.restype = C.c_int64
+    L.aar_dataset_full_len.argtypes = [C.POINTER(CDataset)]
+    L.aar_dataset_free.argtypes = [C.POINTER(CDataset)]
+    L.aar_dataset_free.restype = None
+    L.aar_synth_default.argtypes = [C.POINTER(CSynthDesc), C.c_int32]
+    L.aar_synth_default.restype = None
+    L.aar_synth_generate.argtypes = [C.POINTER(CSynthDesc), C.POINTER(C.POINTER(CDataset))]
+    L.aar_solution_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(CDataset))]
+    for n in ("aar_solution_write", "aar_solution_write_yaml", "aar_detections_write"):
+        getattr(L, n).argtypes = [C.c_char_p, C.POINTER(CDataset)]
+    L.aar_rodrigues_vec2mat.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.aar_rodrigues_vec2mat.restype = None
+    L.aar_rodrigues_mat2vec.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.aar_rodrigues_mat2vec.restype = None
+    L.aar_plan_shards.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32)]
+    L.aar_comm_make_id.argtypes = [C.c_char_p]
+    L.aar_comm_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.aar_comm_destroy.argtypes = [C.c_void_p]
+    L.aar_comm_destroy.restype = None
+    L.aar_problem_desc_from_dataset.argtypes = [C.POINTER(CDataset), C.POINTER(CProblemDesc)]
+    L.aar_problem_desc_from_dataset.restype = None
+    L.aar_problem_create.argtypes = [C.POINTER(CProblemDesc), C.POINTER(C.c_void_p)]
+    L.aar_problem_destroy.argtypes = [C.c_void_p]
+    L.aar_problem_destroy.restype = None
+    for n in ("aar_problem_full_len", "aar_problem_num_vars", "aar_problem_local_obs"):
+        getattr(L, n).argtypes = [C.c_void_p]
+        getattr(L, n).restype = C.c_int64
+    dp = C.POINTER(C.c_double)
+    L.aar_eval_residuals.argtypes = [C.c_void_p, dp, dp, dp]
+    L.aar_eval_normal_equations.argtypes = [C.c_void_p, dp, dp, dp, dp]
+    L.aar_eval_damped_step.argtypes = [C.c_void_p, dp, C.c_double, dp]
+    L.aar_lm_default_params.argtypes = [C.POINTER(CLmParams)]
+    L.aar_lm_default_params.restype = None
+    L.aar_lm_init.argtypes = [C.c_void_p, dp, C.POINTER(CLmParams)]
+    L.aar_lm_step.argtypes = [C.c_void_p, C.POINTER(CLmIter)]
+    L.aar_lm_get_solution.argtypes = [C.c_void_p, dp, dp]
+    L.aar_lm_solve.argtypes = [C.c_void_p, dp, C.POINTER(CLmParams), C.POINTER(CLmReport)]
+    L.aar_get_stage_times.argtypes = [C.c_void_p, C.POINTER(CStageTimes)]
+    L.aar_reproj_stats.argtypes = [C.c_void_p, dp, dp, dp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != AAR_OK:
+        raise AarError(rc, lib().aar_last_error().decode("utf-8", "replace"))
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _np(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+class Dataset:
+    """numpy copy of an aar_dataset (the content of a `.solution` file)."""
+
+    FIELDS = ("cam_ids", "marker_ids", "frame_ids", "image_sizes", "cam_mats", "dist_coeffs", "obs_frame", "obs_cam",
+              "obs_marker", "obs_uv", "x_full", "x_truth")
+
+    def __init__(self, cptr=None):
+        if cptr is None:
+            return
+        d = cptr.contents
+        self.num_cams, self.num_markers, self.num_frames = d.num_cams, d.num_markers, d.num_frames
+        self.root_cam, self.root_marker = d.root_cam, d.root_marker
+        self.marker_size = d.marker_size
+        self.num_obs = d.num_obs
+        Cn, M, F, N = d.num_cams, d.num_markers, d.num_frames, d.num_obs
+        full = 6 * (Cn - 1) + 6 * (M - 1) + 6 * F
+        self.cam_ids = _np(d.cam_ids, Cn, np.int32)
+        self.marker_ids = _np(d.marker_ids, M, np.int32)
+        self.frame_ids = _np(d.frame_ids, F, np.int32)
+        self.image_sizes = _np(d.image_sizes, 2 * Cn, np.int32).reshape(Cn, 2)
+        self.cam_mats = _np(d.cam_mats, 9 * Cn, np.float64).reshape(Cn, 9)
+        self.dist_coeffs = _np(d.dist_coeffs, 5 * Cn, np.float64).reshape(Cn, 5)
+        self.obs_frame = _np(d.obs_frame, N, np.int32)
+        self.obs_cam = _np(d.obs_cam, N, np.int32)
+        self.obs_marker = _np(d.obs_marker, N, np.int32)
+        self.obs_uv = _np(d.obs_uv, 8 * N, np.float32).reshape(N, 8)
+        self.x_full = _np(d.x_full, full, np.float64)
+        self.x_truth = _np(d.x_truth, full, np.float64) if d.x_truth else None
+        self.optimize_cam_poses = bool(d.optimize_cam_poses)
+        self.optimize_marker_poses = bool(d.optimize_marker_poses)
+        self.optimize_object_poses = bool(d.optimize_object_poses)
+        self.optimize_cam_intrinsics = bool(d.optimize_cam_intrinsics)
+
+    @property
+    def full_len(self):
+        return 6 * (self.num_cams - 1) + 6 * (self.num_markers - 1) + 6 * self.num_frames
+
+    def num_vars(self):
+        n = 0
+        if self.optimize_cam_poses:
+            n += 6 * (self.num_cams - 1)
+        if self.optimize_marker_poses:
+            n += 6 * (self.num_markers - 1)
+        if self.optimize_object_poses:
+            n += 6 * self.num_frames
+        return n
+
+    def as_c(self):
+        """A CDataset whose pointers alias this object's arrays (keep `self` alive while it is used)."""
+        d = CDataset()
+        d.num_cams, d.num_markers, d.num_frames = self.num_cams, self.num_markers, self.num_frames
+        d.root_cam, d.root_marker = self.root_cam, self.root_marker
+        d.marker_size = self.marker_size
+        d.num_obs = self.num_obs
+        self._keep = {}
+        for name, ct, dt in (("cam_ids", C.c_int32, np.int32), ("marker_ids", C.c_int32, np.int32),
+                             ("frame_ids", C.c_int32, np.int32), ("image_sizes", C.c_int32, np.int32),
+                             ("cam_mats", C.c_double, np.float64), ("dist_coeffs", C.c_double, np.float64),
+                             ("obs_frame", C.c_int32, np.int32), ("obs_cam", C.c_int32, np.int32),
+                             ("obs_marker", C.c_int32, np.int32), ("obs_uv", C.c_float, np.float32),
+                             ("x_full", C.c_double, np.float64)):
+            a = np.ascontiguousarray(getattr(self, name), dtype=dt)
+            self._keep[name] = a
+            setattr(d, name, a.ctypes.data_as(C.POINTER(ct)))
+        d.x_truth = None
+        d.optimize_cam_poses = int(self.optimize_cam_poses)
+        d.optimize_marker_poses = int(self.optimize_marker_poses)
+        d.optimize_object_poses = int(self.optimize_object_poses)
+        d.optimize_cam_intrinsics = int(self.optimize_cam_intrinsics)
+        return d
+
+
+def synth_desc(config_index, **over):
+    sd = CSynthDesc()
+    lib().aar_synth_default(C.byref(sd), config_index)
+    for k, v in over.items():
+        setattr(sd, k, v)
+    return sd
+
+
+def synth(config_index, **over):
+    """Deterministic synthetic data set; config_index 2..5 = BASELINE.json configs[1..4]."""
+    sd = synth_desc(config_index, **over)
+    p = C.POINTER(CDataset)()
+    _check(lib().aar_synth_generate(C.byref(sd), C.byref(p)))
+    try:
+        return Dataset(p)
+    finally:
+        lib().aar_dataset_free(p)
+
+
+def solution_read(path):
+    p = C.POINTER(CDataset)()
+    _check(lib().aar_solution_read(path.encode(), C.byref(p)))
+    try:
+        return Dataset(p)
+    finally:
+        lib().aar_dataset_free(p)
+
+
+def solution_write(path, ds):
+    c = ds.as_c()
+    _check(lib().aar_solution_write(path.encode(), C.byref(c)))
+
+
+def solution_write_yaml(path, ds):
+    c = ds.as_c()
+    _check(lib().aar_solution_write_yaml(path.encode(), C.byref(c)))
+
+
+def detections_write(path, ds):
+    c = ds.as_c()
+    _check(lib().aar_detections_write(path.encode(), C.byref(c)))
+
+
+def rodrigues_vec2mat(w):
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    R = np.zeros(9)
+    lib().aar_rodrigues_vec2mat(_dptr(w), _dptr(R))
+    return R.reshape(3, 3)
+
+
+def rodrigues_mat2vec(R):
+    R = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+    w = np.zeros(3)
+    lib().aar_rodrigues_mat2vec(_dptr(R), _dptr(w))
+    return w
+
+
+def plan_shards(obs_per_frame, world):
+    c = np.ascontiguousarray(obs_per_frame, dtype=np.int64)
+    begin = np.zeros(world + 1, dtype=np.int32)
+    _check(lib().aar_plan_shards(len(c), c.ctypes.data_as(C.POINTER(C.c_int64)), world,
+                                 begin.ctypes.data_as(C.POINTER(C.c_int32))))
+    return begin
+
+
+def device_count():
+    return lib().aar_device_count()
+
+
+def lm_default_params(**over):
+    p = CLmParams()
+    lib().aar_lm_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+class Comm:
+    """RCCL communicator of one rank (multi-GPU)."""
+
+    @staticmethod
+    def make_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(lib().aar_comm_make_id(buf))
+        return buf.raw
+
+    def __init__(self, uid, world, rank, device):
+        self.handle = C.c_void_p()
+        self.world, self.rank = world, rank
+        _check(lib().aar_comm_create(uid, world, rank, device, C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            lib().aar_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class Problem:
+    """aar_problem: the bundle-adjustment problem resident on one GPU."""
+
+    def __init__(self, ds, residual_mode=RES_F32, device=0, comm=None, optimize=None):
+        self.ds = ds
+        self._cds = ds.as_c()
+        d = CProblemDesc()
+        lib().aar_problem_desc_from_dataset(C.byref(self._cds), C.byref(d))
+        if optimize is not None:
+            d.optimize_cam_poses, d.optimize_marker_poses, d.optimize_object_poses = [int(b) for b in optimize]
+        d.residual_mode = residual_mode
+        d.device_id = device
+        d.comm = comm.handle if comm is not None else None
+        self.handle = C.c_void_p()
+        _check(lib().aar_problem_create(C.byref(d), C.byref(self.handle)))
+        self.full_len = lib().aar_problem_full_len(self.handle)
+        self.num_vars = lib().aar_problem_num_vars(self.handle)
+        self.local_obs = lib().aar_problem_local_obs(self.handle)
+
+    def close(self):
+        if self.handle:
+            lib().aar_problem_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _x(self, x_full):
+        x = np.ascontiguousarray(x_full, dtype=np.float64)
+        assert x.shape == (self.full_len,)
+        return x
+
+    def eval_residuals(self, x_full, want_vector=True):
+        x = self._x(x_full)
+        ss = C.c_double()
+        r = np.zeros(8 * self.ds.num_obs) if want_vector else None
+        _check(lib().aar_eval_residuals(self.handle, _dptr(x), _dptr(r) if want_vector else None, C.byref(ss)))
+        return r, ss.value
+
+    def eval_normal_equations(self, x_full):
+        x = self._x(x_full)
+        P = self.num_vars
+        H = np.zeros((P, P))
+        B = np.zeros(P)
+        ss = C.c_double()
+        _check(lib().aar_eval_normal_equations(self.handle, _dptr(x), _dptr(H), _dptr(B), C.byref(ss)))
+        return H, B, ss.value
+
+    def eval_damped_step(self, x_full, mu):
+        x = self._x(x_full)
+        delta = np.zeros(self.num_vars)
+        _check(lib().aar_eval_damped_step(self.handle, _dptr(x), mu, _dptr(delta)))
+        return delta
+
+    def reproj_stats(self, x_full):
+        x = self._x(x_full)
+        rmse, ss = C.c_double(), C.c_double()
+        _check(lib().aar_reproj_stats(self.handle, _dptr(x), C.byref(rmse), C.byref(ss)))
+        return rmse.value, ss.value
+
+    def lm_init(self, x_full, params=None):
+        x = self._x(x_full)
+        _check(lib().aar_lm_init(self.handle, _dptr(x), C.byref(params) if params is not None else None))
+
+    def lm_step(self):
+        it = CLmIter()
+        _check(lib().aar_lm_step(self.handle, C.byref(it)))
+        return dict(err=it.err, mu=it.mu, gain=it.gain, delta_norm=it.delta_norm, accepted=it.accepted, tries=it.tries)
+
+    def lm_get_solution(self):
+        x = np.array(self.ds.x_full, dtype=np.float64)
+        err = C.c_double()
+        _check(lib().aar_lm_get_solution(self.handle, _dptr(x), C.byref(err)))
+        return x, err.value
+
+    def lm_solve(self, x_full, params=None, trace_cap=256):
+        x = np.array(self._x(x_full), dtype=np.float64)
+        rep = CLmReport()
+        tr = (CLmIter * trace_cap)()
+        rep.trace = tr
+        rep.trace_cap = trace_cap
+        _check(lib().aar_lm_solve(self.handle, _dptr(x), C.byref(params) if params is not None else None, C.byref(rep)))
+        n = min(rep.iterations, trace_cap)
+        trace = [dict(err=tr[i].err, mu=tr[i].mu, gain=tr[i].gain, delta_norm=tr[i].delta_norm,
+                      accepted=tr[i].accepted, tries=tr[i].tries) for i in range(n)]
+        report = dict(iterations=rep.iterations, stop_code=rep.stop_code, initial_err=rep.initial_err,
+                      final_err=rep.final_err, final_mu=rep.final_mu, solve_seconds=rep.solve_seconds,
+                      trial_points=rep.trial_points, trace=trace)
+        return x, report
+
+    def stage_times(self):
+        t = CStageTimes()
+        _check(lib().aar_get_stage_times(self.handle, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in CStageTimes._fields_}

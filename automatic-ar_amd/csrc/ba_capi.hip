@@ -1,0 +1,842 @@
+// C-ABI compute entry points (include/aar.h): problem upload, index structures, the LM loop of
+// ucoslam::SparseLevMarq<double> (libs/sparselevmarq.h:238-249,349-430,440-472) driven from the host
+// with every arithmetic stage on the GPU, and the RCCL exchange for frame-sharded problems.
+//
+// There is deliberately no CPU compute path in this file: without a HIP device every compute entry
+// point returns AAR_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../host/internal.h"
+#include "geom.hpp"
+#include "kernels.h"
+
+using namespace aar;
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return set_error(AAR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, resolved at run time so that libaar.so loads on machines without it (and shares whichever
+// librccl.so.1 the process already holds, e.g. the one PyTorch brought in).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct NcclId { char internal[128]; };
+typedef void *NcclComm;
+struct NcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(NcclComm *, int, NcclId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+NcclApi g_nccl;
+constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;
+
+int load_nccl() {
+    if (g_nccl.ok) return AAR_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        g_nccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_nccl.lib) break;
+    }
+    if (!g_nccl.lib) return set_error(AAR_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
+    g_nccl.GetUniqueId = (int (*)(NcclId *))dlsym(g_nccl.lib, "ncclGetUniqueId");
+    g_nccl.CommInitRank = (int (*)(NcclComm *, int, NcclId, int))dlsym(g_nccl.lib, "ncclCommInitRank");
+    g_nccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, NcclComm, hipStream_t))dlsym(g_nccl.lib, "ncclAllReduce");
+    g_nccl.CommDestroy = (int (*)(NcclComm))dlsym(g_nccl.lib, "ncclCommDestroy");
+    g_nccl.GetErrorString = (const char *(*)(int))dlsym(g_nccl.lib, "ncclGetErrorString");
+    if (!g_nccl.GetUniqueId || !g_nccl.CommInitRank || !g_nccl.AllReduce || !g_nccl.CommDestroy)
+        return set_error(AAR_ERR_COMM, "librccl lacks the expected nccl* symbols");
+    g_nccl.ok = true;
+    return AAR_OK;
+}
+}  // namespace
+
+struct aar_comm {
+    NcclComm comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+};
+
+#define NCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        int _r = (expr);                                                                                        \
+        if (_r != 0)                                                                                            \
+            return set_error(AAR_ERR_COMM, "%s failed: %s", #expr, g_nccl.GetErrorString ? g_nccl.GetErrorString(_r) : "?"); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+struct aar_problem {
+    DeviceProblem P;
+    PoseLayout L;             // global layout (all frames)
+    int f_begin = 0, f_end = 0;  // global frame range owned by this rank
+    int64_t o_begin = 0, N_global = 0;
+    aar_comm *comm = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    double *h_scal = nullptr;   // pinned [8]
+    int32_t *h_flags = nullptr; // pinned [4]
+    double *d_frames_all = nullptr;  // [6 F_global] gather buffer (multi-GPU)
+    double *d_diag = nullptr;        // [n_pad]
+    std::vector<double> h_z;    // staging [6A + 6F_loc]
+    // host copies of the index structure (normal-equation assembly for tests)
+    std::vector<int32_t> h_fslot_start, h_fslot_ent;
+    // LM state (SparseLevMarq members, libs/sparselevmarq.h:129-136)
+    aar_lm_params prm;
+    int cur = 0;
+    double mu = -1, v = 2, currErr = 0, prevErr = 0;
+    bool lm_ready = false;
+    int64_t trial_points = 0, launches = 0;
+    aar_stage_times times;
+    bool stage_timers = false;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(aar_problem *pb, T **ptr, size_t count) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    HIP_TRY(hipMemsetAsync(p, 0, bytes, pb->stream));
+    pb->allocs.push_back(p);
+    *ptr = static_cast<T *>(p);
+    return AAR_OK;
+}
+
+template <class T>
+int dev_upload(aar_problem *pb, T **ptr, const std::vector<T> &h) {
+    int rc = dev_alloc(pb, ptr, h.size());
+    if (rc) return rc;
+    if (!h.empty()) HIP_TRY(hipMemcpyAsync(*ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, pb->stream));
+    return AAR_OK;
+}
+
+int ensure_device(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_error(AAR_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                         e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return set_error(AAR_ERR_INVALID, "device_id %d out of range (%d devices)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    return AAR_OK;
+}
+
+// x_full (reference packing, roots skipped) -> device pose vector [A entities | local frames]
+void pack_z(const aar_problem *pb, const double *x_full, std::vector<double> &z) {
+    const PoseLayout &L = pb->L;
+    const int A = pb->P.A, F = pb->P.F;
+    z.assign((size_t)6 * (A + F), 0.0);
+    for (int c = 0; c < L.C; c++)
+        if (c != L.rc) memcpy(&z[6 * (size_t)c], x_full + L.full_cam0() + 6LL * L.cam_slot(c), 6 * sizeof(double));
+    for (int m = 0; m < L.M; m++)
+        if (m != L.rm) memcpy(&z[6 * (size_t)(L.C + m)], x_full + L.full_mk0() + 6LL * L.mk_slot(m), 6 * sizeof(double));
+    if (F) memcpy(&z[6 * (size_t)A], x_full + L.full_fr0() + 6LL * pb->f_begin, (size_t)6 * F * sizeof(double));
+}
+
+int upload_z(aar_problem *pb, const double *x_full, int which) {
+    pack_z(pb, x_full, pb->h_z);
+    HIP_TRY(hipMemcpyAsync(pb->P.z[which], pb->h_z.data(), pb->h_z.size() * sizeof(double), hipMemcpyHostToDevice, pb->stream));
+    // the staging vector is pageable: make the copy complete before it can be reused
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    return AAR_OK;
+}
+
+int allreduce(aar_problem *pb, double *buf, size_t count, int op) {
+    if (!pb->comm) return AAR_OK;
+    NCCL_TRY(g_nccl.AllReduce(buf, buf, count, NCCL_FLOAT64, op, pb->comm->comm, pb->stream));
+    return AAR_OK;
+}
+
+// device pose vector -> x_full; fixed groups keep the caller's values
+int download_z(aar_problem *pb, int which, double *x_full) {
+    const PoseLayout &L = pb->L;
+    const int A = pb->P.A, F = pb->P.F;
+    std::vector<double> &z = pb->h_z;
+    z.resize((size_t)6 * (A + F));
+    HIP_TRY(hipMemcpyAsync(z.data(), pb->P.z[which], z.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    if (L.oc)
+        for (int c = 0; c < L.C; c++)
+            if (c != L.rc) memcpy(x_full + L.full_cam0() + 6LL * L.cam_slot(c), &z[6 * (size_t)c], 6 * sizeof(double));
+    if (L.om)
+        for (int m = 0; m < L.M; m++)
+            if (m != L.rm) memcpy(x_full + L.full_mk0() + 6LL * L.mk_slot(m), &z[6 * (size_t)(L.C + m)], 6 * sizeof(double));
+    if (L.of) {
+        if (!pb->comm) {
+            if (F) memcpy(x_full + L.full_fr0(), &z[6 * (size_t)A], (size_t)6 * F * sizeof(double));
+        } else {
+            // every rank contributes its own frames to a zeroed vector; the sum is the gather
+            const size_t cnt = (size_t)6 * L.F;
+            HIP_TRY(hipMemsetAsync(pb->d_frames_all, 0, cnt * sizeof(double), pb->stream));
+            if (F)
+                HIP_TRY(hipMemcpyAsync(pb->d_frames_all + 6 * (size_t)pb->f_begin, pb->P.z[which] + 6 * (size_t)A,
+                                       (size_t)6 * F * sizeof(double), hipMemcpyDeviceToDevice, pb->stream));
+            int rc = allreduce(pb, pb->d_frames_all, cnt, NCCL_SUM);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(x_full + L.full_fr0(), pb->d_frames_all, cnt * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+            HIP_TRY(hipStreamSynchronize(pb->stream));
+        }
+    }
+    return AAR_OK;
+}
+
+struct StageTimer {  // optional per-stage device timing (AAR_STAGE_TIMERS=1); costs two event records + a sync per stage
+    aar_problem *pb;
+    double *slot;
+    StageTimer(aar_problem *p, double *s) : pb(p), slot(s) {
+        if (pb->stage_timers) (void)hipEventRecord(pb->ev[0], pb->stream);
+    }
+    ~StageTimer() {
+        if (pb->stage_timers) {
+            (void)hipEventRecord(pb->ev[1], pb->stream);
+            (void)hipEventSynchronize(pb->ev[1]);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, pb->ev[0], pb->ev[1]);
+            *slot += ms * 1e-3;
+        }
+    }
+};
+
+int check_async(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(AAR_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return AAR_OK;
+}
+
+// J^T J blocks and B at z[which]: the "J", "transpose", "Jt*J", "B" stages of libs/sparselevmarq.h:353-367
+int eval_blocks(aar_problem *pb, int which) {
+    DeviceProblem &P = pb->P;
+    {
+        StageTimer t(pb, &pb->times.unpack);
+        launch_unpack(P, which, true, pb->stream);
+    }
+    {
+        StageTimer t(pb, &pb->times.jacobian_normal_eq);
+        launch_passA(P, which, pb->stream);
+        launch_passB(P, which, pb->stream);
+    }
+    pb->launches += 3;
+    return check_async("normal-equation kernels");
+}
+
+// one damped solve + trial residual: fills h_scal / h_flags; z[1-cur] = z[cur] + delta
+int damped_try(aar_problem *pb, double mu, bool with_residual) {
+    DeviceProblem &P = pb->P;
+    const int cur = pb->cur, tr = 1 - cur;
+    {
+        StageTimer t(pb, &pb->times.schur);
+        launch_frame_inv(P, mu, pb->stream);
+        launch_schur(P, pb->stream);
+    }
+    if (pb->comm) {
+        StageTimer t(pb, &pb->times.allreduce);
+        int rc = allreduce(pb, P.S, (size_t)P.n_pad * P.n_pad, NCCL_SUM);
+        if (rc) return rc;
+        rc = allreduce(pb, P.rhs, (size_t)P.n_pad, NCCL_SUM);
+        if (rc) return rc;
+    }
+    {
+        StageTimer t(pb, &pb->times.chol);
+        launch_finalize(P, mu, pb->stream);
+        launch_chol(P, pb->stream);
+    }
+    {
+        StageTimer t(pb, &pb->times.backsub);
+        launch_backsub(P, cur, tr, pb->stream);
+    }
+    pb->launches += 4 + 2 * P.nT;
+    if (with_residual) {
+        {
+            StageTimer t(pb, &pb->times.unpack);
+            launch_unpack(P, tr, false, pb->stream);
+        }
+        {
+            StageTimer t(pb, &pb->times.residual);
+            launch_residual(P, tr, nullptr, pb->stream);
+        }
+        pb->launches += 2;
+        pb->trial_points++;
+    }
+    {
+        StageTimer t(pb, &pb->times.control);
+        launch_reduce_scalars(P, pb->comm != nullptr, pb->stream);
+        pb->launches += 1;
+    }
+    if (pb->comm) {
+        StageTimer t(pb, &pb->times.allreduce);
+        int rc = allreduce(pb, P.scal, 3, NCCL_SUM);  // [sum r^2, sum |delta_f|^2, sum delta.g]
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipMemcpyAsync(pb->h_flags, P.flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    int rc = check_async("damped solve kernels");
+    if (rc) return rc;
+    if (pb->h_flags[0]) {
+        (void)hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream);
+        return set_error(AAR_ERR_NUMERIC, "non-positive pivot (flags=%d) at mu=%g", pb->h_flags[0], mu);
+    }
+    return AAR_OK;
+}
+
+int initial_mu(aar_problem *pb, double tau, double *mu) {
+    DeviceProblem &P = pb->P;
+    if (pb->comm) {
+        // the diagonal of the shared blocks is a sum over ranks; the frame blocks are rank-local
+        HIP_TRY(hipMemcpy2DAsync(pb->d_diag, sizeof(double), P.U0, (size_t)(P.n_pad + 1) * sizeof(double), sizeof(double),
+                                 P.n_pad, hipMemcpyDeviceToDevice, pb->stream));
+        int rc = allreduce(pb, pb->d_diag, P.n_pad, NCCL_SUM);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy2DAsync(P.S, (size_t)(P.n_pad + 1) * sizeof(double), pb->d_diag, sizeof(double), sizeof(double),
+                                 P.n_pad, hipMemcpyDeviceToDevice, pb->stream));
+        // S is scratch here (it is rebuilt from U0 by every damped_try); read the summed diagonal from it
+        DeviceProblem Q = P;
+        Q.U0 = P.S;
+        launch_maxdiag(Q, pb->stream);
+        rc = allreduce(pb, P.scal + 4, 1, NCCL_MAX);
+        if (rc) return rc;
+    } else {
+        launch_maxdiag(P, pb->stream);
+    }
+    pb->launches += 1;
+    HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    *mu = pb->h_scal[4] * tau;
+    return AAR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aar_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int aar_device_synchronize(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    return AAR_OK;
+}
+
+int aar_comm_make_id(char id[AAR_COMM_ID_BYTES]) {
+    int rc = load_nccl();
+    if (rc) return rc;
+    NcclId u;
+    NCCL_TRY(g_nccl.GetUniqueId(&u));
+    memcpy(id, u.internal, AAR_COMM_ID_BYTES);
+    return AAR_OK;
+}
+
+int aar_comm_create(const char id[AAR_COMM_ID_BYTES], int32_t world_size, int32_t rank, int32_t device_id, aar_comm **out) {
+    if (!id || !out || world_size < 1 || rank < 0 || rank >= world_size) return set_error(AAR_ERR_INVALID, "aar_comm_create: bad arguments");
+    int rc = load_nccl();
+    if (rc) return rc;
+    rc = ensure_device(device_id);
+    if (rc) return rc;
+    NcclId u;
+    memcpy(u.internal, id, AAR_COMM_ID_BYTES);
+    aar_comm *c = new aar_comm();
+    c->world = world_size; c->rank = rank; c->device = device_id;
+    int r = g_nccl.CommInitRank(&c->comm, world_size, u, rank);
+    if (r != 0) {
+        delete c;
+        return set_error(AAR_ERR_COMM, "ncclCommInitRank failed: %s", g_nccl.GetErrorString ? g_nccl.GetErrorString(r) : "?");
+    }
+    *out = c;
+    return AAR_OK;
+}
+
+void aar_comm_destroy(aar_comm *c) {
+    if (!c) return;
+    if (c->comm && g_nccl.ok) g_nccl.CommDestroy(c->comm);
+    delete c;
+}
+
+void aar_lm_default_params(aar_lm_params *p) {  // libs/multicam_mapper.cpp:326-330 over libs/sparselevmarq.h:41-49
+    p->max_iters = 10000;
+    p->min_error = 1e-5;
+    p->min_step_error_diff = 0;
+    p->min_average_step_error_diff = 1e-4;
+    p->tau = 1;
+    p->verbose = 0;
+}
+
+void aar_problem_destroy(aar_problem *pb) {
+    if (!pb) return;
+    (void)hipSetDevice(pb->device);
+    if (pb->stream) (void)hipStreamSynchronize(pb->stream);
+    for (void *p : pb->allocs) (void)hipFree(p);
+    if (pb->h_scal) (void)hipHostFree(pb->h_scal);
+    if (pb->h_flags) (void)hipHostFree(pb->h_flags);
+    if (pb->ev[0]) (void)hipEventDestroy(pb->ev[0]);
+    if (pb->ev[1]) (void)hipEventDestroy(pb->ev[1]);
+    if (pb->stream) (void)hipStreamDestroy(pb->stream);
+    delete pb;
+}
+
+int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
+    if (!d || !out) return set_error(AAR_ERR_INVALID, "aar_problem_create: null argument");
+    const int C = d->num_cams, M = d->num_markers, Fg = d->num_frames;
+    const int64_t Ng = d->num_obs;
+    if (C < 1 || M < 1 || Fg < 0 || Ng < 0) return set_error(AAR_ERR_INVALID, "aar_problem_create: bad sizes");
+    if (d->root_cam < 0 || d->root_cam >= C || d->root_marker < 0 || d->root_marker >= M)
+        return set_error(AAR_ERR_INVALID, "aar_problem_create: root index out of range");
+    if (!d->cam_mats || (Ng > 0 && (!d->obs_frame || !d->obs_cam || !d->obs_marker || !d->obs_uv)))
+        return set_error(AAR_ERR_INVALID, "aar_problem_create: null array");
+    if (Ng >= (1LL << 31) || (int64_t)C + M >= 32768) return set_error(AAR_ERR_UNSUPPORTED, "problem too large for 32-bit indexing");
+    std::vector<int64_t> per_frame(Fg, 0);
+    for (int64_t o = 0; o < Ng; o++) {
+        const int f = d->obs_frame[o], c = d->obs_cam[o], m = d->obs_marker[o];
+        if (f < 0 || f >= Fg || c < 0 || c >= C || m < 0 || m >= M) return set_error(AAR_ERR_INVALID, "observation %lld has an index out of range", (long long)o);
+        if (o > 0 && f < d->obs_frame[o - 1]) return set_error(AAR_ERR_INVALID, "observations must be ordered by frame (reference residual order)");
+        per_frame[f]++;
+    }
+    int rc = ensure_device(d->device_id);
+    if (rc) return rc;
+
+    aar_problem *pb = new aar_problem();
+    pb->device = d->device_id;
+    pb->comm = d->comm;
+    aar_lm_default_params(&pb->prm);
+    memset(&pb->times, 0, sizeof pb->times);
+    const char *tenv = getenv("AAR_STAGE_TIMERS");
+    pb->stage_timers = tenv && tenv[0] == '1';
+    auto fail = [&](int code) { aar_problem_destroy(pb); return code; };
+    if (hipStreamCreateWithFlags(&pb->stream, hipStreamNonBlocking) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "hipStreamCreate failed"));
+    (void)hipEventCreate(&pb->ev[0]);
+    (void)hipEventCreate(&pb->ev[1]);
+
+    PoseLayout &L = pb->L;
+    L.C = C; L.M = M; L.F = Fg; L.rc = d->root_cam; L.rm = d->root_marker;
+    L.oc = d->optimize_cam_poses != 0; L.om = d->optimize_marker_poses != 0; L.of = d->optimize_object_poses != 0;
+    pb->N_global = Ng;
+
+    // ---- shard by frame range ----
+    const int world = pb->comm ? pb->comm->world : 1, rank = pb->comm ? pb->comm->rank : 0;
+    std::vector<int32_t> begin(world + 1, 0);
+    if ((rc = aar_plan_shards(Fg, per_frame.data(), world, begin.data()))) return fail(rc);
+    pb->f_begin = begin[rank];
+    pb->f_end = begin[rank + 1];
+    int64_t ob = 0;
+    for (int f = 0; f < pb->f_begin; f++) ob += per_frame[f];
+    int64_t N = 0;
+    for (int f = pb->f_begin; f < pb->f_end; f++) N += per_frame[f];
+    pb->o_begin = ob;
+
+    DeviceProblem &P = pb->P;
+    P.C = C; P.M = M; P.A = C + M; P.F = pb->f_end - pb->f_begin; P.N = N;
+    P.n = 6 * P.A;
+    P.nT = (P.n + CHOL_NB - 1) / CHOL_NB;
+    P.n_pad = P.nT * CHOL_NB;
+    P.res_f32 = d->residual_mode == AAR_RES_F64 ? 0 : 1;
+    P.half_size = (double)((float)d->marker_size / 2.f);
+    P.frames_fixed = L.of ? 0 : 1;
+    const int A = P.A, F = P.F;
+
+    // ---- ordering A (reference order) + per-frame slot lists ----
+    std::vector<int32_t> frame_obs_start(F + 1, 0), fslot_start(F + 1, 0), fslot_ent;
+    std::vector<ObsIdx> a_idx(N);
+    std::vector<float> a_uv((size_t)8 * N);
+    if (N) memcpy(a_uv.data(), d->obs_uv + 8 * ob, sizeof(float) * 8 * N);
+    {
+        int64_t o = 0;
+        std::vector<int32_t> slot_of(A, -1);
+        for (int f = 0; f < F; f++) {
+            frame_obs_start[f] = (int32_t)o;
+            const int64_t cnt = per_frame[pb->f_begin + f];
+            std::vector<int32_t> ents;
+            for (int64_t k = 0; k < cnt; k++) {
+                const int64_t g = ob + o + k;
+                ents.push_back(d->obs_cam[g]);
+                ents.push_back(C + d->obs_marker[g]);
+            }
+            std::sort(ents.begin(), ents.end());
+            ents.erase(std::unique(ents.begin(), ents.end()), ents.end());
+            if (ents.size() > 65535) return fail(set_error(AAR_ERR_UNSUPPORTED, "frame %d touches more than 65535 entities", f));
+            for (size_t s = 0; s < ents.size(); s++) slot_of[ents[s]] = (int32_t)s;
+            for (int64_t k = 0; k < cnt; k++) {
+                const int64_t g = ob + o + k;
+                ObsIdx id;
+                id.frame = f; id.cam = d->obs_cam[g]; id.marker = C + d->obs_marker[g];
+                id.slots = slot_of[id.cam] | (slot_of[id.marker] << 16);
+                a_idx[o + k] = id;
+            }
+            fslot_start[f] = (int32_t)fslot_ent.size();
+            fslot_ent.insert(fslot_ent.end(), ents.begin(), ents.end());
+            P.max_kf = std::max<int>(P.max_kf, (int)ents.size());
+            o += cnt;
+        }
+        frame_obs_start[F] = (int32_t)o;
+        fslot_start[F] = (int32_t)fslot_ent.size();
+    }
+    P.total_slots = (int)fslot_ent.size();
+    const size_t ldsA = ((size_t)P.max_kf * 36 + 32 + 4 * 2048) * sizeof(double);
+    if (ldsA > 160 * 1024) return fail(set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers; the frame-block kernel holds them in LDS (limit ~ %d)", P.max_kf, (160 * 1024 / 8 - 32 - 8192) / 36));
+    if ((size_t)A * 36 * 8 + 2048 > 160 * 1024) return fail(set_error(AAR_ERR_UNSUPPORTED, "%d cameras+markers exceed the Schur row panel held in LDS", A));
+
+    // ---- ordering B: (camera, marker, frame) runs cut into wave-sized chunks ----
+    std::vector<int32_t> perm(N);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) {
+        const ObsIdx &p = a_idx[x], &q = a_idx[y];
+        if (p.cam != q.cam) return p.cam < q.cam;
+        if (p.marker != q.marker) return p.marker < q.marker;
+        return p.frame < q.frame;
+    });
+    std::vector<ObsIdx> b_idx(N);
+    std::vector<float> b_uv((size_t)8 * N);
+    for (int64_t i = 0; i < N; i++) {
+        b_idx[i] = a_idx[perm[i]];
+        memcpy(&b_uv[8 * i], &a_uv[8 * (size_t)perm[i]], 8 * sizeof(float));
+    }
+    int chunk_len = (int)((N / 4096 + 63) / 64 * 64);
+    chunk_len = std::min(std::max(chunk_len, 64), PASSB_CHUNK);
+    std::vector<int32_t> chunk_start;
+    for (int64_t i = 0; i < N;) {
+        int64_t e = i;
+        while (e < N && b_idx[e].cam == b_idx[i].cam && b_idx[e].marker == b_idx[i].marker) e++;
+        for (int64_t s = i; s < e; s += chunk_len) chunk_start.push_back((int32_t)s);
+        i = e;
+    }
+    P.n_chunks = (int)chunk_start.size();
+    chunk_start.push_back((int32_t)N);
+
+    // ---- (entity, frame) incidence for the Schur complement ----
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> inc(A);
+    for (int f = 0; f < F; f++)
+        for (int s = fslot_start[f]; s < fslot_start[f + 1]; s++) inc[fslot_ent[s]].push_back({f, s});
+    std::vector<int32_t> pair_frame, pair_slot, sw_ent, sw_begin, sw_end;
+    const int64_t total_pairs = P.total_slots;
+    int per_item = (int)std::max<int64_t>(8, (total_pairs + 2047) / 2048);
+    per_item = (per_item + 3) / 4 * 4;
+    for (int a = 0; a < A; a++) {
+        const int base = (int)pair_frame.size();
+        for (auto &pr : inc[a]) { pair_frame.push_back(pr.first); pair_slot.push_back(pr.second); }
+        const int cnt = (int)inc[a].size();
+        for (int s = 0; s < cnt; s += per_item) {
+            sw_ent.push_back(a);
+            sw_begin.push_back(base + s);
+            sw_end.push_back(base + std::min(cnt, s + per_item));
+        }
+    }
+    P.n_swork = (int)sw_ent.size();
+
+    std::vector<int32_t> ent_fixed(A, 0);
+    for (int c = 0; c < C; c++) ent_fixed[c] = (c == L.rc || !L.oc) ? 1 : 0;
+    for (int m = 0; m < M; m++) ent_fixed[C + m] = (m == L.rm || !L.om) ? 1 : 0;
+    std::vector<double> Kh(d->cam_mats, d->cam_mats + 9 * (size_t)C);
+
+    // ---- upload ----
+#define UP(field, vec) if ((rc = dev_upload(pb, &P.field, vec))) return fail(rc)
+    UP(K, Kh); UP(a_idx, a_idx); UP(a_uv, a_uv); UP(frame_obs_start, frame_obs_start);
+    UP(fslot_start, fslot_start); UP(fslot_ent, fslot_ent); UP(b_idx, b_idx); UP(b_uv, b_uv);
+    UP(chunk_start, chunk_start); UP(ent_fixed, ent_fixed);
+    UP(sw_ent, sw_ent); UP(sw_begin, sw_begin); UP(sw_end, sw_end); UP(pair_frame, pair_frame); UP(pair_slot, pair_slot);
+#undef UP
+#define AL(field, count) if ((rc = dev_alloc(pb, &P.field, (size_t)(count)))) return fail(rc)
+    AL(z[0], 6 * (size_t)(A + F)); AL(z[1], 6 * (size_t)(A + F));
+    AL(ent[0], (size_t)(A + F) * ENT_STRIDE); AL(ent[1], (size_t)(A + F) * ENT_STRIDE);
+    AL(V, (size_t)F * 36); AL(gf, (size_t)F * 6); AL(W, (size_t)P.total_slots * 36);
+    AL(Vinv, (size_t)F * 36); AL(hf, (size_t)F * 6);
+    AL(U0, (size_t)P.n_pad * P.n_pad); AL(g0, P.n_pad); AL(S, (size_t)P.n_pad * P.n_pad); AL(rhs, P.n_pad);
+    AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(delta_s, P.n_pad);
+    AL(err_part, std::max<size_t>((size_t)F, (size_t)((N + 255) / 256)) + 1);
+    AL(lin_part, 2 * (size_t)(F + 1)); AL(scal, 8); AL(flags, 4);
+#undef AL
+    if ((rc = dev_alloc(pb, &pb->d_diag, P.n_pad))) return fail(rc);
+    if (pb->comm && (rc = dev_alloc(pb, &pb->d_frames_all, 6 * (size_t)std::max(Fg, 1)))) return fail(rc);
+    if (hipHostMalloc((void **)&pb->h_scal, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&pb->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
+        return fail(set_error(AAR_ERR_HIP, "hipHostMalloc failed"));
+    if (hipStreamSynchronize(pb->stream) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "upload failed"));
+    pb->h_fslot_start = fslot_start;
+    pb->h_fslot_ent = fslot_ent;
+    *out = pb;
+    return AAR_OK;
+}
+
+int64_t aar_problem_full_len(const aar_problem *pb) { return pb->L.full_len(); }
+int64_t aar_problem_num_vars(const aar_problem *pb) { return pb->L.z_len(); }
+int64_t aar_problem_local_obs(const aar_problem *pb) { return pb->P.N; }
+
+int aar_eval_residuals(aar_problem *pb, const double *x_full, double *r, double *sum_sq) {
+    if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_eval_residuals: null argument");
+    if (r && pb->comm) return set_error(AAR_ERR_UNSUPPORTED, "residual vector output is single-GPU only");
+    HIP_TRY(hipSetDevice(pb->device));
+    DeviceProblem &P = pb->P;
+    int rc = upload_z(pb, x_full, pb->cur);
+    if (rc) return rc;
+    double *d_r = nullptr;
+    if (r) HIP_TRY(hipMalloc((void **)&d_r, std::max<size_t>(1, 8 * (size_t)P.N) * sizeof(double)));
+    launch_unpack(P, pb->cur, false, pb->stream);
+    launch_residual(P, pb->cur, d_r, pb->stream);
+    HIP_TRY(hipMemsetAsync(P.lin_part, 0, 2 * (size_t)(P.F + 1) * sizeof(double), pb->stream));
+    launch_reduce_scalars(P, false, pb->stream);
+    rc = allreduce(pb, P.scal, 1, NCCL_SUM);
+    if (rc) { if (d_r) (void)hipFree(d_r); return rc; }
+    HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    if (r) HIP_TRY(hipMemcpyAsync(r, d_r, 8 * (size_t)P.N * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    if (d_r) (void)hipFree(d_r);
+    if (sum_sq) *sum_sq = pb->h_scal[0];
+    pb->lm_ready = false;
+    return check_async("residual kernels");
+}
+
+int aar_reproj_stats(aar_problem *pb, const double *x_full, double *rmse, double *sum_sq) {
+    if (!pb) return set_error(AAR_ERR_INVALID, "aar_reproj_stats: null argument");
+    const int saved = pb->P.res_f32;
+    pb->P.res_f32 = 0;
+    double ss = 0;
+    int rc = aar_eval_residuals(pb, x_full, nullptr, &ss);
+    pb->P.res_f32 = saved;
+    if (rc) return rc;
+    if (sum_sq) *sum_sq = ss;
+    if (rmse) *rmse = std::sqrt(ss / (4.0 * (double)pb->N_global));
+    return AAR_OK;
+}
+
+int aar_eval_normal_equations(aar_problem *pb, const double *x_full, double *JtJ, double *B, double *sum_sq) {
+    if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_eval_normal_equations: null argument");
+    if (pb->comm) return set_error(AAR_ERR_UNSUPPORTED, "dense normal-equation output is single-GPU only");
+    HIP_TRY(hipSetDevice(pb->device));
+    DeviceProblem &P = pb->P;
+    const PoseLayout &L = pb->L;
+    int rc = upload_z(pb, x_full, pb->cur);
+    if (rc) return rc;
+    if ((rc = eval_blocks(pb, pb->cur))) return rc;
+    const int A = P.A, F = P.F, np = P.n_pad;
+    std::vector<double> U0((size_t)np * np), g0(np), V((size_t)F * 36), gf((size_t)F * 6), W((size_t)P.total_slots * 36), ep(F);
+    HIP_TRY(hipMemcpyAsync(U0.data(), P.U0, U0.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipMemcpyAsync(g0.data(), P.g0, g0.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    if (F) {
+        HIP_TRY(hipMemcpyAsync(V.data(), P.V, V.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+        HIP_TRY(hipMemcpyAsync(gf.data(), P.gf, gf.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+        HIP_TRY(hipMemcpyAsync(W.data(), P.W, W.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+        HIP_TRY(hipMemcpyAsync(ep.data(), P.err_part, ep.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    pb->lm_ready = false;
+    // reference column of each device parameter (or -1): roots and non-optimised groups have none
+    const int64_t Pz = L.z_len();
+    auto ent_col = [&](int a) -> int64_t {
+        if (a < L.C) { const int s = L.cam_slot(a); return (s < 0 || !L.oc) ? -1 : L.z_cam0() + 6LL * s; }
+        const int s = L.mk_slot(a - L.C);
+        return (s < 0 || !L.om) ? -1 : L.z_mk0() + 6LL * s;
+    };
+    if (JtJ) {
+        std::fill(JtJ, JtJ + Pz * Pz, 0.0);
+        for (int a = 0; a < A; a++) {
+            const int64_t ca = ent_col(a);
+            if (ca < 0) continue;
+            for (int b = 0; b <= a; b++) {
+                const int64_t cb = ent_col(b);
+                if (cb < 0) continue;
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 6; j++) {
+                        if (a == b && j > i) continue;
+                        const double v = U0[(size_t)(6 * a + i) * np + 6 * b + j];
+                        JtJ[(ca + i) * Pz + cb + j] = v;
+                        JtJ[(cb + j) * Pz + ca + i] = v;
+                    }
+            }
+        }
+        if (L.of)
+            for (int f = 0; f < F; f++) {
+                const int64_t cf = L.z_fr0() + 6LL * f;
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 6; j++) JtJ[(cf + i) * Pz + cf + j] = V[(size_t)f * 36 + i * 6 + j];
+                for (int s = pb->h_fslot_start[f]; s < pb->h_fslot_start[f + 1]; s++) {
+                    const int64_t ca = ent_col(pb->h_fslot_ent[s]);
+                    if (ca < 0) continue;
+                    for (int i = 0; i < 6; i++)
+                        for (int j = 0; j < 6; j++) {
+                            const double v = W[(size_t)s * 36 + i * 6 + j];
+                            JtJ[(ca + i) * Pz + cf + j] = v;
+                            JtJ[(cf + j) * Pz + ca + i] = v;
+                        }
+                }
+            }
+    }
+    if (B) {
+        std::fill(B, B + Pz, 0.0);
+        for (int a = 0; a < A; a++) {
+            const int64_t ca = ent_col(a);
+            if (ca < 0) continue;
+            for (int i = 0; i < 6; i++) B[ca + i] = g0[6 * (size_t)a + i];
+        }
+        if (L.of)
+            for (int f = 0; f < F; f++)
+                for (int i = 0; i < 6; i++) B[L.z_fr0() + 6LL * f + i] = gf[(size_t)f * 6 + i];
+    }
+    if (sum_sq) {
+        double s = 0;
+        for (int f = 0; f < F; f++) s += ep[f];
+        *sum_sq = s;
+    }
+    return AAR_OK;
+}
+
+int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, double *delta) {
+    if (!pb || !x_full || !delta) return set_error(AAR_ERR_INVALID, "aar_eval_damped_step: null argument");
+    HIP_TRY(hipSetDevice(pb->device));
+    const PoseLayout &L = pb->L;
+    int rc = upload_z(pb, x_full, pb->cur);
+    if (rc) return rc;
+    if ((rc = eval_blocks(pb, pb->cur))) return rc;
+    if ((rc = damped_try(pb, mu, false))) return rc;
+    pb->lm_ready = false;
+    std::vector<double> x0(x_full, x_full + L.full_len()), x1(x0);
+    if ((rc = download_z(pb, 1 - pb->cur, x1.data()))) return rc;
+    // z ordering of the Config
+    int64_t k = 0;
+    if (L.oc) for (int64_t i = 0; i < 6LL * (L.C - 1); i++) delta[k++] = x1[L.full_cam0() + i] - x0[L.full_cam0() + i];
+    if (L.om) for (int64_t i = 0; i < 6LL * (L.M - 1); i++) delta[k++] = x1[L.full_mk0() + i] - x0[L.full_mk0() + i];
+    if (L.of) for (int64_t i = 0; i < 6LL * L.F; i++) delta[k++] = x1[L.full_fr0() + i] - x0[L.full_fr0() + i];
+    return AAR_OK;
+}
+
+// SparseLevMarq::init, libs/sparselevmarq.h:238-249
+int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm) {
+    if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_lm_init: null argument");
+    HIP_TRY(hipSetDevice(pb->device));
+    if (prm) pb->prm = *prm;
+    DeviceProblem &P = pb->P;
+    pb->cur = 0;
+    int rc = upload_z(pb, x_full, 0);
+    if (rc) return rc;
+    launch_unpack(P, 0, false, pb->stream);
+    launch_residual(P, 0, nullptr, pb->stream);
+    HIP_TRY(hipMemsetAsync(P.lin_part, 0, 2 * (size_t)(P.F + 1) * sizeof(double), pb->stream));
+    launch_reduce_scalars(P, false, pb->stream);
+    if ((rc = allreduce(pb, P.scal, 1, NCCL_SUM))) return rc;
+    HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    if ((rc = check_async("lm_init kernels"))) return rc;
+    pb->currErr = pb->prevErr = pb->h_scal[0];
+    pb->mu = -1;
+    pb->v = 2;  // indeterminate in the reference (libs/sparselevmarq.h:133); every accepted step sets 2 (:411)
+    pb->lm_ready = true;
+    pb->trial_points = 0;
+    pb->launches = 0;
+    memset(&pb->times, 0, sizeof pb->times);
+    return AAR_OK;
+}
+
+// SparseLevMarq::step(f, J), libs/sparselevmarq.h:349-430
+int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
+    if (!pb) return set_error(AAR_ERR_INVALID, "aar_lm_step: null argument");
+    if (!pb->lm_ready) return set_error(AAR_ERR_INVALID, "aar_lm_step: call aar_lm_init first");
+    HIP_TRY(hipSetDevice(pb->device));
+    int rc = eval_blocks(pb, pb->cur);  // J, Jt*J, B at curr_z (:353-367)
+    if (rc) return rc;
+    if (pb->mu < 0) {                   // first time only (:369-377)
+        if ((rc = initial_mu(pb, pb->prm.tau, &pb->mu))) return rc;
+    }
+    double gain = 0, dnorm = 0;
+    int ntries = 0;
+    bool accepted = false;
+    do {
+        if ((rc = damped_try(pb, pb->mu, true))) return rc;
+        const double *sc = pb->h_scal;
+        const double err = sc[0];
+        // L = 0.5 * delta^T (mu*delta - B) (:406); frame pieces were summed over ranks, the shared-parameter
+        // |delta|^2 is replicated and counted once, its delta.g piece is part of the rank sum
+        const double d2 = sc[1] + sc[5];
+        const double dg = pb->comm ? sc[2] : sc[2] + sc[6];
+        const double Lq = 0.5 * (pb->mu * d2 - dg);
+        dnorm = std::sqrt(d2);
+        gain = (err - pb->prevErr) / Lq;
+        if (gain > 0 && ((err - pb->prevErr) < 0)) {  // :409-415
+            pb->mu = pb->mu * std::max(0.33, 1. - std::pow(2 * gain - 1, 3));
+            pb->v = 2.f;
+            pb->currErr = err;
+            pb->cur = 1 - pb->cur;  // curr_z = estimated_z
+            accepted = true;
+        } else {
+            pb->mu = pb->mu * pb->v;
+            pb->v = pb->v * 5;
+        }
+    } while (gain <= 0 && ntries++ < 5 && !accepted);
+    if (out) {
+        out->err = pb->currErr; out->mu = pb->mu; out->gain = gain; out->delta_norm = dnorm;
+        out->accepted = accepted ? 1 : 0;
+        out->tries = ntries + (accepted ? 1 : 0);
+    }
+    if (pb->prm.verbose)
+        fprintf(stderr, "Curr Error=%.5g AErr(prev-curr)=%.5g gain=%.5g dumping factor=%.5g\n", pb->currErr,
+                (pb->prevErr - pb->currErr) / (8.0 * (double)pb->N_global), gain, pb->mu);
+    return AAR_OK;
+}
+
+int aar_lm_get_solution(aar_problem *pb, double *x_full, double *err) {
+    if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_lm_get_solution: null argument");
+    if (!pb->lm_ready) return set_error(AAR_ERR_INVALID, "aar_lm_get_solution: no LM state");
+    HIP_TRY(hipSetDevice(pb->device));
+    if (err) *err = pb->currErr;
+    return download_z(pb, pb->cur, x_full);
+}
+
+// SparseLevMarq::solve(z, f, J), libs/sparselevmarq.h:440-472 (no stop function on this path)
+int aar_lm_solve(aar_problem *pb, double *x_full, const aar_lm_params *prm, aar_lm_report *rep) {
+    if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_lm_solve: null argument");
+    int rc = aar_lm_init(pb, x_full, prm);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    const double rows = 8.0 * (double)pb->N_global;
+    const double initial = pb->currErr;
+    int mustExit = 0, iters = 0;
+    for (int i = 0; i < pb->prm.max_iters && !mustExit; i++) {
+        aar_lm_iter it;
+        if ((rc = aar_lm_step(pb, &it))) return rc;
+        if (pb->currErr < pb->prm.min_error) mustExit = 1;
+        if (std::fabs(pb->prevErr - pb->currErr) <= pb->prm.min_step_error_diff ||
+            std::fabs((pb->prevErr - pb->currErr) / rows) <= pb->prm.min_average_step_error_diff || !it.accepted)
+            mustExit = 2;
+        if (pb->currErr > pb->prevErr) mustExit = 3;
+        if (rep && rep->trace && iters < rep->trace_cap) rep->trace[iters] = it;
+        iters++;
+        pb->prevErr = pb->currErr;
+    }
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    pb->times.total = secs;
+    pb->times.launches = pb->launches;
+    if ((rc = download_z(pb, pb->cur, x_full))) return rc;
+    if (rep) {
+        rep->iterations = iters;
+        rep->stop_code = mustExit;
+        rep->initial_err = initial;
+        rep->final_err = pb->currErr;
+        rep->final_mu = pb->mu;
+        rep->solve_seconds = secs;
+        rep->trial_points = pb->trial_points;
+    }
+    return AAR_OK;
+}
+
+int aar_get_stage_times(aar_problem *pb, aar_stage_times *t) {
+    if (!pb || !t) return set_error(AAR_ERR_INVALID, "aar_get_stage_times: null argument");
+    *t = pb->times;
+    return AAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Host-callable launchers of the HIP kernels (defined in eval_kernels.hip / solve_kernels.hip).
+// All pointers are device pointers unless noted.  Nothing here allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aar {
+
+constexpr int CHOL_NB = 48;       // dense LDL^T tile (8 entity blocks of 6)
+constexpr int PASSB_CHUNK = 256;  // max observations of one (camera, marker) run handled by one wavefront
+
+// Per-observation record of an ordering: {frame (local), camera, marker, slot_c | slot_m << 16}
+struct ObsIdx {
+    int32_t frame, cam, marker, slots;
+};
+
+struct DeviceProblem {
+    // sizes
+    int C = 0, M = 0, A = 0;          // cameras, markers, shared entities A = C + M
+    int F = 0;                        // local frames
+    int64_t N = 0;                    // local observations
+    int n = 0, n_pad = 0, nT = 0;     // reduced system: n = 6A, padded to a multiple of CHOL_NB, tiles
+    int total_slots = 0, max_kf = 0;  // sum / max of distinct shared entities per frame
+    int n_chunks = 0, n_swork = 0;
+    int res_f32 = 1;
+    double half_size = 0;             // (double)((float)marker_size / 2.f)
+    // constant problem data
+    double *K = nullptr;              // [C][9]
+    ObsIdx *a_idx = nullptr;          // ordering A = reference order (frame, camera, detection order)
+    float *a_uv = nullptr;            // [N][8]
+    int32_t *frame_obs_start = nullptr;   // [F+1]
+    int32_t *fslot_start = nullptr;       // [F+1] first W block of each frame
+    int32_t *fslot_ent = nullptr;         // [total_slots] shared entity of each W block (ascending inside a frame)
+    ObsIdx *b_idx = nullptr;          // ordering B = (camera, marker, frame)
+    float *b_uv = nullptr;
+    int32_t *chunk_start = nullptr;   // [n_chunks+1] into ordering B; a chunk never spans two (camera, marker) runs
+    int32_t *ent_fixed = nullptr;     // [A] 1 = root or non-optimised group
+    int frames_fixed = 0;
+    // Schur work list: item w handles pairs [sw_begin[w], sw_end[w]) of entity sw_ent[w]
+    int32_t *sw_ent = nullptr, *sw_begin = nullptr, *sw_end = nullptr;
+    int32_t *pair_frame = nullptr, *pair_slot = nullptr;  // (entity, frame) incidence, grouped by entity
+    // state
+    double *z[2] = {nullptr, nullptr};    // [6A + 6F] pose vectors (current / trial)
+    double *ent[2] = {nullptr, nullptr};  // [(A+F)][ENT_STRIDE]
+    double *V = nullptr, *gf = nullptr;   // [F][36], [F][6]
+    double *W = nullptr;                  // [total_slots][36]   W_af (rows: entity params, cols: frame params)
+    double *Vinv = nullptr, *hf = nullptr;
+    double *U0 = nullptr, *g0 = nullptr;  // [n_pad*n_pad] row-major (lower triangle), [n_pad]: undamped shared part
+    double *S = nullptr, *rhs = nullptr;  // working copy: reduced system, then its LDL^T factor / solution
+    double *Dfac = nullptr;               // [nT][NB*NB] factored diagonal tiles (unit L below, D on the diagonal)
+    double *delta_s = nullptr;            // [n_pad]
+    double *err_part = nullptr;           // [max(F, residual_blocks)] partial sums of squared residuals
+    double *lin_part = nullptr;           // [F+1][2] per-frame ( |delta_f|^2 , delta_f . g_f ), last = shared part
+    double *scal = nullptr;               // [8] reduced scalars
+    int32_t *flags = nullptr;             // [4] device error flags (0: non-positive pivot)
+    double *r_out = nullptr;              // optional [8N]
+};
+
+void launch_unpack(const DeviceProblem &P, int which, bool zero_shared, hipStream_t st);
+void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream_t st);
+void launch_passA(const DeviceProblem &P, int which, hipStream_t st);
+void launch_passB(const DeviceProblem &P, int which, hipStream_t st);
+void launch_maxdiag(const DeviceProblem &P, hipStream_t st);                       // scal[4] = max free diagonal
+void launch_frame_inv(const DeviceProblem &P, double mu, hipStream_t st);          // + copies U0,g0 -> S,rhs
+void launch_schur(const DeviceProblem &P, hipStream_t st);
+void launch_finalize(const DeviceProblem &P, double mu, hipStream_t st);
+void launch_chol(const DeviceProblem &P, hipStream_t st);                          // LDL^T + forward + backward solve -> delta_s
+void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
+void launch_reduce_scalars(const DeviceProblem &P, bool fold_shared, hipStream_t st);  // scal[0..2], scal[5..6]
+int residual_blocks(const DeviceProblem &P);   // entries of err_part written by launch_residual
+
+}  // namespace aar

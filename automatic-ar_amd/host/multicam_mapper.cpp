@@ -1,0 +1,208 @@
+// MultiCamMapper over the C ABI (see multicam_mapper.h).  Only packing / unpacking of parameter
+// vectors and file I/O happen on the host; residuals, Jacobians and the LM solve are HIP kernels.
+#include "multicam_mapper.h"
+
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+#include "internal.h"
+#include "se3.h"
+
+namespace aar {
+
+MultiCamMapper::MultiCamMapper() {
+    solver_params.maxIters = 10000;  // libs/multicam_mapper.cpp:337-343
+    solver_params.min_average_step_error_diff = 1e-4;
+    memset(&last_report, 0, sizeof last_report);
+}
+
+MultiCamMapper::MultiCamMapper(aar_dataset *dataset) : MultiCamMapper() {
+    data_ = dataset;
+    solver_params.verbose = true;  // :327
+    if (data_) {
+        config_.optimize_cam_poses = data_->optimize_cam_poses != 0;
+        config_.optimize_marker_poses = data_->optimize_marker_poses != 0;
+        config_.optimize_object_poses = data_->optimize_object_poses != 0;
+        config_.optimize_cam_intrinsics = data_->optimize_cam_intrinsics != 0;
+        mats2eVec();
+    }
+}
+
+MultiCamMapper::~MultiCamMapper() {
+    drop_problem();
+    aar_dataset_free(data_);
+}
+
+void MultiCamMapper::drop_problem() {
+    if (problem_) aar_problem_destroy(problem_);
+    problem_ = nullptr;
+}
+
+void MultiCamMapper::set_optmize_flag_cam_poses(bool f) { config_.optimize_cam_poses = f; drop_problem(); }
+void MultiCamMapper::set_optmize_flag_marker_poses(bool f) { config_.optimize_marker_poses = f; drop_problem(); }
+void MultiCamMapper::set_optmize_flag_object_poses(bool f) { config_.optimize_object_poses = f; drop_problem(); }
+void MultiCamMapper::set_optmize_flag_cam_intrinsics(bool f) { config_.optimize_cam_intrinsics = f; }
+void MultiCamMapper::set_with_huber(bool wh) { with_huber_ = wh; }
+void MultiCamMapper::set_config(Config &conf) { config_ = conf; drop_problem(); }
+
+size_t MultiCamMapper::get_num_vars(const Config &conf) {  // libs/multicam_mapper.cpp:239-250
+    if (!data_) return 0;
+    size_t n = 0;
+    if (conf.optimize_cam_poses) n += (size_t)(data_->num_cams - 1) * 6;
+    if (conf.optimize_marker_poses) n += (size_t)(data_->num_markers - 1) * 6;
+    if (conf.optimize_object_poses) n += (size_t)data_->num_frames * 6;
+    if (conf.optimize_cam_intrinsics) n += (size_t)data_->num_cams * 9;
+    return n;
+}
+
+// mats2eVec (:445-461): the optimised groups of x_full, cameras | markers | frames | intrinsics
+void MultiCamMapper::mats2eVec() {
+    io_vec.assign(get_num_vars(config_), 0.0);
+    if (!data_) return;
+    PoseLayout L;
+    L.C = data_->num_cams; L.M = data_->num_markers; L.F = data_->num_frames;
+    size_t k = 0;
+    auto copy = [&](int64_t off, int64_t n) { for (int64_t i = 0; i < n; i++) io_vec[k++] = data_->x_full[off + i]; };
+    if (config_.optimize_cam_poses) copy(L.full_cam0(), 6LL * (L.C - 1));
+    if (config_.optimize_marker_poses) copy(L.full_mk0(), 6LL * (L.M - 1));
+    if (config_.optimize_object_poses) copy(L.full_fr0(), 6LL * L.F);
+    if (config_.optimize_cam_intrinsics)
+        for (int c = 0; c < L.C; c++) {  // fill_io_vec_cam_intrinsics, :488-498
+            const double *K = data_->cam_mats + 9 * c;
+            io_vec[k++] = K[0]; io_vec[k++] = K[2]; io_vec[k++] = K[4]; io_vec[k++] = K[5];
+            for (int j = 0; j < 5; j++) io_vec[k++] = data_->dist_coeffs[5 * c + j];
+        }
+}
+
+// eVec2Mats (:595-606)
+void MultiCamMapper::eVec2Mats(const eVector &v) {
+    PoseLayout L;
+    L.C = data_->num_cams; L.M = data_->num_markers; L.F = data_->num_frames;
+    size_t k = 0;
+    auto copy = [&](int64_t off, int64_t n) { for (int64_t i = 0; i < n; i++) data_->x_full[off + i] = v[k++]; };
+    if (config_.optimize_cam_poses) copy(L.full_cam0(), 6LL * (L.C - 1));
+    if (config_.optimize_marker_poses) copy(L.full_mk0(), 6LL * (L.M - 1));
+    if (config_.optimize_object_poses) copy(L.full_fr0(), 6LL * L.F);
+}
+
+int MultiCamMapper::ensure_problem() {
+    if (problem_) return AAR_OK;
+    aar_problem_desc d;
+    aar_problem_desc_from_dataset(data_, &d);
+    d.optimize_cam_poses = config_.optimize_cam_poses;
+    d.optimize_marker_poses = config_.optimize_marker_poses;
+    d.optimize_object_poses = config_.optimize_object_poses;
+    d.residual_mode = residual_mode;
+    d.device_id = device_id;
+    return aar_problem_create(&d, &problem_);
+}
+
+void MultiCamMapper::error_function(const eVector &input, eVector &error) {
+    if (!data_) throw std::runtime_error("MultiCamMapper::error_function: no data set");
+    if (input.size() != get_num_vars(config_) || config_.optimize_cam_intrinsics || with_huber_)
+        throw std::runtime_error("MultiCamMapper::error_function: configuration outside the accelerated path");
+    if (ensure_problem()) throw std::runtime_error(aar_last_error());
+    std::vector<double> keep(data_->x_full, data_->x_full + aar_dataset_full_len(data_));
+    eVec2Mats(input);
+    error.assign(8 * (size_t)data_->num_obs, 0.0);
+    const int rc = aar_eval_residuals(problem_, data_->x_full, error.data(), nullptr);
+    memcpy(data_->x_full, keep.data(), keep.size() * sizeof(double));
+    if (rc) throw std::runtime_error(aar_last_error());
+}
+
+void MultiCamMapper::solve() {
+    if (!data_) throw std::runtime_error("MultiCamMapper::solve: no data set");
+    if (config_.optimize_cam_intrinsics)
+        throw std::runtime_error("MultiCamMapper::solve: optimize_cam_intrinsics is not on the accelerated path (call set_optmize_flag_cam_intrinsics(false) as find_solution does)");
+    if (with_huber_) throw std::runtime_error("MultiCamMapper::solve: -with-huber is not on the accelerated path yet");
+    if (ensure_problem()) throw std::runtime_error(aar_last_error());
+    mats2eVec();
+    double e0 = 0;
+    if (aar_eval_residuals(problem_, data_->x_full, nullptr, &e0)) throw std::runtime_error(aar_last_error());
+    std::cout << "initial_error: " << e0 << "error size: " << 8 * data_->num_obs << std::endl;  // :424
+    hubberDelta = 10;
+    aar_lm_params p;
+    aar_lm_default_params(&p);
+    p.max_iters = solver_params.maxIters;
+    p.min_error = solver_params.minError;
+    p.min_step_error_diff = solver_params.min_step_error_diff;
+    p.min_average_step_error_diff = solver_params.min_average_step_error_diff;
+    p.tau = solver_params.tau;
+    p.verbose = solver_params.verbose ? 1 : 0;
+    memset(&last_report, 0, sizeof last_report);
+    if (aar_lm_solve(problem_, data_->x_full, &p, &last_report)) throw std::runtime_error(aar_last_error());
+    mats2eVec();  // io_vec holds the solution, as after solver.solve(io_vec, ...) in the reference
+}
+
+bool MultiCamMapper::write_solution_file(std::string path) {
+    if (!data_) return false;
+    aar_dataset tmp = *data_;
+    tmp.optimize_cam_poses = config_.optimize_cam_poses;
+    tmp.optimize_marker_poses = config_.optimize_marker_poses;
+    tmp.optimize_object_poses = config_.optimize_object_poses;
+    tmp.optimize_cam_intrinsics = config_.optimize_cam_intrinsics;
+    if (aar_solution_write(path.c_str(), &tmp)) {
+        std::cout << aar_last_error() << std::endl;
+        return false;
+    }
+    return true;
+}
+
+bool MultiCamMapper::read_solution_file(std::string path) {
+    aar_dataset *d = nullptr;
+    if (aar_solution_read(path.c_str(), &d)) {
+        std::cout << aar_last_error() << std::endl;
+        return false;
+    }
+    drop_problem();
+    aar_dataset_free(data_);
+    data_ = d;
+    config_.optimize_cam_poses = d->optimize_cam_poses != 0;
+    config_.optimize_marker_poses = d->optimize_marker_poses != 0;
+    config_.optimize_object_poses = d->optimize_object_poses != 0;
+    config_.optimize_cam_intrinsics = d->optimize_cam_intrinsics != 0;
+    mats2eVec();
+    return true;
+}
+
+void MultiCamMapper::write_text_solution_file(std::string text_path) {
+    if (!data_ || aar_solution_write_yaml(text_path.c_str(), data_)) throw std::runtime_error(aar_last_error());
+}
+
+static Mat44 to44(const Rigid &T) {
+    Mat44 m;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) m[r * 4 + c] = T.R[r * 3 + c];
+        m[r * 4 + 3] = T.t[r];
+    }
+    m[12] = m[13] = m[14] = 0;
+    m[15] = 1;
+    return m;
+}
+
+MultiCamMapper::MatArrays MultiCamMapper::get_mat_arrays() {
+    MatArrays ma;
+    if (!data_) return ma;
+    PoseLayout L;
+    L.C = data_->num_cams; L.M = data_->num_markers; L.F = data_->num_frames; L.rc = data_->root_cam; L.rm = data_->root_marker;
+    for (int c = 0; c < L.C; c++)
+        ma.transforms_to_root_cam[data_->cam_ids[c]] = to44(c == L.rc ? Rigid::identity() : pose_to_rigid(data_->x_full + L.full_cam0() + 6LL * L.cam_slot(c)));
+    for (int m = 0; m < L.M; m++)
+        ma.transforms_to_root_marker[data_->marker_ids[m]] = to44(m == L.rm ? Rigid::identity() : pose_to_rigid(data_->x_full + L.full_mk0() + 6LL * L.mk_slot(m)));
+    for (int f = 0; f < L.F; f++) ma.object_to_global[data_->frame_ids[f]] = to44(pose_to_rigid(data_->x_full + L.full_fr0() + 6LL * f));
+    return ma;
+}
+
+size_t MultiCamMapper::get_root_cam() { return data_ ? (size_t)data_->cam_ids[data_->root_cam] : 0; }
+size_t MultiCamMapper::get_root_marker() { return data_ ? (size_t)data_->marker_ids[data_->root_marker] : 0; }
+double MultiCamMapper::get_marker_size() { return data_ ? data_->marker_size : 0; }
+std::vector<std::array<int, 2>> MultiCamMapper::get_image_sizes() {
+    std::vector<std::array<int, 2>> r;
+    if (data_)
+        for (int c = 0; c < data_->num_cams; c++) r.push_back({data_->image_sizes[2 * c], data_->image_sizes[2 * c + 1]});
+    return r;
+}
+
+}  // namespace aar

@@ -1,0 +1,208 @@
+/*
+ * include/aar.h -- C ABI of the MI355X-native sparse-LM bundle-adjustment path.
+ *
+ * This is the drop-in boundary for ONE path of HSarham/automatic-ar:
+ *   MultiCamMapper::solve()  (libs/multicam_mapper.cpp:419-428)
+ *     -> ucoslam::SparseLevMarq<double>::solve / init / step  (libs/sparselevmarq.h:440-472,238-249,349-430)
+ *     -> MultiCamMapper::error_function / jacobian_function   (libs/multicam_mapper.cpp:731-801)
+ * The reference has no FFI of its own (it is one C++ process); the entry points below are what a
+ * binding of that path would need, and automatic-ar_amd/host/multicam_mapper.{h,cpp} is the C++ class
+ * with the reference's method names that calls them.
+ *
+ * Conventions: plain pointers and sizes, caller-owned host arrays, no exceptions.  Every function that
+ * returns int returns AAR_OK (0) or a negative aar_status; aar_last_error() gives the message of the
+ * calling thread's last failure.  All compute entry points run hand-written HIP kernels on gfx950 and
+ * FAIL (AAR_ERR_NO_DEVICE) when no GPU is present -- there is no CPU fallback.
+ *
+ * Pose vectors.  `x_full` is always the reference's default-Config pose vector
+ *   [ (C-1) cameras | (M-1) markers | F frames ] x (rx,ry,rz,tx,ty,tz)
+ * (fill_io_vec_cams/markers/object_poses, libs/multicam_mapper.cpp:500-522: ascending index, root camera
+ * and root marker skipped) i.e. the pose part of the `.solution` vector (:1085-1089).  Which groups are
+ * optimised is a flag (MultiCamMapper::Config, libs/multicam_mapper.h:75-81); fixed groups keep their
+ * values.  Camera intrinsics are never optimised on this path (apps/find_solution.cpp:140).
+ */
+#ifndef AAR_H
+#define AAR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum aar_status {
+    AAR_OK = 0,
+    AAR_ERR_INVALID = -1,      /* bad argument / malformed problem                        */
+    AAR_ERR_NO_DEVICE = -2,    /* no HIP device: the product has no CPU path              */
+    AAR_ERR_HIP = -3,          /* HIP runtime error                                        */
+    AAR_ERR_UNSUPPORTED = -4,  /* outside the implemented scope            */
+    AAR_ERR_NUMERIC = -5,      /* non-positive pivot in a Cholesky factorisation           */
+    AAR_ERR_IO = -6,           /* file could not be opened / short read                    */
+    AAR_ERR_COMM = -7          /* RCCL failure                                             */
+} aar_status;
+
+const char *aar_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Data set = everything MultiCamMapper holds after init(): ids, intrinsics, undistorted detections
+ * and the pose vector.  Mirrors the content of a `.solution` file (libs/multicam_mapper.cpp:1053-1099).
+ * Arrays are owned by the library (free with aar_dataset_free).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct aar_dataset {
+    int32_t num_cams, num_markers, num_frames;
+    int32_t root_cam, root_marker;   /* INDICES (rank of the root id in ascending id order)          */
+    int32_t *cam_ids;                /* [C] ascending                                                 */
+    int32_t *marker_ids;             /* [M] ascending                                                 */
+    int32_t *frame_ids;              /* [F] ascending                                                 */
+    int32_t *image_sizes;            /* [C][2] width,height                                           */
+    double *cam_mats;                /* [C][9] row-major K                                            */
+    double *dist_coeffs;             /* [C][5] (carried for the file format; unused by the projection) */
+    double marker_size;              /* MultiCamMapper::marker_size: (double)(float)size               */
+    int64_t num_obs;                 /* marker observations in reference residual order                */
+    int32_t *obs_frame, *obs_cam, *obs_marker; /* [N] indices                                          */
+    float *obs_uv;                   /* [N][8] undistorted corners x0 y0 .. x3 y3                       */
+    double *x_full;                  /* [6(C-1)+6(M-1)+6F] current pose vector                          */
+    double *x_truth;                 /* same layout, ground truth (synthetic data only, else NULL)      */
+    int32_t optimize_cam_poses, optimize_marker_poses, optimize_object_poses, optimize_cam_intrinsics;
+} aar_dataset;
+
+void aar_dataset_free(aar_dataset *);
+int64_t aar_dataset_full_len(const aar_dataset *);   /* 6(C-1)+6(M-1)+6F */
+
+/* Deterministic synthetic multi-camera / multi-marker sequence. */
+typedef struct aar_synth_desc {
+    int32_t num_cams, num_markers, num_frames;
+    uint64_t seed;              /* 20190219 + config index                                             */
+    double marker_size;         /* metres (0.05)                                                       */
+    double noise_px;            /* corner noise sigma (0.3)                                            */
+    double init_rot_sigma;      /* rad, perturbation of every rotation-vector component (0.02)         */
+    double init_trans_sigma;    /* m, perturbation of every translation component (0.01)               */
+    double init_scale;          /* multiplies both sigmas (1.0)                                        */
+} aar_synth_desc;
+void aar_synth_default(aar_synth_desc *, int32_t config_index); /* BASELINE.json configs[1..4] -> 2..5 */
+int aar_synth_generate(const aar_synth_desc *, aar_dataset **out);
+
+/* File formats of the path.
+ *  .solution          libs/multicam_mapper.cpp:1053-1099 (write) / :1124-1205 (read)
+ *  .solution.yaml     libs/multicam_mapper.cpp:1233-1268  (cv::FileStorage YAML 1.0 dialect)
+ *  aruco.detections   libs/multicam_mapper.cpp:216-237, libs/initializer.cpp:316-348               */
+int aar_solution_read(const char *path, aar_dataset **out);
+int aar_solution_write(const char *path, const aar_dataset *);
+int aar_solution_write_yaml(const char *path, const aar_dataset *);
+int aar_detections_write(const char *path, const aar_dataset *);
+
+/* cv::Rodrigues as used at libs/multicam_mapper.cpp:470,478 (R row-major 3x3) */
+void aar_rodrigues_vec2mat(const double w[3], double R[9]);
+void aar_rodrigues_mat2vec(const double R[9], double w[3]);
+
+/* Frame-range partition for `world` ranks, balanced by observation count:
+ * rank r owns frames [begin[r], begin[r+1]).  begin has world+1 entries. */
+int aar_plan_shards(int32_t num_frames, const int64_t *obs_per_frame, int32_t world, int32_t *begin);
+
+/* ---------------------------------------------------------------------------------------------
+ * RCCL communicator (multi-GPU only).  Rank 0 makes an id, the launcher hands it to every rank
+ * (bench.py: torch.distributed broadcast), each rank creates its communicator on its own GPU.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct aar_comm aar_comm;
+#define AAR_COMM_ID_BYTES 128
+int aar_comm_make_id(char id[AAR_COMM_ID_BYTES]);
+int aar_comm_create(const char id[AAR_COMM_ID_BYTES], int32_t world_size, int32_t rank, int32_t device_id,
+                    aar_comm **out);
+void aar_comm_destroy(aar_comm *);
+
+/* ---------------------------------------------------------------------------------------------
+ * The problem on the device.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct aar_problem aar_problem;
+
+enum { AAR_RES_F32 = 0,   /* reference-faithful: projection rounded to float, float subtraction
+                             (cv::Point2f store + libs/multicam_mapper.cpp:1012-1013)               */
+       AAR_RES_F64 = 1 }; /* same formula kept in double                                            */
+
+typedef struct aar_problem_desc {
+    int32_t num_cams, num_markers, num_frames;
+    int32_t root_cam, root_marker;            /* indices                                            */
+    const double *cam_mats;                   /* [C][9]                                             */
+    double marker_size;
+    int64_t num_obs;
+    const int32_t *obs_frame, *obs_cam, *obs_marker;  /* frame-nondecreasing (reference order)      */
+    const float *obs_uv;                      /* [N][8]                                             */
+    int32_t optimize_cam_poses, optimize_marker_poses, optimize_object_poses;
+    int32_t residual_mode;                    /* AAR_RES_F32 | AAR_RES_F64                          */
+    int32_t device_id;
+    aar_comm *comm;                           /* NULL = single GPU; else observations are sharded by
+                                                 frame range over the communicator's ranks           */
+} aar_problem_desc;
+
+void aar_problem_desc_from_dataset(const aar_dataset *, aar_problem_desc *);
+int aar_problem_create(const aar_problem_desc *, aar_problem **out);
+void aar_problem_destroy(aar_problem *);
+int64_t aar_problem_full_len(const aar_problem *);    /* length of x_full                            */
+int64_t aar_problem_num_vars(const aar_problem *);    /* length of the reference's z for the Config  */
+int64_t aar_problem_local_obs(const aar_problem *);   /* observations owned by this rank             */
+
+/* error_function (libs/multicam_mapper.cpp:731-737): r (8*num_obs doubles, reference row order; may be
+ * NULL; single-GPU only when non-NULL) and sum of squares (all ranks). */
+int aar_eval_residuals(aar_problem *, const double *x_full, double *r, double *sum_sq);
+
+/* J^T J and B = -J^T r of libs/sparselevmarq.h:355-367 for the analytic Jacobian, assembled DENSE in the
+ * reference's z ordering (P x P row-major, P = aar_problem_num_vars).  For checking the block
+ * accumulation kernels on small problems (single GPU).  Either output may be NULL. */
+int aar_eval_normal_equations(aar_problem *, const double *x_full, double *JtJ, double *B, double *sum_sq);
+
+/* delta of (J^T J + mu I) delta = B through the device Schur-complement + dense Cholesky path
+ * (libs/sparselevmarq.h:384-400), in z ordering. */
+int aar_eval_damped_step(aar_problem *, const double *x_full, double mu, double *delta);
+
+/* ucoslam::SparseLevMarq<T>::Params (libs/sparselevmarq.h:30-50) with the values
+ * MultiCamMapper::init installs (libs/multicam_mapper.cpp:326-330). */
+typedef struct aar_lm_params {
+    int32_t max_iters;                    /* 10000                                                    */
+    double min_error;                     /* 1e-5                                                     */
+    double min_step_error_diff;           /* 0                                                        */
+    double min_average_step_error_diff;   /* 1e-4                                                     */
+    double tau;                           /* 1                                                        */
+    int32_t verbose;
+} aar_lm_params;
+void aar_lm_default_params(aar_lm_params *);
+
+typedef struct aar_lm_iter {              /* one step() */
+    double err, mu, gain, delta_norm;
+    int32_t accepted, tries;
+} aar_lm_iter;
+
+typedef struct aar_lm_report {
+    int32_t iterations;                   /* step() calls made                                        */
+    int32_t stop_code;                    /* mustExit of libs/sparselevmarq.h:458-461 (0 = maxIters)  */
+    double initial_err, final_err;        /* sum of squared residuals                                 */
+    double final_mu;
+    double solve_seconds;                 /* wall time of the loop (device-synchronised)              */
+    int64_t trial_points;                 /* residual evaluations inside step()                        */
+    aar_lm_iter *trace;                   /* optional caller array                                     */
+    int32_t trace_cap;
+} aar_lm_report;
+
+/* step-by-step mode: SparseLevMarq::init / step / getCurrentSolution (libs/sparselevmarq.h:238-249,349-437) */
+int aar_lm_init(aar_problem *, const double *x_full, const aar_lm_params *);
+int aar_lm_step(aar_problem *, aar_lm_iter *out);
+int aar_lm_get_solution(aar_problem *, double *x_full, double *err);
+/* SparseLevMarq::solve(z, f, J) (libs/sparselevmarq.h:440-472): x_full in/out */
+int aar_lm_solve(aar_problem *, double *x_full, const aar_lm_params *, aar_lm_report *);
+
+/* per-stage device time of the last aar_lm_solve, seconds, in the reference's verbose-timer vocabulary
+ * (libs/sparselevmarq.h:425) extended with the stages that only exist here */
+typedef struct aar_stage_times {
+    double unpack, jacobian_normal_eq, schur, chol, backsub, residual, control, allreduce, total;
+    int64_t launches;
+} aar_stage_times;
+int aar_get_stage_times(aar_problem *, aar_stage_times *);
+
+/* fp64 reprojection statistics at x_full (device): per-corner RMSE sqrt(sum r^2 / 4N), sum r^2 */
+int aar_reproj_stats(aar_problem *, const double *x_full, double *rmse, double *sum_sq);
+
+int aar_device_count(void);
+int aar_device_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

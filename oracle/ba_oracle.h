@@ -1,0 +1,99 @@
+/*
+ * oracle/ba_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's sparse-LM bundle-adjustment path
+ * (MultiCamMapper::solve -> ucoslam::SparseLevMarq<double>).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product (automatic-ar_amd/) never links, imports or calls it.
+ *
+ * Parity pin: the reference has no tests / golden vectors for this path (SURVEY.md
+ * section 4), and libs/multicam_mapper.cpp cannot be compiled here (OpenCV absent), so
+ * the residual/Jacobian half is "parity unpinned" against OpenCV's cv::Rodrigues /
+ * cv::Mat arithmetic (restated from their published definitions).  The solver half IS
+ * pinned: oracle/ref_harness.cpp compiles the reference's own libs/sparselevmarq.h +
+ * vendored Eigen in place (oracle/_ref/) and tests/ check this restatement's LM loop,
+ * J^T J and LDL^T solve against it, both live and through tests/golden/ fixtures.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).
+ */
+#ifndef BA_ORACLE_H
+#define BA_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One bundle-adjustment problem in the reference's own terms.
+ * Observation order = residual row order of eval_curr_solution
+ * (libs/multicam_mapper.cpp:1001-1007): ascending frame, ascending camera, detection order.
+ * Indices are ranks of the ids in ascending std::map order (libs/multicam_mapper.h:95-105). */
+typedef struct orc_problem {
+    int32_t num_cams, num_markers, num_frames;
+    int32_t root_cam, root_marker;       /* indices of the root camera / root marker          */
+    const double *K;                     /* [num_cams][9] row-major 3x3 camera matrices        */
+    double marker_size;                  /* MultiCamMapper::marker_size (a float widened)      */
+    int64_t num_obs;                     /* marker observations; residual rows = 8*num_obs     */
+    const int32_t *obs_frame, *obs_cam, *obs_marker;
+    const float *obs_uv;                 /* [num_obs][8]: x0 y0 x1 y1 x2 y2 x3 y3 (undistorted) */
+    int32_t opt_cams, opt_markers, opt_frames;   /* MultiCamMapper::Config (intrinsics off)    */
+    int32_t with_huber;                  /* libs/multicam_mapper.cpp:1014-1019                 */
+    float huber_delta;
+} orc_problem;
+
+enum { ORC_RES_F32 = 0,   /* reference-faithful: projections rounded to float, float subtraction */
+       ORC_RES_F64 = 1 }; /* same formula kept in double                                          */
+enum { ORC_JAC_NUMERIC_F32 = 0, /* reference-faithful central differences, delta=1e-3, float projections */
+       ORC_JAC_NUMERIC_F64 = 1, /* central differences, delta=1e-6, double projections                   */
+       ORC_JAC_ANALYTIC    = 2 };/* closed-form SE(3) Jacobian                     */
+
+typedef struct orc_lm_params {           /* ucoslam::SparseLevMarq<T>::Params, libs/sparselevmarq.h:30-50 */
+    int32_t max_iters;
+    double min_error, min_step_error_diff, min_average_step_error_diff, tau;
+} orc_lm_params;
+
+typedef struct orc_lm_iter {             /* one step() of libs/sparselevmarq.h:349-430 */
+    double err;                          /* currErr after the step                      */
+    double mu;                           /* damping after the step                      */
+    double gain;
+    double delta_norm;                   /* ||delta|| of the last trial                 */
+    int32_t accepted;
+    int32_t tries;
+} orc_lm_iter;
+
+/* length of the full default-Config pose vector: 6(C-1)+6(M-1)+6F (libs/multicam_mapper.cpp:239-250) */
+int64_t orc_full_len(const orc_problem *p);
+/* length of z for the problem's Config flags */
+int64_t orc_num_vars(const orc_problem *p);
+/* z <-> x_full helpers (optimised groups only, reference order cams|markers|frames) */
+void orc_extract_z(const orc_problem *p, const double *x_full, double *z);
+void orc_merge_z(const orc_problem *p, const double *x_full, const double *z, double *x_out);
+
+/* cv::Rodrigues restatement (call sites libs/multicam_mapper.cpp:470,478) */
+void orc_rodrigues_vec2mat(const double w[3], double R[9]);
+void orc_rodrigues_mat2vec(const double R[9], double w[3]);
+
+/* error_function / eval_curr_solution: libs/multicam_mapper.cpp:731-737,996-1028 */
+void orc_residuals(const orc_problem *p, const double *x_full, const double *z, int res_mode, double *r);
+/* jacobian_function: libs/multicam_mapper.cpp:739-801,803-994. Triplets (row, col, val); capacity 8*18*N. */
+int64_t orc_jacobian(const orc_problem *p, const double *x_full, const double *z, int jac_mode,
+                     int32_t *rows, int32_t *cols, double *vals);
+/* dense J^T J (P x P, row-major) and B = -J^T r (libs/sparselevmarq.h:355-367); small problems only */
+void orc_normal_equations_dense(const orc_problem *p, const double *x_full, const double *z, int jac_mode,
+                                int res_mode, double *JtJ, double *B);
+/* (JtJ + mu I) delta = B through this file's own sparse LDL^T (restating :384-400) */
+int orc_damped_solve(const orc_problem *p, const double *x_full, const double *z, int jac_mode, int res_mode,
+                     double mu, double *delta);
+/* SparseLevMarq<double>::solve(z,f,J): libs/sparselevmarq.h:440-472 (Appendix B). Returns final currErr. */
+double orc_lm_solve(const orc_problem *p, const double *x_full, double *z_inout, const orc_lm_params *prm,
+                    int jac_mode, int res_mode, orc_lm_iter *trace, int32_t trace_cap, int32_t *n_iters,
+                    int32_t num_threads);
+/* fp64 reprojection statistics from z: per-corner RMSE sqrt(sum r^2/(4N)) and mean euclidean corner distance */
+void orc_reproj_stats(const orc_problem *p, const double *x_full, const double *z, double *rmse,
+                      double *mean_dist, double *sum_sq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,126 @@
+/*
+ * oracle/ref_harness.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Drives the REAL reference solver, ucoslam::SparseLevMarq<double> from
+ * /root/reference/libs/sparselevmarq.h (consumed in place by include path together with the
+ * vendored Eigen 3.2.92 -- never copied into this repository), with the restated residual /
+ * Jacobian callbacks of ba_oracle.cpp.  libs/multicam_mapper.cpp itself needs OpenCV, which is not
+ * in this image, so the callbacks cannot be the reference's own.
+ *
+ * Built only by oracle/Makefile into oracle/_ref/libref_lm.so (git-ignored, travels with gpurun).
+ * Used to (1) pin the restated LM loop / J^T J / LDL^T solve of ba_oracle.cpp against the real
+ * thing, (2) generate tests/golden/ fixtures, (3) serve as bench.py's cpu_baseline "reference".
+ */
+#include <Eigen/Sparse>
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <vector>
+
+// Test-harness only: lets the trace read the private damping factor `mu` without touching the header.
+#define private public
+#include "sparselevmarq.h"
+#undef private
+
+#include "ba_oracle.h"
+
+typedef ucoslam::SparseLevMarq<double> Solver;
+typedef Solver::eVector eVector;
+
+extern "C" {
+
+/* Params as MultiCamMapper::init sets them (libs/multicam_mapper.cpp:326-330) unless overridden. */
+double ref_lm_solve(const orc_problem *p, const double *x_full, double *z_inout, const orc_lm_params *prm,
+                    int jac_mode, int res_mode, orc_lm_iter *trace, int32_t trace_cap, int32_t *n_iters,
+                    int32_t num_threads, int32_t use_omp_mult) {
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+    const int64_t P = orc_num_vars(p), N = p->num_obs;
+    Solver solver;
+    Solver::Params prms;
+    prms.verbose = false;
+    prms.maxIters = prm->max_iters;
+    prms.minError = prm->min_error;
+    prms.min_step_error_diff = prm->min_step_error_diff;
+    prms.min_average_step_error_diff = prm->min_average_step_error_diff;
+    prms.tau = prm->tau;
+    prms.use_omp = use_omp_mult != 0;
+    solver.setParams(prms);
+    solver.v = 2;  // uninitialised in the reference (libs/sparselevmarq.h:133); pinned for reproducibility
+
+    auto f = [&](const eVector &z, eVector &err) {
+        err.resize(8 * N);
+        orc_residuals(p, x_full, z.data(), res_mode, err.data());
+    };
+    std::vector<int32_t> rows(144 * N), cols(144 * N);
+    std::vector<double> vals(144 * N);
+    auto fJ = [&](const eVector &z, Eigen::SparseMatrix<double> &J) {
+        int64_t nnz = orc_jacobian(p, x_full, z.data(), jac_mode, rows.data(), cols.data(), vals.data());
+        std::vector<Eigen::Triplet<double>> t;
+        t.reserve(nnz);
+        for (int64_t k = 0; k < nnz; k++) t.emplace_back(rows[k], cols[k], vals[k]);
+        J.resize(8 * N, P);
+        J.setFromTriplets(t.begin(), t.end());
+    };
+    int32_t iters = 0;
+    double last_err = -1;
+    solver.setStepCallBackFunc([&](const eVector &) {
+        if (trace && iters < trace_cap) {
+            eVector tmp;
+            double e = solver.getCurrentSolution(tmp);
+            trace[iters].err = e;
+            trace[iters].mu = solver.mu;
+            trace[iters].gain = 0;
+            trace[iters].delta_norm = 0;
+            trace[iters].accepted = (iters == 0 || e != last_err) ? 1 : 0;
+            trace[iters].tries = 0;
+            last_err = e;
+        }
+        iters++;
+    });
+    eVector z(P);
+    std::memcpy(z.data(), z_inout, sizeof(double) * P);
+    double e = solver.solve(z, f, fJ);
+    std::memcpy(z_inout, z.data(), sizeof(double) * P);
+    if (n_iters) *n_iters = iters;
+    return e;
+}
+
+/* Golden linear algebra (SURVEY 8c "G2"): for a Jacobian given as triplets, residual r and damping mu,
+ * JtJ = Jt*J (Eigen), B = -Jt*r, delta = SimplicialLDLT(JtJ + mu*I).solve(B) -- the exact objects of
+ * libs/sparselevmarq.h:355-400.  JtJ_dense is P x P row-major (may be NULL). */
+int ref_damped_solve(int64_t n_rows, int64_t P, int64_t nnz, const int32_t *rows, const int32_t *cols,
+                     const double *vals, const double *r, double mu, double *JtJ_dense, double *B_out,
+                     double *delta_out) {
+    std::vector<Eigen::Triplet<double>> t;
+    t.reserve(nnz);
+    for (int64_t k = 0; k < nnz; k++) t.emplace_back(rows[k], cols[k], vals[k]);
+    Eigen::SparseMatrix<double> J(n_rows, P);
+    J.setFromTriplets(t.begin(), t.end());
+    Eigen::SparseMatrix<double> Jt = J.transpose();
+    Eigen::SparseMatrix<double> JtJ = Jt * J;
+    Eigen::Map<const Eigen::VectorXd> rv(r, n_rows);
+    Eigen::VectorXd B = -(Jt * rv);
+    if (JtJ_dense) {
+        std::memset(JtJ_dense, 0, sizeof(double) * P * P);
+        for (int k = 0; k < JtJ.outerSize(); ++k)
+            for (Eigen::SparseMatrix<double>::InnerIterator it(JtJ, k); it; ++it)
+                JtJ_dense[(int64_t)it.row() * P + it.col()] = it.value();
+    }
+    if (B_out) std::memcpy(B_out, B.data(), sizeof(double) * P);
+    if (delta_out) {
+        Eigen::SparseMatrix<double> I(P, P);
+        I.setIdentity();
+        Eigen::SparseMatrix<double> A = JtJ + I * mu;
+        Eigen::SimplicialLDLT<Eigen::SparseMatrix<double>> chol(A);
+        if (chol.info() != Eigen::Success) return -1;
+        Eigen::VectorXd d = chol.solve(B);
+        std::memcpy(delta_out, d.data(), sizeof(double) * P);
+    }
+    return 0;
+}
+
+/* The reference's own numeric differentiation helper, SparseLevMarq::calcDerivates (libs/sparselevmarq.h:199-220)
+ * is exercised by track(), which is out of scope; not exported. */
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+"""ctypes binding of the CPU checker (oracle/liboracle.so, oracle/_ref/libref_lm.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (automatic-ar_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_lm.so")
+
+RES_F32, RES_F64 = 0, 1
+JAC_NUMERIC_F32, JAC_NUMERIC_F64, JAC_ANALYTIC = 0, 1, 2
+
+
+class OrcProblem(C.Structure):
+    _fields_ = [
+        ("num_cams", C.c_int32), ("num_markers", C.c_int32), ("num_frames", C.c_int32),
+        ("root_cam", C.c_int32), ("root_marker", C.c_int32),
+        ("K", C.POINTER(C.c_double)), ("marker_size", C.c_double), ("num_obs", C.c_int64),
+        ("obs_frame", C.POINTER(C.c_int32)), ("obs_cam", C.POINTER(C.c_int32)), ("obs_marker", C.POINTER(C.c_int32)),
+        ("obs_uv", C.POINTER(C.c_float)),
+        ("opt_cams", C.c_int32), ("opt_markers", C.c_int32), ("opt_frames", C.c_int32),
+        ("with_huber", C.c_int32), ("huber_delta", C.c_float),
+    ]
+
+
+class OrcLmParams(C.Structure):
+    _fields_ = [("max_iters", C.c_int32), ("min_error", C.c_double), ("min_step_error_diff", C.c_double),
+                ("min_average_step_error_diff", C.c_double), ("tau", C.c_double)]
+
+
+class OrcLmIter(C.Structure):
+    _fields_ = [("err", C.c_double), ("mu", C.c_double), ("gain", C.c_double), ("delta_norm", C.c_double),
+                ("accepted", C.c_int32), ("tries", C.c_int32)]
+
+
+def build_oracle(with_ref=True):
+    """Compile the checker (gcc, seconds).  The _ref target needs /root/reference and is skipped without it."""
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"])
+    if with_ref and os.path.exists("/root/reference/libs/sparselevmarq.h"):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_orc = None
+_ref = None
+
+
+def oracle():
+    global _orc
+    if _orc is None:
+        if not os.path.exists(ORACLE_SO):
+            build_oracle(with_ref=False)
+        L = C.CDLL(ORACLE_SO)
+        pp = C.POINTER(OrcProblem)
+        L.orc_full_len.restype = C.c_int64
+        L.orc_full_len.argtypes = [pp]
+        L.orc_num_vars.restype = C.c_int64
+        L.orc_num_vars.argtypes = [pp]
+        L.orc_extract_z.argtypes = [pp, _dp, _dp]
+        L.orc_merge_z.argtypes = [pp, _dp, _dp, _dp]
+        L.orc_rodrigues_vec2mat.argtypes = [_dp, _dp]
+        L.orc_rodrigues_mat2vec.argtypes = [_dp, _dp]
+        L.orc_residuals.argtypes = [pp, _dp, _dp, C.c_int, _dp]
+        L.orc_jacobian.restype = C.c_int64
+        L.orc_jacobian.argtypes = [pp, _dp, _dp, C.c_int, _ip, _ip, _dp]
+        L.orc_normal_equations_dense.argtypes = [pp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]
+        L.orc_damped_solve.argtypes = [pp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp]
+        L.orc_lm_solve.restype = C.c_double
+        L.orc_lm_solve.argtypes = [pp, _dp, _dp, C.POINTER(OrcLmParams), C.c_int, C.c_int, C.POINTER(OrcLmIter),
+                                   C.c_int32, C.POINTER(C.c_int32), C.c_int32]
+        L.orc_reproj_stats.argtypes = [pp, _dp, _dp, _dp, _dp, _dp]
+        _orc = L
+    return _orc
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    """The REAL reference solver (libs/sparselevmarq.h + Eigen) compiled into oracle/_ref/."""
+    global _ref
+    if _ref is None:
+        L = C.CDLL(REF_SO)
+        pp = C.POINTER(OrcProblem)
+        L.ref_lm_solve.restype = C.c_double
+        L.ref_lm_solve.argtypes = [pp, _dp, _dp, C.POINTER(OrcLmParams), C.c_int, C.c_int, C.POINTER(OrcLmIter),
+                                   C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32]
+        L.ref_damped_solve.argtypes = [C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, _dp, C.c_double, _dp, _dp, _dp]
+        _ref = L
+    return _ref
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def mapper_params(**over):
+    """LM parameters as MultiCamMapper::init installs them (libs/multicam_mapper.cpp:326-330)."""
+    p = OrcLmParams(10000, 1e-5, 0.0, 1e-4, 1.0)
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+class Oracle:
+    """One problem bound to the oracle.  `ds` is an aar.Dataset-like object (numpy fields)."""
+
+    def __init__(self, ds, optimize=(True, True, True), with_huber=False, huber_delta=10.0):
+        self.ds = ds
+        self.K = np.ascontiguousarray(ds.cam_mats, dtype=np.float64).reshape(-1)
+        self.of = np.ascontiguousarray(ds.obs_frame, dtype=np.int32)
+        self.oc = np.ascontiguousarray(ds.obs_cam, dtype=np.int32)
+        self.om = np.ascontiguousarray(ds.obs_marker, dtype=np.int32)
+        self.uv = np.ascontiguousarray(ds.obs_uv, dtype=np.float32).reshape(-1)
+        p = OrcProblem()
+        p.num_cams, p.num_markers, p.num_frames = ds.num_cams, ds.num_markers, ds.num_frames
+        p.root_cam, p.root_marker = ds.root_cam, ds.root_marker
+        p.K = _d(self.K)
+        p.marker_size = ds.marker_size
+        p.num_obs = len(self.of)
+        p.obs_frame = self.of.ctypes.data_as(_ip)
+        p.obs_cam = self.oc.ctypes.data_as(_ip)
+        p.obs_marker = self.om.ctypes.data_as(_ip)
+        p.obs_uv = self.uv.ctypes.data_as(C.POINTER(C.c_float))
+        p.opt_cams, p.opt_markers, p.opt_frames = [int(b) for b in optimize]
+        p.with_huber = int(with_huber)
+        p.huber_delta = huber_delta
+        self.p = p
+        self.N = int(p.num_obs)
+        self.full_len = oracle().orc_full_len(C.byref(p))
+        self.num_vars = oracle().orc_num_vars(C.byref(p))
+
+    def extract_z(self, x_full):
+        x = np.ascontiguousarray(x_full, dtype=np.float64)
+        z = np.zeros(self.num_vars)
+        oracle().orc_extract_z(C.byref(self.p), _d(x), _d(z))
+        return z
+
+    def merge_z(self, x_full, z):
+        x = np.ascontiguousarray(x_full, dtype=np.float64)
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        out = np.zeros(self.full_len)
+        oracle().orc_merge_z(C.byref(self.p), _d(x), _d(z), _d(out))
+        return out
+
+    def residuals(self, x_full, z=None, res_mode=RES_F32):
+        x = np.ascontiguousarray(x_full, dtype=np.float64)
+        z = self.extract_z(x) if z is None else np.ascontiguousarray(z, dtype=np.float64)
+        r = np.zeros(8 * self.N)
+        oracle().orc_residuals(C.byref(self.p), _d(x), _d(z), res_mode, _d(r))
+        return r
+
+    def jacobian(self, x_full, z=None, jac_mode=JAC_ANALYTIC):
+        x = np.ascontiguousarray(x_full, dtype=np.float64)
+        z = self.extract_z(x) if z is None else np.ascontiguousarray(z, dtype=np.float64)
+        cap = 144 * self.N
+        rows = np.zeros(cap, dtype=np.int32)
+        cols = np.zeros(cap, dtype=np.int32)
+        vals = np.zeros(cap)
+        n = oracle().orc_jacobian(C.byref(self.p), _d(x), _d(z), jac_mode, rows.ctypes.data_as(_ip),
+                                  cols.ctypes.data_as(_ip), _d(vals))
+        return rows[:n].copy(), cols[:n].copy(), vals[:n].copy()
+
+    def normal_equations(self, x_full, z=None, jac_mode=JAC_ANALYTIC, res_mode=RES_F64):
+        x = np.ascontiguousarray(x_full, dtype=np.float64)
+        z = self.extract_z(x) if z is None else np.ascontiguousarray(z, dtype=np.float64)
+        P = self.num_vars
+        H = np.zeros((P, P))
+        B = np.zeros(P)
+        oracle().orc_normal_equations_dense(C.byref(self.p), _d(x), _d(z), jac_mode, res_mode, _d(H), _d(B))
+        return H, B
+
+    def damped_solve(self, x_full, mu, z=None, jac_mode=JAC_ANALYTIC, res_mode=RES_F64):
+        x = np.ascontiguousarray(x_full, dtype=np.float64)
+        z = self.extract_z(x) if z is None else np.ascontiguousarray(z, dtype=np.float64)
+        d = np.zeros(self.num_vars)
+        rc = oracle().orc_damped_solve(C.byref(self.p), _d(x), _d(z), jac_mode, res_mode, mu, _d(d))
+        assert rc == 0
+        return d
+
+    def _lm(self, fn, x_full, params, jac_mode, res_mode, threads, extra=()):
+        x = np.ascontiguousarray(x_full, dtype=np.float64)
+        z = self.extract_z(x)
+        prm = params if params is not None else mapper_params()
+        cap = 512
+        tr = (OrcLmIter * cap)()
+        n = C.c_int32()
+        err = fn(C.byref(self.p), _d(x), _d(z), C.byref(prm), jac_mode, res_mode, tr, cap, C.byref(n), threads, *extra)
+        trace = [dict(err=tr[i].err, mu=tr[i].mu, gain=tr[i].gain, delta_norm=tr[i].delta_norm,
+                      accepted=tr[i].accepted, tries=tr[i].tries) for i in range(min(n.value, cap))]
+        return self.merge_z(x, z), dict(final_err=err, iterations=n.value, trace=trace)
+
+    def lm_solve(self, x_full, params=None, jac_mode=JAC_NUMERIC_F32, res_mode=RES_F32, threads=0):
+        """The restated LM loop + own sparse LDL^T (the "port")."""
+        return self._lm(oracle().orc_lm_solve, x_full, params, jac_mode, res_mode, threads)
+
+    def ref_lm_solve(self, x_full, params=None, jac_mode=JAC_NUMERIC_F32, res_mode=RES_F32, threads=0, use_omp_mult=True):
+        """The real ucoslam::SparseLevMarq<double>::solve driving the restated callbacks."""
+        return self._lm(ref().ref_lm_solve, x_full, params, jac_mode, res_mode, threads, (int(use_omp_mult),))
+
+    def reproj_stats(self, x_full):
+        x = np.ascontiguousarray(x_full, dtype=np.float64)
+        z = self.extract_z(x)
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        oracle().orc_reproj_stats(C.byref(self.p), _d(x), _d(z), C.byref(a), C.byref(b), C.byref(c))
+        return dict(rmse=a.value, mean_dist=b.value, sum_sq=c.value)
+
+
+def ref_damped_solve(n_rows, P, rows, cols, vals, r, mu, want_dense=True):
+    """Eigen: JtJ = Jt*J, B = -Jt*r, delta = SimplicialLDLT(JtJ + mu I).solve(B)."""
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    H = np.zeros((P, P)) if want_dense else None
+    B = np.zeros(P)
+    d = np.zeros(P)
+    rc = ref().ref_damped_solve(n_rows, P, len(vals), rows.ctypes.data_as(_ip), cols.ctypes.data_as(_ip), _d(vals),
+                                _d(r), mu, _d(H) if want_dense else None, _d(B), _d(d))
+    assert rc == 0
+    return H, B, d
+
+
+def rodrigues_vec2mat(w):
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    R = np.zeros(9)
+    oracle().orc_rodrigues_vec2mat(_d(w), _d(R))
+    return R.reshape(3, 3)
+
+
+def rodrigues_mat2vec(R):
+    R = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+    w = np.zeros(3)
+    oracle().orc_rodrigues_mat2vec(_d(R), _d(w))
+    return w
