@@ -27,8 +27,9 @@ SYMBOLS = [
     "aar_problem_full_len", "aar_problem_num_vars", "aar_problem_local_obs", "aar_eval_residuals",
     "aar_eval_normal_equations", "aar_eval_damped_step", "aar_lm_default_params", "aar_lm_init", "aar_lm_step",
     "aar_lm_get_solution", "aar_lm_solve", "aar_get_stage_times", "aar_reproj_stats", "aar_device_count",
-    "aar_device_synchronize",
+    "aar_device_synchronize", "aar_set_kernel_profiling", "aar_get_kernel_times", "aar_kernel_name",
 ]
+NUM_KERNELS = 13
 
 
 class AarError(RuntimeError):
@@ -147,6 +148,10 @@ def lib():
     L.aar_lm_solve.argtypes = [C.c_void_p, dp, C.POINTER(CLmParams), C.POINTER(CLmReport)]
     L.aar_get_stage_times.argtypes = [C.c_void_p, C.POINTER(CStageTimes)]
     L.aar_reproj_stats.argtypes = [C.c_void_p, dp, dp, dp]
+    L.aar_set_kernel_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.aar_get_kernel_times.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64)]
+    L.aar_kernel_name.argtypes = [C.c_int]
+    L.aar_kernel_name.restype = C.c_char_p
     _lib = L
     return L
 
@@ -427,6 +432,16 @@ class Problem:
                       final_err=rep.final_err, final_mu=rep.final_mu, solve_seconds=rep.solve_seconds,
                       trial_points=rep.trial_points, trace=trace)
         return x, report
+
+    def set_kernel_profiling(self, on):
+        _check(lib().aar_set_kernel_profiling(self.handle, int(on)))
+
+    def kernel_times(self):
+        """{kernel name: (total seconds, launches)} accumulated since profiling was switched on."""
+        sec = np.zeros(NUM_KERNELS)
+        cnt = np.zeros(NUM_KERNELS, dtype=np.int64)
+        _check(lib().aar_get_kernel_times(self.handle, _dptr(sec), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+        return {lib().aar_kernel_name(i).decode(): (float(sec[i]), int(cnt[i])) for i in range(NUM_KERNELS)}
 
     def stage_times(self):
         t = CStageTimes()

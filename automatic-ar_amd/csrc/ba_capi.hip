@@ -103,6 +103,13 @@ struct aar_problem {
     aar_stage_times times;
     bool stage_timers = false;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // per-kernel profiling (aar_set_kernel_profiling)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_kid;       // kernel id of pending pair i (events 2i, 2i+1)
+    size_t ev_used = 0;
+    double k_seconds[KID_COUNT] = {0};
+    int64_t k_launches[KID_COUNT] = {0};
 };
 
 namespace {
@@ -196,6 +203,37 @@ int download_z(aar_problem *pb, int which, double *x_full) {
     return AAR_OK;
 }
 
+void prof_pre(void *ctx, int kid) {
+    aar_problem *pb = static_cast<aar_problem *>(ctx);
+    if (pb->ev_used + 2 > pb->ev_pool.size()) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        pb->ev_pool.push_back(a);
+        pb->ev_pool.push_back(b);
+    }
+    pb->ev_kid.push_back(kid);
+    (void)hipEventRecord(pb->ev_pool[pb->ev_used], pb->stream);
+}
+void prof_post(void *ctx, int) {
+    aar_problem *pb = static_cast<aar_problem *>(ctx);
+    (void)hipEventRecord(pb->ev_pool[pb->ev_used + 1], pb->stream);
+    pb->ev_used += 2;
+}
+// after a stream synchronisation: fold the pending event pairs into the per-kernel totals
+void prof_harvest(aar_problem *pb) {
+    if (!pb->profiling) return;
+    for (size_t i = 0; i < pb->ev_kid.size(); i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pb->ev_pool[2 * i], pb->ev_pool[2 * i + 1]) == hipSuccess) {
+            pb->k_seconds[pb->ev_kid[i]] += ms * 1e-3;
+            pb->k_launches[pb->ev_kid[i]]++;
+        }
+    }
+    pb->ev_kid.clear();
+    pb->ev_used = 0;
+}
+
 struct StageTimer {  // optional per-stage device timing (AAR_STAGE_TIMERS=1); costs two event records + a sync per stage
     aar_problem *pb;
     double *slot;
@@ -286,6 +324,7 @@ int damped_try(aar_problem *pb, double mu, bool with_residual) {
     HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
     HIP_TRY(hipMemcpyAsync(pb->h_flags, P.flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
     HIP_TRY(hipStreamSynchronize(pb->stream));
+    prof_harvest(pb);
     int rc = check_async("damped solve kernels");
     if (rc) return rc;
     if (pb->h_flags[0]) {
@@ -317,6 +356,7 @@ int initial_mu(aar_problem *pb, double tau, double *mu) {
     pb->launches += 1;
     HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
     HIP_TRY(hipStreamSynchronize(pb->stream));
+    prof_harvest(pb);
     *mu = pb->h_scal[4] * tau;
     return AAR_OK;
 }
@@ -388,6 +428,7 @@ void aar_problem_destroy(aar_problem *pb) {
     if (pb->h_flags) (void)hipHostFree(pb->h_flags);
     if (pb->ev[0]) (void)hipEventDestroy(pb->ev[0]);
     if (pb->ev[1]) (void)hipEventDestroy(pb->ev[1]);
+    for (hipEvent_t e : pb->ev_pool) (void)hipEventDestroy(e);
     if (pb->stream) (void)hipStreamDestroy(pb->stream);
     delete pb;
 }
@@ -730,6 +771,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     if ((rc = allreduce(pb, P.scal, 1, NCCL_SUM))) return rc;
     HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
     HIP_TRY(hipStreamSynchronize(pb->stream));
+    prof_harvest(pb);
     if ((rc = check_async("lm_init kernels"))) return rc;
     pb->currErr = pb->prevErr = pb->h_scal[0];
     pb->mu = -1;
@@ -831,6 +873,42 @@ int aar_lm_solve(aar_problem *pb, double *x_full, const aar_lm_params *prm, aar_
         rep->trial_points = pb->trial_points;
     }
     return AAR_OK;
+}
+
+int aar_set_kernel_profiling(aar_problem *pb, int on) {
+    if (!pb) return set_error(AAR_ERR_INVALID, "aar_set_kernel_profiling: null argument");
+    HIP_TRY(hipSetDevice(pb->device));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    pb->ev_kid.clear();
+    pb->ev_used = 0;
+    pb->profiling = on != 0;
+    if (on) {
+        memset(pb->k_seconds, 0, sizeof pb->k_seconds);
+        memset(pb->k_launches, 0, sizeof pb->k_launches);
+        pb->P.hook.pre = prof_pre;
+        pb->P.hook.post = prof_post;
+        pb->P.hook.ctx = pb;
+    } else {
+        pb->P.hook = LaunchHook();
+    }
+    return AAR_OK;
+}
+
+int aar_get_kernel_times(aar_problem *pb, double seconds[AAR_NUM_KERNELS], int64_t launches[AAR_NUM_KERNELS]) {
+    if (!pb || !seconds || !launches) return set_error(AAR_ERR_INVALID, "aar_get_kernel_times: null argument");
+    static_assert(AAR_NUM_KERNELS == KID_COUNT, "kernel id table out of sync with include/aar.h");
+    HIP_TRY(hipSetDevice(pb->device));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    prof_harvest(pb);
+    for (int i = 0; i < KID_COUNT; i++) { seconds[i] = pb->k_seconds[i]; launches[i] = pb->k_launches[i]; }
+    return AAR_OK;
+}
+
+const char *aar_kernel_name(int kid) {
+    static const char *names[KID_COUNT] = {"k_unpack", "k_residual", "k_passA", "k_passB", "k_maxdiag", "k_frame_inv", "k_schur",
+                                           "k_finalize", "k_ldl_panel", "k_ldl_update", "k_ldl_backsolve", "k_backsub",
+                                           "k_reduce_scalars"};
+    return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
 }
 
 int aar_get_stage_times(aar_problem *pb, aar_stage_times *t) {

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const ObsIdx *__restrict__ idx,
         const int i = tid / 6, j = tid % 6;
         Vout[(size_t)f * 36 + tid] = acc[sym6(i, j)];
     }
-    if (tid >= 64 && tid < 70) gout[(size_t)f * 6 + (tid - 64)] = acc[21 + (tid - 64)];
+    if (tid >= 36 && tid < 42) gout[(size_t)f * 6 + (tid - 36)] = acc[21 + (tid - 36)];
     if (tid == 0) err_part[f] = acc[27];
 }
 
@@ -300,14 +300,14 @@ void launch_unpack(const DeviceProblem &P, int which, bool zero_shared, hipStrea
     int blocks = (int)((work + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < (n_ent + 255) / 256) blocks = (n_ent + 255) / 256;
-    hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(256), 0, st, P.z[which], P.ent[which], n_ent, P.U0, za, P.g0, zb);
+    { HookScope _h(P, KID_UNPACK); hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(256), 0, st, P.z[which], P.ent[which], n_ent, P.U0, za, P.g0, zb); }
 }
 
 void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream_t st) {
     const int blocks = (int)((P.N + 255) / 256);
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_residual, dim3(blocks), dim3(256), 0, st, P.a_idx, P.a_uv, P.ent[which], P.K, P.N, P.A,
-                       P.half_size, P.res_f32, r_out, P.err_part);
+    { HookScope _h(P, KID_RESIDUAL); hipLaunchKernelGGL(k_residual, dim3(blocks), dim3(256), 0, st, P.a_idx, P.a_uv, P.ent[which], P.K, P.N, P.A,
+                       P.half_size, P.res_f32, r_out, P.err_part); }
 }
 
 int residual_blocks(const DeviceProblem &P) { return (int)((P.N + 255) / 256); }
@@ -318,27 +318,27 @@ void launch_passA(const DeviceProblem &P, int which, hipStream_t st) {
     if (avg <= 96) {
         constexpr int B = 64;
         const size_t lds = ((size_t)P.max_kf * 36 + 32 + (B / 64) * 2048) * sizeof(double);
-        hipLaunchKernelGGL(k_passA<B>, dim3(P.F), dim3(B), lds, st, P.a_idx, P.a_uv, P.ent[which], P.K,
+        { HookScope _h(P, KID_PASSA); hipLaunchKernelGGL(k_passA<B>, dim3(P.F), dim3(B), lds, st, P.a_idx, P.a_uv, P.ent[which], P.K,
                            P.frame_obs_start, P.fslot_start, P.A, P.half_size, P.res_f32, P.max_kf, P.V, P.gf, P.W,
-                           P.err_part);
+                           P.err_part); }
     } else {
         constexpr int B = 256;
         const size_t lds = ((size_t)P.max_kf * 36 + 32 + (B / 64) * 2048) * sizeof(double);
-        hipLaunchKernelGGL(k_passA<B>, dim3(P.F), dim3(B), lds, st, P.a_idx, P.a_uv, P.ent[which], P.K,
+        { HookScope _h(P, KID_PASSA); hipLaunchKernelGGL(k_passA<B>, dim3(P.F), dim3(B), lds, st, P.a_idx, P.a_uv, P.ent[which], P.K,
                            P.frame_obs_start, P.fslot_start, P.A, P.half_size, P.res_f32, P.max_kf, P.V, P.gf, P.W,
-                           P.err_part);
+                           P.err_part); }
     }
 }
 
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
     if (P.n_chunks == 0) return;
-    hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, P.b_idx, P.b_uv, P.ent[which], P.K,
-                       P.chunk_start, P.n_chunks, P.A, P.half_size, P.res_f32, P.n_pad, P.U0, P.g0);
+    { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, P.b_idx, P.b_uv, P.ent[which], P.K,
+                       P.chunk_start, P.n_chunks, P.A, P.half_size, P.res_f32, P.n_pad, P.U0, P.g0); }
 }
 
 void launch_maxdiag(const DeviceProblem &P, hipStream_t st) {
-    hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, st, P.U0, P.n_pad, P.A, P.ent_fixed, P.V, P.F,
-                       P.frames_fixed, P.scal + 4);
+    { HookScope _h(P, KID_MAXDIAG); hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, st, P.U0, P.n_pad, P.A, P.ent_fixed, P.V, P.F,
+                       P.frames_fixed, P.scal + 4); }
 }
 
 }  // namespace aar

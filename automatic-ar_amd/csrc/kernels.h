@@ -9,6 +9,16 @@ namespace aar {
 constexpr int CHOL_NB = 48;       // dense LDL^T tile (8 entity blocks of 6)
 constexpr int PASSB_CHUNK = 256;  // max observations of one (camera, marker) run handled by one wavefront
 
+// Kernel ids for the optional per-launch timing hooks (aar_get_kernel_times)
+enum KernelId { KID_UNPACK = 0, KID_RESIDUAL, KID_PASSA, KID_PASSB, KID_MAXDIAG, KID_FRAME_INV, KID_SCHUR, KID_FINALIZE,
+                KID_LDL_PANEL, KID_LDL_UPDATE, KID_LDL_BACKSOLVE, KID_BACKSUB, KID_REDUCE, KID_COUNT };
+
+struct LaunchHook {  // called around every kernel launch when profiling is on
+    void (*pre)(void *ctx, int kid) = nullptr;
+    void (*post)(void *ctx, int kid) = nullptr;
+    void *ctx = nullptr;
+};
+
 // Per-observation record of an ordering: {frame (local), camera, marker, slot_c | slot_m << 16}
 struct ObsIdx {
     int32_t frame, cam, marker, slots;
@@ -54,6 +64,14 @@ struct DeviceProblem {
     double *scal = nullptr;               // [8] reduced scalars
     int32_t *flags = nullptr;             // [4] device error flags (0: non-positive pivot)
     double *r_out = nullptr;              // optional [8N]
+    LaunchHook hook;
+};
+
+struct HookScope {  // RAII: pre/post around one launch
+    const DeviceProblem &P;
+    int kid;
+    HookScope(const DeviceProblem &p, int k) : P(p), kid(k) { if (P.hook.pre) P.hook.pre(P.hook.ctx, kid); }
+    ~HookScope() { if (P.hook.post) P.hook.post(P.hook.ctx, kid); }
 };
 
 void launch_unpack(const DeviceProblem &P, int which, bool zero_shared, hipStream_t st);

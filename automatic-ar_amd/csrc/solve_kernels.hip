@@ -461,46 +461,46 @@ void launch_frame_inv(const DeviceProblem &P, double mu, hipStream_t st) {
     if (blocks > 1024) blocks = 1024;
     if (blocks < (P.F + 255) / 256) blocks = (P.F + 255) / 256;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_frame_inv, dim3(blocks), dim3(256), 0, st, P.V, P.gf, P.F, mu, P.frames_fixed, P.Vinv, P.hf,
-                       P.U0, P.g0, P.S, P.rhs, nn, P.n_pad, P.flags);
+    { HookScope _h(P, KID_FRAME_INV); hipLaunchKernelGGL(k_frame_inv, dim3(blocks), dim3(256), 0, st, P.V, P.gf, P.F, mu, P.frames_fixed, P.Vinv, P.hf,
+                       P.U0, P.g0, P.S, P.rhs, nn, P.n_pad, P.flags); }
 }
 
 void launch_schur(const DeviceProblem &P, hipStream_t st) {
     if (P.n_swork == 0) return;
     const size_t lds = ((size_t)P.A * 36 + 8 + 4 * 48) * sizeof(double);
-    hipLaunchKernelGGL(k_schur, dim3(P.n_swork), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_frame,
-                       P.pair_slot, P.fslot_start, P.fslot_ent, P.W, P.Vinv, P.hf, P.A, P.n_pad, P.S, P.rhs);
+    { HookScope _h(P, KID_SCHUR); hipLaunchKernelGGL(k_schur, dim3(P.n_swork), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_frame,
+                       P.pair_slot, P.fslot_start, P.fslot_ent, P.W, P.Vinv, P.hf, P.A, P.n_pad, P.S, P.rhs); }
 }
 
 void launch_finalize(const DeviceProblem &P, double mu, hipStream_t st) {
     const int64_t nn = (int64_t)P.n_pad * P.n_pad;
     int blocks = (int)((nn + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, st, P.S, P.rhs, P.n, P.n_pad, mu, P.ent_fixed);
+    { HookScope _h(P, KID_FINALIZE); hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, st, P.S, P.rhs, P.n, P.n_pad, mu, P.ent_fixed); }
 }
 
 void launch_chol(const DeviceProblem &P, hipStream_t st) {
     for (int s = 0; s < P.nT; s++) {
-        hipLaunchKernelGGL(k_ldl_panel, dim3(P.nT - s + 1), dim3(256), 0, st, P.S, P.rhs, P.Dfac, P.n_pad, s, P.nT, P.flags);
+        { HookScope _h(P, KID_LDL_PANEL); hipLaunchKernelGGL(k_ldl_panel, dim3(P.nT - s + 1), dim3(256), 0, st, P.S, P.rhs, P.Dfac, P.n_pad, s, P.nT, P.flags); }
         const int m = P.nT - s - 1;
         if (m > 0)
-            hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 + m), dim3(256), 0, st, P.S, P.rhs, P.Dfac, P.n_pad, s, P.nT);
+            { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 + m), dim3(256), 0, st, P.S, P.rhs, P.Dfac, P.n_pad, s, P.nT); }
     }
     const size_t lds = ((size_t)P.n_pad + NB * NBP + 5 * NB + NB) * sizeof(double);
-    hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(256), lds, st, P.S, P.rhs, P.Dfac, P.delta_s, P.n_pad, P.nT);
+    { HookScope _h(P, KID_LDL_BACKSOLVE); hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(256), lds, st, P.S, P.rhs, P.Dfac, P.delta_s, P.n_pad, P.nT); }
 }
 
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) {
     const int nfb = (P.F + 3) / 4;
-    hipLaunchKernelGGL(k_backsub, dim3(nfb + 1), dim3(256), 0, st, P.fslot_start, P.fslot_ent, P.W, P.Vinv, P.gf, P.g0,
-                       P.delta_s, P.z[cur], P.z[trial], P.A, P.F, nfb, P.lin_part);
+    { HookScope _h(P, KID_BACKSUB); hipLaunchKernelGGL(k_backsub, dim3(nfb + 1), dim3(256), 0, st, P.fslot_start, P.fslot_ent, P.W, P.Vinv, P.gf, P.g0,
+                       P.delta_s, P.z[cur], P.z[trial], P.A, P.F, nfb, P.lin_part); }
 }
 
 int residual_blocks(const DeviceProblem &P);
 
 void launch_reduce_scalars(const DeviceProblem &P, bool fold_shared, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, P.err_part, residual_blocks(P), P.lin_part, P.F,
-                       fold_shared ? 1 : 0, P.scal);
+    { HookScope _h(P, KID_REDUCE); hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, P.err_part, residual_blocks(P), P.lin_part, P.F,
+                       fold_shared ? 1 : 0, P.scal); }
 }
 
 }  // namespace aar

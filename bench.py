@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- LM iterations/sec of the MI355X-native bundle-adjustment path on synthetic sequences.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 2|3|4|5] [--no-cpu-baseline]
+
+A "step" is one LM iteration = one step() of ucoslam::SparseLevMarq (libs/sparselevmarq.h:349-430): Jacobian /
+normal-equation build at the current point, >= 1 damped solve, >= 1 trial residual, accept/reject.  The timed region
+runs EXACTLY K steps as back-to-back solve() calls from the same initial guess (a solve takes ~15 steps to stop; the last
+one is cut by max_iters so that the total is K), with inputs already resident in HBM, bracketed by a barrier + device
+synchronisation, MAX over ranks.  N > 1: launched by `python -m torch.distributed.run` (one rank per GPU); the same problem
+is sharded by frame range over the ranks (strong scaling), one RCCL all-reduce of the reduced system per damped solve.
+
+Default workload = BASELINE.json's metric configuration: 8 cameras / 40 markers / 500 frames (configs[2], SURVEY "config 3").
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "automatic-ar_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOADS = {2: "synthetic 4-cam/12-marker/100-frame", 3: "synthetic 8-cam/40-marker/500-frame",
+             4: "synthetic 8-cam/40-marker/2000-frame", 5: "synthetic 16-cam/200-marker/5000-frame"}
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6      # vector fp64
+
+
+def run_steps(problem, x0, steps, params_factory):
+    """Exactly `steps` LM iterations as repeated solve() calls from x0.  Returns (iterations, trial_points, last x, last report)."""
+    done, trials, x, rep = 0, 0, None, None
+    while done < steps:
+        prm = params_factory(max_iters=steps - done)
+        x, rep = problem.lm_solve(x0, params=prm, trace_cap=1)
+        if rep["iterations"] <= 0:
+            raise RuntimeError("solve made no progress")
+        done += rep["iterations"]
+        trials += rep["trial_points"]
+    return done, trials, x, rep
+
+
+def algorithmic_bytes(kernel, N, A, F, n_pad):
+    """Algorithmic HBM bytes of ONE launch: the 44-byte observation record is SURVEY.md 8d's unit."""
+    P = 6 * (A + F)
+    rec = 44 * N
+    table = {
+        "k_passA": rec + 8 * P,                       # every record once + the pose vector
+        "k_passB": rec + 8 * P + 8 * (n_pad * n_pad // 2 + n_pad),   # + the shared system it writes (lower triangle)
+        "k_residual": rec + 8 * P,
+        "k_unpack": 8 * P,
+        "k_schur": 8 * (n_pad * n_pad // 2 + n_pad),  # frame-owned W/V traffic is overhead, not algorithmic
+        "k_ldl_panel": 0, "k_ldl_update": 0, "k_ldl_backsolve": 8 * n_pad, "k_frame_inv": 8 * (n_pad * n_pad + n_pad),
+        "k_finalize": 8 * n_pad, "k_backsub": 8 * P, "k_reduce_scalars": 0, "k_maxdiag": 0,
+    }
+    return table.get(kernel, 0)
+
+
+def cpu_baseline(ds, workload, threads):
+    """The reference solver on the host cores, bounded sample (rank 0, N = 1 only)."""
+    import oracle_lib as ol
+    if workload >= 5:
+        return {"value": None, "unit": "LM iterations/s", "cores": threads, "kind": "reference" if ol.have_ref() else "port",
+                "sample": "not run: ONE reference iteration at 1.6 M marker observations takes ~9 min and 15 GB (BASELINE.md section 2)"}
+    cap = {2: 15, 3: 8, 4: 2}[workload]
+    o = ol.Oracle(ds)
+    prm = ol.mapper_params(max_iters=cap)
+    t0 = time.perf_counter()
+    if ol.have_ref():
+        x, rep = o.ref_lm_solve(ds.x_full, params=prm, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=threads)
+        kind = "reference"
+        what = ("real ucoslam::SparseLevMarq<double> + Eigen::SimplicialLDLT (oracle/_ref, g++ -O3 -march=x86-64-v3 -fopenmp) "
+                "driving the restated reference-faithful residual / central-difference float Jacobian")
+    else:
+        x, rep = o.lm_solve(ds.x_full, params=prm, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=threads)
+        kind = "port"
+        what = "oracle/ba_oracle.cpp restatement (numeric float Jacobian, map-based Jt*J, own sparse LDL^T)"
+    dt = time.perf_counter() - t0
+    return {"value": rep["iterations"] / dt, "unit": "LM iterations/s", "cores": threads, "kind": kind,
+            "sample": "first %d LM iterations of the same %s problem from the same start (%.1f s); %s" % (rep["iterations"], WORKLOADS[workload], dt, what),
+            "err_after_sample": rep["final_err"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", type=int, default=3, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...` (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    dist = None
+    if world > 1:
+        # torch.distributed is rendezvous plumbing only (id broadcast, barrier, max over ranks); the data path is RCCL inside libaar
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method="tcp://%s:%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500")),
+                                rank=rank, world_size=world)
+    import numpy as np
+
+    import aar
+
+    if aar.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device (the product has no CPU path)")
+    ds = aar.synth(args.workload)
+    comm = None
+    if world > 1:
+        uid = [aar.Comm.make_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = aar.Comm(uid[0], world, rank, local_rank)
+    problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm)
+
+    def barrier():
+        aar.lib().aar_device_synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    params = lambda **kw: aar.lm_default_params(**kw)
+    # ---- warmup (untimed) ----
+    if args.warmup > 0:
+        run_steps(problem, ds.x_full, args.warmup, params)
+    # ---- timed region: exactly K steps ----
+    barrier()
+    t0 = time.perf_counter()
+    done, trials, _, _ = run_steps(problem, ds.x_full, args.steps, params)
+    aar.lib().aar_device_synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+        dist.barrier()
+    assert done == args.steps
+
+    # ---- full solve for the accuracy half of the metric ----
+    x_fin, rep_fin = problem.lm_solve(ds.x_full, params=params())
+    rmse, ss = problem.reproj_stats(x_fin)
+
+    # ---- per-kernel device time: a second, instrumented pass over the same steps (HIP events on the library's stream) ----
+    roofline, kernels = None, None
+    A, F, n_pad = ds.num_cams + ds.num_markers, ds.num_frames, ((6 * (ds.num_cams + ds.num_markers) + 47) // 48) * 48
+    if not args.no_kernel_profile:
+        problem.set_kernel_profiling(True)
+        run_steps(problem, ds.x_full, args.steps, params)
+        kt = problem.kernel_times()
+        problem.set_kernel_profiling(False)
+        kernels = {k: {"total_ms": 1e3 * s, "launches": c, "avg_us": (1e6 * s / c if c else None)} for k, (s, c) in kt.items() if c}
+        dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+        n_loc = problem.local_obs
+        def roof(k):
+            avg_s = kernels[k]["avg_us"] * 1e-6
+            by = algorithmic_bytes(k, n_loc, A, F, n_pad)
+            return {"kernel": k, "bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": by / avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": by, "avg_us": kernels[k]["avg_us"]}
+        roofline = roof(dom)
+        roofline["observation_pass"] = roof("k_passA")     # the streaming scan the north star prices against HBM
+        # fp64 VALU view of the Jacobian/normal-equation pass (it is arithmetic-bound, not HBM-bound)
+        flops = n_loc * (4800.0)
+        tj = (kernels["k_passA"]["avg_us"] + kernels["k_passB"]["avg_us"]) * 1e-6
+        roofline["fp64_valu"] = {"kernels": "k_passA+k_passB", "achieved": flops / tj / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": flops / tj / 1e12 / FP64_PEAK_TFLOPS, "flops_per_observation": 4800}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                tr = json.load(open(pmc)).get("workload_%d" % args.workload, {})
+                roofline["traffic"] = tr.get(dom)
+                roofline["observation_pass"]["traffic"] = tr.get("k_passA")
+            except Exception:
+                pass
+
+    if rank != 0:
+        problem.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    P = ds.full_len
+    Ps = 6 * (ds.num_cams - 1 + ds.num_markers - 1)
+    t_avg = trials / float(done)
+    b_iter = 44 * ds.num_obs * (1 + t_avg) + 8 * (2 * P + Ps * Ps + Ps)
+    out = {
+        "metric": "LM iterations/sec", "value": done / dt, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / done, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": WORKLOADS[args.workload], "survey_config": args.workload, "cams": ds.num_cams, "markers": ds.num_markers,
+                   "frames": ds.num_frames, "marker_observations": int(ds.num_obs), "residual_rows": int(8 * ds.num_obs), "unknowns": int(P),
+                   "reduced_unknowns": int(Ps), "parallelism": "frames sharded over %d GPU(s)" % world, "seed": 20190219 + args.workload,
+                   "residual_mode": "float32-faithful", "jacobian": "analytic"},
+        "final_rmse_px": rmse, "final_sum_sq": ss, "lm_iterations_to_stop": rep_fin["iterations"], "trial_points_per_step": t_avg,
+        "iteration_hbm": {"bytes_per_iteration": b_iter, "achieved": b_iter * done / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "frac": b_iter * done / dt / 1e9 / HBM_PEAK_GBPS},
+        "roofline": roofline, "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        threads = os.cpu_count() or 1
+        cb = cpu_baseline(ds, args.workload, threads)
+        out["cpu_baseline"] = cb
+        if cb.get("value"):
+            out["gpu_over_cpu"] = out["value"] / cb["value"]
+        # accuracy half of the metric: |RMSE(GPU) - RMSE(reference-faithful CPU, full solve)|, only where the CPU solve is seconds
+        if args.workload == 2:
+            import oracle_lib as ol
+            o = ol.Oracle(ds)
+            xc, _ = (o.ref_lm_solve if ol.have_ref() else o.lm_solve)(ds.x_full, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=threads)
+            out["rmse_delta_vs_cpu_px"] = abs(rmse - o.reproj_stats(xc)["rmse"])
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    problem.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -196,6 +196,14 @@ typedef struct aar_stage_times {
 } aar_stage_times;
 int aar_get_stage_times(aar_problem *, aar_stage_times *);
 
+/* Per-kernel device time: when profiling is on, every kernel launch of this problem is bracketed by two HIP
+ * events on the library's own stream (the stream the kernels run on) and the elapsed times are accumulated
+ * per kernel.  bench.py's roofline figures come from here.  Switching profiling on resets the accumulators. */
+#define AAR_NUM_KERNELS 13
+int aar_set_kernel_profiling(aar_problem *, int on);
+int aar_get_kernel_times(aar_problem *, double seconds[AAR_NUM_KERNELS], int64_t launches[AAR_NUM_KERNELS]);
+const char *aar_kernel_name(int kernel_id);
+
 /* fp64 reprojection statistics at x_full (device): per-corner RMSE sqrt(sum r^2 / 4N), sum r^2 */
 int aar_reproj_stats(aar_problem *, const double *x_full, double *rmse, double *sum_sq);
 

@@ -1,0 +1,96 @@
+"""Generates tests/golden/*.npz.  Run in the build container (needs /root/reference for oracle/_ref):
+
+    python tests/golden/make_golden.py
+
+Every expected output in these files comes from the REAL reference solver -- ucoslam::SparseLevMarq<double>
+(libs/sparselevmarq.h) and Eigen::SimplicialLDLT, compiled in place into oracle/_ref/libref_lm.so -- driving the
+restated residual / Jacobian callbacks of oracle/ba_oracle.cpp in reference-faithful mode (float32-rounded
+projections, central differences with delta = 1e-3), because libs/multicam_mapper.cpp itself cannot be built
+without OpenCV.  The inputs are the deterministic synthetic sequences of SURVEY.md 8d and are
+stored alongside, so a fixture is self-contained data: inputs + expected outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "automatic-ar_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import aar  # noqa: E402
+import oracle_lib as ol  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+DS_FIELDS = ("cam_ids", "marker_ids", "frame_ids", "image_sizes", "cam_mats", "dist_coeffs", "obs_frame", "obs_cam",
+             "obs_marker", "obs_uv", "x_full", "x_truth")
+
+
+def ds_dict(ds):
+    d = {k: getattr(ds, k) for k in DS_FIELDS}
+    d["meta"] = np.array([ds.num_cams, ds.num_markers, ds.num_frames, ds.root_cam, ds.root_marker], dtype=np.int64)
+    d["marker_size"] = np.array([ds.marker_size])
+    return d
+
+
+def trace_arrays(rep, prefix):
+    t = rep["trace"]
+    return {prefix + "err": np.array([e["err"] for e in t]), prefix + "mu": np.array([e["mu"] for e in t]),
+            prefix + "iterations": np.array([rep["iterations"]]), prefix + "final_err": np.array([rep["final_err"]])}
+
+
+def g1(name, ds, synth_args, tau=1.0):
+    """G1: LM trace + final solution of the real solver, reference-faithful callbacks."""
+    o = ol.Oracle(ds)
+    prm = ol.mapper_params(tau=tau)
+    x_ref, rep = o.ref_lm_solve(ds.x_full, params=prm, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=1, use_omp_mult=True)
+    x_acc, rep_acc = o.ref_lm_solve(ds.x_full, params=prm, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32, threads=1, use_omp_mult=True)
+    out = ds_dict(ds)
+    out["synth_args"] = np.array(synth_args, dtype=np.float64)
+    out["tau"] = np.array([tau])
+    out.update(trace_arrays(rep, "faithful_"))
+    out.update(trace_arrays(rep_acc, "analytic_"))
+    out["faithful_x"] = x_ref
+    out["analytic_x"] = x_acc
+    st = o.reproj_stats(x_ref)
+    out["faithful_rmse"] = np.array([st["rmse"], st["mean_dist"], st["sum_sq"]])
+    st = o.reproj_stats(x_acc)
+    out["analytic_rmse"] = np.array([st["rmse"], st["mean_dist"], st["sum_sq"]])
+    out["r0_f32"] = o.residuals(ds.x_full, res_mode=ol.RES_F32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "N", ds.num_obs, "faithful iters", rep["iterations"], "err", rep["final_err"], "analytic iters",
+          rep_acc["iterations"], "err", rep_acc["final_err"], "rmse delta", abs(out["faithful_rmse"][0] - out["analytic_rmse"][0]))
+
+
+def g2(name, ds):
+    """G2: J^T J, B, delta for fixed (J, r, mu) from Eigen (Jt*J, SimplicialLDLT), both Jacobian flavours."""
+    o = ol.Oracle(ds)
+    out = ds_dict(ds)
+    P = o.num_vars
+    for tag, jm, rm in (("faithful_", ol.JAC_NUMERIC_F32, ol.RES_F32), ("analytic_", ol.JAC_ANALYTIC, ol.RES_F64)):
+        rows, cols, vals = o.jacobian(ds.x_full, jac_mode=jm)
+        r = o.residuals(ds.x_full, res_mode=rm)
+        H, B, _ = ol.ref_damped_solve(8 * o.N, P, rows, cols, vals, r, 1.0)
+        mu0 = float(np.diag(H).max())
+        out[tag + "JtJ"] = H
+        out[tag + "B"] = B
+        mus = np.array([mu0, mu0 * 1e-2, mu0 * 1e-4])
+        out[tag + "mu"] = mus
+        out[tag + "delta"] = np.stack([ol.ref_damped_solve(8 * o.N, P, rows, cols, vals, r, m, want_dense=False)[2] for m in mus])
+        out[tag + "J_rows"], out[tag + "J_cols"], out[tag + "J_vals"] = rows, cols, vals
+        out[tag + "r"] = r
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "P", P, "N", ds.num_obs)
+
+
+if __name__ == "__main__":
+    assert ol.have_ref(), "build oracle/_ref first (python -c 'import __graft_entry__ as g; g.build()')"
+    # config 2 of SURVEY.md (BASELINE.json configs[1]): 4 cameras / 12 markers / 100 frames
+    g1("g1_cfg2", aar.synth(2), [2, 4, 12, 100, 1.0])
+    # a cut-down config 3: 8 cameras / 40 markers / 60 frames
+    g1("g1_cfg3_cut", aar.synth(3, num_frames=60), [3, 8, 40, 60, 1.0])
+    # larger initial perturbation (x4): more iterations, exercises the damping schedule harder
+    g1("g1_cfg2_far", aar.synth(2, init_scale=4.0), [2, 4, 12, 100, 4.0])
+    # far start + tiny tau: the first damping tries of some steps are rejected -> exercises the mu*=v; v*=5 branch
+    g1("g1_cfg2_retry", aar.synth(2, init_scale=15.0), [2, 4, 12, 100, 15.0], tau=1e-6)
+    g2("g2_small", aar.synth(2, num_cams=3, num_markers=8, num_frames=20))

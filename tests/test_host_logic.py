@@ -1,0 +1,171 @@
+"""Host-side pieces of the product that need no GPU: synthetic generator, file formats, SE(3) helpers, shard
+planning, the aar_find_solution driver's file contract.  CPU only."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import aar
+import oracle_lib as ol
+from conftest import PKG, load_golden
+
+
+def test_generator_is_deterministic_and_matches_committed_inputs():
+    # the golden fixtures hold the generator's output as of the commit that made them: bit-for-bit
+    for name in ("g1_cfg2", "g1_cfg3_cut", "g1_cfg2_far"):
+        gds, g = load_golden(name)
+        cfg, C, M, F, scale = g["synth_args"]
+        ds = aar.synth(int(cfg), num_cams=int(C), num_markers=int(M), num_frames=int(F), init_scale=float(scale))
+        assert (ds.num_cams, ds.num_markers, ds.num_frames, ds.num_obs) == (gds.num_cams, gds.num_markers, gds.num_frames, gds.num_obs)
+        for k in aar.Dataset.FIELDS:
+            assert np.array_equal(getattr(ds, k), getattr(gds, k)), k
+
+
+def test_generator_statistics():
+    ds = aar.synth(3)
+    assert (ds.num_cams, ds.num_markers) == (8, 40) and ds.num_frames == 500
+    assert 10000 < ds.num_obs < 20000           # ~10 % visibility
+    assert np.all(np.diff(ds.obs_frame) >= 0)   # reference residual order: frame-major ...
+    same = np.diff(ds.obs_frame) == 0
+    assert np.all(np.diff(ds.obs_cam)[same] >= 0)  # ... then camera
+    assert np.bincount(ds.obs_frame, minlength=ds.num_frames).min() >= 2  # libs/initializer.cpp:379
+    o = ol.Oracle(ds)
+    st = o.reproj_stats(ds.x_truth)
+    assert abs(st["rmse"] - 0.3 * np.sqrt(2)) < 0.01   # noise sigma 0.3 px per coordinate
+    assert st["rmse"] < o.reproj_stats(ds.x_full)["rmse"] / 20
+    assert ds.marker_size == float(np.float32(0.05))
+
+
+def test_solution_file_round_trip_and_layout(tmp_path):
+    ds, _ = load_golden("g2_small")
+    path = str(tmp_path / "initial.solution")
+    aar.solution_write(path, ds)
+    back = aar.solution_read(path)
+    for k in ("cam_ids", "marker_ids", "frame_ids", "image_sizes", "cam_mats", "dist_coeffs", "obs_frame", "obs_cam", "obs_marker", "obs_uv"):
+        assert np.array_equal(getattr(back, k), getattr(ds, k)), k
+    assert (back.root_cam, back.root_marker, back.marker_size) == (ds.root_cam, ds.root_marker, ds.marker_size)
+    # poses are stored after a vec -> mat -> vec round trip (libs/multicam_mapper.cpp:1054,1086)
+    np.testing.assert_allclose(back.x_full, ds.x_full, atol=1e-12)
+    # byte layout of the header: size_t C, int32 ids[C], size_t root id, C x (int32 w, int32 h), size_t M ...
+    raw = open(path, "rb").read()
+    C, M, F = ds.num_cams, ds.num_markers, ds.num_frames
+    off = 0
+    assert struct.unpack_from("<Q", raw, off)[0] == C; off += 8
+    assert list(struct.unpack_from("<%di" % C, raw, off)) == list(ds.cam_ids); off += 4 * C
+    assert struct.unpack_from("<Q", raw, off)[0] == ds.cam_ids[ds.root_cam]; off += 8
+    assert list(struct.unpack_from("<%di" % (2 * C), raw, off)) == list(ds.image_sizes.reshape(-1)); off += 8 * C
+    assert struct.unpack_from("<Q", raw, off)[0] == M; off += 8 + 4 * M + 8
+    assert struct.unpack_from("<d", raw, off)[0] == ds.marker_size; off += 8
+    assert struct.unpack_from("<Q", raw, off)[0] == F; off += 8 + 4 * F
+    nvec = 6 * (C - 1) + 6 * (M - 1) + 6 * F + 9 * C   # always the full default-Config vector (:1085-1089)
+    vec = np.frombuffer(raw, dtype="<f8", count=nvec, offset=off); off += 8 * nvec
+    np.testing.assert_allclose(vec[: ds.full_len], ds.x_full, atol=1e-12)
+    assert list(vec[ds.full_len: ds.full_len + 4]) == [1000.0, 640.0, 1000.0, 360.0]  # fx, cx, fy, cy
+    assert struct.unpack_from("<Q", raw, off)[0] == F     # serialize_frame_cam_markers
+    assert raw[-4:] == bytes([1, 1, 1, 0])                # Config flags as 4 bools, intrinsics off
+    n_marker_records = ds.num_obs
+    n_cam_runs = len(set(zip(ds.obs_frame.tolist(), ds.obs_cam.tolist())))
+    assert len(raw) == off + 8 + F * (4 + 8) + n_cam_runs * (4 + 8) + n_marker_records * 36 + 4
+
+
+def test_solution_reader_honours_ids_and_drops_unknown(tmp_path):
+    ds, _ = load_golden("g2_small")
+    ds.cam_ids = ds.cam_ids * 3 + 1          # non-contiguous ids
+    ds.marker_ids = ds.marker_ids * 7 + 5
+    path = str(tmp_path / "ids.solution")
+    aar.solution_write(path, ds)
+    back = aar.solution_read(path)
+    assert np.array_equal(back.cam_ids, ds.cam_ids) and np.array_equal(back.marker_ids, ds.marker_ids)
+    assert np.array_equal(back.obs_cam, ds.obs_cam) and np.array_equal(back.obs_marker, ds.obs_marker)
+    with pytest.raises(aar.AarError) as e:
+        aar.solution_read(str(tmp_path / "missing.solution"))
+    assert e.value.code == aar.AAR_ERR_IO
+    open(str(tmp_path / "short.solution"), "wb").write(open(path, "rb").read()[:100])
+    with pytest.raises(aar.AarError):
+        aar.solution_read(str(tmp_path / "short.solution"))
+
+
+def test_detections_file_layout(tmp_path):
+    # aruco.detections: size_t num_cams, then per frame, per camera: size_t n, n x (int32 id, 8 floats)
+    ds, _ = load_golden("g2_small")
+    path = str(tmp_path / "aruco.detections")
+    aar.detections_write(path, ds)
+    raw = open(path, "rb").read()
+    ncam = struct.unpack_from("<Q", raw, 0)[0]
+    assert ncam == ds.cam_ids.max() + 1
+    off, frame, seen = 8, 0, []
+    while off < len(raw):
+        for c in range(ncam):
+            n = struct.unpack_from("<Q", raw, off)[0]; off += 8
+            for _ in range(n):
+                mid = struct.unpack_from("<i", raw, off)[0]
+                uv = struct.unpack_from("<8f", raw, off + 4)
+                seen.append((frame, c, mid, uv)); off += 36
+        frame += 1
+    assert off == len(raw) and len(seen) == ds.num_obs
+    assert frame == ds.frame_ids.max() + 1     # frame index = position in the file
+    f0 = [(ds.frame_ids[f], ds.cam_ids[c], ds.marker_ids[m]) for f, c, m in zip(ds.obs_frame, ds.obs_cam, ds.obs_marker)]
+    assert [(a, b, c) for a, b, c, _ in seen] == f0
+    assert np.array_equal(np.array([s[3] for s in seen], dtype=np.float32), ds.obs_uv)
+
+
+def test_yaml_solution_is_opencv_filestorage_shaped(tmp_path):
+    ds, _ = load_golden("g2_small")
+    path = str(tmp_path / "final.solution.yaml")
+    aar.solution_write_yaml(path, ds)
+    txt = open(path).read()
+    assert txt.startswith("%YAML:1.0\n---\n")
+    assert txt.count("!!opencv-matrix") == ds.num_cams + ds.num_markers + ds.num_frames
+    for key in ("marker_size:", "transforms_to_root_cam:", "transforms_to_root_marker:", "root_marker_to_root_cam:"):
+        assert key in txt
+    assert txt.count("cam_id:") == ds.num_cams and txt.count("marker_id:") == ds.num_markers and txt.count("frame_id:") == ds.num_frames
+    # root camera: identity, written the FileStorage way ("1." / "0.")
+    first = txt.split("transforms_to_root_cam:")[1].split("}")[0]
+    vals = first.split("data:[")[1].split("]")[0].replace("\n", " ").split(",")
+    assert [v.strip() for v in vals] == ["1.", "0.", "0.", "0.", "0.", "1.", "0.", "0.", "0.", "0.", "1.", "0.", "0.", "0.", "0.", "1."]
+
+
+def test_rodrigues_product_vs_oracle():
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        w = rng.normal(size=3)
+        w *= rng.uniform(0, 3.0) / np.linalg.norm(w)   # |w| < pi: the range cv::Rodrigues returns
+        R = aar.rodrigues_vec2mat(w)
+        np.testing.assert_allclose(R, ol.rodrigues_vec2mat(w), atol=1e-15)
+        np.testing.assert_allclose(aar.rodrigues_mat2vec(R), w, atol=1e-12)
+        np.testing.assert_allclose(aar.rodrigues_mat2vec(R * 1.00001), ol.rodrigues_mat2vec(R * 1.00001), atol=1e-9)
+    for axis in (np.array([0, 0, 1.0]), np.array([2.0, -1.0, 2.0]) / 3):
+        R = aar.rodrigues_vec2mat(axis * np.pi)     # theta = pi branch
+        w = aar.rodrigues_mat2vec(R)
+        np.testing.assert_allclose(aar.rodrigues_vec2mat(w), R, atol=1e-9)
+
+
+def test_plan_shards_balances_observations():
+    rng = np.random.default_rng(0)
+    counts = rng.integers(2, 60, size=500)
+    for world in (1, 2, 3, 4, 8):
+        b = aar.plan_shards(counts, world)
+        assert b[0] == 0 and b[-1] == 500 and np.all(np.diff(b) >= 0)
+        per = np.array([counts[b[r]:b[r + 1]].sum() for r in range(world)])
+        assert per.sum() == counts.sum()
+        assert per.max() - per.min() <= 2 * counts.max()      # balanced by observation count, not frame count
+    assert list(aar.plan_shards([5, 5], 4)) in ([0, 0, 1, 1, 2], [0, 1, 1, 2, 2], [0, 0, 1, 2, 2], [0, 1, 1, 1, 2])  # more ranks than frames
+    assert list(aar.plan_shards([], 2)) == [0, 0, 0]
+
+
+def test_find_solution_driver_file_contract(tmp_path):
+    exe = os.path.join(PKG, "aar_find_solution")
+    folder = str(tmp_path / "box")
+    out = subprocess.run([exe, "--synth", "1", folder], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    for f in ("aruco.detections", "initial.solution", "initial.solution.yaml"):
+        assert os.path.exists(os.path.join(folder, f))
+    ds = aar.solution_read(os.path.join(folder, "initial.solution"))
+    assert (ds.num_cams, ds.num_markers) == (3, 6)          # box-like plumbing case (BASELINE.json configs[0])
+    if aar.device_count() == 0:
+        # no GPU here: the product must fail loudly, not fall back to a CPU path
+        run = subprocess.run([exe, folder, "0.05"], capture_output=True, text=True)
+        assert run.returncode != 0 and "no HIP device" in (run.stderr + run.stdout)
+        assert not os.path.exists(os.path.join(folder, "final.solution"))
