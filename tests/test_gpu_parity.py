@@ -127,15 +127,26 @@ def test_lm_retry_branch():
         assert abs(rep["iterations"] - int(g["analytic_iterations"][0])) <= 2
         rmse, _ = p.reproj_stats(x)
         assert abs(rmse - g["faithful_rmse"][0]) < 1e-4
-    # all six tries rejected -> step() returns false and solve() stops with the start point untouched
-    ds2 = aar.synth(2, init_scale=10.0)
-    o = ol.Oracle(ds2)
-    xo, repo = o.lm_solve(ds2.x_full, params=ol.mapper_params(tau=1e-9), jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
-    with aar.Problem(ds2) as p:
-        x, rep = p.lm_solve(ds2.x_full, params=aar.lm_default_params(tau=1e-9))
-        assert rep["trace"][-1]["tries"] == repo["trace"][-1]["tries"] == 6
-        assert rep["trace"][-1]["accepted"] == 0 and rep["stop_code"] == 2
-        assert rep["iterations"] == repo["iterations"]
+    # Run to the numerical floor (no average-step stop rule): the loop can only end through a step whose six
+    # damping tries are all rejected (step() returns false -> mustExit = 2, libs/sparselevmarq.h:419,459) or through
+    # an exactly repeated error.  Which of the two, and after how many steps, depends on last-bit rounding, so the
+    # checks are structural.
+    ds2, g2 = load_golden("g1_cfg2")
+    with aar.Problem(ds2, residual_mode=aar.RES_F64) as p:
+        x, rep = p.lm_solve(ds2.x_full, params=aar.lm_default_params(min_average_step_error_diff=0.0, max_iters=200))
+        assert rep["iterations"] < 200 and rep["stop_code"] == 2
+        last = rep["trace"][-1]
+        errs = [rep["initial_err"]] + [t["err"] for t in rep["trace"]]
+        assert all(b <= a for a, b in zip(errs[:-1], errs[1:]))
+        if not last["accepted"]:
+            assert last["tries"] == 6 and last["err"] == rep["trace"][-2]["err"]   # curr_z / currErr untouched
+        for t in rep["trace"][:-1]:
+            assert t["accepted"] == 1
+        _, ss = p.eval_residuals(x, want_vector=False)
+        np.testing.assert_allclose(ss, rep["final_err"], rtol=1e-13)              # the returned point is curr_z
+        assert rep["final_err"] <= g2["analytic_err"][-1]
+        rmse, _ = p.reproj_stats(x)
+        assert abs(rmse - g2["faithful_rmse"][0]) < 1e-4
 
 
 def test_step_api_matches_solve():
