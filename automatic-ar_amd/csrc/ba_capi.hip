@@ -291,14 +291,13 @@ int damped_try(aar_problem *pb, double mu, bool with_residual) {
     }
     {
         StageTimer t(pb, &pb->times.chol);
-        launch_finalize(P, mu, pb->stream);
-        launch_chol(P, pb->stream);
+        launch_chol(P, mu, pb->stream);
     }
     {
         StageTimer t(pb, &pb->times.backsub);
         launch_backsub(P, cur, tr, pb->stream);
     }
-    pb->launches += 4 + 2 * P.nT;
+    pb->launches += 3 + 2 * P.nT;
     if (with_residual) {
         {
             StageTimer t(pb, &pb->times.unpack);
@@ -598,7 +597,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     AL(V, (size_t)F * 36); AL(gf, (size_t)F * 6); AL(W, (size_t)P.total_slots * 36);
     AL(Vinv, (size_t)F * 36); AL(hf, (size_t)F * 6);
     AL(U0, (size_t)P.n_pad * P.n_pad); AL(g0, P.n_pad); AL(S, (size_t)P.n_pad * P.n_pad); AL(rhs, P.n_pad);
-    AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(delta_s, P.n_pad);
+    AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Minv, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(delta_s, P.n_pad);
     AL(err_part, std::max<size_t>((size_t)F, (size_t)((N + 255) / 256)) + 1);
     AL(lin_part, 2 * (size_t)(F + 1)); AL(scal, 8); AL(flags, 4);
 #undef AL

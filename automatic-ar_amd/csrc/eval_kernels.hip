@@ -318,12 +318,16 @@ void launch_passA(const DeviceProblem &P, int which, hipStream_t st) {
     if (avg <= 96) {
         constexpr int B = 64;
         const size_t lds = ((size_t)P.max_kf * 36 + 32 + (B / 64) * 2048) * sizeof(double);
+        static size_t granted = 48 * 1024;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B>), lds, granted);
         { HookScope _h(P, KID_PASSA); hipLaunchKernelGGL(k_passA<B>, dim3(P.F), dim3(B), lds, st, P.a_idx, P.a_uv, P.ent[which], P.K,
                            P.frame_obs_start, P.fslot_start, P.A, P.half_size, P.res_f32, P.max_kf, P.V, P.gf, P.W,
                            P.err_part); }
     } else {
         constexpr int B = 256;
         const size_t lds = ((size_t)P.max_kf * 36 + 32 + (B / 64) * 2048) * sizeof(double);
+        static size_t granted = 48 * 1024;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B>), lds, granted);
         { HookScope _h(P, KID_PASSA); hipLaunchKernelGGL(k_passA<B>, dim3(P.F), dim3(B), lds, st, P.a_idx, P.a_uv, P.ent[which], P.K,
                            P.frame_obs_start, P.fslot_start, P.A, P.half_size, P.res_f32, P.max_kf, P.V, P.gf, P.W,
                            P.err_part); }

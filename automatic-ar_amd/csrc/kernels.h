@@ -6,7 +6,7 @@
 
 namespace aar {
 
-constexpr int CHOL_NB = 48;       // dense LDL^T tile (8 entity blocks of 6)
+constexpr int CHOL_NB = 96;       // dense LDL^T tile (16 entity blocks of 6)
 constexpr int PASSB_CHUNK = 256;  // max observations of one (camera, marker) run handled by one wavefront
 
 // Kernel ids for the optional per-launch timing hooks (aar_get_kernel_times)
@@ -58,6 +58,7 @@ struct DeviceProblem {
     double *U0 = nullptr, *g0 = nullptr;  // [n_pad*n_pad] row-major (lower triangle), [n_pad]: undamped shared part
     double *S = nullptr, *rhs = nullptr;  // working copy: reduced system, then its LDL^T factor / solution
     double *Dfac = nullptr;               // [nT][NB*NB] factored diagonal tiles (unit L below, D on the diagonal)
+    double *Minv = nullptr;               // [nT][NB*NB] L_ss^-T D_s^-1 of every diagonal tile
     double *delta_s = nullptr;            // [n_pad]
     double *err_part = nullptr;           // [max(F, residual_blocks)] partial sums of squared residuals
     double *lin_part = nullptr;           // [F+1][2] per-frame ( |delta_f|^2 , delta_f . g_f ), last = shared part
@@ -66,6 +67,14 @@ struct DeviceProblem {
     double *r_out = nullptr;              // optional [8N]
     LaunchHook hook;
 };
+
+// opt in to more than the default dynamic LDS per workgroup (gfx950: 160 KiB per CU); remembered per kernel
+inline void allow_dynamic_lds(const void *kernel, size_t bytes, size_t &granted) {
+    if (bytes > granted) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        granted = bytes;
+    }
+}
 
 struct HookScope {  // RAII: pre/post around one launch
     const DeviceProblem &P;
@@ -82,7 +91,7 @@ void launch_maxdiag(const DeviceProblem &P, hipStream_t st);                    
 void launch_frame_inv(const DeviceProblem &P, double mu, hipStream_t st);          // + copies U0,g0 -> S,rhs
 void launch_schur(const DeviceProblem &P, hipStream_t st);
 void launch_finalize(const DeviceProblem &P, double mu, hipStream_t st);
-void launch_chol(const DeviceProblem &P, hipStream_t st);                          // LDL^T + forward + backward solve -> delta_s
+void launch_chol(const DeviceProblem &P, double mu, hipStream_t st);               // damping + LDL^T + both substitutions -> delta_s
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
 void launch_reduce_scalars(const DeviceProblem &P, bool fold_shared, hipStream_t st);  // scal[0..2], scal[5..6]
 int residual_blocks(const DeviceProblem &P);   // entries of err_part written by launch_residual

@@ -1,7 +1,8 @@
 // HIP kernels (gfx950, wave64) for the damped normal-equation solve of one LM try.  The reference
 // factors the whole sparse (J^T J + mu I) with Eigen::SimplicialLDLT (libs/sparselevmarq.h:384-400); the
 // same elimination is done here in block form: per-frame 6x6 inverses (k_frame_inv), Schur complement
-// onto the cameras+markers (k_schur), dense blocked LDL^T of the reduced system (k_ldl_*), and
+// onto the cameras+markers (k_schur), dense blocked LDL^T of the reduced system (k_ldl_*, which also applies
+// the damping and the gauge rows on first touch), and
 // back-substitution of the frame poses (k_backsub).  mu is added to EVERY diagonal entry, as in the
 // reference (:387-392).  fp64 throughout.
 #include "geom.hpp"
@@ -167,187 +168,278 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
 }
 
 // ------------------------------------------------------------------------------------------------
-// damping + gauge: S += mu I on free rows; rows/columns of fixed entities (root camera, root marker,
-// non-optimised groups) and of the padding become identity with zero rhs, i.e. delta = 0 there.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_finalize(double *__restrict__ S, double *__restrict__ rhs, int n, int n_pad,
-                                                  double mu, const int32_t *__restrict__ ent_fixed) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t nn = (int64_t)n_pad * n_pad;
-    for (int64_t e = gid; e < nn; e += stride) {
-        const int i = (int)(e / n_pad), j = (int)(e - (int64_t)i * n_pad);
-        if (j > i) continue;
-        const bool fi = i >= n || ent_fixed[i / 6], fj = j >= n || ent_fixed[j / 6];
-        if (fi || fj) S[e] = (i == j) ? 1.0 : 0.0;
-        else if (i == j) S[e] += mu;
-    }
-    for (int64_t i = gid; i < n_pad; i += stride)
-        if (i >= n || ent_fixed[i / 6]) rhs[i] = 0.0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Dense LDL^T, right-looking, tile NB = 48, lower triangle row-major in place (L below the diagonal, D on it).
-// Step s = one k_ldl_panel (every row tile of block column s in its own workgroup, each re-deriving the
-// diagonal tile's eliminations in LDS so that no triangular solve is needed; one barrier per column)
-// followed by one k_ldl_update (trailing tiles).  The right-hand side rides along as one more row.
+// Dense LDL^T of the reduced system, right-looking, tile NB = 96, lower triangle row-major.
+//
+// Damping and gauge are applied on the FIRST touch of every element (step 0 of the factorisation), not by
+// a kernel of their own: S(i,j) -> S(i,j) + mu [i == j] on free rows; rows / columns of fixed entities (root
+// camera, root marker, non-optimised groups) and of the padding -> identity with zero rhs, i.e. delta = 0.
+//
+// Step s = one k_ldl_panel + one k_ldl_update.  Panel: every row tile of block column s gets its own
+// workgroup; each keeps the diagonal tile AND its own tile in registers (thread (ty,tx) owns rows ty+16p,
+// columns tx+16q) and replays the diagonal tile's column eliminations, so no triangular solve is needed:
+// per column ONE barrier, the column travels through a double-buffered LDS vector, the pivot reciprocal is
+// computed by the pivot's owner.  Two extra "row tiles" ride along: the right-hand side (a 1-row tile; its
+// output is z_s = D^-1 L^-1 b) and the identity (its output is M_s = L_ss^-T D_s^-1, which turns the backward
+// substitution into matrix-vector products).
 // ------------------------------------------------------------------------------------------------
 constexpr int NB = CHOL_NB;
-constexpr int NBP = CHOL_NB + 1;
 
-__global__ void __launch_bounds__(256) k_ldl_panel(double *__restrict__ S, double *__restrict__ rhs,
-                                                   double *__restrict__ Dfac, int n_pad, int s, int nT,
-                                                   int32_t *__restrict__ flags) {
-    __shared__ double Dg[NB][NBP];
-    __shared__ double Tt[NB][NBP];
-    __shared__ double bv[NB];
-    const int nrt = nT - s, b = blockIdx.x, tid = threadIdx.x;
-    const bool is_rhs = (b == nrt), has_tile = (b > 0 && b < nrt);
-    const int r0 = s * NB, t0 = (s + b) * NB;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, j = e - i * NB;
-        Dg[i][j] = (j <= i) ? S[(size_t)(r0 + i) * n_pad + r0 + j] : 0.0;
-        if (has_tile) Tt[i][j] = S[(size_t)(t0 + i) * n_pad + r0 + j];
-    }
-    if (is_rhs && tid < NB) bv[tid] = rhs[r0 + tid];
+__device__ __forceinline__ double xform_first(double v, int gi, int gj, int n, double mu, const int32_t *__restrict__ ent_fixed) {
+    const bool fi = gi >= n || ent_fixed[gi / 6], fj = gj >= n || ent_fixed[gj / 6];
+    if (fi || fj) return gi == gj ? 1.0 : 0.0;
+    return gi == gj ? v + mu : v;
+}
+
+__device__ __forceinline__ double rcp_refined(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(x, fma(-d, x, 1.0), x);
+    x = fma(x, fma(-d, x, 1.0), x);
+    return x;
+}
+
+// Workgroup roles of one panel launch (block column s, m = nT-s-1 row tiles below the diagonal):
+//   0                 the diagonal tile itself            -> Dfac[s]
+//   1 .. 2m           half row tiles (48 rows x 96 cols)   -> L_ts in place
+//   2m+1              the right-hand side (one row)        -> z_s
+//   2m+2, 2m+3        the two halves of the identity       -> Minv[s]
+__global__ void __launch_bounds__(256) k_ldl_panel(double *__restrict__ S, double *__restrict__ rhs, double *__restrict__ Dfac,
+                                                   double *__restrict__ Minv, int n_pad, int n, int s, int nT, double mu,
+                                                   const int32_t *__restrict__ ent_fixed, int32_t *__restrict__ flags) {
+    constexpr int R = NB / 16, RT = R / 2, HALF = NB / 2;
+    __shared__ double colD[2][NB], colT[2][HALF], pinv[2], dinv[NB];
+    const int m = nT - s - 1, b = blockIdx.x, tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
-    for (int k = 0; k < NB; k++) {
-        __syncthreads();
-        const double dk = Dg[k][k];
-        const double inv = 1.0 / dk;
-        double lj[3], li[3], ti[3];
+    const int r0 = s * NB;
+    const bool first = (s == 0);
+    int kind, row0 = 0;  // row0: first global row (tiles) or first identity row (identity halves)
+    if (b == 0) kind = 0;
+    else if (b <= 2 * m) { kind = 1; row0 = (s + 1) * NB + (b - 1) * HALF; }
+    else if (b == 2 * m + 1) kind = 2;
+    else { kind = 3; row0 = (b - 2 * m - 2) * HALF; }
+    double D[R][R], T[RT][R];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            lj[q] = Dg[tx + 16 * q][k];
-            li[q] = Dg[ty + 16 * q][k] * inv;
-            ti[q] = has_tile ? Tt[ty + 16 * q][k] * inv : 0.0;
+    for (int p = 0; p < R; p++)
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            if (q > p) { D[p][q] = 0.0; continue; }  // strictly above the diagonal blocks: never used
+            const int i = ty + 16 * p, j = tx + 16 * q;
+            double v = 0.0;
+            if (j <= i) {
+                v = S[(size_t)(r0 + i) * n_pad + r0 + j];
+                if (first) v = xform_first(v, r0 + i, r0 + j, n, mu, ent_fixed);
+            }
+            D[p][q] = v;
         }
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
-            const int i = ty + 16 * p;
+    for (int p = 0; p < RT; p++)
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const int j = tx + 16 * q;
-                if (j > k) {
-                    if (i > k && j <= i) Dg[i][j] -= li[p] * lj[q];
-                    if (has_tile) Tt[i][j] -= ti[p] * lj[q];
+        for (int q = 0; q < R; q++) {
+            const int i = ty + 16 * p, j = tx + 16 * q;
+            double t = 0.0;
+            if (kind == 1) {
+                t = S[(size_t)(row0 + i) * n_pad + r0 + j];
+                if (first) t = xform_first(t, row0 + i, r0 + j, n, mu, ent_fixed);
+            } else if (kind == 2) {
+                if (i == 0) {
+                    t = rhs[r0 + j];
+                    if (first && (r0 + j >= n || ent_fixed[(r0 + j) / 6])) t = 0.0;
+                }
+            } else if (kind == 3) {
+                t = (row0 + i == j) ? 1.0 : 0.0;
+            }
+            T[p][q] = t;
+        }
+#pragma unroll
+    for (int kq = 0; kq < R; kq++) {
+        for (int kk = 0; kk < 16; kk++) {
+            const int k = 16 * kq + kk, buf = k & 1;
+            if (tx == kk) {  // owners of column k publish it (final after step k-1)
+#pragma unroll
+                for (int p = 0; p < R; p++)
+                    if (p >= kq) colD[buf][ty + 16 * p] = D[p][kq];
+#pragma unroll
+                for (int p = 0; p < RT; p++) colT[buf][ty + 16 * p] = T[p][kq];
+                if (ty == kk) {  // pivot owner
+                    const double d = D[kq][kq];
+                    const double inv = rcp_refined(d);
+                    pinv[buf] = inv;
+                    dinv[k] = inv;
+                    if (!(d > 0.0) && kind == 0) atomicOr(flags, 2);
                 }
             }
+            __syncthreads();
+            const double inv = pinv[buf];
+            double lj[R], li[R], ti[RT];
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if (q >= kq) {
+                    lj[q] = colD[buf][tx + 16 * q];
+                    li[q] = colD[buf][ty + 16 * q] * inv;
+                }
+#pragma unroll
+            for (int p = 0; p < RT; p++) ti[p] = colT[buf][ty + 16 * p] * inv;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                if (q < kq) continue;  // finished columns (compile-time)
+                const int j = tx + 16 * q;
+                const bool jact = (q > kq) || (j > k);
+#pragma unroll
+                for (int p = 0; p < R; p++) {
+                    if (p < q) continue;  // lower block triangle only (compile-time)
+                    const int i = ty + 16 * p;
+                    const bool act = jact && ((p > kq) || (i > k)) && ((p > q) || (j <= i));
+                    if (act) D[p][q] = fma(-li[p], lj[q], D[p][q]);
+                }
+#pragma unroll
+                for (int p = 0; p < RT; p++)
+                    if (jact) T[p][q] = fma(-ti[p], lj[q], T[p][q]);
+            }
         }
-        if (is_rhs && tid < NB && tid > k) bv[tid] -= Dg[tid][k] * inv * bv[k];
     }
     __syncthreads();
-    if (b == 0) {
-        // The factored diagonal tile goes to Dfac, NOT back into S: the other workgroups of this launch
-        // still read the unfactored tile from S, and nothing orders them against this store.
+    if (kind == 0) {
+        // The factored diagonal tile goes to Dfac, NOT back into S: the other workgroups of this launch read
+        // the unfactored tile from S, and nothing orders them against this store.
         double *out = Dfac + (size_t)s * NB * NB;
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int i = e / NB, j = e - i * NB;
-            out[e] = (j < i) ? Dg[i][j] / Dg[j][j] : (j == i ? Dg[i][i] : 0.0);
+#pragma unroll
+        for (int p = 0; p < R; p++)
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int i = ty + 16 * p, j = tx + 16 * q;
+                out[i * NB + j] = (j < i) ? D[p][q] * dinv[j] : (j == i ? D[p][q] : 0.0);
+            }
+    } else if (kind == 1) {
+#pragma unroll
+        for (int p = 0; p < RT; p++)
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int i = ty + 16 * p, j = tx + 16 * q;
+                S[(size_t)(row0 + i) * n_pad + r0 + j] = T[p][q] * dinv[j];
+            }
+    } else if (kind == 2) {
+        if (ty == 0) {
+#pragma unroll
+            for (int q = 0; q < R; q++) rhs[r0 + tx + 16 * q] = T[0][q] * dinv[tx + 16 * q];
         }
-        if (tid < NB && !(Dg[tid][tid] > 0.0)) atomicOr(flags, 2);
-    } else if (has_tile) {
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int i = e / NB, j = e - i * NB;
-            S[(size_t)(t0 + i) * n_pad + r0 + j] = Tt[i][j] / Dg[j][j];
-        }
-    } else if (tid < NB) {
-        rhs[r0 + tid] = bv[tid];
+    } else {
+        double *out = Minv + (size_t)s * NB * NB;
+#pragma unroll
+        for (int p = 0; p < RT; p++)
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int i = row0 + ty + 16 * p, j = tx + 16 * q;
+                out[i * NB + j] = T[p][q] * dinv[j];
+            }
     }
 }
 
+// trailing update of step s in 32x32 output sub-tiles: S(I, J) -= L_Is D_s L_Js^T; rhs rows: b_t -= L_ts D_s z_s.
+// grid: [tiles (ti >= tj)] x 9 sub-tiles, then one workgroup per rhs row tile.  LDS: Li [32][NB+1], Ljd [32][NB+1]
 __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, double *__restrict__ rhs,
-                                                    const double *__restrict__ Dfac, int n_pad, int s, int nT) {
-    __shared__ double Li[NB][NBP];
-    __shared__ double Lj[NB][NBP];
-    __shared__ double ys[NB];
+                                                    const double *__restrict__ Dfac, int n_pad, int n, int s, int nT,
+                                                    double mu, const int32_t *__restrict__ ent_fixed) {
+    constexpr int LD = NB + 1, SB = 32, NSUB = (NB / SB) * (NB / SB);
+    __shared__ double Li[SB * LD], Lj[SB * LD];
     const int m = nT - s - 1, tid = threadIdx.x;
     const int ntile = m * (m + 1) / 2;
     const int r0 = s * NB;
-    if ((int)blockIdx.x >= ntile) {  // rhs rows of tile t: b_t -= L_ts y_s
-        const int t = s + 1 + ((int)blockIdx.x - ntile);
-        if (tid < NB) ys[tid] = rhs[r0 + tid];
+    const bool first = (s == 0);
+    const double *dd = Dfac + (size_t)s * NB * NB;
+    if ((int)blockIdx.x >= ntile * NSUB) {  // rhs entries of row tile t
+        const int t = s + 1 + ((int)blockIdx.x - ntile * NSUB);
+        double *zs = Li;
+        if (tid < NB) zs[tid] = rhs[r0 + tid] * dd[tid * NB + tid];  // D_s z_s
         __syncthreads();
         if (tid < NB) {
-            const double *row = S + (size_t)(t * NB + tid) * n_pad + r0;
+            const int gi = t * NB + tid;
+            const double *row = S + (size_t)gi * n_pad + r0;
             double acc = 0.0;
 #pragma unroll 8
-            for (int k = 0; k < NB; k++) acc += row[k] * ys[k];
-            rhs[t * NB + tid] -= acc;
+            for (int k = 0; k < NB; k++) acc += row[k] * zs[k];
+            double v = rhs[gi];
+            if (first && (gi >= n || ent_fixed[gi / 6])) v = 0.0;
+            rhs[gi] = v - acc;
         }
         return;
     }
-    int ti = 0, rem = blockIdx.x;  // decode (ti >= tj) from the linear lower-triangular tile index
+    const int tile = blockIdx.x / NSUB, sub = blockIdx.x % NSUB;
+    int ti = 0, rem = tile;  // decode (ti >= tj) from the linear lower-triangular tile index
     while (rem > ti) { rem -= ti + 1; ti++; }
     const int tj = rem;
-    const int i0 = (s + 1 + ti) * NB, j0 = (s + 1 + tj) * NB;
-    for (int e = tid; e < NB * NB; e += 256) {
+    const int si = sub / (NB / SB), sj = sub % (NB / SB);
+    if (ti == tj && sj > si) return;  // above the diagonal
+    const int i0 = (s + 1 + ti) * NB + si * SB, j0 = (s + 1 + tj) * NB + sj * SB;
+    for (int e = tid; e < SB * NB; e += 256) {
         const int i = e / NB, k = e - i * NB;
-        Li[i][k] = S[(size_t)(i0 + i) * n_pad + r0 + k];
-        Lj[i][k] = S[(size_t)(j0 + i) * n_pad + r0 + k] * Dfac[(size_t)s * NB * NB + k * NB + k];  // L_js * D_s
+        Li[i * LD + k] = S[(size_t)(i0 + i) * n_pad + r0 + k];
+        Lj[i * LD + k] = S[(size_t)(j0 + i) * n_pad + r0 + k] * dd[k * NB + k];  // L_Js * D_s
     }
     __syncthreads();
     const int ty = tid >> 4, tx = tid & 15;
-    double acc[3][3];
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-#pragma unroll
-        for (int q = 0; q < 3; q++) acc[p][q] = 0.0;
-#pragma unroll 4
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll 8
     for (int k = 0; k < NB; k++) {
-        double a[3], c[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++) { a[q] = Li[ty + 16 * q][k]; c[q] = Lj[tx + 16 * q][k]; }
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-#pragma unroll
-            for (int q = 0; q < 3; q++) acc[p][q] += a[p] * c[q];
+        const double a0 = Li[ty * LD + k], a1 = Li[(ty + 16) * LD + k];
+        const double c0 = Lj[tx * LD + k], c1 = Lj[(tx + 16) * LD + k];
+        acc[0][0] = fma(a0, c0, acc[0][0]); acc[0][1] = fma(a0, c1, acc[0][1]);
+        acc[1][0] = fma(a1, c0, acc[1][0]); acc[1][1] = fma(a1, c1, acc[1][1]);
     }
 #pragma unroll
-    for (int p = 0; p < 3; p++)
+    for (int p = 0; p < 2; p++)
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const int i = ty + 16 * p, j = tx + 16 * q;
-            if (ti != tj || j <= i) S[(size_t)(i0 + i) * n_pad + j0 + j] -= acc[p][q];
+        for (int q = 0; q < 2; q++) {
+            const int gi = i0 + ty + 16 * p, gj = j0 + tx + 16 * q;
+            if (gj <= gi) {
+                double v = S[(size_t)gi * n_pad + gj];
+                if (first) v = xform_first(v, gi, gj, n, mu, ent_fixed);
+                S[(size_t)gi * n_pad + gj] = v - acc[p][q];
+            }
         }
 }
 
-// z = D^-1 y, then L^T x = z from the last tile up.  One workgroup; the reduced system is small.
-__global__ void __launch_bounds__(256) k_ldl_backsolve(const double *__restrict__ S, const double *__restrict__ rhs,
-                                                       const double *__restrict__ Dfac, double *__restrict__ x,
-                                                       int n_pad, int nT) {
+// L^T x = z from the last tile up, with the tile inverses: x_s = M_s (d_s o (z_s - sum_{t>s} L_ts^T x_t)).
+// One workgroup of 1024 threads; LDS: xs [n_pad] | part [10][NB] | w [NB]
+__global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict__ S, const double *__restrict__ rhs,
+                                                        const double *__restrict__ Dfac, const double *__restrict__ Minv,
+                                                        double *__restrict__ x, int n_pad, int nT) {
     extern __shared__ double lds[];
-    double *xs = lds;                  // [n_pad]
-    double *Ls = xs + n_pad;           // [NB][NBP]
-    double *part = Ls + NB * NBP;      // [5][NB]
-    double *v = part + 5 * NB;         // [NB]
+    double *xs = lds;
+    double *part = xs + n_pad;
+    double *w = part + 10 * NB;
     const int tid = threadIdx.x;
-    for (int i = tid; i < n_pad; i += 256) xs[i] = rhs[i] / Dfac[(size_t)(i / NB) * NB * NB + (i % NB) * (NB + 1)];
-    __syncthreads();
+    constexpr int G = 10;  // row groups: G*NB = 960 threads busy in the reductions
+    const int j = tid % NB, gq = tid / NB;
     for (int s = nT - 1; s >= 0; s--) {
         const int r0 = s * NB;
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int i = e / NB, j = e - i * NB;
-            Ls[i * NBP + j] = (j < i) ? Dfac[(size_t)s * NB * NB + e] : 0.0;
-        }
-        // v_j = z_j - sum_{i >= (s+1)NB} L[i][r0+j] x_i
-        const int j = tid % NB, gq = tid / NB;  // 5 row groups use 240 threads
-        if (gq < 5) {
+        if (gq < G) {
             double acc = 0.0;
-            for (int i = (s + 1) * NB + gq; i < n_pad; i += 5) acc += S[(size_t)i * n_pad + r0 + j] * xs[i];
+            for (int i = (s + 1) * NB + gq; i < n_pad; i += G) acc += S[(size_t)i * n_pad + r0 + j] * xs[i];
             part[gq * NB + j] = acc;
         }
         __syncthreads();
-        if (tid < NB) v[tid] = xs[r0 + tid] - (part[tid] + part[NB + tid] + part[2 * NB + tid] + part[3 * NB + tid] + part[4 * NB + tid]);
-        for (int k = NB - 1; k >= 0; k--) {
-            __syncthreads();
-            if (tid < k) v[tid] -= Ls[k * NBP + tid] * v[k];
+        if (tid < NB) {
+            double a = rhs[r0 + tid];
+#pragma unroll
+            for (int g = 0; g < G; g++) a -= part[g * NB + tid];
+            w[tid] = a * Dfac[(size_t)s * NB * NB + tid * NB + tid];
         }
         __syncthreads();
-        if (tid < NB) xs[r0 + tid] = v[tid];
+        if (gq < G) {  // x_s[j] = sum_c M[j][c] w[c], c >= j (M is upper triangular); group gq takes c = gq, gq+G, ...
+            const double *Mr = Minv + (size_t)s * NB * NB + (size_t)j * NB;
+            double acc = 0.0;
+            for (int c = gq; c < NB; c += G) acc += Mr[c] * w[c];
+            part[gq * NB + j] = acc;
+        }
+        __syncthreads();
+        if (tid < NB) {
+            double a = 0.0;
+#pragma unroll
+            for (int g = 0; g < G; g++) a += part[g * NB + tid];
+            xs[r0 + tid] = a;
+            x[r0 + tid] = a;
+        }
         __syncthreads();
     }
-    for (int i = tid; i < n_pad; i += 256) x[i] = xs[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -468,26 +560,26 @@ void launch_frame_inv(const DeviceProblem &P, double mu, hipStream_t st) {
 void launch_schur(const DeviceProblem &P, hipStream_t st) {
     if (P.n_swork == 0) return;
     const size_t lds = ((size_t)P.A * 36 + 8 + 4 * 48) * sizeof(double);
+    static size_t granted = 48 * 1024;
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_schur), lds, granted);
     { HookScope _h(P, KID_SCHUR); hipLaunchKernelGGL(k_schur, dim3(P.n_swork), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_frame,
                        P.pair_slot, P.fslot_start, P.fslot_ent, P.W, P.Vinv, P.hf, P.A, P.n_pad, P.S, P.rhs); }
 }
 
-void launch_finalize(const DeviceProblem &P, double mu, hipStream_t st) {
-    const int64_t nn = (int64_t)P.n_pad * P.n_pad;
-    int blocks = (int)((nn + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
-    { HookScope _h(P, KID_FINALIZE); hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, st, P.S, P.rhs, P.n, P.n_pad, mu, P.ent_fixed); }
-}
+void launch_finalize(const DeviceProblem &, double, hipStream_t) {}  // folded into the first tile touch of the LDL^T
 
-void launch_chol(const DeviceProblem &P, hipStream_t st) {
+void launch_chol(const DeviceProblem &P, double mu, hipStream_t st) {
     for (int s = 0; s < P.nT; s++) {
-        { HookScope _h(P, KID_LDL_PANEL); hipLaunchKernelGGL(k_ldl_panel, dim3(P.nT - s + 1), dim3(256), 0, st, P.S, P.rhs, P.Dfac, P.n_pad, s, P.nT, P.flags); }
         const int m = P.nT - s - 1;
-        if (m > 0)
-            { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 + m), dim3(256), 0, st, P.S, P.rhs, P.Dfac, P.n_pad, s, P.nT); }
+        { HookScope _h(P, KID_LDL_PANEL); hipLaunchKernelGGL(k_ldl_panel, dim3(2 * m + 4), dim3(256), 0, st, P.S, P.rhs, P.Dfac, P.Minv, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed, P.flags); }
+        if (m > 0) {
+            { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, P.S, P.rhs, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
+        }
     }
-    const size_t lds = ((size_t)P.n_pad + NB * NBP + 5 * NB + NB) * sizeof(double);
-    { HookScope _h(P, KID_LDL_BACKSOLVE); hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(256), lds, st, P.S, P.rhs, P.Dfac, P.delta_s, P.n_pad, P.nT); }
+    const size_t lds = ((size_t)P.n_pad + 10 * NB + NB) * sizeof(double);
+    static size_t granted_bs = 48 * 1024;
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_backsolve), lds, granted_bs);
+    { HookScope _h(P, KID_LDL_BACKSOLVE); hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(1024), lds, st, P.S, P.rhs, P.Dfac, P.Minv, P.delta_s, P.n_pad, P.nT); }
 }
 
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) {

@@ -148,7 +148,7 @@ def main():
 
     # ---- per-kernel device time: a second, instrumented pass over the same steps (HIP events on the library's stream) ----
     roofline, kernels = None, None
-    A, F, n_pad = ds.num_cams + ds.num_markers, ds.num_frames, ((6 * (ds.num_cams + ds.num_markers) + 47) // 48) * 48
+    A, F, n_pad = ds.num_cams + ds.num_markers, ds.num_frames, ((6 * (ds.num_cams + ds.num_markers) + 95) // 96) * 96
     if not args.no_kernel_profile:
         problem.set_kernel_profiling(True)
         run_steps(problem, ds.x_full, args.steps, params)
