@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -87,8 +88,9 @@ struct aar_problem {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
-    double *h_scal = nullptr;   // pinned [8]
-    int32_t *h_flags = nullptr; // pinned [4]
+    double *h_scal = nullptr;   // pinned, mapped [10]: 8 scalars | flags | sequence number (written by the device)
+    int32_t h_flags[4] = {0, 0, 0, 0};
+    unsigned long long seq = 0;
     double *d_frames_all = nullptr;  // [6 F_global] gather buffer (multi-GPU)
     double *d_diag = nullptr;        // [n_pad]
     std::vector<double> h_z;    // staging [6A + 6F_loc]
@@ -96,9 +98,11 @@ struct aar_problem {
     std::vector<int32_t> h_fslot_start, h_fslot_ent;
     // LM state (SparseLevMarq members, libs/sparselevmarq.h:129-136)
     aar_lm_params prm;
-    int cur = 0;
+    int cur = 0;                       // pose buffer / block set of curr_z
     double mu = -1, v = 2, currErr = 0, prevErr = 0;
     bool lm_ready = false;
+    bool blocks_valid = false;         // blk[cur] holds J^T J blocks and B at z[cur], S not yet eliminated
+    double vinv_mu = -1;               // damping for which blk[cur].Vinv / hf are valid (< 0: none)
     int64_t trial_points = 0, launches = 0;
     aar_stage_times times;
     bool stage_timers = false;
@@ -257,74 +261,121 @@ int check_async(const char *what) {
     return AAR_OK;
 }
 
-// J^T J blocks and B at z[which]: the "J", "transpose", "Jt*J", "B" stages of libs/sparselevmarq.h:353-367
-int eval_blocks(aar_problem *pb, int which) {
+int zero_block_set(aar_problem *pb, int which) {
     DeviceProblem &P = pb->P;
-    {
-        StageTimer t(pb, &pb->times.unpack);
-        launch_unpack(P, which, true, pb->stream);
+    HIP_TRY(hipMemsetAsync(P.blk[which].S, 0, (size_t)P.n_pad * P.n_pad * sizeof(double), pb->stream));
+    HIP_TRY(hipMemsetAsync(P.blk[which].rhs, 0, (size_t)P.n_pad * sizeof(double), pb->stream));
+    HIP_TRY(hipMemsetAsync(P.blk[which].g0, 0, (size_t)P.n_pad * sizeof(double), pb->stream));
+    return AAR_OK;
+}
+
+// J^T J blocks and B at z[which] into blk[which] (whose S, rhs, g0 must be zero): the "J", "transpose", "Jt*J", "B"
+// stages of libs/sparselevmarq.h:353-367.  Pass A also leaves the per-frame sums of r^2 in err_part and, for
+// mu_pred >= 0, (V_f + mu_pred I)^-1; zero_blk >= 0 clears that block set on the way.
+int eval_blocks(aar_problem *pb, int which, double mu_pred, int zero_blk) {
+    DeviceProblem &P = pb->P;
+    if (P.F == 0 && zero_blk >= 0) {  // a rank without frames launches no pass A: clear the dead block set here
+        int rc = zero_block_set(pb, zero_blk);
+        if (rc) return rc;
     }
     {
         StageTimer t(pb, &pb->times.jacobian_normal_eq);
-        launch_passA(P, which, pb->stream);
+        launch_passA(P, which, mu_pred, zero_blk, pb->stream);
         launch_passB(P, which, pb->stream);
     }
-    pb->launches += 3;
+    pb->launches += 2;
     return check_async("normal-equation kernels");
 }
 
-// one damped solve + trial residual: fills h_scal / h_flags; z[1-cur] = z[cur] + delta
-int damped_try(aar_problem *pb, double mu, bool with_residual) {
+// Wait for the device to publish record `seq` into the mapped host buffer.  Spinning on the sequence word avoids the
+// two blit kernels and the interrupt latency of memcpy + hipStreamSynchronize on the per-try critical path.
+int wait_result(aar_problem *pb) {
+    volatile unsigned long long *sq = reinterpret_cast<volatile unsigned long long *>(pb->h_scal) + 9;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*sq != pb->seq) {
+        if ((++spins & 0x3fff) == 0) {
+            if (hipStreamQuery(pb->stream) == hipSuccess && *sq != pb->seq) {
+                // the stream drained but the record is stale: an asynchronous failure
+                hipError_t e = hipGetLastError();
+                return set_error(AAR_ERR_HIP, "device did not publish its result: %s", hipGetErrorString(e));
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
+                return set_error(AAR_ERR_HIP, "timed out waiting for the device result");
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    pb->h_flags[0] = (int32_t)reinterpret_cast<volatile long long *>(pb->h_scal)[8];
+    if (pb->profiling || pb->stage_timers) {
+        HIP_TRY(hipStreamSynchronize(pb->stream));
+        prof_harvest(pb);
+    }
+    return AAR_OK;
+}
+
+int read_scalars(aar_problem *pb, int n_err) {
     DeviceProblem &P = pb->P;
-    const int cur = pb->cur, tr = 1 - cur;
-    {
-        StageTimer t(pb, &pb->times.schur);
-        launch_frame_inv(P, mu, pb->stream);
-        launch_schur(P, pb->stream);
-    }
-    if (pb->comm) {
-        StageTimer t(pb, &pb->times.allreduce);
-        int rc = allreduce(pb, P.S, (size_t)P.n_pad * P.n_pad, NCCL_SUM);
-        if (rc) return rc;
-        rc = allreduce(pb, P.rhs, (size_t)P.n_pad, NCCL_SUM);
-        if (rc) return rc;
-    }
-    {
-        StageTimer t(pb, &pb->times.chol);
-        launch_chol(P, mu, pb->stream);
-    }
-    {
-        StageTimer t(pb, &pb->times.backsub);
-        launch_backsub(P, cur, tr, pb->stream);
-    }
-    pb->launches += 3 + 2 * P.nT;
-    if (with_residual) {
-        {
-            StageTimer t(pb, &pb->times.unpack);
-            launch_unpack(P, tr, false, pb->stream);
-        }
-        {
-            StageTimer t(pb, &pb->times.residual);
-            launch_residual(P, tr, nullptr, pb->stream);
-        }
-        pb->launches += 2;
-        pb->trial_points++;
-    }
+    pb->seq++;
     {
         StageTimer t(pb, &pb->times.control);
-        launch_reduce_scalars(P, pb->comm != nullptr, pb->stream);
+        launch_reduce_scalars(P, n_err, pb->comm != nullptr, pb->comm ? 0ull : pb->seq, pb->stream);
         pb->launches += 1;
     }
     if (pb->comm) {
         StageTimer t(pb, &pb->times.allreduce);
         int rc = allreduce(pb, P.scal, 3, NCCL_SUM);  // [sum r^2, sum |delta_f|^2, sum delta.g]
         if (rc) return rc;
+        launch_publish(P, pb->seq, pb->stream);
     }
-    HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-    HIP_TRY(hipMemcpyAsync(pb->h_flags, P.flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
-    HIP_TRY(hipStreamSynchronize(pb->stream));
-    prof_harvest(pb);
-    int rc = check_async("damped solve kernels");
+    int rc = check_async("kernel launch");
+    if (rc) return rc;
+    return wait_result(pb);
+}
+
+// One damped solve from blk[cur] (valid, un-eliminated) and the evaluation of the trial point:
+//   Schur complement -> [all-reduce] -> LDL^T -> back-substitution -> z[1-cur] = z[cur] + delta
+//   -> pass A / pass B at the trial point into blk[1-cur] (speculative: they ARE the next step's Jacobian pass when the
+//      trial is accepted, and the trial's sum r^2 comes out of pass A) -> scalars to the host.
+// blk[cur].S/rhs are consumed; pass A clears them together with blk[cur].g0 on the way.
+int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
+    DeviceProblem &P = pb->P;
+    const int cur = pb->cur, tr = 1 - cur;
+    {
+        StageTimer t(pb, &pb->times.schur);
+        if (pb->vinv_mu != mu) {
+            launch_frame_inv(P, cur, mu, pb->stream);
+            pb->vinv_mu = mu;
+            pb->launches += 1;
+        }
+        launch_schur(P, cur, pb->stream);
+    }
+    if (pb->comm) {
+        StageTimer t(pb, &pb->times.allreduce);
+        int rc = allreduce(pb, P.blk[cur].S, (size_t)P.n_pad * P.n_pad, NCCL_SUM);
+        if (rc) return rc;
+        rc = allreduce(pb, P.blk[cur].rhs, (size_t)P.n_pad, NCCL_SUM);
+        if (rc) return rc;
+    }
+    {
+        StageTimer t(pb, &pb->times.chol);
+        launch_chol(P, cur, mu, pb->stream);
+    }
+    {
+        StageTimer t(pb, &pb->times.backsub);
+        launch_backsub(P, cur, tr, pb->stream);
+    }
+    pb->launches += 3 + 2 * P.nT;
+    pb->blocks_valid = false;  // S of the current point has been eliminated in place
+    if (evaluate_trial) {
+        // predicted damping of the next step: every accepted step of the reference's rule with gain >= 0.94 gives 0.33 mu
+        int rc = eval_blocks(pb, tr, mu * 0.33, cur);
+        if (rc) return rc;
+        pb->trial_points++;
+    } else {
+        HIP_TRY(hipMemsetAsync(P.err_part, 0, sizeof(double) * (size_t)std::max(P.F, 1), pb->stream));
+    }
+    int rc = read_scalars(pb, P.F);
     if (rc) return rc;
     if (pb->h_flags[0]) {
         (void)hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream);
@@ -333,29 +384,44 @@ int damped_try(aar_problem *pb, double mu, bool with_residual) {
     return AAR_OK;
 }
 
+// Rebuild the blocks of the current point after a rejected try consumed them (rare): everything the trial wrote into
+// blk[1-cur] is garbage as well.
+int rebuild_current(aar_problem *pb) {
+    int rc = zero_block_set(pb, pb->cur);
+    if (rc) return rc;
+    if ((rc = zero_block_set(pb, 1 - pb->cur))) return rc;
+    if ((rc = eval_blocks(pb, pb->cur, -1.0, -1))) return rc;
+    pb->blocks_valid = true;
+    pb->vinv_mu = -1;
+    return AAR_OK;
+}
+
 int initial_mu(aar_problem *pb, double tau, double *mu) {
     DeviceProblem &P = pb->P;
+    const int cur = pb->cur;
     if (pb->comm) {
         // the diagonal of the shared blocks is a sum over ranks; the frame blocks are rank-local
-        HIP_TRY(hipMemcpy2DAsync(pb->d_diag, sizeof(double), P.U0, (size_t)(P.n_pad + 1) * sizeof(double), sizeof(double),
+        HIP_TRY(hipMemcpy2DAsync(pb->d_diag, sizeof(double), P.blk[cur].S, (size_t)(P.n_pad + 1) * sizeof(double), sizeof(double),
                                  P.n_pad, hipMemcpyDeviceToDevice, pb->stream));
         int rc = allreduce(pb, pb->d_diag, P.n_pad, NCCL_SUM);
         if (rc) return rc;
-        HIP_TRY(hipMemcpy2DAsync(P.S, (size_t)(P.n_pad + 1) * sizeof(double), pb->d_diag, sizeof(double), sizeof(double),
+        // the trial block set's S is zero and unused at this point: borrow its diagonal for the summed values
+        HIP_TRY(hipMemcpy2DAsync(P.blk[1 - cur].S, (size_t)(P.n_pad + 1) * sizeof(double), pb->d_diag, sizeof(double), sizeof(double),
                                  P.n_pad, hipMemcpyDeviceToDevice, pb->stream));
-        // S is scratch here (it is rebuilt from U0 by every damped_try); read the summed diagonal from it
         DeviceProblem Q = P;
-        Q.U0 = P.S;
-        launch_maxdiag(Q, pb->stream);
+        Q.blk[cur].S = P.blk[1 - cur].S;
+        launch_maxdiag(Q, cur, pb->stream);
+        HIP_TRY(hipMemsetAsync(P.blk[1 - cur].S, 0, (size_t)P.n_pad * P.n_pad * sizeof(double), pb->stream));
         rc = allreduce(pb, P.scal + 4, 1, NCCL_MAX);
         if (rc) return rc;
     } else {
-        launch_maxdiag(P, pb->stream);
+        launch_maxdiag(P, cur, pb->stream);
     }
     pb->launches += 1;
-    HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-    HIP_TRY(hipStreamSynchronize(pb->stream));
-    prof_harvest(pb);
+    pb->seq++;
+    launch_publish(P, pb->seq, pb->stream);
+    int rc2 = wait_result(pb);
+    if (rc2) return rc2;
     *mu = pb->h_scal[4] * tau;
     return AAR_OK;
 }
@@ -424,7 +490,6 @@ void aar_problem_destroy(aar_problem *pb) {
     if (pb->stream) (void)hipStreamSynchronize(pb->stream);
     for (void *p : pb->allocs) (void)hipFree(p);
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
-    if (pb->h_flags) (void)hipHostFree(pb->h_flags);
     if (pb->ev[0]) (void)hipEventDestroy(pb->ev[0]);
     if (pb->ev[1]) (void)hipEventDestroy(pb->ev[1]);
     for (hipEvent_t e : pb->ev_pool) (void)hipEventDestroy(e);
@@ -528,8 +593,8 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         fslot_start[F] = (int32_t)fslot_ent.size();
     }
     P.total_slots = (int)fslot_ent.size();
-    const size_t ldsA = ((size_t)P.max_kf * 36 + 32 + 4 * 2048) * sizeof(double);
-    if (ldsA > 160 * 1024) return fail(set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers; the frame-block kernel holds them in LDS (limit ~ %d)", P.max_kf, (160 * 1024 / 8 - 32 - 8192) / 36));
+    const size_t ldsA = ((size_t)P.max_kf * 36 + 32 + (size_t)(P.max_kf + 1) * ENT_STRIDE + 4 * 2048) * sizeof(double);
+    if (ldsA > 160 * 1024) return fail(set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers; the frame-block kernel holds them in LDS (limit ~ %d)", P.max_kf, (160 * 1024 / 8 - 56 - 8192) / 60));
     if ((size_t)A * 36 * 8 + 2048 > 160 * 1024) return fail(set_error(AAR_ERR_UNSUPPORTED, "%d cameras+markers exceed the Schur row panel held in LDS", A));
 
     // ---- ordering B: (camera, marker, frame) runs cut into wave-sized chunks ----
@@ -594,18 +659,22 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
 #define AL(field, count) if ((rc = dev_alloc(pb, &P.field, (size_t)(count)))) return fail(rc)
     AL(z[0], 6 * (size_t)(A + F)); AL(z[1], 6 * (size_t)(A + F));
     AL(ent[0], (size_t)(A + F) * ENT_STRIDE); AL(ent[1], (size_t)(A + F) * ENT_STRIDE);
-    AL(V, (size_t)F * 36); AL(gf, (size_t)F * 6); AL(W, (size_t)P.total_slots * 36);
-    AL(Vinv, (size_t)F * 36); AL(hf, (size_t)F * 6);
-    AL(U0, (size_t)P.n_pad * P.n_pad); AL(g0, P.n_pad); AL(S, (size_t)P.n_pad * P.n_pad); AL(rhs, P.n_pad);
+    for (int w = 0; w < 2; w++) {
+        AL(blk[w].V, (size_t)F * 36); AL(blk[w].gf, (size_t)F * 6); AL(blk[w].W, (size_t)P.total_slots * 36);
+        AL(blk[w].Vinv, (size_t)F * 36); AL(blk[w].hf, (size_t)F * 6);
+        AL(blk[w].S, (size_t)P.n_pad * P.n_pad); AL(blk[w].rhs, P.n_pad); AL(blk[w].g0, P.n_pad);
+    }
     AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Minv, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(delta_s, P.n_pad);
     AL(err_part, std::max<size_t>((size_t)F, (size_t)((N + 255) / 256)) + 1);
     AL(lin_part, 2 * (size_t)(F + 1)); AL(scal, 8); AL(flags, 4);
 #undef AL
     if ((rc = dev_alloc(pb, &pb->d_diag, P.n_pad))) return fail(rc);
     if (pb->comm && (rc = dev_alloc(pb, &pb->d_frames_all, 6 * (size_t)std::max(Fg, 1)))) return fail(rc);
-    if (hipHostMalloc((void **)&pb->h_scal, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&pb->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc((void **)&pb->h_scal, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
         return fail(set_error(AAR_ERR_HIP, "hipHostMalloc failed"));
+    memset(pb->h_scal, 0, 16 * sizeof(double));
+    if (hipHostGetDevicePointer((void **)&P.host_result, pb->h_scal, 0) != hipSuccess)
+        return fail(set_error(AAR_ERR_HIP, "hipHostGetDevicePointer failed"));
     if (hipStreamSynchronize(pb->stream) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "upload failed"));
     pb->h_fslot_start = fslot_start;
     pb->h_fslot_ent = fslot_ent;
@@ -626,15 +695,17 @@ int aar_eval_residuals(aar_problem *pb, const double *x_full, double *r, double 
     if (rc) return rc;
     double *d_r = nullptr;
     if (r) HIP_TRY(hipMalloc((void **)&d_r, std::max<size_t>(1, 8 * (size_t)P.N) * sizeof(double)));
-    launch_unpack(P, pb->cur, false, pb->stream);
+    launch_unpack(P, pb->cur, pb->stream);
     launch_residual(P, pb->cur, d_r, pb->stream);
     HIP_TRY(hipMemsetAsync(P.lin_part, 0, 2 * (size_t)(P.F + 1) * sizeof(double), pb->stream));
-    launch_reduce_scalars(P, false, pb->stream);
+    launch_reduce_scalars(P, residual_blocks(P), false, 0ull, pb->stream);
     rc = allreduce(pb, P.scal, 1, NCCL_SUM);
     if (rc) { if (d_r) (void)hipFree(d_r); return rc; }
-    HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    pb->seq++;
+    launch_publish(P, pb->seq, pb->stream);
     if (r) HIP_TRY(hipMemcpyAsync(r, d_r, 8 * (size_t)P.N * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
     HIP_TRY(hipStreamSynchronize(pb->stream));
+    if ((rc = wait_result(pb))) { if (d_r) (void)hipFree(d_r); return rc; }
     if (d_r) (void)hipFree(d_r);
     if (sum_sq) *sum_sq = pb->h_scal[0];
     pb->lm_ready = false;
@@ -662,15 +733,17 @@ int aar_eval_normal_equations(aar_problem *pb, const double *x_full, double *JtJ
     const PoseLayout &L = pb->L;
     int rc = upload_z(pb, x_full, pb->cur);
     if (rc) return rc;
-    if ((rc = eval_blocks(pb, pb->cur))) return rc;
+    if ((rc = zero_block_set(pb, pb->cur))) return rc;
+    if ((rc = eval_blocks(pb, pb->cur, -1.0, -1))) return rc;
     const int A = P.A, F = P.F, np = P.n_pad;
+    const DeviceProblem::Blocks &bk = P.blk[pb->cur];
     std::vector<double> U0((size_t)np * np), g0(np), V((size_t)F * 36), gf((size_t)F * 6), W((size_t)P.total_slots * 36), ep(F);
-    HIP_TRY(hipMemcpyAsync(U0.data(), P.U0, U0.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-    HIP_TRY(hipMemcpyAsync(g0.data(), P.g0, g0.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipMemcpyAsync(U0.data(), bk.S, U0.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipMemcpyAsync(g0.data(), bk.g0, g0.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
     if (F) {
-        HIP_TRY(hipMemcpyAsync(V.data(), P.V, V.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-        HIP_TRY(hipMemcpyAsync(gf.data(), P.gf, gf.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-        HIP_TRY(hipMemcpyAsync(W.data(), P.W, W.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+        HIP_TRY(hipMemcpyAsync(V.data(), bk.V, V.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+        HIP_TRY(hipMemcpyAsync(gf.data(), bk.gf, gf.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+        HIP_TRY(hipMemcpyAsync(W.data(), bk.W, W.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
         HIP_TRY(hipMemcpyAsync(ep.data(), P.err_part, ep.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
     }
     HIP_TRY(hipStreamSynchronize(pb->stream));
@@ -741,7 +814,9 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     const PoseLayout &L = pb->L;
     int rc = upload_z(pb, x_full, pb->cur);
     if (rc) return rc;
-    if ((rc = eval_blocks(pb, pb->cur))) return rc;
+    if ((rc = zero_block_set(pb, pb->cur))) return rc;
+    if ((rc = eval_blocks(pb, pb->cur, -1.0, -1))) return rc;
+    pb->vinv_mu = -1;
     if ((rc = damped_try(pb, mu, false))) return rc;
     pb->lm_ready = false;
     std::vector<double> x0(x_full, x_full + L.full_len()), x1(x0);
@@ -754,31 +829,30 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     return AAR_OK;
 }
 
-// SparseLevMarq::init, libs/sparselevmarq.h:238-249
+// SparseLevMarq::init, libs/sparselevmarq.h:238-249.  The residual of the start point comes out of the same pass that
+// builds its normal equations (the first step() needs them anyway).
 int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm) {
     if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_lm_init: null argument");
     HIP_TRY(hipSetDevice(pb->device));
     if (prm) pb->prm = *prm;
     DeviceProblem &P = pb->P;
     pb->cur = 0;
-    int rc = upload_z(pb, x_full, 0);
-    if (rc) return rc;
-    launch_unpack(P, 0, false, pb->stream);
-    launch_residual(P, 0, nullptr, pb->stream);
-    HIP_TRY(hipMemsetAsync(P.lin_part, 0, 2 * (size_t)(P.F + 1) * sizeof(double), pb->stream));
-    launch_reduce_scalars(P, false, pb->stream);
-    if ((rc = allreduce(pb, P.scal, 1, NCCL_SUM))) return rc;
-    HIP_TRY(hipMemcpyAsync(pb->h_scal, P.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-    HIP_TRY(hipStreamSynchronize(pb->stream));
-    prof_harvest(pb);
-    if ((rc = check_async("lm_init kernels"))) return rc;
-    pb->currErr = pb->prevErr = pb->h_scal[0];
-    pb->mu = -1;
-    pb->v = 2;  // indeterminate in the reference (libs/sparselevmarq.h:133); every accepted step sets 2 (:411)
-    pb->lm_ready = true;
     pb->trial_points = 0;
     pb->launches = 0;
     memset(&pb->times, 0, sizeof pb->times);
+    int rc = upload_z(pb, x_full, 0);
+    if (rc) return rc;
+    if ((rc = zero_block_set(pb, 0))) return rc;
+    if ((rc = zero_block_set(pb, 1))) return rc;
+    if ((rc = eval_blocks(pb, 0, -1.0, -1))) return rc;
+    HIP_TRY(hipMemsetAsync(P.lin_part, 0, 2 * (size_t)(P.F + 1) * sizeof(double), pb->stream));
+    if ((rc = read_scalars(pb, P.F))) return rc;
+    pb->currErr = pb->prevErr = pb->h_scal[0];
+    pb->blocks_valid = true;
+    pb->vinv_mu = -1;
+    pb->mu = -1;
+    pb->v = 2;  // indeterminate in the reference (libs/sparselevmarq.h:133); every accepted step sets 2 (:411)
+    pb->lm_ready = true;
     return AAR_OK;
 }
 
@@ -787,33 +861,37 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
     if (!pb) return set_error(AAR_ERR_INVALID, "aar_lm_step: null argument");
     if (!pb->lm_ready) return set_error(AAR_ERR_INVALID, "aar_lm_step: call aar_lm_init first");
     HIP_TRY(hipSetDevice(pb->device));
-    int rc = eval_blocks(pb, pb->cur);  // J, Jt*J, B at curr_z (:353-367)
-    if (rc) return rc;
-    if (pb->mu < 0) {                   // first time only (:369-377)
+    int rc;
+    if (!pb->blocks_valid && (rc = rebuild_current(pb))) return rc;  // J, Jt*J, B at curr_z (:353-367)
+    if (pb->mu < 0) {                                                  // first time only (:369-377)
         if ((rc = initial_mu(pb, pb->prm.tau, &pb->mu))) return rc;
     }
     double gain = 0, dnorm = 0;
     int ntries = 0;
     bool accepted = false;
     do {
-        if ((rc = damped_try(pb, pb->mu, true))) return rc;
+        if (!pb->blocks_valid && (rc = rebuild_current(pb))) return rc;  // a rejected try consumed them
+        const double mu_used = pb->mu;
+        if ((rc = damped_try(pb, mu_used, true))) return rc;
         const double *sc = pb->h_scal;
         const double err = sc[0];
         // L = 0.5 * delta^T (mu*delta - B) (:406); frame pieces were summed over ranks, the shared-parameter
         // |delta|^2 is replicated and counted once, its delta.g piece is part of the rank sum
         const double d2 = sc[1] + sc[5];
         const double dg = pb->comm ? sc[2] : sc[2] + sc[6];
-        const double Lq = 0.5 * (pb->mu * d2 - dg);
+        const double Lq = 0.5 * (mu_used * d2 - dg);
         dnorm = std::sqrt(d2);
         gain = (err - pb->prevErr) / Lq;
         if (gain > 0 && ((err - pb->prevErr) < 0)) {  // :409-415
-            pb->mu = pb->mu * std::max(0.33, 1. - std::pow(2 * gain - 1, 3));
+            pb->mu = mu_used * std::max(0.33, 1. - std::pow(2 * gain - 1, 3));
             pb->v = 2.f;
             pb->currErr = err;
-            pb->cur = 1 - pb->cur;  // curr_z = estimated_z
+            pb->cur = 1 - pb->cur;  // curr_z = estimated_z; its blocks were built speculatively by the try
+            pb->blocks_valid = true;
+            pb->vinv_mu = mu_used * 0.33;  // what pass A inverted for
             accepted = true;
         } else {
-            pb->mu = pb->mu * pb->v;
+            pb->mu = mu_used * pb->v;
             pb->v = pb->v * 5;
         }
     } while (gain <= 0 && ntries++ < 5 && !accepted);

@@ -1,8 +1,9 @@
 // HIP kernels (gfx950, wave64) for the observation passes of one LM iteration:
-//   k_unpack    z -> per-entity {R, t, J_l}            (eVec2Mats, libs/multicam_mapper.cpp:595-606)
-//   k_residual  sum of squared residuals of a trial point (error_function, :731-737, :996-1028)
-//   k_passA     frame-owned blocks V_f, g_f, W_cf, W_mf   \  together: J^T J and B = -J^T r of
-//   k_passB     shared blocks U_cc, U_mm, W_cm, g_c, g_m  /  libs/sparselevmarq.h:355-367 in block form
+//   k_passA     z -> per-entity {R, t, J_l} staged in LDS (eVec2Mats, libs/multicam_mapper.cpp:595-606), then the
+//               frame-owned blocks V_f, g_f, W_cf, W_mf, the frame's sum r^2 (error_function, :731-737) and
+//               (V_f + mu I)^-1 for the predicted damping        \  together: J^T J and B = -J^T r of
+//   k_passB     shared blocks U_cc, U_mm, W_cm, g_c, g_m         /  libs/sparselevmarq.h:355-367 in block form
+//   k_unpack, k_residual   residual rows only (aar_eval_residuals)
 // The reference builds J by central differences and multiplies sparse matrices; here each observation's
 // analytic 8x18 Jacobian lives only in registers and its 6x6 block products are reduced on chip.
 // fp64 throughout.  No atomics on frame-owned data; shared blocks get one fp64 atomic per value per
@@ -42,13 +43,9 @@ __device__ __forceinline__ void wave_sum_lds(const double (&vals)[NV], double *_
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void k_unpack(const double *__restrict__ z, double *__restrict__ ent, int n_ent, double *__restrict__ zero_a,
-                         int64_t zero_a_n, double *__restrict__ zero_b, int64_t zero_b_n) {
+__global__ void k_unpack(const double *__restrict__ z, double *__restrict__ ent, int n_ent) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     if (gid < n_ent) make_ent_row(z + 6 * gid, ent + gid * ENT_STRIDE);
-    for (int64_t i = gid; i < zero_a_n; i += stride) zero_a[i] = 0.0;
-    for (int64_t i = gid; i < zero_b_n; i += stride) zero_b[i] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -94,36 +91,69 @@ __global__ void __launch_bounds__(256) k_residual(const ObsIdx *__restrict__ idx
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pass A: one workgroup per frame.  Threads stride over the frame's observations.  Frame-owned
-// accumulators: V_f (symmetric 6x6), g_f, sum r^2 in registers -> wave sum -> LDS; W_cf / W_mf blocks
-// accumulate in LDS (ds_add_f64) at the frame-local slot of the camera / marker and leave as one
-// coalesced copy.  Nothing here is shared with another workgroup, so there are no global atomics.
-// LDS: [max_kf*36] W blocks | [28] V,g,err | [nwaves*2048] wave-sum scratch
+__device__ __forceinline__ void load_ent_lds(const double *row, Ent &e) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) e.R[i] = row[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) e.t[i] = row[9 + i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) e.Jl[i] = row[12 + i];
+}
+
 // ------------------------------------------------------------------------------------------------
+// Pass A: one workgroup per frame.  The SE(3) parameters of everything the frame touches (its own pose and the
+// k_f cameras / markers of its slot list) are turned into {R, t, J_l} rows in LDS first; threads then stride over
+// the frame's observations.  Frame-owned accumulators: V_f (symmetric 6x6), g_f, sum r^2 in registers -> wave sum ->
+// LDS; W_cf / W_mf blocks accumulate in LDS (ds_add_f64) at the frame-local slot of the camera / marker and leave as
+// one coalesced copy.  Nothing here is shared with another workgroup: no global atomics.  The epilogue inverts
+// V_f + mu_pred I (the damping the NEXT solve is expected to use) and clears a dead block set grid-stride.
+// LDS: [max_kf*36] W blocks | [32] V,g,err | [(max_kf+1)*24] entity rows | [nwaves*2048] wave-sum scratch
+// ------------------------------------------------------------------------------------------------
+struct PassAArgs {
+    const ObsIdx *idx; const float *uv; const double *z; const double *Kmat;
+    const int32_t *frame_obs_start, *fslot_start, *fslot_ent;
+    int A, F, res_f32, max_kf, frames_fixed;
+    double h, mu_pred;
+    double *ent_out, *V, *gf, *W, *Vinv, *hf, *err_part;
+    double *zero0; int64_t zero0_n; double *zero1; int64_t zero1_n; double *zero2; int64_t zero2_n;
+    int32_t *flags;
+};
+
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_passA(const ObsIdx *__restrict__ idx, const float *__restrict__ uv,
-                                                 const double *__restrict__ ent, const double *__restrict__ Kmat,
-                                                 const int32_t *__restrict__ frame_obs_start,
-                                                 const int32_t *__restrict__ fslot_start, int A, double h, int res_f32,
-                                                 int max_kf, double *__restrict__ Vout, double *__restrict__ gout,
-                                                 double *__restrict__ Wout, double *__restrict__ err_part) {
+__global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
     extern __shared__ double lds[];
-    double *Wl = lds;                       // [kf][36]
-    double *acc = lds + (size_t)max_kf * 36;  // [28]
-    double *scratch = acc + 32;             // [BLOCK/64][2048]
+    double *Wl = lds;                                   // [kf][36]
+    double *acc = lds + (size_t)a.max_kf * 36;            // [32]
+    double *entl = acc + 32;                            // [(max_kf+1)][24]
+    double *scratch = entl + (size_t)(a.max_kf + 1) * ENT_STRIDE;  // [BLOCK/64][2048]
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int o0 = frame_obs_start[f], o1 = frame_obs_start[f + 1];
-    const int s0 = fslot_start[f], kf = fslot_start[f + 1] - s0;
+    const int o0 = a.frame_obs_start[f], o1 = a.frame_obs_start[f + 1];
+    const int s0 = a.fslot_start[f], kf = a.fslot_start[f + 1] - s0;
     for (int i = tid; i < kf * 36; i += BLOCK) Wl[i] = 0.0;
     if (tid < 32) acc[tid] = 0.0;
+    // entity rows of this frame's slot list (+ the frame itself at row kf), also published to the global table:
+    // the frame row by its own workgroup, shared row e by workgroup e % F
+    for (int t = tid; t <= kf; t += BLOCK) {
+        const int e = (t < kf) ? a.fslot_ent[s0 + t] : a.A + f;
+        make_ent_row(a.z + 6 * (size_t)e, entl + (size_t)t * ENT_STRIDE);
+    }
+    for (int e = f + tid * a.F; e < a.A; e += BLOCK * a.F) make_ent_row(a.z + 6 * (size_t)e, a.ent_out + (size_t)e * ENT_STRIDE);
+    // grid-stride clearing of the block set that is dead by now
+    {
+        const int64_t gid = (int64_t)blockIdx.x * BLOCK + tid, stride = (int64_t)gridDim.x * BLOCK;
+        for (int64_t i = gid; i < a.zero0_n; i += stride) a.zero0[i] = 0.0;
+        for (int64_t i = gid; i < a.zero1_n; i += stride) a.zero1[i] = 0.0;
+        for (int64_t i = gid; i < a.zero2_n; i += stride) a.zero2[i] = 0.0;
+    }
     __syncthreads();
+    if (tid < ENT_STRIDE) a.ent_out[(size_t)(a.A + f) * ENT_STRIDE + tid] = entl[(size_t)kf * ENT_STRIDE + tid];
 
     double vals[28];  // 21 V (packed lower), 6 g, 1 err
 #pragma unroll
     for (int i = 0; i < 28; i++) vals[i] = 0.0;
 
     Ent ef;
-    load_ent(ent, A + f, ef);
+    load_ent_lds(entl + (size_t)kf * ENT_STRIDE, ef);
     const int nobs = o1 - o0;
     // Interleaved assignment: consecutive lanes take observations `stride` apart so that lanes of one wave
     // mostly hold different cameras (the order inside a frame is camera-major); this keeps the ds_add_f64
@@ -132,33 +162,34 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const ObsIdx *__restrict__ idx,
     if (nobs > 16) {
         stride = nobs / 8 + 1;
         while (true) {  // gcd(stride, nobs) == 1
-            int a = stride, b = nobs;
-            while (b) { int t = a % b; a = b; b = t; }
-            if (a == 1) break;
+            int x = stride, y = nobs;
+            while (y) { int t = x % y; x = y; y = t; }
+            if (x == 1) break;
             stride++;
         }
     }
     for (int it = tid; it < nobs; it += BLOCK) {
         const int o = o0 + (int)(((int64_t)it * stride) % nobs);
-        const ObsIdx id = idx[o];
-        const float4 uv0 = reinterpret_cast<const float4 *>(uv)[2 * (int64_t)o];
-        const float4 uv1 = reinterpret_cast<const float4 *>(uv)[2 * (int64_t)o + 1];
+        const ObsIdx id = a.idx[o];
+        const float4 uv0 = reinterpret_cast<const float4 *>(a.uv)[2 * (int64_t)o];
+        const float4 uv1 = reinterpret_cast<const float4 *>(a.uv)[2 * (int64_t)o + 1];
         const float ou[8] = {uv0.x, uv0.y, uv0.z, uv0.w, uv1.x, uv1.y, uv1.z, uv1.w};
+        const int sc = id.slots & 0xffff, sm = (id.slots >> 16) & 0xffff;
         Ent ec, em;
-        load_ent(ent, id.cam, ec);
-        load_ent(ent, id.marker, em);
+        load_ent_lds(entl + (size_t)sc * ENT_STRIDE, ec);
+        load_ent_lds(entl + (size_t)sm * ENT_STRIDE, em);
         double K[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) K[i] = Kmat[9 * id.cam + i];
+        for (int i = 0; i < 9; i++) K[i] = a.Kmat[9 * id.cam + i];
         double Wc[36], Wm[36];
 #pragma unroll
         for (int i = 0; i < 36; i++) { Wc[i] = 0.0; Wm[i] = 0.0; }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             CornerGeom g;
-            project_corner(ec, em, ef, K, h, k, g);
+            project_corner(ec, em, ef, K, a.h, k, g);
             double r[2];
-            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, res_f32, r[0], r[1]);
+            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, a.res_f32, r[0], r[1]);
             double Gc[2][6], Gm[2][6], Gf[2][6];
             corner_jacobian<true, true, true>(ec, em, ef, K, g, Gc, Gm, Gf);
 #pragma unroll
@@ -177,8 +208,8 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const ObsIdx *__restrict__ idx,
                 }
             }
         }
-        double *wc = Wl + (id.slots & 0xffff) * 36;
-        double *wm = Wl + ((id.slots >> 16) & 0xffff) * 36;
+        double *wc = Wl + sc * 36;
+        double *wm = Wl + sm * 36;
 #pragma unroll
         for (int i = 0; i < 36; i++) atomicAdd(wc + i, Wc[i]);
 #pragma unroll
@@ -188,13 +219,37 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const ObsIdx *__restrict__ idx,
     wave_sum_lds<28>(vals, scratch + wave * 2048, lane, [&](int i, double s) { atomicAdd(acc + i, s); });
     __syncthreads();
     // coalesced write-out
-    for (int i = tid; i < kf * 36; i += BLOCK) Wout[(size_t)s0 * 36 + i] = Wl[i];
+    for (int i = tid; i < kf * 36; i += BLOCK) a.W[(size_t)s0 * 36 + i] = Wl[i];
     if (tid < 36) {
         const int i = tid / 6, j = tid % 6;
-        Vout[(size_t)f * 36 + tid] = acc[sym6(i, j)];
+        a.V[(size_t)f * 36 + tid] = acc[sym6(i, j)];
     }
-    if (tid >= 36 && tid < 42) gout[(size_t)f * 6 + (tid - 36)] = acc[21 + (tid - 36)];
-    if (tid == 0) err_part[f] = acc[27];
+    if (tid >= 36 && tid < 42) a.gf[(size_t)f * 6 + (tid - 36)] = acc[21 + (tid - 36)];
+    if (tid == 42) a.err_part[f] = acc[27];
+    if (a.mu_pred >= 0.0 && tid == 63) {  // (V_f + mu I)^-1 and h_f for the damping the next solve is expected to use
+        double out[36];
+        if (a.frames_fixed) {
+#pragma unroll
+            for (int i = 0; i < 36; i++) out[i] = 0.0;
+        } else {
+            double m[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) m[i][j] = acc[sym6(i, j)] + (i == j ? a.mu_pred : 0.0);
+            if (!spd6_inverse(m, out)) atomicOr(a.flags, 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double hv = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                a.Vinv[(size_t)f * 36 + i * 6 + j] = out[i * 6 + j];
+                hv += out[i * 6 + j] * acc[21 + j];
+            }
+            a.hf[(size_t)f * 6 + i] = hv;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -207,7 +262,7 @@ __global__ void __launch_bounds__(256) k_passB(const ObsIdx *__restrict__ idx, c
                                                const double *__restrict__ ent, const double *__restrict__ Kmat,
                                                const int32_t *__restrict__ chunk_start, int n_chunks, int A, double h,
                                                int res_f32, int n_pad, double *__restrict__ U0,
-                                               double *__restrict__ g0) {
+                                               double *__restrict__ g0) {  // U0 = blk.S (zeroed), g0 = blk.g0
     __shared__ double scratch[4 * 2048];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x * 4 + wave;
@@ -293,14 +348,9 @@ __global__ void __launch_bounds__(256) k_maxdiag(const double *__restrict__ U0, 
 }
 
 // ------------------------------------------------------------------------------------------------
-void launch_unpack(const DeviceProblem &P, int which, bool zero_shared, hipStream_t st) {
+void launch_unpack(const DeviceProblem &P, int which, hipStream_t st) {
     const int n_ent = P.A + P.F;
-    const int64_t za = zero_shared ? (int64_t)P.n_pad * P.n_pad : 0, zb = zero_shared ? P.n_pad : 0;
-    int64_t work = n_ent > za ? n_ent : za;
-    int blocks = (int)((work + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < (n_ent + 255) / 256) blocks = (n_ent + 255) / 256;
-    { HookScope _h(P, KID_UNPACK); hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(256), 0, st, P.z[which], P.ent[which], n_ent, P.U0, za, P.g0, zb); }
+    { HookScope _h(P, KID_UNPACK); hipLaunchKernelGGL(k_unpack, dim3((n_ent + 255) / 256), dim3(256), 0, st, P.z[which], P.ent[which], n_ent); }
 }
 
 void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream_t st) {
@@ -312,36 +362,48 @@ void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream
 
 int residual_blocks(const DeviceProblem &P) { return (int)((P.N + 255) / 256); }
 
-void launch_passA(const DeviceProblem &P, int which, hipStream_t st) {
+template <int B>
+static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, hipStream_t st) {
+    const size_t lds = ((size_t)P.max_kf * 36 + 32 + (size_t)(P.max_kf + 1) * ENT_STRIDE + (B / 64) * 2048) * sizeof(double);
+    static size_t granted = 48 * 1024;
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B>), lds, granted);
+    { HookScope _h(P, KID_PASSA); hipLaunchKernelGGL(k_passA<B>, dim3(P.F), dim3(B), lds, st, a); }
+}
+
+size_t passA_lds_bytes(int max_kf, int block) {
+    return ((size_t)max_kf * 36 + 32 + (size_t)(max_kf + 1) * ENT_STRIDE + (block / 64) * 2048) * sizeof(double);
+}
+
+void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st) {
     if (P.F == 0) return;
-    const double avg = (double)P.N / (double)P.F;
-    if (avg <= 96) {
-        constexpr int B = 64;
-        const size_t lds = ((size_t)P.max_kf * 36 + 32 + (B / 64) * 2048) * sizeof(double);
-        static size_t granted = 48 * 1024;
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B>), lds, granted);
-        { HookScope _h(P, KID_PASSA); hipLaunchKernelGGL(k_passA<B>, dim3(P.F), dim3(B), lds, st, P.a_idx, P.a_uv, P.ent[which], P.K,
-                           P.frame_obs_start, P.fslot_start, P.A, P.half_size, P.res_f32, P.max_kf, P.V, P.gf, P.W,
-                           P.err_part); }
-    } else {
-        constexpr int B = 256;
-        const size_t lds = ((size_t)P.max_kf * 36 + 32 + (B / 64) * 2048) * sizeof(double);
-        static size_t granted = 48 * 1024;
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B>), lds, granted);
-        { HookScope _h(P, KID_PASSA); hipLaunchKernelGGL(k_passA<B>, dim3(P.F), dim3(B), lds, st, P.a_idx, P.a_uv, P.ent[which], P.K,
-                           P.frame_obs_start, P.fslot_start, P.A, P.half_size, P.res_f32, P.max_kf, P.V, P.gf, P.W,
-                           P.err_part); }
+    PassAArgs a;
+    a.idx = P.a_idx; a.uv = P.a_uv; a.z = P.z[which]; a.Kmat = P.K;
+    a.frame_obs_start = P.frame_obs_start; a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent;
+    a.A = P.A; a.F = P.F; a.res_f32 = P.res_f32; a.max_kf = P.max_kf; a.frames_fixed = P.frames_fixed;
+    a.h = P.half_size; a.mu_pred = mu_pred;
+    const DeviceProblem::Blocks &b = P.blk[which];
+    a.ent_out = P.ent[which]; a.V = b.V; a.gf = b.gf; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf; a.err_part = P.err_part;
+    a.zero0 = a.zero1 = a.zero2 = nullptr; a.zero0_n = a.zero1_n = a.zero2_n = 0;
+    if (zero_blk >= 0) {
+        const DeviceProblem::Blocks &zb = P.blk[zero_blk];
+        a.zero0 = zb.S; a.zero0_n = (int64_t)P.n_pad * P.n_pad;
+        a.zero1 = zb.rhs; a.zero1_n = P.n_pad;
+        a.zero2 = zb.g0; a.zero2_n = P.n_pad;
     }
+    a.flags = P.flags;
+    const double avg = (double)P.N / (double)P.F;
+    if (avg <= 96) launch_passA_t<64>(P, a, st);
+    else launch_passA_t<256>(P, a, st);
 }
 
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
     if (P.n_chunks == 0) return;
     { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, P.b_idx, P.b_uv, P.ent[which], P.K,
-                       P.chunk_start, P.n_chunks, P.A, P.half_size, P.res_f32, P.n_pad, P.U0, P.g0); }
+                       P.chunk_start, P.n_chunks, P.A, P.half_size, P.res_f32, P.n_pad, P.blk[which].S, P.blk[which].g0); }
 }
 
-void launch_maxdiag(const DeviceProblem &P, hipStream_t st) {
-    { HookScope _h(P, KID_MAXDIAG); hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, st, P.U0, P.n_pad, P.A, P.ent_fixed, P.V, P.F,
+void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st) {
+    { HookScope _h(P, KID_MAXDIAG); hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, st, P.blk[which].S, P.n_pad, P.A, P.ent_fixed, P.blk[which].V, P.F,
                        P.frames_fixed, P.scal + 4); }
 }
 

@@ -197,6 +197,50 @@ __device__ __forceinline__ void corner_jacobian(const Ent &ec, const Ent &em, co
     }
 }
 
+// 6x6 SPD inverse through Cholesky, one thread, registers only: out = (a)^-1 (row-major), returns false on a
+// non-positive pivot.
+__device__ __forceinline__ bool spd6_inverse(double a[6][6], double out[36]) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        double d = a[k][k];
+#pragma unroll
+        for (int p = 0; p < k; p++) d -= a[k][p] * a[k][p];
+        if (!(d > 0.0)) { ok = false; d = 1.0; }
+        const double l = sqrt(d), il = 1.0 / l;
+        a[k][k] = l;
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+            double s = a[i][k];
+#pragma unroll
+            for (int p = 0; p < k; p++) s -= a[i][p] * a[k][p];
+            a[i][k] = s * il;
+        }
+    }
+    double li[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            if (i < c) { li[i][c] = 0.0; continue; }
+            double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int p = c; p < i; p++) s -= a[i][p] * li[p][c];
+            li[i][c] = s / a[i][i];
+        }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double s = 0.0;
+#pragma unroll
+            for (int p = 0; p < 6; p++)
+                if (p >= i && p >= j) s += li[p][i] * li[p][j];
+            out[i * 6 + j] = s;
+        }
+    return ok;
+}
+
 // packed lower-triangular index of a symmetric 6x6: (i>=j) -> i(i+1)/2 + j
 __device__ __host__ __forceinline__ constexpr int sym6(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 

@@ -49,20 +49,27 @@ struct DeviceProblem {
     // Schur work list: item w handles pairs [sw_begin[w], sw_end[w]) of entity sw_ent[w]
     int32_t *sw_ent = nullptr, *sw_begin = nullptr, *sw_end = nullptr;
     int32_t *pair_frame = nullptr, *pair_slot = nullptr;  // (entity, frame) incidence, grouped by entity
-    // state
-    double *z[2] = {nullptr, nullptr};    // [6A + 6F] pose vectors (current / trial)
+    // state: everything that depends on a pose vector exists twice (index 0/1 = the two pose buffers), so that the
+    // blocks of a trial point can be built while those of the current point are still needed for a mu retry
+    double *z[2] = {nullptr, nullptr};    // [6A + 6F] pose vectors
     double *ent[2] = {nullptr, nullptr};  // [(A+F)][ENT_STRIDE]
-    double *V = nullptr, *gf = nullptr;   // [F][36], [F][6]
-    double *W = nullptr;                  // [total_slots][36]   W_af (rows: entity params, cols: frame params)
-    double *Vinv = nullptr, *hf = nullptr;
-    double *U0 = nullptr, *g0 = nullptr;  // [n_pad*n_pad] row-major (lower triangle), [n_pad]: undamped shared part
-    double *S = nullptr, *rhs = nullptr;  // working copy: reduced system, then its LDL^T factor / solution
+    struct Blocks {
+        double *V = nullptr, *gf = nullptr;   // [F][36], [F][6]
+        double *W = nullptr;                  // [total_slots][36]   W_af (rows: entity params, cols: frame params)
+        double *Vinv = nullptr, *hf = nullptr;// (V_f + mu I)^-1, (V_f + mu I)^-1 g_f
+        double *S = nullptr;                  // [n_pad*n_pad] row-major lower triangle: shared blocks (pass B), then minus
+                                              // the Schur terms, then (in place) its LDL^T factor
+        double *rhs = nullptr;                // [n_pad] Schur part of the right-hand side, then z = D^-1 L^-1 b
+        double *g0 = nullptr;                 // [n_pad] shared part of B = -J^T r (kept for the gain denominator)
+    } blk[2];
     double *Dfac = nullptr;               // [nT][NB*NB] factored diagonal tiles (unit L below, D on the diagonal)
     double *Minv = nullptr;               // [nT][NB*NB] L_ss^-T D_s^-1 of every diagonal tile
     double *delta_s = nullptr;            // [n_pad]
     double *err_part = nullptr;           // [max(F, residual_blocks)] partial sums of squared residuals
     double *lin_part = nullptr;           // [F+1][2] per-frame ( |delta_f|^2 , delta_f . g_f ), last = shared part
     double *scal = nullptr;               // [8] reduced scalars
+    // host-visible (pinned, mapped) result record the reduction kernel publishes: [0..7] scalars, [8] flags, [9] sequence
+    double *host_result = nullptr;        // device pointer to the mapped host record (10 x 8 bytes)
     int32_t *flags = nullptr;             // [4] device error flags (0: non-positive pivot)
     double *r_out = nullptr;              // optional [8N]
     LaunchHook hook;
@@ -83,17 +90,19 @@ struct HookScope {  // RAII: pre/post around one launch
     ~HookScope() { if (P.hook.post) P.hook.post(P.hook.ctx, kid); }
 };
 
-void launch_unpack(const DeviceProblem &P, int which, bool zero_shared, hipStream_t st);
+void launch_unpack(const DeviceProblem &P, int which, hipStream_t st);             // z -> ent (only for the residual-vector API)
 void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream_t st);
-void launch_passA(const DeviceProblem &P, int which, hipStream_t st);
-void launch_passB(const DeviceProblem &P, int which, hipStream_t st);
-void launch_maxdiag(const DeviceProblem &P, hipStream_t st);                       // scal[4] = max free diagonal
-void launch_frame_inv(const DeviceProblem &P, double mu, hipStream_t st);          // + copies U0,g0 -> S,rhs
-void launch_schur(const DeviceProblem &P, hipStream_t st);
-void launch_finalize(const DeviceProblem &P, double mu, hipStream_t st);
-void launch_chol(const DeviceProblem &P, double mu, hipStream_t st);               // damping + LDL^T + both substitutions -> delta_s
+// pass A at z[which]: entity table, V, g_f, W, per-frame sum r^2 (err_part[f]); mu_pred >= 0 also gives Vinv, h_f for that
+// damping; zero_blk >= 0 clears S, rhs, g0 of that block set (they are dead / about to be rebuilt)
+void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st);
+void launch_passB(const DeviceProblem &P, int which, hipStream_t st);              // accumulates into blk[which].S, .g0 (must be zero)
+void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st);            // scal[4] = max free diagonal
+void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st);
+void launch_schur(const DeviceProblem &P, int which, hipStream_t st);
+void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st);    // damping + LDL^T + both substitutions -> delta_s
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
-void launch_reduce_scalars(const DeviceProblem &P, bool fold_shared, hipStream_t st);  // scal[0..2], scal[5..6]
+void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st);  // scal[0..2], scal[5..6]
+void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st);       // scal/flags -> host record
 int residual_blocks(const DeviceProblem &P);   // entries of err_part written by launch_residual
 
 }  // namespace aar

@@ -11,85 +11,35 @@
 namespace aar {
 
 // ------------------------------------------------------------------------------------------------
-// (V_f + mu I)^-1 and h_f = (V_f + mu I)^-1 g_f, one thread per frame; the same launch refreshes the
-// working copy S <- U0, rhs <- g0 (grid-stride), so a mu retry needs no Jacobian pass.
+// (V_f + mu I)^-1 and h_f = (V_f + mu I)^-1 g_f, one thread per frame.  Only launched when pass A's prediction of the
+// damping was wrong (first step, a rejected try, gain < 0.94): a mu retry needs no Jacobian pass.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_frame_inv(const double *__restrict__ V, const double *__restrict__ gf, int F,
                                                    double mu, int frames_fixed, double *__restrict__ Vinv,
-                                                   double *__restrict__ hf, const double *__restrict__ U0,
-                                                   const double *__restrict__ g0, double *__restrict__ S,
-                                                   double *__restrict__ rhs, int64_t nn, int n_pad,
-                                                   int32_t *__restrict__ flags) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // 16-byte copies of the shared system
-    const double2 *src = reinterpret_cast<const double2 *>(U0);
-    double2 *dst = reinterpret_cast<double2 *>(S);
-    for (int64_t i = gid; i < nn / 2; i += stride) dst[i] = src[i];
-    for (int64_t i = gid; i < n_pad; i += stride) rhs[i] = g0[i];
-    if (gid >= F) return;
-    const int f = (int)gid;
-    double a[6][6];
+                                                   double *__restrict__ hf, int32_t *__restrict__ flags) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    double out[36];
     if (frames_fixed) {
 #pragma unroll
-        for (int i = 0; i < 36; i++) Vinv[(size_t)f * 36 + i] = 0.0;
+        for (int i = 0; i < 36; i++) out[i] = 0.0;
+    } else {
+        double a[6][6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) hf[(size_t)f * 6 + i] = 0.0;
-        return;
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) a[i][j] = V[(size_t)f * 36 + i * 6 + j] + (i == j ? mu : 0.0);
+        if (!spd6_inverse(a, out)) atomicOr(flags, 1);
     }
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = 0; j < 6; j++) a[i][j] = V[(size_t)f * 36 + i * 6 + j] + (i == j ? mu : 0.0);
-    // Cholesky a = L L^T (lower), in place
-    bool bad = false;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        double d = a[k][k];
-#pragma unroll
-        for (int p = 0; p < k; p++) d -= a[k][p] * a[k][p];
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double l = sqrt(d), il = 1.0 / l;
-        a[k][k] = l;
-#pragma unroll
-        for (int i = k + 1; i < 6; i++) {
-            double s = a[i][k];
-#pragma unroll
-            for (int p = 0; p < k; p++) s -= a[i][p] * a[k][p];
-            a[i][k] = s * il;
-        }
-    }
-    if (bad) atomicOr(flags, 1);
-    // Linv (lower): column by column
-    double li[6][6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            if (i < c) { li[i][c] = 0.0; continue; }
-            double s = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int p = c; p < i; p++) s -= a[i][p] * li[p][c];
-            li[i][c] = s / a[i][i];
-        }
-    }
-    // Vinv = Linv^T Linv
-    double g[6], hv[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) g[i] = gf[(size_t)f * 6 + i];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        hv[i] = 0.0;
+        double hv = 0.0;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            double s = 0.0;
-#pragma unroll
-            for (int p = 0; p < 6; p++)
-                if (p >= i && p >= j) s += li[p][i] * li[p][j];
-            Vinv[(size_t)f * 36 + i * 6 + j] = s;
-            hv[i] += s * g[j];
+            Vinv[(size_t)f * 36 + i * 6 + j] = out[i * 6 + j];
+            hv += out[i * 6 + j] * gf[(size_t)f * 6 + j];
         }
-        hf[(size_t)f * 6 + i] = hv[i];
+        hf[(size_t)f * 6 + i] = hv;
     }
 }
 
@@ -202,9 +152,10 @@ __device__ __forceinline__ double rcp_refined(double d) {
 //   1 .. 2m           half row tiles (48 rows x 96 cols)   -> L_ts in place
 //   2m+1              the right-hand side (one row)        -> z_s
 //   2m+2, 2m+3        the two halves of the identity       -> Minv[s]
-__global__ void __launch_bounds__(256) k_ldl_panel(double *__restrict__ S, double *__restrict__ rhs, double *__restrict__ Dfac,
-                                                   double *__restrict__ Minv, int n_pad, int n, int s, int nT, double mu,
-                                                   const int32_t *__restrict__ ent_fixed, int32_t *__restrict__ flags) {
+__global__ void __launch_bounds__(256) k_ldl_panel(double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
+                                                   double *__restrict__ Dfac, double *__restrict__ Minv, int n_pad, int n, int s,
+                                                   int nT, double mu, const int32_t *__restrict__ ent_fixed,
+                                                   int32_t *__restrict__ flags) {
     constexpr int R = NB / 16, RT = R / 2, HALF = NB / 2;
     __shared__ double colD[2][NB], colT[2][HALF], pinv[2], dinv[NB];
     const int m = nT - s - 1, b = blockIdx.x, tid = threadIdx.x;
@@ -242,7 +193,7 @@ __global__ void __launch_bounds__(256) k_ldl_panel(double *__restrict__ S, doubl
             } else if (kind == 2) {
                 if (i == 0) {
                     t = rhs[r0 + j];
-                    if (first && (r0 + j >= n || ent_fixed[(r0 + j) / 6])) t = 0.0;
+                    if (first) t = (r0 + j >= n || ent_fixed[(r0 + j) / 6]) ? 0.0 : t + g0[r0 + j];  // B = g0 + Schur part
                 }
             } else if (kind == 3) {
                 t = (row0 + i == j) ? 1.0 : 0.0;
@@ -335,7 +286,7 @@ __global__ void __launch_bounds__(256) k_ldl_panel(double *__restrict__ S, doubl
 
 // trailing update of step s in 32x32 output sub-tiles: S(I, J) -= L_Is D_s L_Js^T; rhs rows: b_t -= L_ts D_s z_s.
 // grid: [tiles (ti >= tj)] x 9 sub-tiles, then one workgroup per rhs row tile.  LDS: Li [32][NB+1], Ljd [32][NB+1]
-__global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, double *__restrict__ rhs,
+__global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
                                                     const double *__restrict__ Dfac, int n_pad, int n, int s, int nT,
                                                     double mu, const int32_t *__restrict__ ent_fixed) {
     constexpr int LD = NB + 1, SB = 32, NSUB = (NB / SB) * (NB / SB);
@@ -357,7 +308,7 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
 #pragma unroll 8
             for (int k = 0; k < NB; k++) acc += row[k] * zs[k];
             double v = rhs[gi];
-            if (first && (gi >= n || ent_fixed[gi / 6])) v = 0.0;
+            if (first) v = (gi >= n || ent_fixed[gi / 6]) ? 0.0 : v + g0[gi];
             rhs[gi] = v - acc;
         }
         return;
@@ -515,13 +466,29 @@ __global__ void __launch_bounds__(256) k_backsub(const int32_t *__restrict__ fsl
 
 // ------------------------------------------------------------------------------------------------
 // fixed-order sums of the per-block / per-frame partials:
-//   scal[0] = sum err_part[0..n_err)   scal[1] = sum |delta_f|^2   scal[2] = sum delta_f.g_f
+//   scal[0] = sum err_part[0..n_err)  (per-frame sums of pass A, or per-block sums of k_residual)   scal[1] = sum |delta_f|^2   scal[2] = sum delta_f.g_f
 //   scal[5], scal[6] = the shared-parameter pieces |delta_s|^2 (identical on every rank; NOT all-reduced)
 //   and delta_s.g0 (folded into scal[2] when fold_shared, because g0 is a per-rank partial sum)
 // ------------------------------------------------------------------------------------------------
+// publish the scalars and the error flags to the mapped host record; the sequence number goes last, system scope
+__device__ __forceinline__ void publish_host(const double *__restrict__ scal, const int32_t *__restrict__ flags,
+                                             double *__restrict__ host, unsigned long long seq) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) host[i] = scal[i];
+    reinterpret_cast<long long *>(host)[8] = (long long)(flags[0] | flags[1] | flags[2] | flags[3]);
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(host) + 9, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_publish(const double *__restrict__ scal, const int32_t *__restrict__ flags, double *__restrict__ host,
+                          unsigned long long seq) {
+    if (threadIdx.x == 0) publish_host(scal, flags, host, seq);
+}
+
 __global__ void __launch_bounds__(256) k_reduce_scalars(const double *__restrict__ err_part, int n_err,
                                                         const double *__restrict__ lin_part, int F, int fold_shared,
-                                                        double *__restrict__ scal) {
+                                                        double *__restrict__ scal, const int32_t *__restrict__ flags,
+                                                        double *__restrict__ host, unsigned long long publish_seq) {
     __shared__ double red[3][256];
     const int tid = threadIdx.x;
     double e = 0.0, d2 = 0.0, dg = 0.0;
@@ -542,57 +509,56 @@ __global__ void __launch_bounds__(256) k_reduce_scalars(const double *__restrict
         // multi-GPU: delta_s . g0 uses this rank's piece of the shared gradient, so it joins the rank sum
         scal[2] = red[2][0] + (fold_shared ? lin_part[2 * (size_t)F + 1] : 0.0);
         scal[5] = lin_part[2 * (size_t)F]; scal[6] = lin_part[2 * (size_t)F + 1];
+        if (publish_seq) publish_host(scal, flags, host, publish_seq);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-void launch_frame_inv(const DeviceProblem &P, double mu, hipStream_t st) {
-    const int64_t nn = (int64_t)P.n_pad * P.n_pad;
-    int64_t work = nn / 2 > P.F ? nn / 2 : P.F;
-    int blocks = (int)((work + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < (P.F + 255) / 256) blocks = (P.F + 255) / 256;
-    if (blocks < 1) blocks = 1;
-    { HookScope _h(P, KID_FRAME_INV); hipLaunchKernelGGL(k_frame_inv, dim3(blocks), dim3(256), 0, st, P.V, P.gf, P.F, mu, P.frames_fixed, P.Vinv, P.hf,
-                       P.U0, P.g0, P.S, P.rhs, nn, P.n_pad, P.flags); }
+void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st) {
+    if (P.F == 0) return;
+    const DeviceProblem::Blocks &b = P.blk[which];
+    { HookScope _h(P, KID_FRAME_INV); hipLaunchKernelGGL(k_frame_inv, dim3((P.F + 255) / 256), dim3(256), 0, st, b.V, b.gf, P.F, mu, P.frames_fixed, b.Vinv, b.hf, P.flags); }
 }
 
-void launch_schur(const DeviceProblem &P, hipStream_t st) {
+void launch_schur(const DeviceProblem &P, int which, hipStream_t st) {
     if (P.n_swork == 0) return;
+    const DeviceProblem::Blocks &b = P.blk[which];
     const size_t lds = ((size_t)P.A * 36 + 8 + 4 * 48) * sizeof(double);
     static size_t granted = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_schur), lds, granted);
     { HookScope _h(P, KID_SCHUR); hipLaunchKernelGGL(k_schur, dim3(P.n_swork), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_frame,
-                       P.pair_slot, P.fslot_start, P.fslot_ent, P.W, P.Vinv, P.hf, P.A, P.n_pad, P.S, P.rhs); }
+                       P.pair_slot, P.fslot_start, P.fslot_ent, b.W, b.Vinv, b.hf, P.A, P.n_pad, b.S, b.rhs); }
 }
 
-void launch_finalize(const DeviceProblem &, double, hipStream_t) {}  // folded into the first tile touch of the LDL^T
-
-void launch_chol(const DeviceProblem &P, double mu, hipStream_t st) {
+void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
+    const DeviceProblem::Blocks &b = P.blk[which];
     for (int s = 0; s < P.nT; s++) {
         const int m = P.nT - s - 1;
-        { HookScope _h(P, KID_LDL_PANEL); hipLaunchKernelGGL(k_ldl_panel, dim3(2 * m + 4), dim3(256), 0, st, P.S, P.rhs, P.Dfac, P.Minv, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed, P.flags); }
+        { HookScope _h(P, KID_LDL_PANEL); hipLaunchKernelGGL(k_ldl_panel, dim3(2 * m + 4), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.Minv, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed, P.flags); }
         if (m > 0) {
-            { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, P.S, P.rhs, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
+            { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
         }
     }
     const size_t lds = ((size_t)P.n_pad + 10 * NB + NB) * sizeof(double);
     static size_t granted_bs = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_backsolve), lds, granted_bs);
-    { HookScope _h(P, KID_LDL_BACKSOLVE); hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(1024), lds, st, P.S, P.rhs, P.Dfac, P.Minv, P.delta_s, P.n_pad, P.nT); }
+    { HookScope _h(P, KID_LDL_BACKSOLVE); hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.Minv, P.delta_s, P.n_pad, P.nT); }
 }
 
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) {
+    const DeviceProblem::Blocks &b = P.blk[cur];
     const int nfb = (P.F + 3) / 4;
-    { HookScope _h(P, KID_BACKSUB); hipLaunchKernelGGL(k_backsub, dim3(nfb + 1), dim3(256), 0, st, P.fslot_start, P.fslot_ent, P.W, P.Vinv, P.gf, P.g0,
+    { HookScope _h(P, KID_BACKSUB); hipLaunchKernelGGL(k_backsub, dim3(nfb + 1), dim3(256), 0, st, P.fslot_start, P.fslot_ent, b.W, b.Vinv, b.gf, b.g0,
                        P.delta_s, P.z[cur], P.z[trial], P.A, P.F, nfb, P.lin_part); }
 }
 
-int residual_blocks(const DeviceProblem &P);
+void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st) {
+    { HookScope _h(P, KID_REDUCE); hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, P.err_part, n_err, P.lin_part, P.F,
+                       fold_shared ? 1 : 0, P.scal, P.flags, P.host_result, publish_seq); }
+}
 
-void launch_reduce_scalars(const DeviceProblem &P, bool fold_shared, hipStream_t st) {
-    { HookScope _h(P, KID_REDUCE); hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, P.err_part, residual_blocks(P), P.lin_part, P.F,
-                       fold_shared ? 1 : 0, P.scal); }
+void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, P.scal, P.flags, P.host_result, publish_seq);
 }
 
 }  // namespace aar

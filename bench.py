@@ -100,12 +100,13 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...` (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AAR_FORCE_COMM") == "1":
         # torch.distributed is rendezvous plumbing only (id broadcast, barrier, max over ranks); the data path is RCCL inside libaar
         import torch
         import torch.distributed as dist
-        dist.init_process_group("gloo", init_method="tcp://%s:%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500")),
-                                rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
     import numpy as np
 
     import aar
@@ -114,9 +115,10 @@ def main():
         raise SystemExit("bench.py: no HIP device (the product has no CPU path)")
     ds = aar.synth(args.workload)
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get("AAR_FORCE_COMM") == "1":   # the env switch exercises the RCCL path on one GPU
         uid = [aar.Comm.make_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
         comm = aar.Comm(uid[0], world, rank, local_rank)
     problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm)
 
