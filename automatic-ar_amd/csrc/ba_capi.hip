@@ -365,7 +365,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         StageTimer t(pb, &pb->times.backsub);
         launch_backsub(P, cur, tr, pb->stream);
     }
-    pb->launches += 3 + 2 * P.nT;
+    pb->launches += 3 + 3 * P.nT;
     pb->blocks_valid = false;  // S of the current point has been eliminated in place
     if (evaluate_trial) {
         // predicted damping of the next step: every accepted step of the reference's rule with gain >= 0.94 gives 0.33 mu
@@ -664,7 +664,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         AL(blk[w].Vinv, (size_t)F * 36); AL(blk[w].hf, (size_t)F * 6);
         AL(blk[w].S, (size_t)P.n_pad * P.n_pad); AL(blk[w].rhs, P.n_pad); AL(blk[w].g0, P.n_pad);
     }
-    AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Minv, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(delta_s, P.n_pad);
+    AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad);
     AL(err_part, std::max<size_t>((size_t)F, (size_t)((N + 255) / 256)) + 1);
     AL(lin_part, 2 * (size_t)(F + 1)); AL(scal, 8); AL(flags, 4);
 #undef AL
@@ -983,7 +983,7 @@ int aar_get_kernel_times(aar_problem *pb, double seconds[AAR_NUM_KERNELS], int64
 
 const char *aar_kernel_name(int kid) {
     static const char *names[KID_COUNT] = {"k_unpack", "k_residual", "k_passA", "k_passB", "k_maxdiag", "k_frame_inv", "k_schur",
-                                           "k_finalize", "k_ldl_panel", "k_ldl_update", "k_ldl_backsolve", "k_backsub",
+                                           "k_ldl_diag", "k_ldl_trsm", "k_ldl_update", "k_ldl_backsolve", "k_backsub",
                                            "k_reduce_scalars"};
     return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
 }

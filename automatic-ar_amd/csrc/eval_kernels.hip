@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
     const int o0 = a.frame_obs_start[f], o1 = a.frame_obs_start[f + 1];
     const int s0 = a.fslot_start[f], kf = a.fslot_start[f + 1] - s0;
     for (int i = tid; i < kf * 36; i += BLOCK) Wl[i] = 0.0;
-    if (tid < 32) acc[tid] = 0.0;
+    for (int t = tid; t < 32; t += BLOCK) acc[t] = 0.0;
     // entity rows of this frame's slot list (+ the frame itself at row kf), also published to the global table:
     // the frame row by its own workgroup, shared row e by workgroup e % F
     for (int t = tid; t <= kf; t += BLOCK) {
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
         for (int64_t i = gid; i < a.zero2_n; i += stride) a.zero2[i] = 0.0;
     }
     __syncthreads();
-    if (tid < ENT_STRIDE) a.ent_out[(size_t)(a.A + f) * ENT_STRIDE + tid] = entl[(size_t)kf * ENT_STRIDE + tid];
+    for (int t = tid; t < ENT_STRIDE; t += BLOCK) a.ent_out[(size_t)(a.A + f) * ENT_STRIDE + t] = entl[(size_t)kf * ENT_STRIDE + t];
 
     double vals[28];  // 21 V (packed lower), 6 g, 1 err
 #pragma unroll
@@ -220,13 +220,10 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
     __syncthreads();
     // coalesced write-out
     for (int i = tid; i < kf * 36; i += BLOCK) a.W[(size_t)s0 * 36 + i] = Wl[i];
-    if (tid < 36) {
-        const int i = tid / 6, j = tid % 6;
-        a.V[(size_t)f * 36 + tid] = acc[sym6(i, j)];
-    }
-    if (tid >= 36 && tid < 42) a.gf[(size_t)f * 6 + (tid - 36)] = acc[21 + (tid - 36)];
-    if (tid == 42) a.err_part[f] = acc[27];
-    if (a.mu_pred >= 0.0 && tid == 63) {  // (V_f + mu I)^-1 and h_f for the damping the next solve is expected to use
+    for (int t = tid; t < 36; t += BLOCK) a.V[(size_t)f * 36 + t] = acc[sym6(t / 6, t % 6)];
+    for (int t = tid; t < 6; t += BLOCK) a.gf[(size_t)f * 6 + t] = acc[21 + t];
+    if (tid == 0) a.err_part[f] = acc[27];
+    if (a.mu_pred >= 0.0 && tid == BLOCK - 1) {  // (V_f + mu I)^-1 and h_f for the damping the next solve is expected to use
         double out[36];
         if (a.frames_fixed) {
 #pragma unroll
@@ -391,6 +388,8 @@ void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_bl
         a.zero2 = zb.g0; a.zero2_n = P.n_pad;
     }
     a.flags = P.flags;
+    // block = 32 lanes for sparse frames (a 64-wide wave would be half empty at ~25 observations per frame), one wave up
+    // to ~96, four waves above
     const double avg = (double)P.N / (double)P.F;
     if (avg <= 96) launch_passA_t<64>(P, a, st);
     else launch_passA_t<256>(P, a, st);

@@ -10,8 +10,8 @@ constexpr int CHOL_NB = 96;       // dense LDL^T tile (16 entity blocks of 6)
 constexpr int PASSB_CHUNK = 256;  // max observations of one (camera, marker) run handled by one wavefront
 
 // Kernel ids for the optional per-launch timing hooks (aar_get_kernel_times)
-enum KernelId { KID_UNPACK = 0, KID_RESIDUAL, KID_PASSA, KID_PASSB, KID_MAXDIAG, KID_FRAME_INV, KID_SCHUR, KID_FINALIZE,
-                KID_LDL_PANEL, KID_LDL_UPDATE, KID_LDL_BACKSOLVE, KID_BACKSUB, KID_REDUCE, KID_COUNT };
+enum KernelId { KID_UNPACK = 0, KID_RESIDUAL, KID_PASSA, KID_PASSB, KID_MAXDIAG, KID_FRAME_INV, KID_SCHUR, KID_LDL_DIAG,
+                KID_LDL_TRSM, KID_LDL_UPDATE, KID_LDL_BACKSOLVE, KID_BACKSUB, KID_REDUCE, KID_COUNT };
 
 struct LaunchHook {  // called around every kernel launch when profiling is on
     void (*pre)(void *ctx, int kid) = nullptr;
@@ -63,7 +63,7 @@ struct DeviceProblem {
         double *g0 = nullptr;                 // [n_pad] shared part of B = -J^T r (kept for the gain denominator)
     } blk[2];
     double *Dfac = nullptr;               // [nT][NB*NB] factored diagonal tiles (unit L below, D on the diagonal)
-    double *Minv = nullptr;               // [nT][NB*NB] L_ss^-T D_s^-1 of every diagonal tile
+    double *Linv16 = nullptr;             // [nT][6][16*16] inverses of the 16x16 diagonal sub-blocks of every L_ss
     double *delta_s = nullptr;            // [n_pad]
     double *err_part = nullptr;           // [max(F, residual_blocks)] partial sums of squared residuals
     double *lin_part = nullptr;           // [F+1][2] per-frame ( |delta_f|^2 , delta_f . g_f ), last = shared part

@@ -120,19 +120,29 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
 // ------------------------------------------------------------------------------------------------
 // Dense LDL^T of the reduced system, right-looking, tile NB = 96, lower triangle row-major.
 //
-// Damping and gauge are applied on the FIRST touch of every element (step 0 of the factorisation), not by
-// a kernel of their own: S(i,j) -> S(i,j) + mu [i == j] on free rows; rows / columns of fixed entities (root
-// camera, root marker, non-optimised groups) and of the padding -> identity with zero rhs, i.e. delta = 0.
+// Damping and gauge are applied on the FIRST touch of every element (step 0 of the factorisation), not by a kernel of
+// their own: S(i,j) -> S(i,j) + mu [i == j] on free rows; rows / columns of fixed entities (root camera, root marker,
+// non-optimised groups) and of the padding -> identity with zero rhs, i.e. delta = 0; rhs -> g0 + (Schur part).
 //
-// Step s = one k_ldl_panel + one k_ldl_update.  Panel: every row tile of block column s gets its own
-// workgroup; each keeps the diagonal tile AND its own tile in registers (thread (ty,tx) owns rows ty+16p,
-// columns tx+16q) and replays the diagonal tile's column eliminations, so no triangular solve is needed:
-// per column ONE barrier, the column travels through a double-buffered LDS vector, the pivot reciprocal is
-// computed by the pivot's owner.  Two extra "row tiles" ride along: the right-hand side (a 1-row tile; its
-// output is z_s = D^-1 L^-1 b) and the identity (its output is M_s = L_ss^-T D_s^-1, which turns the backward
-// substitution into matrix-vector products).
+// Step s = three launches:
+//   k_ldl_diag    ONE workgroup factors the diagonal tile: the serial part.  The tile lives in registers (thread (ty,tx)
+//                 owns rows ty+16p, columns tx+16q), one barrier per column, the column travels through a double-buffered
+//                 LDS vector, the pivot reciprocal is computed by the pivot's owner.  Epilogue: inverses of the six 16x16
+//                 diagonal sub-blocks of L_ss, which turn every triangular solve below into small matrix products.
+//   k_ldl_trsm    every 48-row slab of block column s (and the right-hand side as a 1-row slab): X = A L_ss^-T by
+//                 blocked substitution over 16-column blocks, then L_ts = X D^-1.
+//   k_ldl_update  trailing tiles: S(I,J) -= L_Is D_s L_Js^T, rhs rows likewise.
 // ------------------------------------------------------------------------------------------------
+#ifdef AAR_STAMPS  // diagnostic build only (scripts/probe): cycle stamps of one workgroup, never compiled into libaar.so
+__device__ unsigned long long g_stamps[64];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 constexpr int NB = CHOL_NB;
+constexpr int SBK = 16;           // sub-block of the triangular solves
+constexpr int NSB = NB / SBK;     // 6
 
 __device__ __forceinline__ double xform_first(double v, int gi, int gj, int n, double mu, const int32_t *__restrict__ ent_fixed) {
     const bool fi = gi >= n || ent_fixed[gi / 6], fj = gj >= n || ent_fixed[gj / 6];
@@ -147,27 +157,18 @@ __device__ __forceinline__ double rcp_refined(double d) {
     return x;
 }
 
-// Workgroup roles of one panel launch (block column s, m = nT-s-1 row tiles below the diagonal):
-//   0                 the diagonal tile itself            -> Dfac[s]
-//   1 .. 2m           half row tiles (48 rows x 96 cols)   -> L_ts in place
-//   2m+1              the right-hand side (one row)        -> z_s
-//   2m+2, 2m+3        the two halves of the identity       -> Minv[s]
-__global__ void __launch_bounds__(256) k_ldl_panel(double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
-                                                   double *__restrict__ Dfac, double *__restrict__ Minv, int n_pad, int n, int s,
-                                                   int nT, double mu, const int32_t *__restrict__ ent_fixed,
-                                                   int32_t *__restrict__ flags) {
-    constexpr int R = NB / 16, RT = R / 2, HALF = NB / 2;
-    __shared__ double colD[2][NB], colT[2][HALF], pinv[2], dinv[NB];
-    const int m = nT - s - 1, b = blockIdx.x, tid = threadIdx.x;
-    const int ty = tid >> 4, tx = tid & 15;
+// LDS (dynamic): Lf [NB][NB+2] (epilogue copy of L_ss) ; static: column vector, pivot reciprocals
+__global__ void __launch_bounds__(256) k_ldl_diag(const double *__restrict__ S, double *__restrict__ Dfac, double *__restrict__ Linv16,
+                                                  int n_pad, int n, int s, double mu, const int32_t *__restrict__ ent_fixed,
+                                                  int32_t *__restrict__ flags) {
+    constexpr int R = NB / 16, LD = NB + 2;
+    extern __shared__ double Lf[];
+    __shared__ double colD[2][NB], pinv[2], dinv[NB];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int r0 = s * NB;
     const bool first = (s == 0);
-    int kind, row0 = 0;  // row0: first global row (tiles) or first identity row (identity halves)
-    if (b == 0) kind = 0;
-    else if (b <= 2 * m) { kind = 1; row0 = (s + 1) * NB + (b - 1) * HALF; }
-    else if (b == 2 * m + 1) kind = 2;
-    else { kind = 3; row0 = (b - 2 * m - 2) * HALF; }
-    double D[R][R], T[RT][R];
+    STAMP(0);
+    double D[R][R];
 #pragma unroll
     for (int p = 0; p < R; p++)
 #pragma unroll
@@ -181,54 +182,33 @@ __global__ void __launch_bounds__(256) k_ldl_panel(double *__restrict__ S, doubl
             }
             D[p][q] = v;
         }
-#pragma unroll
-    for (int p = 0; p < RT; p++)
-#pragma unroll
-        for (int q = 0; q < R; q++) {
-            const int i = ty + 16 * p, j = tx + 16 * q;
-            double t = 0.0;
-            if (kind == 1) {
-                t = S[(size_t)(row0 + i) * n_pad + r0 + j];
-                if (first) t = xform_first(t, row0 + i, r0 + j, n, mu, ent_fixed);
-            } else if (kind == 2) {
-                if (i == 0) {
-                    t = rhs[r0 + j];
-                    if (first) t = (r0 + j >= n || ent_fixed[(r0 + j) / 6]) ? 0.0 : t + g0[r0 + j];  // B = g0 + Schur part
-                }
-            } else if (kind == 3) {
-                t = (row0 + i == j) ? 1.0 : 0.0;
-            }
-            T[p][q] = t;
-        }
+    STAMP(1);
 #pragma unroll
     for (int kq = 0; kq < R; kq++) {
+        STAMP(2 + kq);
         for (int kk = 0; kk < 16; kk++) {
             const int k = 16 * kq + kk, buf = k & 1;
             if (tx == kk) {  // owners of column k publish it (final after step k-1)
 #pragma unroll
                 for (int p = 0; p < R; p++)
                     if (p >= kq) colD[buf][ty + 16 * p] = D[p][kq];
-#pragma unroll
-                for (int p = 0; p < RT; p++) colT[buf][ty + 16 * p] = T[p][kq];
                 if (ty == kk) {  // pivot owner
                     const double d = D[kq][kq];
                     const double inv = rcp_refined(d);
                     pinv[buf] = inv;
                     dinv[k] = inv;
-                    if (!(d > 0.0) && kind == 0) atomicOr(flags, 2);
+                    if (!(d > 0.0)) atomicOr(flags, 2);
                 }
             }
             __syncthreads();
             const double inv = pinv[buf];
-            double lj[R], li[R], ti[RT];
+            double lj[R], li[R];
 #pragma unroll
             for (int q = 0; q < R; q++)
                 if (q >= kq) {
                     lj[q] = colD[buf][tx + 16 * q];
                     li[q] = colD[buf][ty + 16 * q] * inv;
                 }
-#pragma unroll
-            for (int p = 0; p < RT; p++) ti[p] = colT[buf][ty + 16 * p] * inv;
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 if (q < kq) continue;  // finished columns (compile-time)
@@ -241,47 +221,169 @@ __global__ void __launch_bounds__(256) k_ldl_panel(double *__restrict__ S, doubl
                     const bool act = jact && ((p > kq) || (i > k)) && ((p > q) || (j <= i));
                     if (act) D[p][q] = fma(-li[p], lj[q], D[p][q]);
                 }
-#pragma unroll
-                for (int p = 0; p < RT; p++)
-                    if (jact) T[p][q] = fma(-ti[p], lj[q], T[p][q]);
             }
         }
     }
     __syncthreads();
-    if (kind == 0) {
-        // The factored diagonal tile goes to Dfac, NOT back into S: the other workgroups of this launch read
-        // the unfactored tile from S, and nothing orders them against this store.
-        double *out = Dfac + (size_t)s * NB * NB;
+    STAMP(8);
+    // factored tile: unit L below the diagonal, D on it.  It goes to Dfac (not back into S) and into LDS for the inverses.
+    double *out = Dfac + (size_t)s * NB * NB;
 #pragma unroll
-        for (int p = 0; p < R; p++)
+    for (int p = 0; p < R; p++)
 #pragma unroll
-            for (int q = 0; q < R; q++) {
-                const int i = ty + 16 * p, j = tx + 16 * q;
-                out[i * NB + j] = (j < i) ? D[p][q] * dinv[j] : (j == i ? D[p][q] : 0.0);
-            }
-    } else if (kind == 1) {
-#pragma unroll
-        for (int p = 0; p < RT; p++)
-#pragma unroll
-            for (int q = 0; q < R; q++) {
-                const int i = ty + 16 * p, j = tx + 16 * q;
-                S[(size_t)(row0 + i) * n_pad + r0 + j] = T[p][q] * dinv[j];
-            }
-    } else if (kind == 2) {
-        if (ty == 0) {
-#pragma unroll
-            for (int q = 0; q < R; q++) rhs[r0 + tx + 16 * q] = T[0][q] * dinv[tx + 16 * q];
+        for (int q = 0; q < R; q++) {
+            const int i = ty + 16 * p, j = tx + 16 * q;
+            const double v = (j < i) ? D[p][q] * dinv[j] : (j == i ? D[p][q] : 0.0);
+            out[i * NB + j] = v;
+            Lf[i * LD + j] = v;
         }
-    } else {
-        double *out = Minv + (size_t)s * NB * NB;
+    __syncthreads();
+    STAMP(9);
+    // inverses of the unit-lower 16x16 diagonal sub-blocks: lane c < 16 of a wave solves L x = e_c
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int q = wave; q < NSB; q += 4) {
+        if (lane < SBK) {
+            const int c = lane, o = q * SBK;
+            double x[SBK];
 #pragma unroll
-        for (int p = 0; p < RT; p++)
+            for (int i = 0; i < SBK; i++) {
+                // x_p = 0 for p < c, so the full row can be used: the L loads are lane-uniform and independent of x
+                double acc = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int q = 0; q < R; q++) {
-                const int i = row0 + ty + 16 * p, j = tx + 16 * q;
-                out[i * NB + j] = T[p][q] * dinv[j];
+                for (int pp = 0; pp < i; pp++) acc = fma(-Lf[(o + i) * LD + o + pp], x[pp], acc);
+                x[i] = acc;
             }
+            double *li = Linv16 + ((size_t)s * NSB + q) * SBK * SBK;
+#pragma unroll
+            for (int i = 0; i < SBK; i++) li[i * SBK + c] = x[i];
+        }
     }
+    STAMP(10);
+}
+
+// X = A L_ss^-T D^-1 for one 48-row slab of block column s (blockIdx < 2m), or for the right-hand side (last block),
+// right-looking over 16-column blocks.  Thread (rb, c) keeps rows rb+16a (a < 3), column c of all six blocks in
+// registers: X_q = R_q inv(L_qq)^T, then every later block gets R_q'' -= X_q L(q'', q)^T.
+// LDS (dynamic): Ls [NB][NB+2] | Xq [48][18] | Rt [48][18] | Li [NSB][16][18] | dinv [NB]
+__global__ void __launch_bounds__(256) k_ldl_trsm(double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
+                                                  const double *__restrict__ Dfac, const double *__restrict__ Linv16, int n_pad,
+                                                  int n, int s, int nT, double mu, const int32_t *__restrict__ ent_fixed) {
+    constexpr int LD = NB + 2, ROWS = NB / 2, PL = SBK + 2;
+    extern __shared__ double lds[];
+    double *Ls = lds;
+    double *Xq = Ls + NB * LD;
+    double *Rt = Xq + ROWS * PL;
+    double *Li = Rt + ROWS * PL;
+    double *dinv = Li + NSB * SBK * PL;
+    const int m = nT - s - 1, b = blockIdx.x, tid = threadIdx.x;
+    const int r0 = s * NB;
+    const bool first = (s == 0), is_rhs = (b == 2 * m);
+    const int row0 = (s + 1) * NB + b * ROWS;
+    const double *dd = Dfac + (size_t)s * NB * NB;
+    const int c = tid & 15, rb = tid >> 4;
+    STAMP(16);
+    double acc[3][NSB];
+    {   // every global load is issued before the first use
+        constexpr int NL = NB * NB / 256, NI = NSB * SBK * SBK / 256;
+        double vl[NL], vi[NI];
+#pragma unroll
+        for (int u = 0; u < NL; u++) vl[u] = dd[tid + 256 * u];
+#pragma unroll
+        for (int u = 0; u < NI; u++) vi[u] = Linv16[(size_t)s * NSB * SBK * SBK + tid + 256 * u];
+        const double dv = (tid < NB) ? dd[tid * NB + tid] : 1.0;
+        if (!is_rhs) {
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int q = 0; q < NSB; q++) acc[a][q] = S[(size_t)(row0 + rb + 16 * a) * n_pad + r0 + 16 * q + c];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int q = 0; q < NSB; q++) acc[a][q] = (a == 0 && rb == 0) ? rhs[r0 + 16 * q + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int e = tid + 256 * u, i = e / NB, j = e - i * NB;
+            Ls[i * LD + j] = (j < i) ? vl[u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NI; u++) {
+            const int e = tid + 256 * u, q = e / (SBK * SBK), r = (e / SBK) % SBK, cc = e % SBK;
+            Li[(q * SBK + r) * PL + cc] = vi[u];
+        }
+        if (tid < NB) dinv[tid] = rcp_refined(dv);
+        if (first) {
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int q = 0; q < NSB; q++) {
+                    const int gj = r0 + 16 * q + c;
+                    if (!is_rhs) acc[a][q] = xform_first(acc[a][q], row0 + rb + 16 * a, gj, n, mu, ent_fixed);
+                    else if (a == 0 && rb == 0) acc[a][q] = (gj >= n || ent_fixed[gj / 6]) ? 0.0 : acc[a][q] + g0[gj];  // B = g0 + Schur part
+                }
+        }
+    }
+    STAMP(17);
+#pragma unroll
+    for (int q = 0; q < NSB; q++) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) Rt[(rb + 16 * a) * PL + c] = acc[a][q];
+        __syncthreads();
+        STAMP(18 + q);
+        // X_q = R_q inv(L_qq)^T : X[r][c] = sum_p R[r][p] inv(L_qq)[c][p]   (inv(L) is lower: entries p > c are 0)
+        double lic[SBK];
+        {
+            const double2 *lp = reinterpret_cast<const double2 *>(Li + (q * SBK + c) * PL);
+#pragma unroll
+            for (int h = 0; h < SBK / 2; h++) { const double2 v = lp[h]; lic[2 * h] = v.x; lic[2 * h + 1] = v.y; }
+        }
+        double x[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double2 *rp = reinterpret_cast<const double2 *>(Rt + (rb + 16 * a) * PL);
+            double xa = 0.0;
+#pragma unroll
+            for (int h = 0; h < SBK / 2; h++) {
+                const double2 v = rp[h];
+                xa = fma(v.x, lic[2 * h], xa);
+                xa = fma(v.y, lic[2 * h + 1], xa);
+            }
+            x[a] = xa;
+            Xq[(rb + 16 * a) * PL + c] = xa;
+        }
+        const double dq = dinv[16 * q + c];
+        if (!is_rhs) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) S[(size_t)(row0 + rb + 16 * a) * n_pad + r0 + 16 * q + c] = x[a] * dq;
+        } else if (rb == 0) {
+            rhs[r0 + 16 * q + c] = x[0] * dq;
+        }
+        __syncthreads();
+        // R_q'' -= X_q L(q'', q)^T for every later block
+#pragma unroll
+        for (int q2 = 0; q2 < NSB; q2++) {
+            if (q2 <= q) continue;
+            double l[SBK];
+            const double2 *lp = reinterpret_cast<const double2 *>(Ls + (16 * q2 + c) * LD + 16 * q);
+#pragma unroll
+            for (int h = 0; h < SBK / 2; h++) { const double2 v = lp[h]; l[2 * h] = v.x; l[2 * h + 1] = v.y; }
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const double2 *xp = reinterpret_cast<const double2 *>(Xq + (rb + 16 * a) * PL);
+                double r = acc[a][q2];
+#pragma unroll
+                for (int h = 0; h < SBK / 2; h++) {
+                    const double2 v = xp[h];
+                    r = fma(-v.x, l[2 * h], r);
+                    r = fma(-v.y, l[2 * h + 1], r);
+                }
+                acc[a][q2] = r;
+            }
+        }
+    }
+    STAMP(24);
+    STAMP(25);
 }
 
 // trailing update of step s in 32x32 output sub-tiles: S(I, J) -= L_Is D_s L_Js^T; rhs rows: b_t -= L_ts D_s z_s.
@@ -320,10 +422,22 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
     const int si = sub / (NB / SB), sj = sub % (NB / SB);
     if (ti == tj && sj > si) return;  // above the diagonal
     const int i0 = (s + 1 + ti) * NB + si * SB, j0 = (s + 1 + tj) * NB + sj * SB;
-    for (int e = tid; e < SB * NB; e += 256) {
-        const int i = e / NB, k = e - i * NB;
-        Li[i * LD + k] = S[(size_t)(i0 + i) * n_pad + r0 + k];
-        Lj[i * LD + k] = S[(size_t)(j0 + i) * n_pad + r0 + k] * dd[k * NB + k];  // L_Js * D_s
+    {
+        constexpr int NU = SB * NB / 256;
+        double va[NU], vb[NU], vd[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int e = tid + 256 * u, i = e / NB, k = e - i * NB;
+            va[u] = S[(size_t)(i0 + i) * n_pad + r0 + k];
+            vb[u] = S[(size_t)(j0 + i) * n_pad + r0 + k];
+            vd[u] = dd[k * NB + k];
+        }
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int e = tid + 256 * u, i = e / NB, k = e - i * NB;
+            Li[i * LD + k] = va[u];
+            Lj[i * LD + k] = vb[u] * vd[u];  // L_Js * D_s
+        }
     }
     __syncthreads();
     const int ty = tid >> 4, tx = tid & 15;
@@ -348,23 +462,51 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
         }
 }
 
-// L^T x = z from the last tile up, with the tile inverses: x_s = M_s (d_s o (z_s - sum_{t>s} L_ts^T x_t)).
-// One workgroup of 1024 threads; LDS: xs [n_pad] | part [10][NB] | w [NB]
+// L^T x = z from the last tile up.  Per tile: w = z_s - sum_{t>s} L_ts^T x_t (a column reduction over all rows below), then
+// L_ss^T x_s = w by blocked back-substitution with the 16x16 inverses.  One workgroup of 1024 threads.
+// LDS (dynamic): xs [n_pad] | Ls [NB][NB+1] | part [16][NB] | w [NB] | Li [NSB][16][17]
 __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict__ S, const double *__restrict__ rhs,
-                                                        const double *__restrict__ Dfac, const double *__restrict__ Minv,
+                                                        const double *__restrict__ Dfac, const double *__restrict__ Linv16,
                                                         double *__restrict__ x, int n_pad, int nT) {
+    constexpr int LD = NB + 1, G = 10;
     extern __shared__ double lds[];
     double *xs = lds;
-    double *part = xs + n_pad;
-    double *w = part + 10 * NB;
+    double *Ls = xs + n_pad;
+    double *part = Ls + NB * LD;
+    double *w = part + 16 * NB;
+    double *Li = w + NB;
     const int tid = threadIdx.x;
-    constexpr int G = 10;  // row groups: G*NB = 960 threads busy in the reductions
-    const int j = tid % NB, gq = tid / NB;
+    const int j = tid % NB, gq = tid / NB;  // G*NB = 960 threads busy in the tall reduction
     for (int s = nT - 1; s >= 0; s--) {
         const int r0 = s * NB;
+        const double *dd = Dfac + (size_t)s * NB * NB;
+        {
+            constexpr int NL = NB * NB / 1024;
+            double vl[NL], vi[2];
+#pragma unroll
+            for (int u = 0; u < NL; u++) vl[u] = dd[tid + 1024 * u];
+#pragma unroll
+            for (int u = 0; u < 2; u++) vi[u] = (tid + 1024 * u < NSB * SBK * SBK) ? Linv16[(size_t)s * NSB * SBK * SBK + tid + 1024 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < NL; u++) {
+                const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
+                Ls[i * LD + jj] = (jj < i) ? vl[u] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int e = tid + 1024 * u;
+                if (e < NSB * SBK * SBK) Li[((e / (SBK * SBK)) * SBK + (e / SBK) % SBK) * 17 + e % SBK] = vi[u];
+            }
+        }
         if (gq < G) {
             double acc = 0.0;
-            for (int i = (s + 1) * NB + gq; i < n_pad; i += G) acc += S[(size_t)i * n_pad + r0 + j] * xs[i];
+            int i = (s + 1) * NB + gq;
+            for (; i + 3 * G < n_pad; i += 4 * G) {  // four independent loads in flight
+                const double a0 = S[(size_t)i * n_pad + r0 + j], a1 = S[(size_t)(i + G) * n_pad + r0 + j];
+                const double a2 = S[(size_t)(i + 2 * G) * n_pad + r0 + j], a3 = S[(size_t)(i + 3 * G) * n_pad + r0 + j];
+                acc += a0 * xs[i] + a1 * xs[i + G] + a2 * xs[i + 2 * G] + a3 * xs[i + 3 * G];
+            }
+            for (; i < n_pad; i += G) acc += S[(size_t)i * n_pad + r0 + j] * xs[i];
             part[gq * NB + j] = acc;
         }
         __syncthreads();
@@ -372,24 +514,34 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
             double a = rhs[r0 + tid];
 #pragma unroll
             for (int g = 0; g < G; g++) a -= part[g * NB + tid];
-            w[tid] = a * Dfac[(size_t)s * NB * NB + tid * NB + tid];
+            w[tid] = a;
         }
         __syncthreads();
-        if (gq < G) {  // x_s[j] = sum_c M[j][c] w[c], c >= j (M is upper triangular); group gq takes c = gq, gq+G, ...
-            const double *Mr = Minv + (size_t)s * NB * NB + (size_t)j * NB;
+        // blocked back-substitution inside the tile: x_q = inv(L_qq)^T (w_q - sum_{i >= 16(q+1)} L[i][16q + c] x_i)
+        const int c = tid & 15, pr = tid >> 4;  // 64 partial-sum groups of 16 columns
+        for (int q = NSB - 1; q >= 0; q--) {
             double acc = 0.0;
-            for (int c = gq; c < NB; c += G) acc += Mr[c] * w[c];
-            part[gq * NB + j] = acc;
-        }
-        __syncthreads();
-        if (tid < NB) {
-            double a = 0.0;
+            for (int i = (q + 1) * SBK + pr; i < NB; i += 64) acc += Ls[i * LD + q * SBK + c] * xs[r0 + i];
+            if (pr < 16) part[pr * NB + c] = 0.0;
+            __syncthreads();
+            if (acc != 0.0) atomicAdd(&part[(pr & 15) * NB + c], acc);
+            __syncthreads();
+            if (tid < SBK) {
+                double v = w[q * SBK + tid];
 #pragma unroll
-            for (int g = 0; g < G; g++) a += part[g * NB + tid];
-            xs[r0 + tid] = a;
-            x[r0 + tid] = a;
+                for (int g = 0; g < 16; g++) v -= part[g * NB + tid];
+                part[15 * NB + 32 + tid] = v;  // v_q
+            }
+            __syncthreads();
+            if (tid < SBK) {
+                double xv = 0.0;
+#pragma unroll
+                for (int pp = 0; pp < SBK; pp++) xv = fma(Li[(q * SBK + pp) * 17 + tid], part[15 * NB + 32 + pp], xv);  // sum_p inv(L)[p][c] v_p
+                xs[r0 + q * SBK + tid] = xv;
+                x[r0 + q * SBK + tid] = xv;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -532,17 +684,22 @@ void launch_schur(const DeviceProblem &P, int which, hipStream_t st) {
 
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];
+    const size_t lds_diag = (size_t)NB * (NB + 2) * sizeof(double);
+    const size_t lds_trsm = ((size_t)NB * (NB + 2) + 2 * (NB / 2) * (SBK + 2) + NSB * SBK * (SBK + 2) + NB) * sizeof(double);
+    static size_t g_diag = 48 * 1024, g_trsm = 48 * 1024, g_bs = 48 * 1024;
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_trsm), lds_trsm, g_trsm);
     for (int s = 0; s < P.nT; s++) {
         const int m = P.nT - s - 1;
-        { HookScope _h(P, KID_LDL_PANEL); hipLaunchKernelGGL(k_ldl_panel, dim3(2 * m + 4), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.Minv, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed, P.flags); }
+        { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags); }
+        { HookScope _h(P, KID_LDL_TRSM); hipLaunchKernelGGL(k_ldl_trsm, dim3(2 * m + 1), dim3(256), lds_trsm, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
         if (m > 0) {
             { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
         }
     }
-    const size_t lds = ((size_t)P.n_pad + 10 * NB + NB) * sizeof(double);
-    static size_t granted_bs = 48 * 1024;
-    allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_backsolve), lds, granted_bs);
-    { HookScope _h(P, KID_LDL_BACKSOLVE); hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.Minv, P.delta_s, P.n_pad, P.nT); }
+    const size_t lds = ((size_t)P.n_pad + NB * (NB + 1) + 16 * NB + NB + NSB * SBK * 17) * sizeof(double);
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_backsolve), lds, g_bs);
+    { HookScope _h(P, KID_LDL_BACKSOLVE); hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.Linv16, P.delta_s, P.n_pad, P.nT); }
 }
 
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) {
