@@ -28,6 +28,7 @@ SYMBOLS = [
     "aar_eval_normal_equations", "aar_eval_damped_step", "aar_lm_default_params", "aar_lm_init", "aar_lm_step",
     "aar_lm_get_solution", "aar_lm_solve", "aar_get_stage_times", "aar_reproj_stats", "aar_device_count",
     "aar_device_synchronize", "aar_set_kernel_profiling", "aar_get_kernel_times", "aar_kernel_name",
+    "aar_problem_set_huber_delta", "aar_problem_get_huber_delta",
 ]
 NUM_KERNELS = 13
 
@@ -68,7 +69,7 @@ class CProblemDesc(C.Structure):
         ("obs_frame", C.POINTER(C.c_int32)), ("obs_cam", C.POINTER(C.c_int32)), ("obs_marker", C.POINTER(C.c_int32)),
         ("obs_uv", C.POINTER(C.c_float)),
         ("optimize_cam_poses", C.c_int32), ("optimize_marker_poses", C.c_int32), ("optimize_object_poses", C.c_int32),
-        ("residual_mode", C.c_int32), ("device_id", C.c_int32), ("comm", C.c_void_p),
+        ("residual_mode", C.c_int32), ("with_huber", C.c_int32), ("device_id", C.c_int32), ("comm", C.c_void_p),
     ]
 
 
@@ -152,6 +153,9 @@ def lib():
     L.aar_get_kernel_times.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64)]
     L.aar_kernel_name.argtypes = [C.c_int]
     L.aar_kernel_name.restype = C.c_char_p
+    L.aar_problem_set_huber_delta.argtypes = [C.c_void_p, C.c_float]
+    L.aar_problem_get_huber_delta.argtypes = [C.c_void_p]
+    L.aar_problem_get_huber_delta.restype = C.c_float
     _lib = L
     return L
 
@@ -343,7 +347,7 @@ class Comm:
 class Problem:
     """aar_problem: the bundle-adjustment problem resident on one GPU."""
 
-    def __init__(self, ds, residual_mode=RES_F32, device=0, comm=None, optimize=None):
+    def __init__(self, ds, residual_mode=RES_F32, device=0, comm=None, optimize=None, with_huber=False):
         self.ds = ds
         self._cds = ds.as_c()
         d = CProblemDesc()
@@ -351,6 +355,7 @@ class Problem:
         if optimize is not None:
             d.optimize_cam_poses, d.optimize_marker_poses, d.optimize_object_poses = [int(b) for b in optimize]
         d.residual_mode = residual_mode
+        d.with_huber = int(with_huber)
         d.device_id = device
         d.comm = comm.handle if comm is not None else None
         self.handle = C.c_void_p()
@@ -432,6 +437,12 @@ class Problem:
                       final_err=rep.final_err, final_mu=rep.final_mu, solve_seconds=rep.solve_seconds,
                       trial_points=rep.trial_points, trace=trace)
         return x, report
+
+    def set_huber_delta(self, delta):
+        _check(lib().aar_problem_set_huber_delta(self.handle, float(delta)))
+
+    def get_huber_delta(self):
+        return float(lib().aar_problem_get_huber_delta(self.handle))
 
     def set_kernel_profiling(self, on):
         _check(lib().aar_set_kernel_profiling(self.handle, int(on)))

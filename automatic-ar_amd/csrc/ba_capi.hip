@@ -101,6 +101,8 @@ struct aar_problem {
     int cur = 0;                       // pose buffer / block set of curr_z
     double mu = -1, v = 2, currErr = 0, prevErr = 0;
     bool lm_ready = false;
+    bool with_huber = false;
+    float hubber_delta = 2.5f;         // MultiCamMapper::hubberDelta (libs/multicam_mapper.h:41)
     bool blocks_valid = false;         // blk[cur] holds J^T J blocks and B at z[cur], S not yet eliminated
     double vinv_mu = -1;               // damping for which blk[cur].Vinv / hf are valid (< 0: none)
     int64_t trial_points = 0, launches = 0;
@@ -552,6 +554,8 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     P.nT = (P.n + CHOL_NB - 1) / CHOL_NB;
     P.n_pad = P.nT * CHOL_NB;
     P.res_f32 = d->residual_mode == AAR_RES_F64 ? 0 : 1;
+    pb->with_huber = d->with_huber != 0;
+    P.huber = pb->with_huber ? pb->hubber_delta : -1.f;
     P.half_size = (double)((float)d->marker_size / 2.f);
     P.frames_fixed = L.of ? 0 : 1;
     const int A = P.A, F = P.F;
@@ -686,6 +690,14 @@ int64_t aar_problem_full_len(const aar_problem *pb) { return pb->L.full_len(); }
 int64_t aar_problem_num_vars(const aar_problem *pb) { return pb->L.z_len(); }
 int64_t aar_problem_local_obs(const aar_problem *pb) { return pb->P.N; }
 
+int aar_problem_set_huber_delta(aar_problem *pb, float delta) {
+    if (!pb || !(delta > 0.f)) return set_error(AAR_ERR_INVALID, "aar_problem_set_huber_delta: bad argument");
+    pb->hubber_delta = delta;
+    if (pb->with_huber) pb->P.huber = delta;
+    return AAR_OK;
+}
+float aar_problem_get_huber_delta(const aar_problem *pb) { return pb ? pb->hubber_delta : 0.f; }
+
 int aar_eval_residuals(aar_problem *pb, const double *x_full, double *r, double *sum_sq) {
     if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_eval_residuals: null argument");
     if (r && pb->comm) return set_error(AAR_ERR_UNSUPPORTED, "residual vector output is single-GPU only");
@@ -715,10 +727,13 @@ int aar_eval_residuals(aar_problem *pb, const double *x_full, double *r, double 
 int aar_reproj_stats(aar_problem *pb, const double *x_full, double *rmse, double *sum_sq) {
     if (!pb) return set_error(AAR_ERR_INVALID, "aar_reproj_stats: null argument");
     const int saved = pb->P.res_f32;
+    const float saved_h = pb->P.huber;
     pb->P.res_f32 = 0;
+    pb->P.huber = -1.f;
     double ss = 0;
     int rc = aar_eval_residuals(pb, x_full, nullptr, &ss);
     pb->P.res_f32 = saved;
+    pb->P.huber = saved_h;
     if (rc) return rc;
     if (sum_sq) *sum_sq = ss;
     if (rmse) *rmse = std::sqrt(ss / (4.0 * (double)pb->N_global));
@@ -917,6 +932,10 @@ int aar_lm_get_solution(aar_problem *pb, double *x_full, double *err) {
 // SparseLevMarq::solve(z, f, J), libs/sparselevmarq.h:440-472 (no stop function on this path)
 int aar_lm_solve(aar_problem *pb, double *x_full, const aar_lm_params *prm, aar_lm_report *rep) {
     if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_lm_solve: null argument");
+    if (pb->with_huber) {  // MultiCamMapper::solve sets hubberDelta = 10 before solver.solve (libs/multicam_mapper.cpp:425)
+        pb->hubber_delta = 10;
+        pb->P.huber = pb->hubber_delta;
+    }
     int rc = aar_lm_init(pb, x_full, prm);
     if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
@@ -933,6 +952,10 @@ int aar_lm_solve(aar_problem *pb, double *x_full, const aar_lm_params *prm, aar_
         if (pb->currErr > pb->prevErr) mustExit = 3;
         if (rep && rep->trace && iters < rep->trace_cap) rep->trace[iters] = it;
         iters++;
+        if (pb->with_huber && pb->hubber_delta > 2.5) {  // optCallBack, libs/multicam_mapper.cpp:412-417 (float -= double)
+            pb->hubber_delta = (float)((double)pb->hubber_delta - 7.5 / 500);
+            pb->P.huber = pb->hubber_delta;
+        }
         pb->prevErr = pb->currErr;
     }
     HIP_TRY(hipStreamSynchronize(pb->stream));

@@ -52,7 +52,7 @@ __global__ void k_unpack(const double *__restrict__ z, double *__restrict__ ent,
 // one thread per observation; per-frame partial sums are not needed here, so per-block partials
 __global__ void __launch_bounds__(256) k_residual(const ObsIdx *__restrict__ idx, const float *__restrict__ uv,
                                                   const double *__restrict__ ent, const double *__restrict__ Kmat,
-                                                  int64_t N, int A, double h, int res_f32, double *__restrict__ r_out,
+                                                  int64_t N, int A, double h, int res_f32, float huber, double *__restrict__ r_out,
                                                   double *__restrict__ err_part) {
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double ss = 0;
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) k_residual(const ObsIdx *__restrict__ idx
             CornerGeom g;
             project_corner(ec, em, ef, K, h, k, g);
             double rx, ry;
-            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, res_f32, rx, ry);
+            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, res_f32, huber, rx, ry);
             ss += rx * rx + ry * ry;
             if (r_out) {
                 r_out[8 * o + 2 * k] = rx;
@@ -113,6 +113,7 @@ struct PassAArgs {
     const ObsIdx *idx; const float *uv; const double *z; const double *Kmat;
     const int32_t *frame_obs_start, *fslot_start, *fslot_ent;
     int A, F, res_f32, max_kf, frames_fixed;
+    float huber;
     double h, mu_pred;
     double *ent_out, *V, *gf, *W, *Vinv, *hf, *err_part;
     double *zero0; int64_t zero0_n; double *zero1; int64_t zero1_n; double *zero2; int64_t zero2_n;
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
             CornerGeom g;
             project_corner(ec, em, ef, K, a.h, k, g);
             double r[2];
-            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, a.res_f32, r[0], r[1]);
+            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, a.res_f32, a.huber, r[0], r[1]);
             double Gc[2][6], Gm[2][6], Gf[2][6];
             corner_jacobian<true, true, true>(ec, em, ef, K, g, Gc, Gm, Gf);
 #pragma unroll
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
 __global__ void __launch_bounds__(256) k_passB(const ObsIdx *__restrict__ idx, const float *__restrict__ uv,
                                                const double *__restrict__ ent, const double *__restrict__ Kmat,
                                                const int32_t *__restrict__ chunk_start, int n_chunks, int A, double h,
-                                               int res_f32, int n_pad, double *__restrict__ U0,
+                                               int res_f32, float huber, int n_pad, double *__restrict__ U0,
                                                double *__restrict__ g0) {  // U0 = blk.S (zeroed), g0 = blk.g0
     __shared__ double scratch[4 * 2048];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -287,7 +288,7 @@ __global__ void __launch_bounds__(256) k_passB(const ObsIdx *__restrict__ idx, c
             CornerGeom g;
             project_corner(ec, em, ef, K, h, k, g);
             double r[2];
-            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, res_f32, r[0], r[1]);
+            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, res_f32, huber, r[0], r[1]);
             double Gc[2][6], Gm[2][6], Gf[2][6];
             corner_jacobian<true, true, false>(ec, em, ef, K, g, Gc, Gm, Gf);
 #pragma unroll
@@ -354,7 +355,7 @@ void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream
     const int blocks = (int)((P.N + 255) / 256);
     if (blocks == 0) return;
     { HookScope _h(P, KID_RESIDUAL); hipLaunchKernelGGL(k_residual, dim3(blocks), dim3(256), 0, st, P.a_idx, P.a_uv, P.ent[which], P.K, P.N, P.A,
-                       P.half_size, P.res_f32, r_out, P.err_part); }
+                       P.half_size, P.res_f32, P.huber, r_out, P.err_part); }
 }
 
 int residual_blocks(const DeviceProblem &P) { return (int)((P.N + 255) / 256); }
@@ -377,6 +378,7 @@ void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_bl
     a.idx = P.a_idx; a.uv = P.a_uv; a.z = P.z[which]; a.Kmat = P.K;
     a.frame_obs_start = P.frame_obs_start; a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent;
     a.A = P.A; a.F = P.F; a.res_f32 = P.res_f32; a.max_kf = P.max_kf; a.frames_fixed = P.frames_fixed;
+    a.huber = P.huber;
     a.h = P.half_size; a.mu_pred = mu_pred;
     const DeviceProblem::Blocks &b = P.blk[which];
     a.ent_out = P.ent[which]; a.V = b.V; a.gf = b.gf; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf; a.err_part = P.err_part;
@@ -398,7 +400,7 @@ void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_bl
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
     if (P.n_chunks == 0) return;
     { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, P.b_idx, P.b_uv, P.ent[which], P.K,
-                       P.chunk_start, P.n_chunks, P.A, P.half_size, P.res_f32, P.n_pad, P.blk[which].S, P.blk[which].g0); }
+                       P.chunk_start, P.n_chunks, P.A, P.half_size, P.res_f32, P.huber, P.n_pad, P.blk[which].S, P.blk[which].g0); }
 }
 
 void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st) {

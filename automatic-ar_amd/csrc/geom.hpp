@@ -130,7 +130,10 @@ __device__ __forceinline__ void project_corner(const EC &ec, const EM &em, const
 
 // residual of one corner: observed - projected.  f32 mode reproduces the reference's cv::Point2f store and
 // float subtraction (libs/multicam_mapper.cpp:644-647,1012-1013).
-__device__ __forceinline__ void corner_residual(float ou, float ov, double u, double v, int res_f32, double &rx,
+// huber >= 0: both rows are scaled by w = sqrt(rho(e)/e), e = rx^2 + ry^2, rho(e) = e if e <= delta^2 else 2 delta sqrt(e) - delta^2
+// with delta^2 and 2 delta rounded to float (hubberMono / getHubberMonoWeight, libs/multicam_mapper.cpp:11-24,1014-1019).
+// The Jacobian is NOT re-weighted, as in the reference (:976-994).
+__device__ __forceinline__ void corner_residual(float ou, float ov, double u, double v, int res_f32, float huber, double &rx,
                                                 double &ry) {
     if (res_f32) {
         rx = (double)(ou - (float)u);
@@ -138,6 +141,16 @@ __device__ __forceinline__ void corner_residual(float ou, float ov, double u, do
     } else {
         rx = (double)ou - u;
         ry = (double)ov - v;
+    }
+    if (huber >= 0.f) {
+        const double e = rx * rx + ry * ry;
+        if (e != 0.0) {
+            const float dsq = huber * huber, d2 = 2 * huber;
+            const double rho = (e <= (double)dsq) ? e : (double)d2 * sqrt(e) - (double)dsq;
+            const double w = sqrt(rho / e);
+            rx *= w;
+            ry *= w;
+        }
     }
 }
 

@@ -33,6 +33,7 @@ struct DeviceProblem {
     int total_slots = 0, max_kf = 0;  // sum / max of distinct shared entities per frame
     int n_chunks = 0, n_swork = 0;
     int res_f32 = 1;
+    float huber = -1.f;               // Huber delta of the residual weights (< 0: plain residuals)
     double half_size = 0;             // (double)((float)marker_size / 2.f)
     // constant problem data
     double *K = nullptr;              // [C][9]

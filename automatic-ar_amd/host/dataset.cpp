@@ -77,6 +77,7 @@ void aar_problem_desc_from_dataset(const aar_dataset *d, aar_problem_desc *p) {
     p->optimize_marker_poses = d->optimize_marker_poses;
     p->optimize_object_poses = d->optimize_object_poses;
     p->residual_mode = AAR_RES_F32;
+    p->with_huber = 0;
     p->device_id = 0;
     p->comm = nullptr;
 }

@@ -44,7 +44,7 @@ void MultiCamMapper::set_optmize_flag_cam_poses(bool f) { config_.optimize_cam_p
 void MultiCamMapper::set_optmize_flag_marker_poses(bool f) { config_.optimize_marker_poses = f; drop_problem(); }
 void MultiCamMapper::set_optmize_flag_object_poses(bool f) { config_.optimize_object_poses = f; drop_problem(); }
 void MultiCamMapper::set_optmize_flag_cam_intrinsics(bool f) { config_.optimize_cam_intrinsics = f; }
-void MultiCamMapper::set_with_huber(bool wh) { with_huber_ = wh; }
+void MultiCamMapper::set_with_huber(bool wh) { with_huber_ = wh; drop_problem(); }
 void MultiCamMapper::set_config(Config &conf) { config_ = conf; drop_problem(); }
 
 size_t MultiCamMapper::get_num_vars(const Config &conf) {  // libs/multicam_mapper.cpp:239-250
@@ -95,15 +95,19 @@ int MultiCamMapper::ensure_problem() {
     d.optimize_marker_poses = config_.optimize_marker_poses;
     d.optimize_object_poses = config_.optimize_object_poses;
     d.residual_mode = residual_mode;
+    d.with_huber = with_huber_ ? 1 : 0;
     d.device_id = device_id;
-    return aar_problem_create(&d, &problem_);
+    int rc = aar_problem_create(&d, &problem_);
+    if (!rc && with_huber_) rc = aar_problem_set_huber_delta(problem_, hubberDelta);
+    return rc;
 }
 
 void MultiCamMapper::error_function(const eVector &input, eVector &error) {
     if (!data_) throw std::runtime_error("MultiCamMapper::error_function: no data set");
-    if (input.size() != get_num_vars(config_) || config_.optimize_cam_intrinsics || with_huber_)
+    if (input.size() != get_num_vars(config_) || config_.optimize_cam_intrinsics)
         throw std::runtime_error("MultiCamMapper::error_function: configuration outside the accelerated path");
     if (ensure_problem()) throw std::runtime_error(aar_last_error());
+    if (with_huber_ && aar_problem_set_huber_delta(problem_, hubberDelta)) throw std::runtime_error(aar_last_error());
     std::vector<double> keep(data_->x_full, data_->x_full + aar_dataset_full_len(data_));
     eVec2Mats(input);
     error.assign(8 * (size_t)data_->num_obs, 0.0);
@@ -116,7 +120,6 @@ void MultiCamMapper::solve() {
     if (!data_) throw std::runtime_error("MultiCamMapper::solve: no data set");
     if (config_.optimize_cam_intrinsics)
         throw std::runtime_error("MultiCamMapper::solve: optimize_cam_intrinsics is not on the accelerated path (call set_optmize_flag_cam_intrinsics(false) as find_solution does)");
-    if (with_huber_) throw std::runtime_error("MultiCamMapper::solve: -with-huber is not on the accelerated path yet");
     if (ensure_problem()) throw std::runtime_error(aar_last_error());
     mats2eVec();
     double e0 = 0;
@@ -133,6 +136,7 @@ void MultiCamMapper::solve() {
     p.verbose = solver_params.verbose ? 1 : 0;
     memset(&last_report, 0, sizeof last_report);
     if (aar_lm_solve(problem_, data_->x_full, &p, &last_report)) throw std::runtime_error(aar_last_error());
+    if (with_huber_) hubberDelta = aar_problem_get_huber_delta(problem_);  // where optCallBack's schedule left it
     mats2eVec();  // io_vec holds the solution, as after solver.solve(io_vec, ...) in the reference
 }
 

@@ -59,7 +59,7 @@ class MultiCamMapper {
     void set_optmize_flag_marker_poses(bool);
     void set_optmize_flag_object_poses(bool);
     void set_optmize_flag_cam_intrinsics(bool);  // true is rejected at solve(): outside this path (apps/find_solution.cpp:140)
-    void set_with_huber(bool);                   // true is rejected at solve(): SURVEY.md 8f "next" #4
+    void set_with_huber(bool);                   // Huber-weighted residual rows + optCallBack's delta schedule (:412-417)
     void set_config(Config &conf);
     size_t get_num_vars(const Config &conf);
 

@@ -44,17 +44,24 @@ def run_steps(problem, x0, steps, params_factory):
 
 
 def algorithmic_bytes(kernel, N, A, F, n_pad):
-    """Algorithmic HBM bytes of ONE launch: the 44-byte observation record is SURVEY.md 8d's unit."""
+    """Algorithmic HBM bytes of ONE launch (DESIGN.md section 5): the 44-byte observation record is SURVEY.md 8d's unit;
+    the dense factorisation kernels are charged the tiles of the reduced system they must read and write once."""
     P = 6 * (A + F)
     rec = 44 * N
+    nT = max(1, n_pad // 96)
+    tile = 8 * 96 * 96
+    avg_rows = (nT + 1) / 2.0                      # row tiles in an average block column (diagonal included)
     table = {
         "k_passA": rec + 8 * P,                       # every record once + the pose vector
-        "k_passB": rec + 8 * P + 8 * (n_pad * n_pad // 2 + n_pad),   # + the shared system it writes (lower triangle)
+        "k_passB": rec + 8 * P + 8 * (n_pad * n_pad // 2 + n_pad),   # + the shared system it accumulates (lower triangle)
         "k_residual": rec + 8 * P,
         "k_unpack": 8 * P,
         "k_schur": 8 * (n_pad * n_pad // 2 + n_pad),  # frame-owned W/V traffic is overhead, not algorithmic (SURVEY 8d)
-        "k_ldl_panel": 0, "k_ldl_update": 0, "k_ldl_backsolve": 8 * n_pad, "k_frame_inv": 8 * (n_pad * n_pad + n_pad),
-        "k_finalize": 8 * n_pad, "k_backsub": 8 * P, "k_reduce_scalars": 0, "k_maxdiag": 0,
+        "k_ldl_diag": 2 * tile,                       # diagonal tile in, factor out
+        "k_ldl_trsm": 2 * tile * (avg_rows - 1) + tile,             # the block column below the diagonal in/out + L_ss
+        "k_ldl_update": 2 * 8 * (n_pad * n_pad // 2) / max(1, nT - 1) if nT > 1 else 0,   # trailing matrix, amortised over the steps
+        "k_ldl_backsolve": 8 * (n_pad * n_pad // 2 + 2 * n_pad),
+        "k_frame_inv": 8 * 48 * F * 2, "k_backsub": 8 * P * 2, "k_reduce_scalars": 8 * 3 * F, "k_maxdiag": 8 * (n_pad + 6 * F),
     }
     return table.get(kernel, 0)
 

@@ -128,6 +128,9 @@ typedef struct aar_problem_desc {
     const float *obs_uv;                      /* [N][8]                                             */
     int32_t optimize_cam_poses, optimize_marker_poses, optimize_object_poses;
     int32_t residual_mode;                    /* AAR_RES_F32 | AAR_RES_F64                          */
+    int32_t with_huber;                       /* MultiCamMapper::set_with_huber (libs/multicam_mapper.cpp:31-33,1014-1019): residual
+                                                 rows scaled by sqrt(rho(e)/e); aar_lm_solve then also runs optCallBack's delta
+                                                 schedule (:412-417): 10 at the start of solve(), -7.5/500 per step down to 2.5   */
     int32_t device_id;
     aar_comm *comm;                           /* NULL = single GPU; else observations are sharded by
                                                  frame range over the communicator's ranks           */
@@ -139,6 +142,9 @@ void aar_problem_destroy(aar_problem *);
 int64_t aar_problem_full_len(const aar_problem *);    /* length of x_full                            */
 int64_t aar_problem_num_vars(const aar_problem *);    /* length of the reference's z for the Config  */
 int64_t aar_problem_local_obs(const aar_problem *);   /* observations owned by this rank             */
+/* MultiCamMapper::hubberDelta: the delta the next residual evaluations use (only meaningful with with_huber) */
+int aar_problem_set_huber_delta(aar_problem *, float delta);
+float aar_problem_get_huber_delta(const aar_problem *);
 
 /* error_function (libs/multicam_mapper.cpp:731-737): r (8*num_obs doubles, reference row order; may be
  * NULL; single-GPU only when non-NULL) and sum of squares (all ranks). */

@@ -779,12 +779,17 @@ int orc_damped_solve(const orc_problem *p, const double *x_full, const double *z
 }
 
 // SparseLevMarq<T>::solve / init / step, libs/sparselevmarq.h:238-249,349-430,440-472
-double orc_lm_solve(const orc_problem *p, const double *x_full, double *z_inout, const orc_lm_params *prm,
+double orc_lm_solve(const orc_problem *p_in, const double *x_full, double *z_inout, const orc_lm_params *prm,
                     int jac_mode, int res_mode, orc_lm_iter *trace, int32_t trace_cap, int32_t *n_iters,
                     int32_t num_threads) {
 #ifdef _OPENMP
     if (num_threads > 0) omp_set_num_threads(num_threads);
 #endif
+    // with_huber: MultiCamMapper::solve sets hubberDelta = 10 before solver.solve (libs/multicam_mapper.cpp:425) and
+    // optCallBack lowers it by 7.5/500 after every step while it is above 2.5 (:412-417)
+    orc_problem pw = *p_in;
+    if (pw.with_huber) pw.huber_delta = 10;
+    const orc_problem *p = &pw;
     Layout L(p);
     const int64_t P = L.z_len, rowsN = 8 * p->num_obs;
     std::vector<double> curr_z(z_inout, z_inout + P), x64(rowsN);
@@ -845,6 +850,7 @@ double orc_lm_solve(const orc_problem *p, const double *x_full, double *z_inout,
             trace[iters].tries = ntries + (accepted ? 1 : 0);
         }
         iters++;
+        if (pw.with_huber && pw.huber_delta > 2.5) pw.huber_delta = (float)((double)pw.huber_delta - 7.5 / 500);  // optCallBack
         prevErr = currErr;
     }
     std::memcpy(z_inout, curr_z.data(), sizeof(double) * P);

@@ -31,10 +31,15 @@ typedef Solver::eVector eVector;
 extern "C" {
 
 /* Params as MultiCamMapper::init sets them (libs/multicam_mapper.cpp:326-330) unless overridden. */
-double ref_lm_solve(const orc_problem *p, const double *x_full, double *z_inout, const orc_lm_params *prm,
+double ref_lm_solve(const orc_problem *p_in, const double *x_full, double *z_inout, const orc_lm_params *prm,
                     int jac_mode, int res_mode, orc_lm_iter *trace, int32_t trace_cap, int32_t *n_iters,
                     int32_t num_threads, int32_t use_omp_mult) {
     if (num_threads > 0) omp_set_num_threads(num_threads);
+    // with_huber: hubberDelta = 10 at the start of MultiCamMapper::solve, lowered by optCallBack after every step
+    // (libs/multicam_mapper.cpp:412-417,425); the step callback below is where the reference does it
+    orc_problem pw = *p_in;
+    if (pw.with_huber) pw.huber_delta = 10;
+    const orc_problem *p = &pw;
     const int64_t P = orc_num_vars(p), N = p->num_obs;
     Solver solver;
     Solver::Params prms;
@@ -77,6 +82,7 @@ double ref_lm_solve(const orc_problem *p, const double *x_full, double *z_inout,
             last_err = e;
         }
         iters++;
+        if (pw.with_huber && pw.huber_delta > 2.5) pw.huber_delta = (float)((double)pw.huber_delta - 7.5 / 500);
     });
     eVector z(P);
     std::memcpy(z.data(), z_inout, sizeof(double) * P);

@@ -39,9 +39,9 @@ def trace_arrays(rep, prefix):
             prefix + "iterations": np.array([rep["iterations"]]), prefix + "final_err": np.array([rep["final_err"]])}
 
 
-def g1(name, ds, synth_args, tau=1.0):
+def g1(name, ds, synth_args, tau=1.0, with_huber=False):
     """G1: LM trace + final solution of the real solver, reference-faithful callbacks."""
-    o = ol.Oracle(ds)
+    o = ol.Oracle(ds, with_huber=with_huber)
     prm = ol.mapper_params(tau=tau)
     x_ref, rep = o.ref_lm_solve(ds.x_full, params=prm, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=1, use_omp_mult=True)
     x_acc, rep_acc = o.ref_lm_solve(ds.x_full, params=prm, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32, threads=1, use_omp_mult=True)
@@ -56,7 +56,8 @@ def g1(name, ds, synth_args, tau=1.0):
     out["faithful_rmse"] = np.array([st["rmse"], st["mean_dist"], st["sum_sq"]])
     st = o.reproj_stats(x_acc)
     out["analytic_rmse"] = np.array([st["rmse"], st["mean_dist"], st["sum_sq"]])
-    out["r0_f32"] = o.residuals(ds.x_full, res_mode=ol.RES_F32)
+    out["r0_f32"] = o.residuals(ds.x_full, res_mode=ol.RES_F32)   # with_huber: weighted with the oracle's delta (10)
+    out["with_huber"] = np.array([int(with_huber)])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name, "N", ds.num_obs, "faithful iters", rep["iterations"], "err", rep["final_err"], "analytic iters",
           rep_acc["iterations"], "err", rep_acc["final_err"], "rmse delta", abs(out["faithful_rmse"][0] - out["analytic_rmse"][0]))
@@ -93,4 +94,12 @@ if __name__ == "__main__":
     g1("g1_cfg2_far", aar.synth(2, init_scale=4.0), [2, 4, 12, 100, 4.0])
     # far start + tiny tau: the first damping tries of some steps are rejected -> exercises the mu*=v; v*=5 branch
     g1("g1_cfg2_retry", aar.synth(2, init_scale=15.0), [2, 4, 12, 100, 15.0], tau=1e-6)
+    # -with-huber: 3 % of the detections corrupted by ~25 px; the delta schedule (10 -> 2.5 in 500 steps) keeps the solver
+    # running for ~500 iterations, as it does in the reference
+    dsh = aar.synth(2)
+    rng = np.random.default_rng(11)
+    bad = rng.random(dsh.num_obs) < 0.03
+    dsh.obs_uv = dsh.obs_uv.copy()
+    dsh.obs_uv[bad] += rng.normal(0, 25, size=(int(bad.sum()), 8)).astype(np.float32)
+    g1("g1_cfg2_huber", dsh, [2, 4, 12, 100, 1.0], with_huber=True)
     g2("g2_small", aar.synth(2, num_cams=3, num_markers=8, num_frames=20))

@@ -147,6 +147,35 @@ def test_lm_retry_branch():
         assert rep["final_err"] <= g2["analytic_err"][-1]   # the floor lies below where the 1e-4 stop rule halts
 
 
+def test_huber_rows_and_schedule():
+    # libs/multicam_mapper.cpp:11-24,1014-1019 (weights) and :412-417,425 (delta schedule driven by the step callback)
+    ds, g = load_golden("g1_cfg2_huber")
+    o = ol.Oracle(ds, with_huber=True, huber_delta=10.0)
+    with aar.Problem(ds, with_huber=True) as p:
+        p.set_huber_delta(10.0)
+        r, _ = p.eval_residuals(ds.x_full)
+        assert np.array_equal(r, g["r0_f32"])                       # weighted rows, bit-exact
+        p.set_huber_delta(3.25)
+        r2, _ = p.eval_residuals(ds.x_full)
+        o2 = ol.Oracle(ds, with_huber=True, huber_delta=3.25)
+        assert np.array_equal(r2, o2.residuals(ds.x_full, res_mode=ol.RES_F32))
+        assert not np.array_equal(r, r2)
+        # B uses the weighted residual with the UNweighted Jacobian (the reference does not re-weight J, :976-994)
+        p.set_huber_delta(10.0)
+        H, B, _ = p.eval_normal_equations(ds.x_full)
+        Ho, Bo = o.normal_equations(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+        assert np.abs(H - Ho).max() / np.abs(Ho).max() < 1e-12
+        assert np.abs(B - Bo).max() / np.abs(Bo).max() < 1e-11
+        x, rep = p.lm_solve(ds.x_full, trace_cap=600)
+        assert rep["iterations"] == int(g["analytic_iterations"][0])
+        err = np.array([t["err"] for t in rep["trace"]])
+        np.testing.assert_allclose(err, g["analytic_err"], rtol=1e-5)
+        np.testing.assert_allclose(x, g["analytic_x"], atol=1e-4)
+        assert abs(p.get_huber_delta() - 2.5) < 0.02                  # where optCallBack leaves it
+        rmse, _ = p.reproj_stats(x)                                   # unweighted statistic
+        assert abs(rmse - g["faithful_rmse"][0]) < 1e-4
+
+
 def test_step_api_matches_solve():
     ds, g = load_golden("g1_cfg2")
     with aar.Problem(ds) as p:

@@ -116,6 +116,22 @@ def test_rodrigues_restatement():
     np.testing.assert_allclose(ol.rodrigues_mat2vec(R * (1 + 1e-6)), [0.3, -0.2, 0.5], atol=1e-9)
 
 
+def test_port_lm_with_huber_schedule_matches_real_solver():
+    # -with-huber: hubberDelta = 10 at the start of solve(), lowered by 7.5/500 after every step down to 2.5
+    # (libs/multicam_mapper.cpp:412-417,425); the changing delta keeps the solver running for ~500 steps
+    ds, g = load_golden("g1_cfg2_huber")
+    o = ol.Oracle(ds, with_huber=True)
+    x, rep = o.lm_solve(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32, threads=2)
+    assert rep["iterations"] == int(g["analytic_iterations"][0]) == 505
+    err = np.array([t["err"] for t in rep["trace"]])
+    np.testing.assert_allclose(err, g["analytic_err"], rtol=1e-5)
+    np.testing.assert_allclose(x, g["analytic_x"], atol=1e-4)
+    assert abs(o.reproj_stats(x)["rmse"] - g["faithful_rmse"][0]) < 1e-4
+    # the outliers are down-weighted: the unweighted optimum is pulled away from where the Huber one sits
+    plain_x, _ = ol.Oracle(ds).lm_solve(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32, threads=2)
+    assert np.abs(plain_x - x).max() > 1e-3
+
+
 def test_huber_weight_restatement():
     # libs/multicam_mapper.cpp:11-24,1014-1019: rows scaled by sqrt(rho(e)/e); inliers untouched
     ds, _ = load_golden("g2_small")
