@@ -66,28 +66,35 @@ def algorithmic_bytes(kernel, N, A, F, n_pad):
     return table.get(kernel, 0)
 
 
-def cpu_baseline(ds, workload, threads):
-    """The reference solver on the host cores, bounded sample (rank 0, N = 1 only)."""
+def cpu_baseline(ds, workload, max_threads):
+    """The reference solver on the host cores, bounded sample (rank 0, N = 1 only).  OpenMP with every core of a large
+    host is not the reference's best case (its mult() does not scale), so a few thread counts are timed and the best
+    is reported together with the count that produced it."""
     import oracle_lib as ol
+    kind = "reference" if ol.have_ref() else "port"
     if workload >= 5:
-        return {"value": None, "unit": "LM iterations/s", "cores": threads, "kind": "reference" if ol.have_ref() else "port",
-                "sample": "not run: ONE reference iteration at 1.6 M marker observations takes ~9 min and 15 GB (BASELINE.md section 2)"}
-    cap = {2: 15, 3: 8, 4: 2}[workload]
+        return {"value": None, "unit": "LM iterations/s", "cores": max_threads, "kind": kind,
+                "sample": "not run: ONE reference iteration at 1.3 M marker observations takes ~9 min and 15 GB (BASELINE.md section 2)"}
+    cap = {2: 15, 3: 4, 4: 1}[workload]
     o = ol.Oracle(ds)
     prm = ol.mapper_params(max_iters=cap)
-    t0 = time.perf_counter()
-    if ol.have_ref():
-        x, rep = o.ref_lm_solve(ds.x_full, params=prm, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=threads)
-        kind = "reference"
-        what = ("real ucoslam::SparseLevMarq<double> + Eigen::SimplicialLDLT (oracle/_ref, g++ -O3 -march=x86-64-v3 -fopenmp) "
-                "driving the restated reference-faithful residual / central-difference float Jacobian")
-    else:
-        x, rep = o.lm_solve(ds.x_full, params=prm, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=threads)
-        kind = "port"
-        what = "oracle/ba_oracle.cpp restatement (numeric float Jacobian, map-based Jt*J, own sparse LDL^T)"
-    dt = time.perf_counter() - t0
-    return {"value": rep["iterations"] / dt, "unit": "LM iterations/s", "cores": threads, "kind": kind,
-            "sample": "first %d LM iterations of the same %s problem from the same start (%.1f s); %s" % (rep["iterations"], WORKLOADS[workload], dt, what),
+    what = ("real ucoslam::SparseLevMarq<double> + Eigen::SimplicialLDLT (oracle/_ref, g++ -O3 -march=x86-64-v3 -fopenmp) driving the "
+            "restated reference-faithful residual / central-difference float Jacobian") if kind == "reference" else \
+           "oracle/ba_oracle.cpp restatement (numeric float Jacobian, map-based Jt*J, own sparse LDL^T)"
+    best, tried = None, []
+    for th in sorted(set([min(8, max_threads), min(32, max_threads), max_threads])):
+        t0 = time.perf_counter()
+        fn = o.ref_lm_solve if kind == "reference" else o.lm_solve
+        x, rep = fn(ds.x_full, params=prm, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=th)
+        dt = time.perf_counter() - t0
+        rate = rep["iterations"] / dt
+        tried.append({"threads": th, "it_per_s": rate, "seconds": dt})
+        if best is None or rate > best[0]:
+            best = (rate, th, rep, dt)
+    rate, th, rep, dt = best
+    return {"value": rate, "unit": "LM iterations/s", "cores": th, "kind": kind, "host_cores": max_threads, "thread_counts_tried": tried,
+            "sample": "first %d LM iterations of the same %s problem from the same start (%.1f s at the best thread count); %s"
+                      % (rep["iterations"], WORKLOADS[workload], dt, what),
             "err_after_sample": rep["final_err"]}
 
 
