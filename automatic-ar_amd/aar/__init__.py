@@ -28,7 +28,7 @@ SYMBOLS = [
     "aar_eval_normal_equations", "aar_eval_damped_step", "aar_lm_default_params", "aar_lm_init", "aar_lm_step",
     "aar_lm_get_solution", "aar_lm_solve", "aar_get_stage_times", "aar_reproj_stats", "aar_device_count",
     "aar_device_synchronize", "aar_set_kernel_profiling", "aar_get_kernel_times", "aar_kernel_name",
-    "aar_problem_set_huber_delta", "aar_problem_get_huber_delta",
+    "aar_problem_set_huber_delta", "aar_problem_get_huber_delta", "aar_track",
 ]
 NUM_KERNELS = 13
 
@@ -153,6 +153,7 @@ def lib():
     L.aar_get_kernel_times.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64)]
     L.aar_kernel_name.argtypes = [C.c_int]
     L.aar_kernel_name.restype = C.c_char_p
+    L.aar_track.argtypes = [C.c_void_p, dp, C.POINTER(CLmParams), C.POINTER(C.c_int32), dp]
     L.aar_problem_set_huber_delta.argtypes = [C.c_void_p, C.c_float]
     L.aar_problem_get_huber_delta.argtypes = [C.c_void_p]
     L.aar_problem_get_huber_delta.restype = C.c_float
@@ -437,6 +438,15 @@ class Problem:
                       final_err=rep.final_err, final_mu=rep.final_mu, solve_seconds=rep.solve_seconds,
                       trial_points=rep.trial_points, trace=trace)
         return x, report
+
+    def track(self, x_full, params=None):
+        """MultiCamMapper::track() for every frame at once: returns (x_full with refined frame poses, iterations[F], err[F])."""
+        x = np.array(self._x(x_full), dtype=np.float64)
+        it = np.zeros(self.ds.num_frames, dtype=np.int32)
+        err = np.zeros(self.ds.num_frames)
+        _check(lib().aar_track(self.handle, _dptr(x), C.byref(params) if params is not None else None,
+                               it.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(err)))
+        return x, it, err
 
     def set_huber_delta(self, delta):
         _check(lib().aar_problem_set_huber_delta(self.handle, float(delta)))

@@ -975,6 +975,43 @@ int aar_lm_solve(aar_problem *pb, double *x_full, const aar_lm_params *prm, aar_
     return AAR_OK;
 }
 
+int aar_track(aar_problem *pb, double *x_full, const aar_lm_params *prm, int32_t *iterations, double *final_err) {
+    if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_track: null argument");
+    HIP_TRY(hipSetDevice(pb->device));
+    DeviceProblem &P = pb->P;
+    aar_lm_params p;
+    if (prm) p = *prm; else aar_lm_default_params(&p);
+    pb->lm_ready = false;
+    const int F = P.F;
+    int rc = upload_z(pb, x_full, pb->cur);
+    if (rc) return rc;
+    int32_t *d_it = nullptr;
+    double *d_err = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_it, std::max(F, 1) * sizeof(int32_t)));
+    if (hipMalloc((void **)&d_err, std::max(F, 1) * sizeof(double)) != hipSuccess) { (void)hipFree(d_it); return set_error(AAR_ERR_HIP, "hipMalloc failed"); }
+    launch_unpack(P, pb->cur, pb->stream);  // rows of the fixed cameras / markers
+    launch_track(P, pb->cur, p.max_iters, p.min_error, p.min_step_error_diff, p.min_average_step_error_diff, p.tau, d_it, d_err, pb->stream);
+    std::vector<int32_t> h_it(std::max(F, 1));
+    std::vector<double> h_err(std::max(F, 1));
+    hipError_t e1 = hipMemcpyAsync(h_it.data(), d_it, std::max(F, 1) * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream);
+    hipError_t e2 = hipMemcpyAsync(h_err.data(), d_err, std::max(F, 1) * sizeof(double), hipMemcpyDeviceToHost, pb->stream);
+    hipError_t e3 = hipStreamSynchronize(pb->stream);
+    (void)hipFree(d_it);
+    (void)hipFree(d_err);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return set_error(AAR_ERR_HIP, "aar_track: %s", hipGetErrorString(e3 != hipSuccess ? e3 : (e1 != hipSuccess ? e1 : e2)));
+    if ((rc = check_async("track kernel"))) return rc;
+    // only the frame poses move; download_z honours the Config flags, so force "frames on, shared off" for this call
+    PoseLayout keep = pb->L;
+    pb->L.oc = false; pb->L.om = false; pb->L.of = true;
+    rc = download_z(pb, pb->cur, x_full);
+    pb->L = keep;
+    if (rc) return rc;
+    // per-frame outputs are indexed by global frame; a sharded problem returns its own range and zeros elsewhere
+    if (iterations) { std::fill(iterations, iterations + pb->L.F, 0); for (int f = 0; f < F; f++) iterations[pb->f_begin + f] = h_it[f]; }
+    if (final_err) { std::fill(final_err, final_err + pb->L.F, 0.0); for (int f = 0; f < F; f++) final_err[pb->f_begin + f] = h_err[f]; }
+    return AAR_OK;
+}
+
 int aar_set_kernel_profiling(aar_problem *pb, int on) {
     if (!pb) return set_error(AAR_ERR_INVALID, "aar_set_kernel_profiling: null argument");
     HIP_TRY(hipSetDevice(pb->device));

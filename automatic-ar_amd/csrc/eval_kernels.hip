@@ -409,3 +409,190 @@ void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st) {
 }
 
 }  // namespace aar
+
+// ================================================================================================
+// track(): MultiCamMapper::track (libs/multicam_mapper.cpp:430-443) for a batch of frames.  Cameras and markers are
+// fixed; every frame refines its own 6-DoF object pose with the same LM rules (SparseLevMarq::solve(z, f),
+// libs/sparselevmarq.h:223-228,440-472) on error_function_tracking (:678-729: residuals kept in double, optional Huber
+// weights with a fixed delta).  One wavefront runs the WHOLE loop of one frame on the device: lanes stride over the
+// frame's observations, the 6x6 normal equations are reduced with wave shuffles, every lane solves the damped system
+// redundantly, no host round trip.  The Jacobian is the analytic 2x6 frame block instead of calcDerivates_omp's central
+// differences (:165-196).
+// ================================================================================================
+namespace aar {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+struct TrackArgs {
+    const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat; const int32_t *frame_obs_start;
+    int A, F; float huber; double h;
+    int max_iters; double min_error, min_step_error_diff, min_average_step_error_diff, tau;
+    double *z;            // [6(A+F)]: frame poses in/out
+    int32_t *iters_out;   // [F]
+    double *err_out;      // [F]
+};
+
+// residual sum (and optionally V (21 packed), g (6)) of one frame at pose zf, summed over the wave
+template <bool WITH_J>
+__device__ __forceinline__ double track_eval(const TrackArgs &a, int f, const double zf[6], int lane, double V[21], double g[6]) {
+    double row[ENT_STRIDE];
+    make_ent_row(zf, row);
+    Ent ef;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { ef.R[i] = row[i]; ef.Jl[i] = row[12 + i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) ef.t[i] = row[9 + i];
+    double acc[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) acc[i] = 0.0;
+    const int o0 = a.frame_obs_start[f], o1 = a.frame_obs_start[f + 1];
+    for (int o = o0 + lane; o < o1; o += 64) {
+        const ObsIdx id = a.idx[o];
+        const float4 uv0 = reinterpret_cast<const float4 *>(a.uv)[2 * (int64_t)o];
+        const float4 uv1 = reinterpret_cast<const float4 *>(a.uv)[2 * (int64_t)o + 1];
+        const float ou[8] = {uv0.x, uv0.y, uv0.z, uv0.w, uv1.x, uv1.y, uv1.z, uv1.w};
+        Ent ec, em;
+        load_ent(a.ent, id.cam, ec);
+        load_ent(a.ent, id.marker, em);
+        double K[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) K[i] = a.Kmat[9 * id.cam + i];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            CornerGeom gm;
+            project_corner(ec, em, ef, K, a.h, k, gm);
+            double r[2];
+            corner_residual(ou[2 * k], ou[2 * k + 1], gm.u, gm.v, 0, -1.f, r[0], r[1]);  // double residuals (:712-713), unweighted
+            // Huber: track() differentiates the WEIGHTED error function numerically (calcDerivates), so the weight's own
+            // derivative belongs to the Jacobian here (unlike solve(), whose Jacobian ignores the weights):
+            //   r_w = w r,  w = sqrt(rho)/s,  s = |r|,  rho = 2 delta s - delta^2  (outliers; w = 1 otherwise)
+            //   d r_w = w dr + r (dw/ds) (r . dr)/s
+            double w = 1.0, cw = 0.0;
+            if (a.huber >= 0.f) {
+                const double e = r[0] * r[0] + r[1] * r[1];
+                const float dsq = a.huber * a.huber, d2 = 2 * a.huber;
+                if (e != 0.0 && e > (double)dsq) {
+                    const double sn = sqrt(e), rho = (double)d2 * sn - (double)dsq, sr = sqrt(rho);
+                    w = sr / sn;
+                    cw = ((double)a.huber / sr - sr / sn) / e;  // (dw/ds) / s
+                }
+            }
+            acc[27] += w * w * (r[0] * r[0] + r[1] * r[1]);
+            if (WITH_J) {
+                double Gc[2][6], Gm[2][6], Gf[2][6];
+                corner_jacobian<false, false, true>(ec, em, ef, K, gm, Gc, Gm, Gf);
+                if (cw != 0.0 || w != 1.0) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        const double rg = r[0] * Gf[0][i] + r[1] * Gf[1][i];
+                        Gf[0][i] = w * Gf[0][i] + cw * r[0] * rg;
+                        Gf[1][i] = w * Gf[1][i] + cw * r[1] * rg;
+                    }
+                }
+                r[0] *= w;
+                r[1] *= w;
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        acc[21 + i] += Gf[rr][i] * r[rr];
+#pragma unroll
+                        for (int j = 0; j <= i; j++) acc[i * (i + 1) / 2 + j] += Gf[rr][i] * Gf[rr][j];
+                    }
+            }
+        }
+    }
+    if (WITH_J) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) V[i] = wave_sum(acc[i]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) g[i] = wave_sum(acc[21 + i]);
+    }
+    return wave_sum(acc[27]);
+}
+
+__global__ void __launch_bounds__(256) k_track(const TrackArgs a) {
+    const int lane = threadIdx.x & 63, f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= a.F) return;
+    double z[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) z[i] = a.z[6 * (size_t)(a.A + f) + i];
+    const double rows = 8.0 * (double)(a.frame_obs_start[f + 1] - a.frame_obs_start[f]);
+    double V[21], g[6];
+    // init (:238-249): the first evaluation also yields the first step's normal equations
+    double currErr = track_eval<true>(a, f, z, lane, V, g), prevErr = currErr;
+    double mu = -1.0, v = 2.0;
+    int mustExit = 0, iters = 0;
+    for (int it = 0; it < a.max_iters && !mustExit && rows > 0; it++) {
+        if (it > 0) (void)track_eval<true>(a, f, z, lane, V, g);  // J, Jt*J, B at curr_z (:353-367)
+        if (mu < 0) {                                                 // :369-377
+            double mx = V[0];
+#pragma unroll
+            for (int i = 1; i < 6; i++) mx = fmax(mx, V[i * (i + 1) / 2 + i]);
+            mu = mx * a.tau;
+        }
+        double gain = 0.0;
+        int ntries = 0;
+        bool accepted = false;
+        do {
+            double m[6][6], inv[36], d[6], zt[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) m[i][j] = V[sym6(i, j)] + (i == j ? mu : 0.0);
+            (void)spd6_inverse(m, inv);
+            double d2 = 0.0, dg = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) s += inv[i * 6 + j] * g[j];
+                d[i] = s;
+                zt[i] = z[i] + s;
+                d2 += s * s;
+                dg += s * g[i];
+            }
+            double dummyV[21], dummyg[6];
+            const double err = track_eval<false>(a, f, zt, lane, dummyV, dummyg);
+            const double Lq = 0.5 * (mu * d2 - dg);                  // :406
+            gain = (err - prevErr) / Lq;
+            if (gain > 0 && (err - prevErr) < 0) {                   // :409-415
+                const double t = 2 * gain - 1;
+                mu = mu * fmax(0.33, 1.0 - t * t * t);
+                v = 2.0;
+                currErr = err;
+#pragma unroll
+                for (int i = 0; i < 6; i++) z[i] = zt[i];
+                accepted = true;
+            } else {
+                mu = mu * v;
+                v = v * 5;
+            }
+        } while (gain <= 0 && ntries++ < 5 && !accepted);
+        if (currErr < a.min_error) mustExit = 1;                      // :458-461
+        if (fabs(prevErr - currErr) <= a.min_step_error_diff || fabs((prevErr - currErr) / rows) <= a.min_average_step_error_diff || !accepted)
+            mustExit = 2;
+        if (currErr > prevErr) mustExit = 3;
+        iters++;
+        prevErr = currErr;
+    }
+    if (lane < 6) a.z[6 * (size_t)(a.A + f) + lane] = z[lane];
+    if (lane == 0) { a.iters_out[f] = iters; a.err_out[f] = currErr; }
+}
+
+void launch_track(const DeviceProblem &P, int which, int max_iters, double min_error, double min_step, double min_avg, double tau,
+                  int32_t *iters_out, double *err_out, hipStream_t st) {
+    if (P.F == 0) return;
+    TrackArgs a;
+    a.idx = P.a_idx; a.uv = P.a_uv; a.ent = P.ent[which]; a.Kmat = P.K; a.frame_obs_start = P.frame_obs_start;
+    a.A = P.A; a.F = P.F; a.huber = P.huber; a.h = P.half_size;
+    a.max_iters = max_iters; a.min_error = min_error; a.min_step_error_diff = min_step; a.min_average_step_error_diff = min_avg; a.tau = tau;
+    a.z = P.z[which]; a.iters_out = iters_out; a.err_out = err_out;
+    hipLaunchKernelGGL(k_track, dim3((P.F + 3) / 4), dim3(256), 0, st, a);
+}
+
+}  // namespace aar

@@ -105,5 +105,8 @@ void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st);  // scal[0..2], scal[5..6]
 void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st);       // scal/flags -> host record
 int residual_blocks(const DeviceProblem &P);   // entries of err_part written by launch_residual
+// track(): every frame's own 6-DoF LM, whole loop on the device; needs ent[which] rows of the shared entities (launch_unpack)
+void launch_track(const DeviceProblem &P, int which, int max_iters, double min_error, double min_step, double min_avg, double tau,
+                  int32_t *iters_out, double *err_out, hipStream_t st);
 
 }  // namespace aar

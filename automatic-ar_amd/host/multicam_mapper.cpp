@@ -140,6 +140,26 @@ void MultiCamMapper::solve() {
     mats2eVec();  // io_vec holds the solution, as after solver.solve(io_vec, ...) in the reference
 }
 
+// track(): the reference refines ONE frame per call (apps/track.cpp:127-131 re-inits the mapper with the frame's detections
+// each time); here every frame held by the data set is refined in one launch, each with its own LM.
+void MultiCamMapper::track() {
+    if (!data_) throw std::runtime_error("MultiCamMapper::track: no data set");
+    if (ensure_problem()) throw std::runtime_error(aar_last_error());
+    hubberDelta = 10;  // :439
+    if (with_huber_ && aar_problem_set_huber_delta(problem_, hubberDelta)) throw std::runtime_error(aar_last_error());
+    aar_lm_params p;
+    aar_lm_default_params(&p);
+    p.max_iters = solver_params.maxIters;
+    p.min_error = solver_params.minError;
+    p.min_step_error_diff = solver_params.min_step_error_diff;
+    p.min_average_step_error_diff = solver_params.min_average_step_error_diff;
+    p.tau = solver_params.tau;
+    track_iterations.assign(data_->num_frames, 0);
+    track_errors.assign(data_->num_frames, 0.0);
+    if (aar_track(problem_, data_->x_full, &p, track_iterations.data(), track_errors.data())) throw std::runtime_error(aar_last_error());
+    mats2eVec();
+}
+
 bool MultiCamMapper::write_solution_file(std::string path) {
     if (!data_) return false;
     aar_dataset tmp = *data_;

@@ -64,6 +64,7 @@ class MultiCamMapper {
     size_t get_num_vars(const Config &conf);
 
     void solve();                                               // libs/multicam_mapper.cpp:419-428
+    void track();                                               // :430-443, every frame of the data set at once
     void error_function(const eVector &input, eVector &error);  // :731-737
     bool write_solution_file(std::string path);                 // :1053-1099
     bool read_solution_file(std::string path);                  // :1124-1205
@@ -79,6 +80,8 @@ class MultiCamMapper {
     float hubberDelta = 2.5;
     SparseLevMarq<double>::Params solver_params;  // what MultiCamMapper::init installs (:326-330)
     aar_lm_report last_report;                    // iterations, errors and timing of the last solve()
+    std::vector<int32_t> track_iterations;        // per frame, after track()
+    std::vector<double> track_errors;
     int device_id = 0;
     int residual_mode = AAR_RES_F32;
 

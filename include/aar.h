@@ -194,6 +194,13 @@ int aar_lm_get_solution(aar_problem *, double *x_full, double *err);
 /* SparseLevMarq::solve(z, f, J) (libs/sparselevmarq.h:440-472): x_full in/out */
 int aar_lm_solve(aar_problem *, double *x_full, const aar_lm_params *, aar_lm_report *);
 
+/* MultiCamMapper::track() (libs/multicam_mapper.cpp:430-443) for every frame of the problem at once: cameras and markers
+ * stay at their x_full values, each frame's object pose is refined on its own by the LM of SparseLevMarq::solve(z, f)
+ * (libs/sparselevmarq.h:223-228) over error_function_tracking (libs/multicam_mapper.cpp:678-729: double residuals, Huber
+ * weights with the problem's current delta when with_huber).  The whole loop of a frame runs on the device.
+ * iterations / final_err: optional [num_frames] outputs (step() calls made, final sum of squares per frame). */
+int aar_track(aar_problem *, double *x_full, const aar_lm_params *, int32_t *iterations, double *final_err);
+
 /* per-stage device time of the last aar_lm_solve, seconds, in the reference's verbose-timer vocabulary
  * (libs/sparselevmarq.h:425) extended with the stages that only exist here */
 typedef struct aar_stage_times {

@@ -408,8 +408,8 @@ int64_t jacobian_impl(const orc_problem *p, const double *x_full, const double *
         // obtain_transformation_derivs / obtain_marker_derivs: libs/multicam_mapper.cpp:803-994.
         // Central differences, rotation perturbed in Rodrigues-vector space (:905-911), translation
         // perturbed directly in the matrix (:913-916).
-        const bool f32 = (jac_mode == ORC_JAC_NUMERIC_F32);
-        const double delta = f32 ? 1e-3 : 1e-6;  // J_delta, libs/multicam_mapper.h:189
+        const bool f32 = (jac_mode == ORC_JAC_NUMERIC_F32), track = (jac_mode == ORC_JAC_TRACK);
+        const double delta = (f32 || track) ? 1e-3 : 1e-6;  // J_delta, libs/multicam_mapper.h:189 ; der_epsilon, libs/sparselevmarq.h:47
         Mats ma;
         build_mats(L, x, ma);
 #pragma omp parallel for schedule(static)
@@ -434,18 +434,27 @@ int64_t jacobian_impl(const orc_problem *p, const double *x_full, const double *
                     double pa[8], ps[8];
                     project_marker(p, L, which == 0 ? Ta : ma.cam[c], which == 2 ? Ta : ma.fr[f], which == 1 ? Ta : ma.mk[m], c, m, pa);
                     project_marker(p, L, which == 0 ? Ts : ma.cam[c], which == 2 ? Ts : ma.fr[f], which == 1 ? Ts : ma.mk[m], c, m, ps);
+                    double ra[8], rs[8];
+                    if (track) {  // calcDerivates differentiates the whole error function, Huber weights included
+                        obs_residual(p, pa, uv, ORC_RES_F64, ra);
+                        obs_residual(p, ps, uv, ORC_RES_F64, rs);
+                    }
                     for (int k = 0; k < 8; k++) {
                         double ea, es;
-                        if (f32) {
+                        if (track) {
+                            ea = ra[k]; es = rs[k];
+                        } else if (f32) {
                             ea = (double)(uv[k] - (float)pa[k]);
                             es = (double)(uv[k] - (float)ps[k]);
                         } else {
                             ea = (double)uv[k] - pa[k];
                             es = (double)uv[k] - ps[k];
                         }
+                        const double dv = (ea - es) / (2 * delta);
+                        if (track && !(std::fabs(dv) > 1e-4)) continue;  // libs/sparselevmarq.h:182,215
                         rows[base + n] = (int32_t)(8 * o + k);
                         cols[base + n] = (int32_t)(col0 + i);
-                        vals[base + n] = (ea - es) / (2 * delta);
+                        vals[base + n] = dv;
                         n++;
                     }
                 }
@@ -788,7 +797,7 @@ double orc_lm_solve(const orc_problem *p_in, const double *x_full, double *z_ino
     // with_huber: MultiCamMapper::solve sets hubberDelta = 10 before solver.solve (libs/multicam_mapper.cpp:425) and
     // optCallBack lowers it by 7.5/500 after every step while it is above 2.5 (:412-417)
     orc_problem pw = *p_in;
-    if (pw.with_huber) pw.huber_delta = 10;
+    if (pw.with_huber && !prm->huber_fixed) pw.huber_delta = 10;
     const orc_problem *p = &pw;
     Layout L(p);
     const int64_t P = L.z_len, rowsN = 8 * p->num_obs;
@@ -850,7 +859,7 @@ double orc_lm_solve(const orc_problem *p_in, const double *x_full, double *z_ino
             trace[iters].tries = ntries + (accepted ? 1 : 0);
         }
         iters++;
-        if (pw.with_huber && pw.huber_delta > 2.5) pw.huber_delta = (float)((double)pw.huber_delta - 7.5 / 500);  // optCallBack
+        if (pw.with_huber && !prm->huber_fixed && pw.huber_delta > 2.5) pw.huber_delta = (float)((double)pw.huber_delta - 7.5 / 500);  // optCallBack
         prevErr = currErr;
     }
     std::memcpy(z_inout, curr_z.data(), sizeof(double) * P);

@@ -46,11 +46,15 @@ enum { ORC_RES_F32 = 0,   /* reference-faithful: projections rounded to float, f
        ORC_RES_F64 = 1 }; /* same formula kept in double                                          */
 enum { ORC_JAC_NUMERIC_F32 = 0, /* reference-faithful central differences, delta=1e-3, float projections */
        ORC_JAC_NUMERIC_F64 = 1, /* central differences, delta=1e-6, double projections                   */
-       ORC_JAC_ANALYTIC    = 2 };/* closed-form SE(3) Jacobian                     */
+       ORC_JAC_ANALYTIC    = 2, /* closed-form SE(3) Jacobian                     */
+       ORC_JAC_TRACK       = 3 };/* SparseLevMarq::calcDerivates (libs/sparselevmarq.h:165-220): central differences,
+                                    der_epsilon = 1e-3, double residuals, entries with |d| <= 1e-4 dropped (track()) */
 
 typedef struct orc_lm_params {           /* ucoslam::SparseLevMarq<T>::Params, libs/sparselevmarq.h:30-50 */
     int32_t max_iters;
     double min_error, min_step_error_diff, min_average_step_error_diff, tau;
+    int32_t huber_fixed;   /* 0: solve() semantics (delta = 10 then optCallBack's schedule); 1: track() semantics: the
+                              problem's huber_delta is used as is for the whole solve (no step callback is installed) */
 } orc_lm_params;
 
 typedef struct orc_lm_iter {             /* one step() of libs/sparselevmarq.h:349-430 */

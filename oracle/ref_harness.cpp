@@ -92,6 +92,38 @@ double ref_lm_solve(const orc_problem *p_in, const double *x_full, double *z_ino
     return e;
 }
 
+/* MultiCamMapper::track() for ONE frame (libs/multicam_mapper.cpp:430-443): the real solver's solve(z, f) overload, i.e. its
+ * own automatic differentiation calcDerivates_omp (libs/sparselevmarq.h:165-196,223-228), on the restated
+ * error_function_tracking (double residuals, Huber with the problem's fixed delta).  `p` must describe a single frame with
+ * opt flags (0,0,1); z is that frame's 6-vector. */
+double ref_track_solve(const orc_problem *p, const double *x_full, double *z_inout, const orc_lm_params *prm,
+                       int32_t *n_iters, int32_t num_threads) {
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+    const int64_t P = orc_num_vars(p), N = p->num_obs;
+    Solver solver;
+    Solver::Params prms;
+    prms.verbose = false;
+    prms.maxIters = prm->max_iters;
+    prms.minError = prm->min_error;
+    prms.min_step_error_diff = prm->min_step_error_diff;
+    prms.min_average_step_error_diff = prm->min_average_step_error_diff;
+    prms.tau = prm->tau;
+    solver.setParams(prms);
+    solver.v = 2;
+    auto f = [&](const eVector &z, eVector &err) {
+        err.resize(8 * N);
+        orc_residuals(p, x_full, z.data(), ORC_RES_F64, err.data());
+    };
+    int32_t iters = 0;
+    solver.setStepCallBackFunc([&](const eVector &) { iters++; });
+    eVector z(P);
+    std::memcpy(z.data(), z_inout, sizeof(double) * P);
+    double e = solver.solve(z, f);
+    std::memcpy(z_inout, z.data(), sizeof(double) * P);
+    if (n_iters) *n_iters = iters;
+    return e;
+}
+
 /* Golden linear algebra (SURVEY 8c "G2"): for a Jacobian given as triplets, residual r and damping mu,
  * JtJ = Jt*J (Eigen), B = -Jt*r, delta = SimplicialLDLT(JtJ + mu*I).solve(B) -- the exact objects of
  * libs/sparselevmarq.h:355-400.  JtJ_dense is P x P row-major (may be NULL). */

@@ -84,6 +84,21 @@ def g2(name, ds):
     print(name, "P", P, "N", ds.num_obs)
 
 
+def g_track(name, ds, with_huber):
+    """track(): cameras / markers at their optimum, every frame's pose refined on its own by the REAL solver's solve(z, f)
+    (automatic differentiation calcDerivates_omp) over the restated error_function_tracking."""
+    o = ol.Oracle(ds)
+    x_opt, _ = o.ref_lm_solve(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32, threads=1)
+    ns = 6 * (ds.num_cams - 1) + 6 * (ds.num_markers - 1)
+    x0 = x_opt.copy()
+    x0[ns:] = ds.x_full[ns:]          # frame poses back at the perturbed initial guess
+    xr, it, err = ol.track_frames(ds, x0, with_huber=with_huber, huber_delta=10.0, use_ref=True)
+    out = ds_dict(ds)
+    out.update(track_x0=x0, track_x=xr, track_iterations=it, track_err=err, with_huber=np.array([int(with_huber)]))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "frames", ds.num_frames, "iterations", it.min(), it.max(), "sum err", err.sum())
+
+
 if __name__ == "__main__":
     assert ol.have_ref(), "build oracle/_ref first (python -c 'import __graft_entry__ as g; g.build()')"
     # config 2 of SURVEY.md (BASELINE.json configs[1]): 4 cameras / 12 markers / 100 frames
@@ -102,4 +117,6 @@ if __name__ == "__main__":
     dsh.obs_uv = dsh.obs_uv.copy()
     dsh.obs_uv[bad] += rng.normal(0, 25, size=(int(bad.sum()), 8)).astype(np.float32)
     g1("g1_cfg2_huber", dsh, [2, 4, 12, 100, 1.0], with_huber=True)
+    g_track("g_track_cfg2", aar.synth(2), False)
+    g_track("g_track_cfg2_huber", dsh, True)
     g2("g2_small", aar.synth(2, num_cams=3, num_markers=8, num_frames=20))

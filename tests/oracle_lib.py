@@ -15,7 +15,7 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_lm.so")
 
 RES_F32, RES_F64 = 0, 1
-JAC_NUMERIC_F32, JAC_NUMERIC_F64, JAC_ANALYTIC = 0, 1, 2
+JAC_NUMERIC_F32, JAC_NUMERIC_F64, JAC_ANALYTIC, JAC_TRACK = 0, 1, 2, 3
 
 
 class OrcProblem(C.Structure):
@@ -32,7 +32,7 @@ class OrcProblem(C.Structure):
 
 class OrcLmParams(C.Structure):
     _fields_ = [("max_iters", C.c_int32), ("min_error", C.c_double), ("min_step_error_diff", C.c_double),
-                ("min_average_step_error_diff", C.c_double), ("tau", C.c_double)]
+                ("min_average_step_error_diff", C.c_double), ("tau", C.c_double), ("huber_fixed", C.c_int32)]
 
 
 class OrcLmIter(C.Structure):
@@ -94,6 +94,8 @@ def ref():
         L.ref_lm_solve.restype = C.c_double
         L.ref_lm_solve.argtypes = [pp, _dp, _dp, C.POINTER(OrcLmParams), C.c_int, C.c_int, C.POINTER(OrcLmIter),
                                    C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32]
+        L.ref_track_solve.restype = C.c_double
+        L.ref_track_solve.argtypes = [pp, _dp, _dp, C.POINTER(OrcLmParams), C.POINTER(C.c_int32), C.c_int32]
         L.ref_damped_solve.argtypes = [C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, _dp, C.c_double, _dp, _dp, _dp]
         _ref = L
     return _ref
@@ -105,7 +107,7 @@ def _d(a):
 
 def mapper_params(**over):
     """LM parameters as MultiCamMapper::init installs them (libs/multicam_mapper.cpp:326-330)."""
-    p = OrcLmParams(10000, 1e-5, 0.0, 1e-4, 1.0)
+    p = OrcLmParams(10000, 1e-5, 0.0, 1e-4, 1.0, 0)
     for k, v in over.items():
         setattr(p, k, v)
     return p
@@ -213,6 +215,52 @@ class Oracle:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         oracle().orc_reproj_stats(C.byref(self.p), _d(x), _d(z), C.byref(a), C.byref(b), C.byref(c))
         return dict(rmse=a.value, mean_dist=b.value, sum_sq=c.value)
+
+
+def frame_subproblem(ds, f):
+    """The single-frame data set MultiCamMapper::init(object_poses, fcm) leaves for track() (libs/multicam_mapper.cpp:272-279)."""
+    import copy
+    sub = copy.copy(ds)
+    keep = np.asarray(ds.obs_frame) == f
+    sub.obs_frame = np.zeros(int(keep.sum()), dtype=np.int32)
+    sub.obs_cam = np.asarray(ds.obs_cam)[keep]
+    sub.obs_marker = np.asarray(ds.obs_marker)[keep]
+    sub.obs_uv = np.asarray(ds.obs_uv)[keep]
+    sub.num_obs = int(keep.sum())
+    sub.num_frames = 1
+    sub.frame_ids = np.asarray(ds.frame_ids)[f:f + 1]
+    ns = 6 * (ds.num_cams - 1) + 6 * (ds.num_markers - 1)
+    sub.x_full = np.concatenate([np.asarray(ds.x_full)[:ns], np.asarray(ds.x_full)[ns + 6 * f: ns + 6 * f + 6]])
+    sub.x_truth = None
+    return sub
+
+
+def track_frames(ds, x_full, with_huber=False, huber_delta=10.0, use_ref=False, threads=1, params=None):
+    """track() frame by frame on the CPU: the restated LM with the calcDerivates Jacobian (port) or, with use_ref, the real
+    solver's own solve(z, f).  Returns (x_full with refined frame poses, iterations[F], err[F])."""
+    x = np.array(x_full, dtype=np.float64)
+    ns = 6 * (ds.num_cams - 1) + 6 * (ds.num_markers - 1)
+    its = np.zeros(ds.num_frames, dtype=np.int32)
+    errs = np.zeros(ds.num_frames)
+    prm = params if params is not None else mapper_params(huber_fixed=1)
+    dsx = type("D", (), {})()
+    dsx.__dict__.update(ds.__dict__)
+    dsx.x_full = x
+    for f in range(ds.num_frames):
+        sub = frame_subproblem(dsx, f)
+        o = Oracle(sub, optimize=(False, False, True), with_huber=with_huber, huber_delta=huber_delta)
+        if use_ref:
+            z = np.ascontiguousarray(sub.x_full[ns:ns + 6])
+            xs = np.ascontiguousarray(sub.x_full)
+            n = C.c_int32()
+            e = ref().ref_track_solve(C.byref(o.p), _d(xs), _d(z), C.byref(prm), C.byref(n), threads)
+            x[ns + 6 * f: ns + 6 * f + 6] = z
+            its[f], errs[f] = n.value, e
+        else:
+            xs, rep = o.lm_solve(sub.x_full, params=prm, jac_mode=JAC_TRACK, res_mode=RES_F64, threads=threads)
+            x[ns + 6 * f: ns + 6 * f + 6] = xs[ns:ns + 6]
+            its[f], errs[f] = rep["iterations"], rep["final_err"]
+    return x, its, errs
 
 
 def ref_damped_solve(n_rows, P, rows, cols, vals, r, mu, want_dense=True):

@@ -176,6 +176,37 @@ def test_huber_rows_and_schedule():
         assert abs(rmse - g["faithful_rmse"][0]) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["g_track_cfg2", "g_track_cfg2_huber"])
+def test_track_frames_vs_real_solver(name):
+    # MultiCamMapper::track(): per-frame 6-DoF LM, cameras / markers fixed; golden = the real solver's own solve(z, f)
+    ds, g = load_golden(name)
+    hub = bool(g["with_huber"][0])
+    with aar.Problem(ds, with_huber=hub) as p:
+        if hub:
+            p.set_huber_delta(10.0)            # track() sets hubberDelta = 10 and installs no schedule (:439)
+        x, it, err = p.track(g["track_x0"])
+        ns = 6 * (ds.num_cams - 1) + 6 * (ds.num_markers - 1)
+        assert np.array_equal(x[:ns], g["track_x0"][:ns])                  # cameras and markers do not move
+        # analytic Jacobian vs the reference's central differences (delta 1e-3, small entries dropped): same optimum
+        # (with Huber the Jacobian includes the weight's derivative, as the reference's numeric differentiation of the
+        #  weighted error function does)
+        np.testing.assert_allclose(err, g["track_err"], rtol=1e-5, atol=1e-6)
+        assert np.abs(x[ns:] - g["track_x"][ns:]).max() < 2e-4
+        assert np.abs(it - g["track_iterations"]).max() <= 1 and np.mean(it == g["track_iterations"]) > 0.9
+        # against the CPU port driven with the SAME analytic Jacobian the trajectories coincide (plain residuals only:
+        # the oracle's analytic Jacobian follows solve()'s convention and does not differentiate the weights)
+        for f in ([] if hub else [0, ds.num_frames // 2, ds.num_frames - 1]):
+            dsx = type("D", (), {})()
+            dsx.__dict__.update(ds.__dict__)
+            dsx.x_full = g["track_x0"]
+            sub = ol.frame_subproblem(dsx, f)
+            o = ol.Oracle(sub, optimize=(False, False, True), with_huber=hub, huber_delta=10.0)
+            xs, rep = o.lm_solve(sub.x_full, params=ol.mapper_params(huber_fixed=1), jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F64)
+            assert rep["iterations"] == it[f]
+            np.testing.assert_allclose(rep["final_err"], err[f], rtol=1e-9)
+            np.testing.assert_allclose(xs[ns:ns + 6], x[ns + 6 * f: ns + 6 * f + 6], atol=1e-9)
+
+
 def test_step_api_matches_solve():
     ds, g = load_golden("g1_cfg2")
     with aar.Problem(ds) as p:

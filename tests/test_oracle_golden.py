@@ -132,6 +132,20 @@ def test_port_lm_with_huber_schedule_matches_real_solver():
     assert np.abs(plain_x - x).max() > 1e-3
 
 
+@pytest.mark.parametrize("name", ["g_track_cfg2", "g_track_cfg2_huber"])
+def test_track_port_matches_real_solver_autodiff(name):
+    # track(): the restated calcDerivates (central differences, der_epsilon 1e-3, |d| <= 1e-4 dropped) + LM loop against the
+    # golden produced by the real solver's own solve(z, f) (libs/sparselevmarq.h:165-228)
+    ds, g = load_golden(name)
+    hub = bool(g["with_huber"][0])
+    x, it, err = ol.track_frames(ds, g["track_x0"], with_huber=hub, huber_delta=10.0)
+    assert np.array_equal(it, g["track_iterations"])
+    np.testing.assert_allclose(err, g["track_err"], rtol=1e-9)
+    np.testing.assert_allclose(x, g["track_x"], atol=1e-10)
+    ns = 6 * (ds.num_cams - 1) + 6 * (ds.num_markers - 1)
+    assert np.array_equal(x[:ns], g["track_x0"][:ns])
+
+
 def test_huber_weight_restatement():
     # libs/multicam_mapper.cpp:11-24,1014-1019: rows scaled by sqrt(rho(e)/e); inliers untouched
     ds, _ = load_golden("g2_small")
