@@ -634,8 +634,11 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         for (int s = fslot_start[f]; s < fslot_start[f + 1]; s++) inc[fslot_ent[s]].push_back({f, s});
     std::vector<int32_t> pair_frame, pair_slot, sw_ent, sw_begin, sw_end;
     const int64_t total_pairs = P.total_slots;
-    int per_item = (int)std::max<int64_t>(8, (total_pairs + 2047) / 2048);
+    // (entity, frame) pairs per workgroup: measured optimum 16 (config 3) ... 64 (configs 4, 5); every workgroup ends with
+    // an atomic flush of its row panel, so fewer, longer items win once the grid is large enough to fill the chip
+    int per_item = (int)std::min<int64_t>(64, std::max<int64_t>(16, total_pairs / 1024));
     per_item = (per_item + 3) / 4 * 4;
+    if (const char *e = getenv("AAR_SCHUR_ITEM")) per_item = std::max(4, atoi(e));  // tuning knob (pairs per workgroup)
     for (int a = 0; a < A; a++) {
         const int base = (int)pair_frame.size();
         for (auto &pr : inc[a]) { pair_frame.push_back(pr.first); pair_slot.push_back(pr.second); }

@@ -194,6 +194,23 @@ def main():
             except Exception:
                 pass
 
+    # ---- next-row extra (not the headline metric): track(), every frame's own 6-DoF LM in one launch ----
+    track = None
+    if world == 1:
+        ns = 6 * (ds.num_cams - 1) + 6 * (ds.num_markers - 1)
+        x_tr = np.array(x_fin)
+        x_tr[ns:] = ds.x_full[ns:]                 # cameras / markers at the solution, frame poses back at the initial guess
+        problem.track(x_tr)                         # warm-up
+        aar.lib().aar_device_synchronize()
+        t1 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            xt, it_t, err_t = problem.track(x_tr)
+        aar.lib().aar_device_synchronize()
+        dt_tr = (time.perf_counter() - t1) / reps
+        track = {"frames": int(ds.num_frames), "seconds_per_call": dt_tr, "frames_per_s": ds.num_frames / dt_tr,
+                 "mean_lm_iterations_per_frame": float(np.mean(it_t)), "max_pose_delta_vs_bundle_solution": float(np.abs(xt[ns:] - x_fin[ns:]).max())}
+
     if rank != 0:
         problem.close()
         if dist is not None:
@@ -215,7 +232,7 @@ def main():
         "final_rmse_px": rmse, "final_sum_sq": ss, "lm_iterations_to_stop": rep_fin["iterations"], "trial_points_per_step": t_avg,
         "iteration_hbm": {"bytes_per_iteration": b_iter, "achieved": b_iter * done / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                           "frac": b_iter * done / dt / 1e9 / HBM_PEAK_GBPS},
-        "roofline": roofline, "kernels": kernels,
+        "roofline": roofline, "kernels": kernels, "track": track,
     }
     if world == 1 and not args.no_cpu_baseline:
         threads = os.cpu_count() or 1
@@ -229,6 +246,19 @@ def main():
             o = ol.Oracle(ds)
             xc, _ = (o.ref_lm_solve if ol.have_ref() else o.lm_solve)(ds.x_full, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=threads)
             out["rmse_delta_vs_cpu_px"] = abs(rmse - o.reproj_stats(xc)["rmse"])
+        if track is not None and args.workload <= 3:
+            import oracle_lib as ol
+            nf = min(ds.num_frames, 100)
+            sub = aar.Dataset.__new__(aar.Dataset)
+            sub.__dict__.update(ds.__dict__)
+            keep = ds.obs_frame < nf
+            for k in ("obs_frame", "obs_cam", "obs_marker", "obs_uv"):
+                setattr(sub, k, getattr(ds, k)[keep])
+            sub.num_obs, sub.num_frames, sub.frame_ids = int(keep.sum()), nf, ds.frame_ids[:nf]
+            t2 = time.perf_counter()
+            ol.track_frames(sub, x_tr[: ns + 6 * nf], use_ref=ol.have_ref())
+            track["cpu_reference_frames_per_s"] = nf / (time.perf_counter() - t2)
+            track["cpu_sample"] = "first %d frames, real SparseLevMarq::solve(z,f) with its own calcDerivates, 1 thread" % nf
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
