@@ -105,6 +105,10 @@ struct aar_problem {
     float hubber_delta = 2.5f;         // MultiCamMapper::hubberDelta (libs/multicam_mapper.h:41)
     bool blocks_valid = false;         // blk[cur] holds J^T J blocks and B at z[cur], S not yet eliminated
     double vinv_mu = -1;               // damping for which blk[cur].Vinv / hf are valid (< 0: none)
+    double schur_mu = -1;              // damping whose Schur terms are already subtracted from blk[cur].S / rhs (< 0: none)
+    hipStream_t stream2 = nullptr;     // pass B of the trial point runs here, beside the speculative Schur complement
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = false;              // AAR_OVERLAP=1: pass B of the trial point on a second stream beside the Schur complement
     int64_t trial_points = 0, launches = 0;
     aar_stage_times times;
     bool stage_timers = false;
@@ -274,7 +278,9 @@ int zero_block_set(aar_problem *pb, int which) {
 // J^T J blocks and B at z[which] into blk[which] (whose S, rhs, g0 must be zero): the "J", "transpose", "Jt*J", "B"
 // stages of libs/sparselevmarq.h:353-367.  Pass A also leaves the per-frame sums of r^2 in err_part and, for
 // mu_pred >= 0, (V_f + mu_pred I)^-1; zero_blk >= 0 clears that block set on the way.
-int eval_blocks(aar_problem *pb, int which, double mu_pred, int zero_blk) {
+// spec_schur: also subtract the Schur terms for mu_pred right away (they only need pass A's output), on the main stream,
+// while pass B accumulates the shared blocks into the same S on a second stream (both only add into S: they commute).
+int eval_blocks(aar_problem *pb, int which, double mu_pred, int zero_blk, bool spec_schur = false) {
     DeviceProblem &P = pb->P;
     if (P.F == 0 && zero_blk >= 0) {  // a rank without frames launches no pass A: clear the dead block set here
         int rc = zero_block_set(pb, zero_blk);
@@ -283,9 +289,19 @@ int eval_blocks(aar_problem *pb, int which, double mu_pred, int zero_blk) {
     {
         StageTimer t(pb, &pb->times.jacobian_normal_eq);
         launch_passA(P, which, mu_pred, zero_blk, pb->stream);
-        launch_passB(P, which, pb->stream);
+        if (spec_schur && pb->overlap && !pb->profiling && !pb->stage_timers) {
+            HIP_TRY(hipEventRecord(pb->ev_fork, pb->stream));
+            HIP_TRY(hipStreamWaitEvent(pb->stream2, pb->ev_fork, 0));
+            launch_passB(P, which, pb->stream2);
+            HIP_TRY(hipEventRecord(pb->ev_join, pb->stream2));
+            launch_schur(P, which, 1.0, pb->stream);
+            HIP_TRY(hipStreamWaitEvent(pb->stream, pb->ev_join, 0));
+        } else {
+            launch_passB(P, which, pb->stream);
+            if (spec_schur) launch_schur(P, which, 1.0, pb->stream);
+        }
     }
-    pb->launches += 2;
+    pb->launches += spec_schur ? 3 : 2;
     return check_async("normal-equation kernels");
 }
 
@@ -343,15 +359,24 @@ int read_scalars(aar_problem *pb, int n_err) {
 int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     DeviceProblem &P = pb->P;
     const int cur = pb->cur, tr = 1 - cur;
-    {
+    if (pb->schur_mu != mu) {  // not already done speculatively by the try that produced this point
         StageTimer t(pb, &pb->times.schur);
+        if (pb->schur_mu >= 0) {
+            // the speculative Schur complement was taken with another damping than the step now needs (gain < 0.94): take it
+            // back with the inverses it used (still in Vinv), keeping the blocks -- and the residual they were built from --
+            // exactly those of the accepted trial, as the reference's x64 / J are
+            launch_schur(P, cur, -1.0, pb->stream);
+            pb->launches += 1;
+        }
         if (pb->vinv_mu != mu) {
             launch_frame_inv(P, cur, mu, pb->stream);
             pb->vinv_mu = mu;
             pb->launches += 1;
         }
-        launch_schur(P, cur, pb->stream);
+        launch_schur(P, cur, 1.0, pb->stream);
+        pb->launches += 1;
     }
+    pb->schur_mu = -1;
     if (pb->comm) {
         StageTimer t(pb, &pb->times.allreduce);
         int rc = allreduce(pb, P.blk[cur].S, (size_t)P.n_pad * P.n_pad, NCCL_SUM);
@@ -367,11 +392,11 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         StageTimer t(pb, &pb->times.backsub);
         launch_backsub(P, cur, tr, pb->stream);
     }
-    pb->launches += 3 + 3 * P.nT;
+    pb->launches += 2 + 3 * P.nT;
     pb->blocks_valid = false;  // S of the current point has been eliminated in place
     if (evaluate_trial) {
         // predicted damping of the next step: every accepted step of the reference's rule with gain >= 0.94 gives 0.33 mu
-        int rc = eval_blocks(pb, tr, mu * 0.33, cur);
+        int rc = eval_blocks(pb, tr, mu * 0.33, cur, /*spec_schur=*/true);
         if (rc) return rc;
         pb->trial_points++;
     } else {
@@ -395,6 +420,7 @@ int rebuild_current(aar_problem *pb) {
     if ((rc = eval_blocks(pb, pb->cur, -1.0, -1))) return rc;
     pb->blocks_valid = true;
     pb->vinv_mu = -1;
+    pb->schur_mu = -1;
     return AAR_OK;
 }
 
@@ -495,6 +521,9 @@ void aar_problem_destroy(aar_problem *pb) {
     if (pb->ev[0]) (void)hipEventDestroy(pb->ev[0]);
     if (pb->ev[1]) (void)hipEventDestroy(pb->ev[1]);
     for (hipEvent_t e : pb->ev_pool) (void)hipEventDestroy(e);
+    if (pb->ev_fork) (void)hipEventDestroy(pb->ev_fork);
+    if (pb->ev_join) (void)hipEventDestroy(pb->ev_join);
+    if (pb->stream2) { (void)hipStreamSynchronize(pb->stream2); (void)hipStreamDestroy(pb->stream2); }
     if (pb->stream) (void)hipStreamDestroy(pb->stream);
     delete pb;
 }
@@ -530,6 +559,11 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     if (hipStreamCreateWithFlags(&pb->stream, hipStreamNonBlocking) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "hipStreamCreate failed"));
     (void)hipEventCreate(&pb->ev[0]);
     (void)hipEventCreate(&pb->ev[1]);
+    if (hipStreamCreateWithFlags(&pb->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&pb->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&pb->ev_join, hipEventDisableTiming) != hipSuccess)
+        return fail(set_error(AAR_ERR_HIP, "second stream / events could not be created"));
+    { const char *e = getenv("AAR_OVERLAP"); pb->overlap = (e && e[0] == '1'); }  // measured slower than one stream at config 3: off by default
 
     PoseLayout &L = pb->L;
     L.C = C; L.M = M; L.F = Fg; L.rc = d->root_cam; L.rm = d->root_marker;
@@ -835,6 +869,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     if ((rc = zero_block_set(pb, pb->cur))) return rc;
     if ((rc = eval_blocks(pb, pb->cur, -1.0, -1))) return rc;
     pb->vinv_mu = -1;
+    pb->schur_mu = -1;
     if ((rc = damped_try(pb, mu, false))) return rc;
     pb->lm_ready = false;
     std::vector<double> x0(x_full, x_full + L.full_len()), x1(x0);
@@ -868,6 +903,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     pb->currErr = pb->prevErr = pb->h_scal[0];
     pb->blocks_valid = true;
     pb->vinv_mu = -1;
+    pb->schur_mu = -1;
     pb->mu = -1;
     pb->v = 2;  // indeterminate in the reference (libs/sparselevmarq.h:133); every accepted step sets 2 (:411)
     pb->lm_ready = true;
@@ -905,8 +941,9 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
             pb->v = 2.f;
             pb->currErr = err;
             pb->cur = 1 - pb->cur;  // curr_z = estimated_z; its blocks were built speculatively by the try
-            pb->blocks_valid = true;
-            pb->vinv_mu = mu_used * 0.33;  // what pass A inverted for
+            pb->vinv_mu = mu_used * 0.33;   // what pass A inverted for
+            pb->schur_mu = mu_used * 0.33;  // ... and what the speculative Schur complement was taken with
+            pb->blocks_valid = true;        // (a damping other than the predicted one is repaired in damped_try)
             accepted = true;
         } else {
             pb->mu = mu_used * pb->v;

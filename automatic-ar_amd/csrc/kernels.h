@@ -99,7 +99,7 @@ void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_bl
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st);              // accumulates into blk[which].S, .g0 (must be zero)
 void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st);            // scal[4] = max free diagonal
 void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st);
-void launch_schur(const DeviceProblem &P, int which, hipStream_t st);
+void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st);   // S -= sign * W (V+mu I)^-1 W^T (sign -1 takes it back)
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st);    // damping + LDL^T + both substitutions -> delta_s
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st);  // scal[0..2], scal[5..6]

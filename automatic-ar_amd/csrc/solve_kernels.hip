@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
                                                const int32_t *__restrict__ pair_slot, const int32_t *__restrict__ fslot_start,
                                                const int32_t *__restrict__ fslot_ent, const double *__restrict__ W,
                                                const double *__restrict__ Vinv, const double *__restrict__ hf, int A,
-                                               int n_pad, double *__restrict__ S, double *__restrict__ rhs) {
+                                               int n_pad, double sign, double *__restrict__ S, double *__restrict__ rhs) {
     extern __shared__ double lds[];
     double *panel = lds;
     double *pg = lds + (size_t)A * 36;
@@ -111,10 +111,10 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
         const double v = panel[idx];
         if (v != 0.0) {
             const int b = idx / 36, e = idx - b * 36, i = e / 6, j = e - i * 6;
-            atomicAdd(S + (size_t)(6 * a + i) * n_pad + 6 * b + j, -v);
+            atomicAdd(S + (size_t)(6 * a + i) * n_pad + 6 * b + j, -sign * v);
         }
     }
-    if (tid < 6) atomicAdd(rhs + 6 * a + tid, -pg[tid]);
+    if (tid < 6) atomicAdd(rhs + 6 * a + tid, -sign * pg[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -672,14 +672,14 @@ void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t 
     { HookScope _h(P, KID_FRAME_INV); hipLaunchKernelGGL(k_frame_inv, dim3((P.F + 255) / 256), dim3(256), 0, st, b.V, b.gf, P.F, mu, P.frames_fixed, b.Vinv, b.hf, P.flags); }
 }
 
-void launch_schur(const DeviceProblem &P, int which, hipStream_t st) {
+void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st) {
     if (P.n_swork == 0) return;
     const DeviceProblem::Blocks &b = P.blk[which];
     const size_t lds = ((size_t)P.A * 36 + 8 + 4 * 48) * sizeof(double);
     static size_t granted = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_schur), lds, granted);
     { HookScope _h(P, KID_SCHUR); hipLaunchKernelGGL(k_schur, dim3(P.n_swork), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_frame,
-                       P.pair_slot, P.fslot_start, P.fslot_ent, b.W, b.Vinv, b.hf, P.A, P.n_pad, b.S, b.rhs); }
+                       P.pair_slot, P.fslot_start, P.fslot_ent, b.W, b.Vinv, b.hf, P.A, P.n_pad, sign, b.S, b.rhs); }
 }
 
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
