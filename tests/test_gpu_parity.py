@@ -296,6 +296,23 @@ def test_full_size_config3_properties():
         assert np.abs(B1).max() < 1e-3 * np.abs(B0).max()
 
 
+def test_config4_size_against_oracle():
+    # BASELINE.json configs[3] (8 cameras / 40 markers / 2000 frames, 50 k marker observations) at full size: residual rows
+    # bit-exact, one damped step against the oracle's sparse LDL^T (12 276 unknowns), three reduced-system tiles
+    ds = aar.synth(4)
+    o = ol.Oracle(ds)
+    with aar.Problem(ds) as p:
+        r, ss = p.eval_residuals(ds.x_full)
+        assert np.array_equal(r, o.residuals(ds.x_full, res_mode=ol.RES_F32))
+        mu = 1e6
+        d = p.eval_damped_step(ds.x_full, mu)
+        do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+        assert np.abs(d - do).max() / np.abs(do).max() < 1e-9
+        x, rep = p.lm_solve(ds.x_full)
+        rmse, _ = p.reproj_stats(x)
+        assert rep["iterations"] < 30 and abs(rmse - 0.3 * np.sqrt(2)) < 0.02
+
+
 def test_single_rank_communicator_path():
     # world_size 1 through RCCL: exercises the sharded code path (all-reduces of S, rhs, scalars) on one GPU
     ds, g = load_golden("g1_cfg2")
