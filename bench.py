@@ -92,9 +92,22 @@ def cpu_baseline(ds, workload, max_threads):
         if best is None or rate > best[0]:
             best = (rate, th, rep, dt)
     rate, th, rep, dt = best
+    # the reported sample: ~15 s of CPU work at the best thread count (or the whole solve, if it converges earlier)
+    long_cap = int(min(10000, max(cap, 15.0 * rate)))
+    reps = 0
+    if long_cap > cap:
+        its, dt = 0, 0.0
+        while dt < 10.0 and reps < 200:      # the whole solve repeated from the same start until ~10 s have been timed
+            t0 = time.perf_counter()
+            x, rep = fn(ds.x_full, params=ol.mapper_params(max_iters=long_cap), jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=th)
+            dt += time.perf_counter() - t0
+            its += rep["iterations"]
+            reps += 1
+        rate = its / dt
+        rep = dict(rep, iterations=its)
     return {"value": rate, "unit": "LM iterations/s", "cores": th, "kind": kind, "host_cores": max_threads, "thread_counts_tried": tried,
-            "sample": "first %d LM iterations of the same %s problem from the same start (%.1f s at the best thread count); %s"
-                      % (rep["iterations"], WORKLOADS[workload], dt, what),
+            "sample": "%d LM iterations (%d solve(s) from the same start, each run until the solver stops by itself or the cap) of the same %s problem, %.1f s at the best thread count found by the short sweep; %s"
+                      % (rep["iterations"], max(reps, 1), WORKLOADS[workload], dt, what),
             "err_after_sample": rep["final_err"]}
 
 
