@@ -5,6 +5,7 @@
 // the damping and the gauge rows on first touch), and
 // back-substitution of the frame poses (k_backsub).  mu is added to EVERY diagonal entry, as in the
 // reference (:387-392).  fp64 throughout.
+#include <type_traits>
 #include "geom.hpp"
 #include "kernels.h"
 
@@ -125,19 +126,35 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
 // non-optimised groups) and of the padding -> identity with zero rhs, i.e. delta = 0; rhs -> g0 + (Schur part).
 //
 // Step s = three launches:
-//   k_ldl_diag    ONE workgroup factors the diagonal tile: the serial part.  The tile lives in registers (thread (ty,tx)
-//                 owns rows ty+16p, columns tx+16q), one barrier per column, the column travels through a double-buffered
-//                 LDS vector, the pivot reciprocal is computed by the pivot's owner.  Epilogue: inverses of the six 16x16
-//                 diagonal sub-blocks of L_ss, which turn every triangular solve below into small matrix products.
+//   k_ldl_diag    ONE workgroup factors the diagonal tile: the serial part, walked in 6x6 block pivots (see the kernel).
+//                 Epilogue: inverses of the six 16x16 diagonal sub-blocks of L_ss, which turn every triangular solve
+//                 below into small matrix products.
 //   k_ldl_trsm    every 48-row slab of block column s (and the right-hand side as a 1-row slab): X = A L_ss^-T by
 //                 blocked substitution over 16-column blocks, then L_ts = X D^-1.
 //   k_ldl_update  trailing tiles: S(I,J) -= L_Is D_s L_Js^T, rhs rows likewise.
 // ------------------------------------------------------------------------------------------------
+#ifndef AAR_CVAR
+#define AAR_CVAR 0
+#endif
 #ifdef AAR_STAMPS  // diagnostic build only (scripts/probe): cycle stamps of one workgroup, never compiled into libaar.so
 __device__ unsigned long long g_stamps[64];
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// completed work: everything before the stamp has retired, nothing after it has been hoisted above it
+#define STAMPW(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMPW(i) do { } while (0)
+#endif
+#ifdef AAR_TIMELINE
+__device__ unsigned long long g_tl[3 * 16 * 5];   // per-step timeline of three wavefronts of k_ldl_diag, kept in LDS until the end
+#define TL_DECL __shared__ unsigned long long tl_lds[3 * 16 * 5];
+#define TL(k, p) do { __builtin_amdgcn_sched_barrier(0); const int w_ = threadIdx.x == 0 ? 0 : (threadIdx.x == 896 ? 1 : (threadIdx.x == 320 ? 2 : -1)); \
+                      if (w_ >= 0) tl_lds[(w_ * 16 + (k)) * 5 + (p)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TL_DUMP do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x < 240) g_tl[threadIdx.x] = tl_lds[threadIdx.x]; } while (0)
+#else
+#define TL_DECL
+#define TL(k, p) do { } while (0)
+#define TL_DUMP do { } while (0)
 #endif
 
 constexpr int NB = CHOL_NB;
@@ -157,108 +174,200 @@ __device__ __forceinline__ double rcp_refined(double d) {
     return x;
 }
 
-// LDS (dynamic): Lf [NB][NB+2] (epilogue copy of L_ss) ; static: column vector, pivot reciprocals
-__global__ void __launch_bounds__(256) k_ldl_diag(const double *__restrict__ S, double *__restrict__ Dfac, double *__restrict__ Linv16,
-                                                  int n_pad, int n, int s, double mu, const int32_t *__restrict__ ent_fixed,
-                                                  int32_t *__restrict__ flags) {
-    constexpr int R = NB / 16, LD = NB + 2;
-    extern __shared__ double Lf[];
-    __shared__ double colD[2][NB], pinv[2], dinv[NB];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+// The tile is walked in 6x6 block pivots (16 block steps instead of 96 column steps; a column step is latency, not work).
+// A lone wavefront issues an instruction every 5-8 cycles here whatever the instruction is, so the design rule is few
+// instructions per wavefront per step: 16 wavefronts, the trailing matrix in fp64 MFMA accumulators as the 21 lower 16x16
+// sub-tiles (one per wavefront, two for five of them), dealt out in the order in which their columns retire.  Block step k:
+//   rows(k)  one row thread per row below the pivot block (6(15-k) of them) reads its six entries of block column k and the
+//            pivot block from LDS; EVERY one of them factors the pivot block in registers (same instruction stream, so the
+//            redundancy costs no time and saves a barrier) and substitutes its own row in the shadow of the reciprocals:
+//            Y = A_ik L_kk^-T, L_ik = Y D_k^-1.  L goes into the LDS tile in place, -Y into a panel padded to 8 columns.
+//   C(k)     every live sub-tile: A -= L Y^T as two v_mfma_f64_16x16x4 (rank 6, padded to 8), operands straight from the
+//            tile and the panel; the sub-tiles that hold block column k+1 publish it to LDS.
+// Two barriers per block step.  The pivot blocks themselves stay unfactored in the tile until the epilogue, which factors
+// all 16 at once; then the factored tile goes to Dfac, plus the inverses of the six 16x16 diagonal sub-blocks of L_ss,
+// which turn every triangular solve below into small matrix products.
+// f64 MFMA lane maps (cdna_hip_programming.md section 4, checked by scripts/probe/issue_probe.hip):
+//   A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row = (l>>4) + 4 reg][col = l&15].
+// LDS (dynamic): T [NB][NB+2] | Yn [NB][8]
+typedef double dg_acc_t __attribute__((ext_vector_type(4)));
+constexpr int DG_THREADS = 1024, DG_ROW0 = 896;
+
+// LDL^T of the 6x6 pivot block at (c0, c0) in registers plus the substitution of row g of block column c0:
+// on return y = (row g) L_kk^-T = L_g D and inv = 1 / D
+__device__ __forceinline__ void dg_factor_row(const double *__restrict__ T, int c0, int g, double (&a)[6][6], double (&y)[6], double (&inv)[6]) {
+    constexpr int LD = NB + 2;
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int p = 0; p <= q; p++) a[q][p] = T[(c0 + q) * LD + c0 + p];
+    {
+        const double2 *rp = reinterpret_cast<const double2 *>(T + g * LD + c0);
+        const double2 y0 = rp[0], y1 = rp[1], y2 = rp[2];
+        y[0] = y0.x; y[1] = y0.y; y[2] = y1.x; y[3] = y1.y; y[4] = y2.x; y[5] = y2.y;
+    }
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        inv[p] = rcp_refined(a[p][p]);
+        double l[6];
+#pragma unroll
+        for (int q = p + 1; q < 6; q++) l[q] = a[q][p] * inv[p];
+#pragma unroll
+        for (int q = p + 1; q < 6; q++)
+#pragma unroll
+            for (int r = p + 1; r <= q; r++) a[q][r] = fma(-l[q], a[r][p], a[q][r]);
+#pragma unroll
+        for (int c = p + 1; c < 6; c++) y[c] = fma(-y[p], l[c], y[c]);
+    }
+}
+
+// rows(k): rt = 6.. numbers the rows from the pivot block down
+__device__ __forceinline__ void dg_rows(double *__restrict__ T, double *__restrict__ Yn, int k, int rt) {
+    constexpr int LD = NB + 2;
+    const int c0 = 6 * k, g = c0 + rt;
+    if (rt < 6 || g >= NB) return;
+    double a[6][6], y[6], inv[6];
+    dg_factor_row(T, c0, g, a, y, inv);
+    double2 *lt = reinterpret_cast<double2 *>(T + g * LD + c0);
+    lt[0] = make_double2(y[0] * inv[0], y[1] * inv[1]);
+    lt[1] = make_double2(y[2] * inv[2], y[3] * inv[3]);
+    lt[2] = make_double2(y[4] * inv[4], y[5] * inv[5]);
+    double2 *yp = reinterpret_cast<double2 *>(Yn + g * 8);
+    yp[0] = make_double2(-y[0], -y[1]);
+    yp[1] = make_double2(-y[2], -y[3]);
+    yp[2] = make_double2(-y[4], -y[5]);
+}
+
+__global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restrict__ S, double *__restrict__ Dfac, double *__restrict__ Linv16,
+                                                         int n_pad, int n, int s, double mu, const int32_t *__restrict__ ent_fixed,
+                                                         int32_t *__restrict__ flags) {
+    constexpr int LD = NB + 2, NBK = NB / 6, PER = NB * NB / DG_THREADS, NT16 = NB / 16, NTILE = NT16 * (NT16 + 1) / 2, NWAVE = DG_THREADS / 64;
+    static_assert(NB % 16 == 0 && NB % 6 == 0 && NB * NB % DG_THREADS == 0 && NWAVE >= NSB && DG_THREADS - DG_ROW0 >= NB - 6 &&
+                  NTILE <= 2 * NWAVE, "diag tile mapping");
+    extern __shared__ __align__(16) double T[];
+    TL_DECL
+    double *Yn = T + NB * LD;   // [NB][8]: minus (L D) of the current block column, columns 6, 7 zero
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = s * NB;
     const bool first = (s == 0);
     STAMP(0);
-    double D[R][R];
+    {   // tile -> LDS, coalesced; damping / gauge on first touch; zeros above the diagonal
+        double v[PER];
 #pragma unroll
-    for (int p = 0; p < R; p++)
-#pragma unroll
-        for (int q = 0; q < R; q++) {
-            if (q > p) { D[p][q] = 0.0; continue; }  // strictly above the diagonal blocks: never used
-            const int i = ty + 16 * p, j = tx + 16 * q;
-            double v = 0.0;
-            if (j <= i) {
-                v = S[(size_t)(r0 + i) * n_pad + r0 + j];
-                if (first) v = xform_first(v, r0 + i, r0 + j, n, mu, ent_fixed);
-            }
-            D[p][q] = v;
+        for (int u = 0; u < PER; u++) {
+            const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
+            v[u] = (j <= i) ? S[(size_t)(r0 + i) * n_pad + r0 + j] : 0.0;
         }
-    STAMP(1);
+        if (tid < NB * 8) Yn[tid] = 0.0;
 #pragma unroll
-    for (int kq = 0; kq < R; kq++) {
-        STAMP(2 + kq);
-        for (int kk = 0; kk < 16; kk++) {
-            const int k = 16 * kq + kk, buf = k & 1;
-            if (tx == kk) {  // owners of column k publish it (final after step k-1)
-#pragma unroll
-                for (int p = 0; p < R; p++)
-                    if (p >= kq) colD[buf][ty + 16 * p] = D[p][kq];
-                if (ty == kk) {  // pivot owner
-                    const double d = D[kq][kq];
-                    const double inv = rcp_refined(d);
-                    pinv[buf] = inv;
-                    dinv[k] = inv;
-                    if (!(d > 0.0)) atomicOr(flags, 2);
-                }
-            }
-            __syncthreads();
-            const double inv = pinv[buf];
-            double lj[R], li[R];
-#pragma unroll
-            for (int q = 0; q < R; q++)
-                if (q >= kq) {
-                    lj[q] = colD[buf][tx + 16 * q];
-                    li[q] = colD[buf][ty + 16 * q] * inv;
-                }
-#pragma unroll
-            for (int q = 0; q < R; q++) {
-                if (q < kq) continue;  // finished columns (compile-time)
-                const int j = tx + 16 * q;
-                const bool jact = (q > kq) || (j > k);
-#pragma unroll
-                for (int p = 0; p < R; p++) {
-                    if (p < q) continue;  // lower block triangle only (compile-time)
-                    const int i = ty + 16 * p;
-                    const bool act = jact && ((p > kq) || (i > k)) && ((p > q) || (j <= i));
-                    if (act) D[p][q] = fma(-li[p], lj[q], D[p][q]);
-                }
-            }
+        for (int u = 0; u < PER; u++) {
+            const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
+            double x = v[u];
+            if (first && j <= i) x = xform_first(x, r0 + i, r0 + j, n, mu, ent_fixed);
+            T[i * LD + j] = x;
         }
     }
     __syncthreads();
-    STAMP(8);
-    // factored tile: unit L below the diagonal, D on it.  It goes to Dfac (not back into S) and into LDS for the inverses.
-    double *out = Dfac + (size_t)s * NB * NB;
+    STAMP(1);
+    const int rt = tid - DG_ROW0 + 6;     // row thread: row number counted from the pivot block (< 6: not one)
+    // sub-tiles of this wavefront (wave-uniform): tile number 16 slot + wave in the order (column descending, row ascending)
+    int j16[2], aoff[2], boff[2], toff[2];
+    bool has[2];
+    dg_acc_t acc[2];
+    const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-    for (int p = 0; p < R; p++)
+    for (int sl = 0; sl < 2; sl++) {
+        const int nn = NWAVE * sl + wave;
+        int jj = 0;
+        while ((jj + 1) * (jj + 2) / 2 <= nn) jj++;
+        has[sl] = nn < NTILE;
+        const int tj = has[sl] ? NT16 - 1 - jj : 0, ti = has[sl] ? tj + nn - jj * (jj + 1) / 2 : 0;
+        j16[sl] = 16 * tj;
+        aoff[sl] = (16 * ti + lc) * LD + lr;          // A operand: L(row, c0 + k) in the tile
+        boff[sl] = (16 * tj + lc) * 8 + lr;           // B operand: -(L D)(col, k) in the panel
+        toff[sl] = (16 * ti + lr) * LD + 16 * tj + lc;   // accumulator register r: row + 4 r
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            const int i = ty + 16 * p, j = tx + 16 * q;
-            const double v = (j < i) ? D[p][q] * dinv[j] : (j == i ? D[p][q] : 0.0);
-            out[i * NB + j] = v;
-            Lf[i * LD + j] = v;
-        }
+        for (int r = 0; r < 4; r++) acc[sl][r] = T[toff[sl] + 4 * r * LD];
+    }
+    dg_rows(T, Yn, 0, rt);
     __syncthreads();
+
+    for (int k = 0; k + 1 < NBK; k++) {
+        const int c0 = 6 * k, lim = c0 + 6;
+        TL(k, 0);
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {
+            if (!has[sl] || j16[sl] + 16 <= lim) continue;   // no such tile / column retired (wave-uniform)
+            const double a1 = T[aoff[sl] + c0], a2 = T[aoff[sl] + c0 + 4];   // rank columns 6, 7: whatever follows in the row, times the zeros of the panel
+            const double b1 = Yn[boff[sl]], b2 = Yn[boff[sl] + 4];
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[sl], 0, 0, 0);
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[sl], 0, 0, 0);
+            if (j16[sl] < lim + 6) {   // the sub-tile holds (part of) block column k+1 (wave-uniform): publish it
+                const int col = j16[sl] + lc;
+                if (col >= lim && col < lim + 6) {   // rows above the block land above the diagonal
+#pragma unroll
+                    for (int r = 0; r < 4; r++) T[toff[sl] + 4 * r * LD] = acc[sl][r];
+                }
+            }
+        }
+        TL(k, 1);
+        __syncthreads();
+        TL(k, 2);
+        dg_rows(T, Yn, k + 1, rt);
+        TL(k, 3);
+        __syncthreads();
+        TL(k, 4);
+    }
+    STAMP(8);
+    {   // the 16 pivot blocks, still unfactored: thread (block, row) -> unit L left of the diagonal, D on it, zeros right of it
+        const int c0 = 6 * (tid / 6), q = tid % 6;
+        double o[6];
+        if (tid < NB) {
+            double a[6][6], y[6], inv[6];
+            dg_factor_row(T, c0, c0 + q, a, y, inv);
+#pragma unroll
+            for (int c = 0; c < 6; c++) o[c] = (c < q) ? y[c] * inv[c] : (c == q ? y[c] : 0.0);
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < 6; c++) bad |= !(a[c][c] > 0.0);
+            if (bad && q == 0) atomicOr(flags, 2);
+        }
+        __syncthreads();   // every row thread of a block has read it before any of them stores
+        if (tid < NB) {
+            double2 *lt = reinterpret_cast<double2 *>(T + (c0 + q) * LD + c0);
+            lt[0] = make_double2(o[0], o[1]);
+            lt[1] = make_double2(o[2], o[3]);
+            lt[2] = make_double2(o[4], o[5]);
+        }
+    }
+    __syncthreads();
+    {   // factored tile -> Dfac (not back into S: other workgroups may still be reading it)
+        double *outp = Dfac + (size_t)s * NB * NB;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
+            outp[idx] = (j <= i) ? T[i * LD + j] : 0.0;
+        }
+    }
     STAMP(9);
     // inverses of the unit-lower 16x16 diagonal sub-blocks: lane c < 16 of a wave solves L x = e_c
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int q = wave; q < NSB; q += 4) {
-        if (lane < SBK) {
-            const int c = lane, o = q * SBK;
-            double x[SBK];
+    if (wave < NSB && lane < SBK) {
+        const int q = wave, c = lane, o = q * SBK;
+        double x[SBK];
 #pragma unroll
-            for (int i = 0; i < SBK; i++) {
-                // x_p = 0 for p < c, so the full row can be used: the L loads are lane-uniform and independent of x
-                double acc = (i == c) ? 1.0 : 0.0;
+        for (int i = 0; i < SBK; i++) {
+            // x_p = 0 for p < c, so the full row can be used: the L loads are lane-uniform and independent of x
+            double acc2 = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-                for (int pp = 0; pp < i; pp++) acc = fma(-Lf[(o + i) * LD + o + pp], x[pp], acc);
-                x[i] = acc;
-            }
-            double *li = Linv16 + ((size_t)s * NSB + q) * SBK * SBK;
-#pragma unroll
-            for (int i = 0; i < SBK; i++) li[i * SBK + c] = x[i];
+            for (int pp = 0; pp < i; pp++) acc2 = fma(-T[(o + i) * LD + o + pp], x[pp], acc2);
+            x[i] = acc2;
         }
+        double *li = Linv16 + ((size_t)s * NSB + q) * SBK * SBK;
+#pragma unroll
+        for (int i = 0; i < SBK; i++) li[i * SBK + c] = x[i];
     }
     STAMP(10);
+    TL_DUMP;
 }
 
 // X = A L_ss^-T D^-1 for one 48-row slab of block column s (blockIdx < 2m), or for the right-hand side (last block),
@@ -684,14 +793,14 @@ void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
 
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];
-    const size_t lds_diag = (size_t)NB * (NB + 2) * sizeof(double);
+    const size_t lds_diag = ((size_t)NB * (NB + 2) + NB * 8) * sizeof(double);
     const size_t lds_trsm = ((size_t)NB * (NB + 2) + 2 * (NB / 2) * (SBK + 2) + NSB * SBK * (SBK + 2) + NB) * sizeof(double);
     static size_t g_diag = 48 * 1024, g_trsm = 48 * 1024, g_bs = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_trsm), lds_trsm, g_trsm);
     for (int s = 0; s < P.nT; s++) {
         const int m = P.nT - s - 1;
-        { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags); }
+        { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags); }
         { HookScope _h(P, KID_LDL_TRSM); hipLaunchKernelGGL(k_ldl_trsm, dim3(2 * m + 1), dim3(256), lds_trsm, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
         if (m > 0) {
             { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }

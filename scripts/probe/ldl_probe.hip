@@ -28,9 +28,20 @@ int main() {
         unsigned long long st[64];
         (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st);
         printf("rep %d: launch_chol %.1f us\n", rep, ms*1e3);
-        printf("  diag (last step): load %llu | col blocks", st[1]-st[0]);
-        for (int k = 0; k < 6; k++) printf(" %llu", st[k+3 > 7 ? 8 : k+3] - st[k+2]);
-        printf(" | store %llu | inverses %llu  (cycles)\n", st[9]-st[8], st[10]-st[9]);
+        printf("  diag (last step): load %llu | 16 block steps %llu | store %llu | inverses %llu  (cycles)\n",
+               st[1]-st[0], st[8]-st[1], st[9]-st[8], st[10]-st[9]);
+#ifdef AAR_TIMELINE
+        if (rep == 2) {
+            unsigned long long tl[240];
+            (void)hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_tl), sizeof tl);
+            const char *nm[3] = {"wave 0", "wave 14 (rows)", "wave 5"};
+            for (int w = 0; w < 3; w++) {
+                printf("  %s: per step [C work | wait X | rows | wait Y]\n   ", nm[w]);
+                for (int k = 0; k < 16; k++) { const unsigned long long *t = tl + (w * 16 + k) * 5; printf(" %d:[%llu|%llu|%llu|%llu]", k, t[1]-t[0], t[2]-t[1], t[3]-t[2], t[4]-t[3]); }
+                printf("\n");
+            }
+        }
+#endif
         printf("  trsm (last step): load %llu | blocks", st[17]-st[16]);
         for (int q = 0; q < 6; q++) printf(" %llu", (q < 5 ? st[19+q] : st[24]) - st[18+q]);
         printf(" | store %llu\n", st[25]-st[24]);
