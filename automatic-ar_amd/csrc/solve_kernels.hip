@@ -167,11 +167,12 @@ __device__ __forceinline__ double xform_first(double v, int gi, int gj, int n, d
     return gi == gj ? v + mu : v;
 }
 
+// 1/d: v_rcp_f64 is good to 2^-24.4 (scripts/probe/rcp_probe.hip); one cubic step 1/d = x (1 + e + e^2 + ...), e = 1 - d x,
+// leaves 2^-73 and matches the IEEE quotient on 4 M samples -- one instruction less than two Newton steps
 __device__ __forceinline__ double rcp_refined(double d) {
-    double x = __builtin_amdgcn_rcp(d);
-    x = fma(x, fma(-d, x, 1.0), x);
-    x = fma(x, fma(-d, x, 1.0), x);
-    return x;
+    const double x = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, x, 1.0);
+    return fma(x, fma(e, e, e), x);
 }
 
 // The tile is walked in 6x6 block pivots (16 block steps instead of 96 column steps; a column step is latency, not work).
@@ -189,7 +190,7 @@ __device__ __forceinline__ double rcp_refined(double d) {
 // which turn every triangular solve below into small matrix products.
 // f64 MFMA lane maps (cdna_hip_programming.md section 4, checked by scripts/probe/issue_probe.hip):
 //   A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row = (l>>4) + 4 reg][col = l&15].
-// LDS (dynamic): T [NB][NB+2] | Yn [NB][8]
+// LDS (dynamic): T [NB][NB+2] | Yn [2][NB][8]
 typedef double dg_acc_t __attribute__((ext_vector_type(4)));
 constexpr int DG_THREADS = 1024, DG_ROW0 = 896;
 
@@ -240,13 +241,14 @@ __device__ __forceinline__ void dg_rows(double *__restrict__ T, double *__restri
 
 __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restrict__ S, double *__restrict__ Dfac, double *__restrict__ Linv16,
                                                          int n_pad, int n, int s, double mu, const int32_t *__restrict__ ent_fixed,
-                                                         int32_t *__restrict__ flags) {
-    constexpr int LD = NB + 2, NBK = NB / 6, PER = NB * NB / DG_THREADS, NT16 = NB / 16, NTILE = NT16 * (NT16 + 1) / 2, NWAVE = DG_THREADS / 64;
+                                                         int32_t *__restrict__ flags, int nT, const double *__restrict__ rhs,
+                                                         const double *__restrict__ g0, double *__restrict__ xout) {
+    constexpr int LD = NB + 2, NBK = NB / 6, PER = NB * NB / DG_THREADS, NT16 = NB / 16, NTILE = NT16 * (NT16 + 1) / 2, NWAVE = DG_THREADS / 64, NMW = DG_ROW0 / 64;
     static_assert(NB % 16 == 0 && NB % 6 == 0 && NB * NB % DG_THREADS == 0 && NWAVE >= NSB && DG_THREADS - DG_ROW0 >= NB - 6 &&
-                  NTILE <= 2 * NWAVE, "diag tile mapping");
+                  NTILE <= 2 * NMW && DG_ROW0 % 64 == 0, "diag tile mapping");
     extern __shared__ __align__(16) double T[];
     TL_DECL
-    double *Yn = T + NB * LD;   // [NB][8]: minus (L D) of the current block column, columns 6, 7 zero
+    double *Yn = T + NB * LD;   // [2][NB][8]: minus (L D) of block column k in buffer k & 1, columns 6, 7 zero
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = s * NB;
     const bool first = (s == 0);
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
             const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
             v[u] = (j <= i) ? S[(size_t)(r0 + i) * n_pad + r0 + j] : 0.0;
         }
-        if (tid < NB * 8) Yn[tid] = 0.0;
+        for (int i = tid; i < 2 * NB * 8; i += DG_THREADS) Yn[i] = 0.0;
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
@@ -270,17 +272,17 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
     __syncthreads();
     STAMP(1);
     const int rt = tid - DG_ROW0 + 6;     // row thread: row number counted from the pivot block (< 6: not one)
-    // sub-tiles of this wavefront (wave-uniform): tile number 16 slot + wave in the order (column descending, row ascending)
+    // sub-tiles of a matrix wavefront (wave-uniform): tile number 14 slot + wave in the order (column descending, row ascending)
     int j16[2], aoff[2], boff[2], toff[2];
     bool has[2];
     dg_acc_t acc[2];
     const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
     for (int sl = 0; sl < 2; sl++) {
-        const int nn = NWAVE * sl + wave;
+        const int nn = NMW * sl + wave;
         int jj = 0;
         while ((jj + 1) * (jj + 2) / 2 <= nn) jj++;
-        has[sl] = nn < NTILE;
+        has[sl] = wave < NMW && nn < NTILE;
         const int tj = has[sl] ? NT16 - 1 - jj : 0, ti = has[sl] ? tj + nn - jj * (jj + 1) / 2 : 0;
         j16[sl] = 16 * tj;
         aoff[sl] = (16 * ti + lc) * LD + lr;          // A operand: L(row, c0 + k) in the tile
@@ -294,39 +296,52 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
 
     for (int k = 0; k + 1 < NBK; k++) {
         const int c0 = 6 * k, lim = c0 + 6;
+        const double *yk = Yn + (k & 1) * NB * 8;
         TL(k, 0);
 #pragma unroll
-        for (int sl = 0; sl < 2; sl++) {
-            if (!has[sl] || j16[sl] + 16 <= lim) continue;   // no such tile / column retired (wave-uniform)
+        for (int sl = 0; sl < 2; sl++) {   // first the sub-tiles that hold (part of) block column k+1: update, publish
+            if (!has[sl] || j16[sl] + 16 <= lim || j16[sl] >= lim + 6) continue;   // wave-uniform
             const double a1 = T[aoff[sl] + c0], a2 = T[aoff[sl] + c0 + 4];   // rank columns 6, 7: whatever follows in the row, times the zeros of the panel
-            const double b1 = Yn[boff[sl]], b2 = Yn[boff[sl] + 4];
+            const double b1 = yk[boff[sl]], b2 = yk[boff[sl] + 4];
             acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[sl], 0, 0, 0);
             acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[sl], 0, 0, 0);
-            if (j16[sl] < lim + 6) {   // the sub-tile holds (part of) block column k+1 (wave-uniform): publish it
-                const int col = j16[sl] + lc;
-                if (col >= lim && col < lim + 6) {   // rows above the block land above the diagonal
+            const int col = j16[sl] + lc;
+            if (col >= lim && col < lim + 6) {   // rows above the block land above the diagonal
 #pragma unroll
-                    for (int r = 0; r < 4; r++) T[toff[sl] + 4 * r * LD] = acc[sl][r];
-                }
+                for (int r = 0; r < 4; r++) T[toff[sl] + 4 * r * LD] = acc[sl][r];
             }
         }
         TL(k, 1);
         __syncthreads();
         TL(k, 2);
-        dg_rows(T, Yn, k + 1, rt);
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {   // then the other live sub-tiles, beside rows(k+1) on the row wavefronts
+            if (!has[sl] || j16[sl] < lim + 6) continue;   // wave-uniform
+            const double a1 = T[aoff[sl] + c0], a2 = T[aoff[sl] + c0 + 4];
+            const double b1 = yk[boff[sl]], b2 = yk[boff[sl] + 4];
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[sl], 0, 0, 0);
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[sl], 0, 0, 0);
+        }
+        dg_rows(T, Yn + ((k + 1) & 1) * NB * 8, k + 1, rt);
         TL(k, 3);
         __syncthreads();
         TL(k, 4);
     }
     STAMP(8);
-    {   // the 16 pivot blocks, still unfactored: thread (block, row) -> unit L left of the diagonal, D on it, zeros right of it
+    double *dsave = Yn;   // [NB] the pivots (the panel is free after the last block step)
+    {   // the 16 pivot blocks, still unfactored: thread (block, row) -> unit L left of the diagonal, zeros from it on; D aside
         const int c0 = 6 * (tid / 6), q = tid % 6;
         double o[6];
         if (tid < NB) {
             double a[6][6], y[6], inv[6];
             dg_factor_row(T, c0, c0 + q, a, y, inv);
+            double dq = 0.0;
 #pragma unroll
-            for (int c = 0; c < 6; c++) o[c] = (c < q) ? y[c] * inv[c] : (c == q ? y[c] : 0.0);
+            for (int c = 0; c < 6; c++) {
+                o[c] = (c < q) ? y[c] * inv[c] : 0.0;
+                dq = (c == q) ? y[c] : dq;
+            }
+            dsave[c0 + q] = dq;   // D: kept beside the tile, whose diagonal stays zero for the triangular solves below
             bool bad = false;
 #pragma unroll
             for (int c = 0; c < 6; c++) bad |= !(a[c][c] > 0.0);
@@ -339,14 +354,54 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
             lt[1] = make_double2(o[2], o[3]);
             lt[2] = make_double2(o[4], o[5]);
         }
+#pragma unroll
+        for (int u = 0; u < PER; u++) {   // what the publications left above the diagonal blocks
+            const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
+            if (j / 6 > i / 6) T[i * LD + j] = 0.0;
+        }
     }
     __syncthreads();
+    if (s == nT - 1 && wave == NWAVE - 1) {
+        // The last tile has no panel below it: its right-hand side is solved here, forward and backward, by one wavefront
+        // beside the stores and inverses of the others -- instead of a k_ldl_trsm launch and a tile of k_ldl_backsolve.
+        // Lane l keeps rows l and l + 64; column by column, the finished entry travels through v_readlane.
+        const int i0 = lane, i1 = lane + 64;
+        const bool h1 = i1 < NB;
+        double b0 = rhs[r0 + i0], b1 = h1 ? rhs[r0 + i1] : 0.0;
+        if (first) {   // B = g0 + Schur part on free rows, 0 on gauge / padding rows (as k_ldl_trsm does for its rhs slab)
+            const int g0i = r0 + i0, g1i = r0 + i1;
+            b0 = (g0i >= n || ent_fixed[g0i / 6]) ? 0.0 : b0 + g0[g0i];
+            if (h1) b1 = (g1i >= n || ent_fixed[g1i / 6]) ? 0.0 : b1 + g0[g1i];
+        }
+        const double *c0p = T + i0 * LD, *c1p = T + (h1 ? i1 : 0) * LD;
+        auto bcast = [&](double v0, double v1, int j) -> double {   // entry j of the vector held as (v0: rows 0-63, v1: rows 64-95)
+            const double v = j < 64 ? v0 : v1;
+            const int lo = __builtin_amdgcn_readlane(__double2loint(v), j & 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), j & 63);
+            return __hiloint2double(hi, lo);
+        };
+#pragma unroll
+        for (int j = 0; j < NB - 1; j++) {   // L y = b, unit lower: T is zero on and above the diagonal, so no masks
+            const double yj = bcast(b0, b1, j);
+            if (j < 63) b0 = fma(-c0p[j], yj, b0);
+            b1 = fma(-c1p[j], yj, b1);
+        }
+        b0 *= rcp_refined(dsave[i0]);           // z = D^-1 y
+        b1 *= rcp_refined(h1 ? dsave[i1] : 1.0);
+#pragma unroll
+        for (int j = NB - 1; j > 0; j--) {   // L^T x = z: row j of L against x_j
+            const double xj = bcast(b0, b1, j);
+            b0 = fma(-T[j * LD + i0], xj, b0);
+            if (j > 64) b1 = fma(-T[j * LD + i1], xj, b1);
+        }
+        xout[r0 + i0] = b0;
+        if (h1) xout[r0 + i1] = b1;
+    }
     {   // factored tile -> Dfac (not back into S: other workgroups may still be reading it)
         double *outp = Dfac + (size_t)s * NB * NB;
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
-            outp[idx] = (j <= i) ? T[i * LD + j] : 0.0;
+            outp[idx] = (i == j) ? dsave[i] : T[i * LD + j];
         }
     }
     STAMP(9);
@@ -396,7 +451,10 @@ __global__ void __launch_bounds__(256) k_ldl_trsm(double *__restrict__ S, double
         constexpr int NL = NB * NB / 256, NI = NSB * SBK * SBK / 256;
         double vl[NL], vi[NI];
 #pragma unroll
-        for (int u = 0; u < NL; u++) vl[u] = dd[tid + 256 * u];
+        for (int u = 0; u < NL; u++) {   // only the strictly lower part of L_ss is used, so only that is fetched
+            const int e = tid + 256 * u, i = e / NB, j = e - i * NB;
+            vl[u] = (j < i) ? dd[e] : 0.0;
+        }
 #pragma unroll
         for (int u = 0; u < NI; u++) vi[u] = Linv16[(size_t)s * NSB * SBK * SBK + tid + 256 * u];
         const double dv = (tid < NB) ? dd[tid * NB + tid] : 1.0;
@@ -414,7 +472,7 @@ __global__ void __launch_bounds__(256) k_ldl_trsm(double *__restrict__ S, double
 #pragma unroll
         for (int u = 0; u < NL; u++) {
             const int e = tid + 256 * u, i = e / NB, j = e - i * NB;
-            Ls[i * LD + j] = (j < i) ? vl[u] : 0.0;
+            Ls[i * LD + j] = vl[u];
         }
 #pragma unroll
         for (int u = 0; u < NI; u++) {
@@ -586,20 +644,25 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
     double *Li = w + NB;
     const int tid = threadIdx.x;
     const int j = tid % NB, gq = tid / NB;  // G*NB = 960 threads busy in the tall reduction
-    for (int s = nT - 1; s >= 0; s--) {
+    if (tid < NB) xs[(nT - 1) * NB + tid] = x[(nT - 1) * NB + tid];   // the last tile was solved by k_ldl_diag
+    __syncthreads();
+    for (int s = nT - 2; s >= 0; s--) {
         const int r0 = s * NB;
         const double *dd = Dfac + (size_t)s * NB * NB;
         {
             constexpr int NL = NB * NB / 1024;
             double vl[NL], vi[2];
 #pragma unroll
-            for (int u = 0; u < NL; u++) vl[u] = dd[tid + 1024 * u];
+            for (int u = 0; u < NL; u++) {   // strictly lower part only
+                const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
+                vl[u] = (jj < i) ? dd[e] : 0.0;
+            }
 #pragma unroll
             for (int u = 0; u < 2; u++) vi[u] = (tid + 1024 * u < NSB * SBK * SBK) ? Linv16[(size_t)s * NSB * SBK * SBK + tid + 1024 * u] : 0.0;
 #pragma unroll
             for (int u = 0; u < NL; u++) {
                 const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
-                Ls[i * LD + jj] = (jj < i) ? vl[u] : 0.0;
+                Ls[i * LD + jj] = vl[u];
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -793,22 +856,23 @@ void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
 
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];
-    const size_t lds_diag = ((size_t)NB * (NB + 2) + NB * 8) * sizeof(double);
+    const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * 8) * sizeof(double);
     const size_t lds_trsm = ((size_t)NB * (NB + 2) + 2 * (NB / 2) * (SBK + 2) + NSB * SBK * (SBK + 2) + NB) * sizeof(double);
     static size_t g_diag = 48 * 1024, g_trsm = 48 * 1024, g_bs = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_trsm), lds_trsm, g_trsm);
     for (int s = 0; s < P.nT; s++) {
         const int m = P.nT - s - 1;
-        { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags); }
-        { HookScope _h(P, KID_LDL_TRSM); hipLaunchKernelGGL(k_ldl_trsm, dim3(2 * m + 1), dim3(256), lds_trsm, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
-        if (m > 0) {
+        { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags,
+                                                         P.nT, b.rhs, b.g0, P.delta_s); }
+        if (m > 0) {   // the last tile's right-hand side is solved inside k_ldl_diag
+            { HookScope _h(P, KID_LDL_TRSM); hipLaunchKernelGGL(k_ldl_trsm, dim3(2 * m + 1), dim3(256), lds_trsm, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
             { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
         }
     }
     const size_t lds = ((size_t)P.n_pad + NB * (NB + 1) + 16 * NB + NB + NSB * SBK * 17) * sizeof(double);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_backsolve), lds, g_bs);
-    { HookScope _h(P, KID_LDL_BACKSOLVE); hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.Linv16, P.delta_s, P.n_pad, P.nT); }
+    if (P.nT > 1) { HookScope _h(P, KID_LDL_BACKSOLVE); hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.Linv16, P.delta_s, P.n_pad, P.nT); }
 }
 
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) {

@@ -27,6 +27,22 @@ __global__ void k_fma_dep(unsigned long long *out, int iters) {
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) { out[2 * (threadIdx.x >> 6)] = t1 - t0; out[2 * (threadIdx.x >> 6) + 1] = (unsigned long long)a; }
 }
+__global__ void k_fma_masked(unsigned long long *out, int iters, int active) {
+    double a[8];
+    for (int i = 0; i < 8; i++) a[i] = threadIdx.x * 1e-3 + i;
+    const double m = 0.999 + threadIdx.x * 1e-9, c = 1e-6;
+    unsigned long long t0 = 0, t1 = 0;
+    if ((int)(threadIdx.x & 63) < active) {
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = fma(a[j], m, c);
+        }
+        t1 = __builtin_amdgcn_s_memtime();
+    }
+    double s = 0; for (int i = 0; i < 8; i++) s += a[i];
+    if ((threadIdx.x & 63) == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)s; }
+}
 template <int NACC>
 __global__ void k_mfma(unsigned long long *out, int iters) {
     double4v acc[NACC];
@@ -59,6 +75,11 @@ int main() {
         hipLaunchKernelGGL(k_fma_indep, dim3(1), dim3(threads), 0, 0, d, it);
         hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
         printf("indep DFMA  threads %4d: %.2f cycles per wave-instruction (wave 0)\n", threads, (double)h[0] / (8.0 * it));
+    }
+    for (int active : {64, 48, 32, 16, 8, 1}) {
+        hipLaunchKernelGGL(k_fma_masked, dim3(1), dim3(64), 0, 0, d, it, active);
+        hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+        printf("indep DFMA, %2d active lanes: %.2f cycles per wave-instruction\n", active, (double)h[0] / (8.0 * it));
     }
     hipLaunchKernelGGL(k_fma_dep, dim3(1), dim3(64), 0, 0, d, it);
     hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
