@@ -426,27 +426,29 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
 }
 
 // X = A L_ss^-T D^-1 for one 48-row slab of block column s (blockIdx < 2m), or for the right-hand side (last block),
-// right-looking over 16-column blocks.  Thread (rb, c) keeps rows rb+16a (a < 3), column c of all six blocks in
-// registers: X_q = R_q inv(L_qq)^T, then every later block gets R_q'' -= X_q L(q'', q)^T.
-// LDS (dynamic): Ls [NB][NB+2] | Xq [48][18] | Rt [48][18] | Li [NSB][16][18] | dinv [NB]
+// right-looking over 16-column blocks on the matrix pipes.  Wavefront w < 3 owns rows 16w..16w+15 of the slab as six 16x16
+// fp64 MFMA accumulator tiles and never talks to the others: per block q
+//   X_q = R_q inv(L_qq)^T        (4 MFMAs; R_q goes through a wave-private LDS tile to become the A operand)
+//   R_q'' -= X_q L(q'', q)^T      for every later block (4 MFMAs each, B straight from the LDS copy of L_ss)
+// and L_ts = X_q D^-1 goes to global memory.  The fourth wavefront only helps to stage L_ss.
+// LDS (dynamic): Ls [NB][NB+2] | Li [NSB][16][18] | dinv [NB] | St [3][16][18]
 __global__ void __launch_bounds__(256) k_ldl_trsm(double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
                                                   const double *__restrict__ Dfac, const double *__restrict__ Linv16, int n_pad,
                                                   int n, int s, int nT, double mu, const int32_t *__restrict__ ent_fixed) {
     constexpr int LD = NB + 2, ROWS = NB / 2, PL = SBK + 2;
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     double *Ls = lds;
-    double *Xq = Ls + NB * LD;
-    double *Rt = Xq + ROWS * PL;
-    double *Li = Rt + ROWS * PL;
+    double *Li = Ls + NB * LD;
     double *dinv = Li + NSB * SBK * PL;
-    const int m = nT - s - 1, b = blockIdx.x, tid = threadIdx.x;
+    double *Stg = dinv + NB;
+    const int m = nT - s - 1, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = s * NB;
     const bool first = (s == 0), is_rhs = (b == 2 * m);
-    const int row0 = (s + 1) * NB + b * ROWS;
+    const int row0 = (s + 1) * NB + b * ROWS + 16 * wave;   // first slab row of this wavefront
     const double *dd = Dfac + (size_t)s * NB * NB;
-    const int c = tid & 15, rb = tid >> 4;
+    const int lr = lane >> 4, lc = lane & 15;
     STAMP(16);
-    double acc[3][NSB];
+    dg_acc_t acc[NSB];
     {   // every global load is issued before the first use
         constexpr int NL = NB * NB / 256, NI = NSB * SBK * SBK / 256;
         double vl[NL], vi[NI];
@@ -458,17 +460,17 @@ __global__ void __launch_bounds__(256) k_ldl_trsm(double *__restrict__ S, double
 #pragma unroll
         for (int u = 0; u < NI; u++) vi[u] = Linv16[(size_t)s * NSB * SBK * SBK + tid + 256 * u];
         const double dv = (tid < NB) ? dd[tid * NB + tid] : 1.0;
-        if (!is_rhs) {
 #pragma unroll
-            for (int a = 0; a < 3; a++)
+        for (int q = 0; q < NSB; q++)
 #pragma unroll
-                for (int q = 0; q < NSB; q++) acc[a][q] = S[(size_t)(row0 + rb + 16 * a) * n_pad + r0 + 16 * q + c];
-        } else {
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int q = 0; q < NSB; q++) acc[a][q] = (a == 0 && rb == 0) ? rhs[r0 + 16 * q + c] : 0.0;
-        }
+            for (int r = 0; r < 4; r++) {   // accumulator register r of tile q: slab row lr + 4 r, column 16 q + lc
+                double v = 0.0;
+                if (wave < 3) {
+                    if (!is_rhs) v = S[(size_t)(row0 + lr + 4 * r) * n_pad + r0 + 16 * q + lc];
+                    else if (wave == 0 && lr + 4 * r == 0) v = rhs[r0 + 16 * q + lc];
+                }
+                acc[q][r] = v;
+            }
 #pragma unroll
         for (int u = 0; u < NL; u++) {
             const int e = tid + 256 * u, i = e / NB, j = e - i * NB;
@@ -480,74 +482,53 @@ __global__ void __launch_bounds__(256) k_ldl_trsm(double *__restrict__ S, double
             Li[(q * SBK + r) * PL + cc] = vi[u];
         }
         if (tid < NB) dinv[tid] = rcp_refined(dv);
-        if (first) {
+        if (first && wave < 3) {
 #pragma unroll
-            for (int a = 0; a < 3; a++)
+            for (int q = 0; q < NSB; q++)
 #pragma unroll
-                for (int q = 0; q < NSB; q++) {
-                    const int gj = r0 + 16 * q + c;
-                    if (!is_rhs) acc[a][q] = xform_first(acc[a][q], row0 + rb + 16 * a, gj, n, mu, ent_fixed);
-                    else if (a == 0 && rb == 0) acc[a][q] = (gj >= n || ent_fixed[gj / 6]) ? 0.0 : acc[a][q] + g0[gj];  // B = g0 + Schur part
+                for (int r = 0; r < 4; r++) {
+                    const int gj = r0 + 16 * q + lc;
+                    if (!is_rhs) acc[q][r] = xform_first(acc[q][r], row0 + lr + 4 * r, gj, n, mu, ent_fixed);
+                    else if (wave == 0 && lr + 4 * r == 0) acc[q][r] = (gj >= n || ent_fixed[gj / 6]) ? 0.0 : acc[q][r] + g0[gj];  // B = g0 + Schur part
                 }
         }
     }
+    __syncthreads();
     STAMP(17);
+    if (wave >= 3 || (is_rhs && wave > 0)) return;
+    double *St = Stg + wave * SBK * PL;
 #pragma unroll
     for (int q = 0; q < NSB; q++) {
+        // R_q -> wave-private LDS tile (accumulator layout: row lr + 4 r, column lc), read back as the A operand A[i = lc][k = lr]
 #pragma unroll
-        for (int a = 0; a < 3; a++) Rt[(rb + 16 * a) * PL + c] = acc[a][q];
-        __syncthreads();
-        STAMP(18 + q);
-        // X_q = R_q inv(L_qq)^T : X[r][c] = sum_p R[r][p] inv(L_qq)[c][p]   (inv(L) is lower: entries p > c are 0)
-        double lic[SBK];
-        {
-            const double2 *lp = reinterpret_cast<const double2 *>(Li + (q * SBK + c) * PL);
+        for (int r = 0; r < 4; r++) St[(lr + 4 * r) * PL + lc] = acc[q][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        dg_acc_t x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int h = 0; h < SBK / 2; h++) { const double2 v = lp[h]; lic[2 * h] = v.x; lic[2 * h + 1] = v.y; }
+        for (int t = 0; t < 4; t++)   // X[r][c] = sum_p R[r][p] inv(L_qq)[c][p]
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(St[lc * PL + 4 * t + lr], Li[(q * SBK + lc) * PL + 4 * t + lr], x, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+        const double dq = dinv[16 * q + lc];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            St[(lr + 4 * r) * PL + lc] = -x[r];
+            if (!is_rhs) S[(size_t)(row0 + lr + 4 * r) * n_pad + r0 + 16 * q + lc] = x[r] * dq;
+            else if (lr + 4 * r == 0) rhs[r0 + 16 * q + lc] = x[r] * dq;
         }
-        double x[3];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (q + 1 < NSB) {
+            double ax[4];
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const double2 *rp = reinterpret_cast<const double2 *>(Rt + (rb + 16 * a) * PL);
-            double xa = 0.0;
+            for (int t = 0; t < 4; t++) ax[t] = St[lc * PL + 4 * t + lr];   // -X_q as the A operand
 #pragma unroll
-            for (int h = 0; h < SBK / 2; h++) {
-                const double2 v = rp[h];
-                xa = fma(v.x, lic[2 * h], xa);
-                xa = fma(v.y, lic[2 * h + 1], xa);
-            }
-            x[a] = xa;
-            Xq[(rb + 16 * a) * PL + c] = xa;
+            for (int q2 = q + 1; q2 < NSB; q2++)   // R_q2[r][c] -= sum_p X[r][p] L(16 q2 + c, 16 q + p)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc[q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[t], Ls[(16 * q2 + lc) * LD + 16 * q + 4 * t + lr], acc[q2], 0, 0, 0);
         }
-        const double dq = dinv[16 * q + c];
-        if (!is_rhs) {
-#pragma unroll
-            for (int a = 0; a < 3; a++) S[(size_t)(row0 + rb + 16 * a) * n_pad + r0 + 16 * q + c] = x[a] * dq;
-        } else if (rb == 0) {
-            rhs[r0 + 16 * q + c] = x[0] * dq;
-        }
-        __syncthreads();
-        // R_q'' -= X_q L(q'', q)^T for every later block
-#pragma unroll
-        for (int q2 = 0; q2 < NSB; q2++) {
-            if (q2 <= q) continue;
-            double l[SBK];
-            const double2 *lp = reinterpret_cast<const double2 *>(Ls + (16 * q2 + c) * LD + 16 * q);
-#pragma unroll
-            for (int h = 0; h < SBK / 2; h++) { const double2 v = lp[h]; l[2 * h] = v.x; l[2 * h + 1] = v.y; }
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                const double2 *xp = reinterpret_cast<const double2 *>(Xq + (rb + 16 * a) * PL);
-                double r = acc[a][q2];
-#pragma unroll
-                for (int h = 0; h < SBK / 2; h++) {
-                    const double2 v = xp[h];
-                    r = fma(-v.x, l[2 * h], r);
-                    r = fma(-v.y, l[2 * h + 1], r);
-                }
-                acc[a][q2] = r;
-            }
-        }
+        __builtin_amdgcn_wave_barrier();
     }
     STAMP(24);
     STAMP(25);
@@ -857,7 +838,7 @@ void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];
     const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * 8) * sizeof(double);
-    const size_t lds_trsm = ((size_t)NB * (NB + 2) + 2 * (NB / 2) * (SBK + 2) + NSB * SBK * (SBK + 2) + NB) * sizeof(double);
+    const size_t lds_trsm = ((size_t)NB * (NB + 2) + NSB * SBK * (SBK + 2) + NB + 3 * SBK * (SBK + 2)) * sizeof(double);
     static size_t g_diag = 48 * 1024, g_trsm = 48 * 1024, g_bs = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_trsm), lds_trsm, g_trsm);
