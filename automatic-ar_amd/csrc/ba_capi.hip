@@ -684,6 +684,38 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         }
     }
     P.n_swork = (int)sw_ent.size();
+    // many shared entities: the MFMA kernel owns 16 x 32-entity blocks of S and streams frame ranges (solve_kernels.hip);
+    // frame ranges are cut so that the grid is a few workgroups per CU
+    std::vector<int32_t> sm_ga, sm_gb, sm_fb, sm_fe, slot_frame;
+    std::vector<uint16_t> slot_of;
+    // Measured at config 5 (A = 216): 1.72 ms against 1.69 ms for the output-stationary kernel -- both sit at the ~3 TB/s this
+    // access pattern gets out of L2 / HBM -- so it is opt-in (AAR_SCHUR_MFMA=1) until its blocks of S are
+    // large enough to cut the re-reads further; tests force it on to keep it correct.
+    bool schur_mfma = false;
+    if (const char *e = getenv("AAR_SCHUR_MFMA")) schur_mfma = atoi(e) != 0 && F > 0;
+    if (schur_mfma) {
+        const int nga = (A + 15) / 16;
+        int pairs = 0;
+        for (int ga = 0; ga < nga; ga++) pairs += std::min((16 * ga + 15) / 32, (A - 1) / 32) + 1;
+        int nsplit = std::max(1, std::min(F / 32, (1536 + pairs - 1) / pairs));
+        if (const char *e = getenv("AAR_SCHUR_SPLIT")) nsplit = std::max(1, atoi(e));
+        int flen = ((F + nsplit - 1) / nsplit + 1) / 2 * 2;   // even: frames go through the kernel two at a time
+        // frame range outermost: the workgroups that run at the same time then stream the same frames, so a W / Y row
+        // comes from HBM once and from L2 / MALL for the other blocks of S that need it
+        for (int f0 = 0; f0 < F; f0 += flen)
+            for (int ga = 0; ga < nga; ga++)
+                for (int gb = 0; gb <= std::min((16 * ga + 15) / 32, (A - 1) / 32); gb++) {
+                    sm_ga.push_back(ga); sm_gb.push_back(gb); sm_fb.push_back(f0); sm_fe.push_back(std::min(F, f0 + flen));
+                }
+        slot_of.assign((size_t)F * A, 0xFFFF);
+        slot_frame.resize(P.total_slots);
+        for (int f = 0; f < F; f++)
+            for (int s = fslot_start[f]; s < fslot_start[f + 1]; s++) {
+                slot_of[(size_t)f * A + fslot_ent[s]] = (uint16_t)(s - fslot_start[f]);
+                slot_frame[s] = f;
+            }
+        P.n_smwork = (int)sm_ga.size();
+    }
 
     std::vector<int32_t> ent_fixed(A, 0);
     for (int c = 0; c < C; c++) ent_fixed[c] = (c == L.rc || !L.oc) ? 1 : 0;
@@ -696,6 +728,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     UP(fslot_start, fslot_start); UP(fslot_ent, fslot_ent); UP(b_idx, b_idx); UP(b_uv, b_uv);
     UP(chunk_start, chunk_start); UP(ent_fixed, ent_fixed);
     UP(sw_ent, sw_ent); UP(sw_begin, sw_begin); UP(sw_end, sw_end); UP(pair_frame, pair_frame); UP(pair_slot, pair_slot);
+    if (P.n_smwork) { UP(sm_ga, sm_ga); UP(sm_gb, sm_gb); UP(sm_fb, sm_fb); UP(sm_fe, sm_fe); UP(slot_of, slot_of); UP(slot_frame, slot_frame); }
 #undef UP
 #define AL(field, count) if ((rc = dev_alloc(pb, &P.field, (size_t)(count)))) return fail(rc)
     AL(z[0], 6 * (size_t)(A + F)); AL(z[1], 6 * (size_t)(A + F));
@@ -705,6 +738,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         AL(blk[w].Vinv, (size_t)F * 36); AL(blk[w].hf, (size_t)F * 6);
         AL(blk[w].S, (size_t)P.n_pad * P.n_pad); AL(blk[w].rhs, P.n_pad); AL(blk[w].g0, P.n_pad);
     }
+    if (P.n_smwork) AL(Yw, (size_t)P.total_slots * 36);
     AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad);
     AL(err_part, std::max<size_t>((size_t)F, (size_t)((N + 255) / 256)) + 1);
     AL(lin_part, 2 * (size_t)(F + 1)); AL(scal, 8); AL(flags, 4);

@@ -50,6 +50,13 @@ struct DeviceProblem {
     // Schur work list: item w handles pairs [sw_begin[w], sw_end[w]) of entity sw_ent[w]
     int32_t *sw_ent = nullptr, *sw_begin = nullptr, *sw_end = nullptr;
     int32_t *pair_frame = nullptr, *pair_slot = nullptr;  // (entity, frame) incidence, grouped by entity
+    // Schur work list of the MFMA kernel (many shared entities): item w = block (16 entities sm_ga[w]) x (32 entities sm_gb[w])
+    // of S over frames [sm_fb[w], sm_fe[w])
+    int n_smwork = 0;
+    int32_t *sm_ga = nullptr, *sm_gb = nullptr, *sm_fb = nullptr, *sm_fe = nullptr;
+    uint16_t *slot_of = nullptr;          // [F][A] frame-local W slot of an entity, 0xFFFF = not seen in that frame
+    int32_t *slot_frame = nullptr;        // [total_slots] frame of every W block
+    double *Yw = nullptr;                 // [total_slots][36] W_af (V_f + mu I)^-1
     // state: everything that depends on a pose vector exists twice (index 0/1 = the two pose buffers), so that the
     // blocks of a trial point can be built while those of the current point are still needed for a mu retry
     double *z[2] = {nullptr, nullptr};    // [6A + 6F] pose vectors

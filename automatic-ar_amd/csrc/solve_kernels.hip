@@ -11,6 +11,8 @@
 
 namespace aar {
 
+typedef double dg_acc_t __attribute__((ext_vector_type(4)));   // one lane's share of a 16x16 fp64 MFMA accumulator tile
+
 // ------------------------------------------------------------------------------------------------
 // (V_f + mu I)^-1 and h_f = (V_f + mu I)^-1 g_f, one thread per frame.  Only launched when pass A's prediction of the
 // damping was wrong (first step, a rejected try, gain < 0.94): a mu retry needs no Jacobian pass.
@@ -119,6 +121,154 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
 }
 
 // ------------------------------------------------------------------------------------------------
+// Schur complement for many shared entities (A >= SM_MIN_A), on the matrix pipes.  The output-stationary kernel above
+// reads every W_bf once per (a, f) pair it meets -- at 216 entities that is 36x the bytes of W from HBM.  Here a workgroup
+// owns a 96 x 192 block of S (16 entities a x 32 entities b) in fp64 MFMA accumulators (8 wavefronts x 9 sub-tiles) and
+// streams a range of frames through LDS two at a time: rows of Y_af = W_af (V_f + mu I)^-1 (k_schur_y) for its a's, rows
+// of W_bf for its b's, absent entities as zero rows; K = 2 frames x 6 = 12 = three v_mfma_f64_16x16x4 per sub-tile, no
+// padding.  Every W / Y row is fetched once per block of S that needs it (at most 14 / 7 times at config 5).
+// LDS (dynamic): stage [2][288][14]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_schur_y(const int32_t *__restrict__ slot_frame, const double *__restrict__ W,
+                                                 const double *__restrict__ Vinv, int total_slots, double *__restrict__ Yw) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t sl = gid / 6;
+    const int i = (int)(gid - sl * 6);
+    if (sl >= total_slots) return;
+    const int f = slot_frame[sl];
+    const double2 *wp = reinterpret_cast<const double2 *>(W + sl * 36 + i * 6);
+    const double2 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+    const double w[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+    double y[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double2 *vp = reinterpret_cast<const double2 *>(Vinv + (size_t)f * 36 + k * 6);
+        const double2 v0 = vp[0], v1 = vp[1], v2 = vp[2];
+        y[0] = fma(w[k], v0.x, y[0]); y[1] = fma(w[k], v0.y, y[1]); y[2] = fma(w[k], v1.x, y[2]);
+        y[3] = fma(w[k], v1.y, y[3]); y[4] = fma(w[k], v2.x, y[4]); y[5] = fma(w[k], v2.y, y[5]);
+    }
+    double2 *yp = reinterpret_cast<double2 *>(Yw + sl * 36 + i * 6);
+    yp[0] = make_double2(y[0], y[1]); yp[1] = make_double2(y[2], y[3]); yp[2] = make_double2(y[4], y[5]);
+}
+
+constexpr int SM_GA = 16, SM_GB = 32, SM_AR = 6 * SM_GA, SM_BR = 6 * SM_GB, SM_ROWS = SM_AR + SM_BR, SM_PS = 14;
+__global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ w_ga, const int32_t *__restrict__ w_gb,
+                                                    const int32_t *__restrict__ w_fb, const int32_t *__restrict__ w_fe,
+                                                    const uint16_t *__restrict__ slot_of, const int32_t *__restrict__ fslot_start,
+                                                    const double *__restrict__ W, const double *__restrict__ Yw,
+                                                    const double *__restrict__ gf, int A, int n_pad, double sign,
+                                                    double *__restrict__ S, double *__restrict__ rhs) {
+    extern __shared__ __align__(16) double stage[];   // [2][SM_ROWS][SM_PS]
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ga = w_ga[w], gb = w_gb[w], fb = w_fb[w], fe = w_fe[w];
+    const int lr = lane >> 4, lc = lane & 15;
+    // staging role: thread t < 288 owns row t of the stage: (entity, parameter) of the a side (t < 96) or of the b side
+    const bool isA = tid < SM_AR;
+    const int e = isA ? SM_GA * ga + tid / 6 : SM_GB * gb + (tid - SM_AR) / 6;
+    const int pi = isA ? tid % 6 : (tid - SM_AR) % 6;
+    const bool ev = tid < SM_ROWS && e < A;
+    const bool do_rhs = isA && gb == 0 && ev;
+    const double *src = isA ? Yw : W;
+    double racc = 0.0;
+    dg_acc_t acc[3][3];
+#pragma unroll
+    for (int x = 0; x < 3; x++)
+#pragma unroll
+        for (int y = 0; y < 3; y++) acc[x][y] = dg_acc_t{0.0, 0.0, 0.0, 0.0};
+    const int rt0 = 3 * (wave & 1), ct0 = 3 * (wave >> 1);
+
+    // two-deep pipeline: slots of step s+2, rows of step s+1, MFMAs of step s
+    auto fetch_slots = [&](int f0, unsigned (&sl)[2], int (&fs)[2]) {   // nothing here waits: the values are used one step later
+#pragma unroll
+        for (int ff = 0; ff < 2; ff++) {
+            const int f = f0 + ff;
+            sl[ff] = (ev && f < fe) ? (unsigned)slot_of[(size_t)f * A + e] : 0xFFFFu;
+            fs[ff] = f < fe ? fslot_start[f] : 0;
+        }
+    };
+    auto fetch_rows = [&](int f0, const unsigned (&sl)[2], const int (&fs)[2], double (&v)[12], double (&g)[12]) {
+#pragma unroll
+        for (int ff = 0; ff < 2; ff++) {
+            if (sl[ff] != 0xFFFFu) {
+                const double2 *p = reinterpret_cast<const double2 *>(src + ((int64_t)fs[ff] + sl[ff]) * 36 + pi * 6);
+                const double2 a0 = p[0], a1 = p[1], a2 = p[2];
+                v[6 * ff] = a0.x; v[6 * ff + 1] = a0.y; v[6 * ff + 2] = a1.x; v[6 * ff + 3] = a1.y; v[6 * ff + 4] = a2.x; v[6 * ff + 5] = a2.y;
+                if (do_rhs) {
+                    const double2 *q = reinterpret_cast<const double2 *>(gf + (size_t)(f0 + ff) * 6);
+                    const double2 g0 = q[0], g1 = q[1], g2 = q[2];
+                    g[6 * ff] = g0.x; g[6 * ff + 1] = g0.y; g[6 * ff + 2] = g1.x; g[6 * ff + 3] = g1.y; g[6 * ff + 4] = g2.x; g[6 * ff + 5] = g2.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) { v[6 * ff + j] = 0.0; g[6 * ff + j] = 0.0; }
+            }
+        }
+    };
+    auto put_rows = [&](int buf, const double (&v)[12], const double (&g)[12]) {
+        if (tid < SM_ROWS) {
+            double2 *d = reinterpret_cast<double2 *>(stage + ((size_t)buf * SM_ROWS + tid) * SM_PS);
+#pragma unroll
+            for (int h = 0; h < 6; h++) d[h] = make_double2(v[2 * h], v[2 * h + 1]);
+        }
+        if (do_rhs) {
+#pragma unroll
+            for (int j = 0; j < 12; j++) racc = fma(v[j], g[j], racc);
+        }
+    };
+    unsigned sl_n[2], sl_nn[2];
+    int fs_n[2], fs_nn[2];
+    double v[12], g[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) g[j] = 0.0;
+    fetch_slots(fb, sl_n, fs_n);
+    fetch_rows(fb, sl_n, fs_n, v, g);
+    fetch_slots(fb + 2, sl_n, fs_n);
+    put_rows(0, v, g);
+    __syncthreads();
+    int buf = 0;
+    for (int f0 = fb; f0 < fe; f0 += 2) {
+        const bool more = f0 + 2 < fe;
+        if (more) {
+            fetch_rows(f0 + 2, sl_n, fs_n, v, g);      // in flight while the matrix pipes work on this step
+            fetch_slots(f0 + 4, sl_nn, fs_nn);
+        }
+        const double *sb = stage + (size_t)buf * SM_ROWS * SM_PS;
+        double av[3][3], bv[3][3];
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                av[x][t] = sb[(16 * (rt0 + x) + lc) * SM_PS + 4 * t + lr];            // A[i = lc][k = lr]: Y rows
+                bv[x][t] = sb[(SM_AR + 16 * (ct0 + x) + lc) * SM_PS + 4 * t + lr];    // B[k = lr][j = lc]: W rows
+            }
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int x = 0; x < 3; x++)
+#pragma unroll
+                for (int y = 0; y < 3; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x][t], bv[y][t], acc[x][y], 0, 0, 0);
+        if (more) {
+            put_rows(buf ^ 1, v, g);
+            sl_n[0] = sl_nn[0]; sl_n[1] = sl_nn[1]; fs_n[0] = fs_nn[0]; fs_n[1] = fs_nn[1];
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    // S(a rows, b cols) -= sign * acc, lower triangle only; exact zeros (entity pairs never seen together) are skipped
+#pragma unroll
+    for (int x = 0; x < 3; x++)
+#pragma unroll
+        for (int y = 0; y < 3; y++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = SM_AR * ga + 16 * (rt0 + x) + lr + 4 * r, col = SM_BR * gb + 16 * (ct0 + y) + lc;
+                const double val = acc[x][y][r];
+                if (val != 0.0 && col <= row && row < 6 * A) atomicAdd(S + (size_t)row * n_pad + col, -sign * val);
+            }
+    if (do_rhs && racc != 0.0) atomicAdd(rhs + SM_AR * ga + tid, -sign * racc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dense LDL^T of the reduced system, right-looking, tile NB = 96, lower triangle row-major.
 //
 // Damping and gauge are applied on the FIRST touch of every element (step 0 of the factorisation), not by a kernel of
@@ -191,7 +341,6 @@ __device__ __forceinline__ double rcp_refined(double d) {
 // f64 MFMA lane maps (cdna_hip_programming.md section 4, checked by scripts/probe/issue_probe.hip):
 //   A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row = (l>>4) + 4 reg][col = l&15].
 // LDS (dynamic): T [NB][NB+2] | Yn [2][NB][8]
-typedef double dg_acc_t __attribute__((ext_vector_type(4)));
 constexpr int DG_THREADS = 1024, DG_ROW0 = 896;
 
 // LDL^T of the 6x6 pivot block at (c0, c0) in registers plus the substitution of row g of block column c0:
@@ -826,8 +975,18 @@ void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t 
 }
 
 void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st) {
-    if (P.n_swork == 0) return;
     const DeviceProblem::Blocks &b = P.blk[which];
+    if (P.n_smwork > 0) {   // many shared entities: block-of-S-stationary MFMA kernel
+        const size_t lds = (size_t)2 * SM_ROWS * SM_PS * sizeof(double);
+        static size_t granted = 48 * 1024;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_schur_mfma), lds, granted);
+        HookScope _h(P, KID_SCHUR);
+        hipLaunchKernelGGL(k_schur_y, dim3((unsigned)(((int64_t)P.total_slots * 6 + 255) / 256)), dim3(256), 0, st, P.slot_frame, b.W, b.Vinv, P.total_slots, P.Yw);
+        hipLaunchKernelGGL(k_schur_mfma, dim3(P.n_smwork), dim3(512), lds, st, P.sm_ga, P.sm_gb, P.sm_fb, P.sm_fe, P.slot_of, P.fslot_start, b.W, P.Yw, b.gf,
+                           P.A, P.n_pad, sign, b.S, b.rhs);
+        return;
+    }
+    if (P.n_swork == 0) return;
     const size_t lds = ((size_t)P.A * 36 + 8 + 4 * 48) * sizeof(double);
     static size_t granted = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_schur), lds, granted);

@@ -58,6 +58,21 @@ __global__ void k_mfma(unsigned long long *out, int iters) {
     double s = 0; for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][3];
     if ((threadIdx.x & 63) == 0) { out[2 * (threadIdx.x >> 6)] = t1 - t0; out[2 * (threadIdx.x >> 6) + 1] = (unsigned long long)s; }
 }
+// sustained fp64 MFMA on the whole chip: shader clock (s_memtime ticks per 100 MHz s_memrealtime tick) and cycles per MFMA
+__global__ void k_mfma_chip(unsigned long long *out, int iters) {
+    double4v acc[9];
+    for (int i = 0; i < 9; i++) acc[i] = double4v{0, 0, 0, 0};
+    const double a = threadIdx.x * 1e-3 + blockIdx.x, b = 1.0 - threadIdx.x * 1e-4;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0; for (int i = 0; i < 9; i++) s += acc[i][0] + acc[i][3];
+    if (threadIdx.x == 0) { out[3 * blockIdx.x] = t1 - t0; out[3 * blockIdx.x + 1] = r1 - r0; out[3 * blockIdx.x + 2] = (unsigned long long)s; }
+}
 // layout check: C = A(16x4) * B(4x16) with integer data
 __global__ void k_layout(double *out) {
     const int l = threadIdx.x;
@@ -91,6 +106,22 @@ int main() {
         hipLaunchKernelGGL(k_mfma<4>, dim3(1), dim3(threads), 0, 0, d, it);
         hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
         printf("MFMA f64 16x16x4 independent (4 acc) threads %4d: %.2f cycles per instruction\n", threads, (double)h[0] / (4.0 * it));
+    }
+    {
+        unsigned long long *d2, *h2 = new unsigned long long[3 * 1024];
+        hipMalloc(&d2, sizeof(unsigned long long) * 3 * 1024);
+        for (int blocks : {1, 256, 1024}) for (int threads : {256, 512}) {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            const int iters = 20000;
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_mfma_chip, dim3(blocks), dim3(threads), 0, 0, d2, iters);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(h2, d2, sizeof(unsigned long long) * 3 * blocks, hipMemcpyDeviceToHost);
+            const double flop = 2.0 * 1024 * 9.0 * iters * (threads / 64) * blocks;
+            printf("fp64 MFMA chip load: %4d blocks x %d threads: %.2f ms, %.1f TFLOP/s, block 0: clock %.0f MHz, %.1f cycles per MFMA (its wave 0)\n",
+                   blocks, threads, ms, flop / ms / 1e9, 100.0 * h2[0] / h2[1], (double)h2[0] / (9.0 * iters));
+        }
     }
     double *o, ho[256];
     hipMalloc(&o, sizeof ho);

@@ -313,6 +313,45 @@ def test_config4_size_against_oracle():
         assert rep["iterations"] < 30 and abs(rmse - 0.3 * np.sqrt(2)) < 0.02
 
 
+@pytest.mark.parametrize("name,split", [("g1_cfg2", "1"), ("g1_cfg3_cut", "3")])
+def test_schur_mfma_kernel_forced_on_small_problems(name, split, monkeypatch):
+    # the block-of-S-stationary MFMA Schur kernel (normally A >= 96) forced on the golden problems: odd frame ranges, a
+    # partial last entity group, blocks of S on and off the diagonal; same damped step and LM trace as the oracle / golden
+    ds, g = load_golden(name)
+    o = ol.Oracle(ds)
+    monkeypatch.setenv("AAR_SCHUR_MFMA", "1")
+    monkeypatch.setenv("AAR_SCHUR_SPLIT", split)
+    with aar.Problem(ds, residual_mode=aar.RES_F64) as p:
+        Ho, _ = o.normal_equations(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F64)
+        for mu in (float(np.diag(Ho).max()) * 1e-3, 1.0):
+            d = p.eval_damped_step(ds.x_full, mu)
+            do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F64)
+            assert np.abs(d - do).max() / np.abs(do).max() < 1e-8, mu
+    with aar.Problem(ds) as p:
+        x, rep = p.lm_solve(ds.x_full)
+        np.testing.assert_allclose([t["err"] for t in rep["trace"]], g["analytic_err"], rtol=1e-7)
+        np.testing.assert_allclose(x, g["analytic_x"], atol=1e-7)
+
+
+@pytest.mark.parametrize("mfma", ["0", "1"])
+def test_many_entities_schur_against_oracle(mfma, monkeypatch):
+    # 4 cameras / 62 markers / 40 frames: A = 66 shared entities (5 entity groups of 16, a partial last one), 5 tiles of the
+    # reduced system, both Schur kernels
+    monkeypatch.setenv("AAR_SCHUR_MFMA", mfma)
+    ds = aar.synth(3, num_cams=4, num_markers=62, num_frames=40)
+    o = ol.Oracle(ds)
+    with aar.Problem(ds) as p:
+        r, ss = p.eval_residuals(ds.x_full)
+        assert np.array_equal(r, o.residuals(ds.x_full, res_mode=ol.RES_F32))
+        for mu in (1e6, 1e2):
+            d = p.eval_damped_step(ds.x_full, mu)
+            do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+            assert np.abs(d - do).max() / np.abs(do).max() < 1e-8, mu
+        x, rep = p.lm_solve(ds.x_full)
+        rmse, _ = p.reproj_stats(x)
+        assert rep["iterations"] < 40 and abs(rmse - 0.3 * np.sqrt(2)) < 0.03
+
+
 def test_single_rank_communicator_path():
     # world_size 1 through RCCL: exercises the sharded code path (all-reduces of S, rhs, scalars) on one GPU
     ds, g = load_golden("g1_cfg2")
