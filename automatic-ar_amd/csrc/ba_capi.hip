@@ -739,7 +739,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         AL(blk[w].S, (size_t)P.n_pad * P.n_pad); AL(blk[w].rhs, P.n_pad); AL(blk[w].g0, P.n_pad);
     }
     if (P.n_smwork) AL(Yw, (size_t)P.total_slots * 36);
-    AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad);
+    AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad); AL(bs_flags, (size_t)P.nT + 1);
     AL(err_part, std::max<size_t>((size_t)F, (size_t)((N + 255) / 256)) + 1);
     AL(lin_part, 2 * (size_t)(F + 1)); AL(scal, 8); AL(flags, 4);
 #undef AL

@@ -73,6 +73,8 @@ struct DeviceProblem {
     double *Dfac = nullptr;               // [nT][NB*NB] factored diagonal tiles (unit L below, D on the diagonal)
     double *Linv16 = nullptr;             // [nT][6][16*16] inverses of the 16x16 diagonal sub-blocks of every L_ss
     double *delta_s = nullptr;            // [n_pad]
+    int32_t *bs_flags = nullptr;          // [nT] k_ldl_backsolve: flag[s] == bs_epoch <=> x_s of the current launch is in memory
+    mutable int bs_epoch = 0;
     double *err_part = nullptr;           // [max(F, residual_blocks)] partial sums of squared residuals
     double *lin_part = nullptr;           // [F+1][2] per-frame ( |delta_f|^2 , delta_f . g_f ), last = shared part
     double *scal = nullptr;               // [8] reduced scalars

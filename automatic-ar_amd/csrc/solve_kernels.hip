@@ -759,91 +759,91 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
         }
 }
 
-// L^T x = z from the last tile up.  Per tile: w = z_s - sum_{t>s} L_ts^T x_t (a column reduction over all rows below), then
-// L_ss^T x_s = w by blocked back-substitution with the 16x16 inverses.  One workgroup of 1024 threads.
-// LDS (dynamic): xs [n_pad] | Ls [NB][NB+1] | part [16][NB] | w [NB] | Li [NSB][16][17]
+// L^T x = z for the tiles above the last one (k_ldl_diag has solved that).  One workgroup per tile column s, all resident at
+// once, chained by flags in global memory: workgroup s accumulates w_s = z_s - sum_{t>s} L_ts^T x_t block by block as the
+// x_t are published (block (t, s) is already in registers when the flag arrives), then one wavefront back-substitutes
+// L_ss^T x_s = w_s column by column (v_readlane sweep, no barriers) and publishes x_s.  Every CU fetches only its own tile
+// column, so the solve no longer pulls all of L through one CU.  flag[s] == epoch means "x_s of this launch is in memory";
+// release / acquire at agent scope carry the data across the XCDs' L2s.
+// LDS (dynamic): Ls [NB][NB+2] | xs [NB] | w [NB] | part [10][NB]
 __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict__ S, const double *__restrict__ rhs,
-                                                        const double *__restrict__ Dfac, const double *__restrict__ Linv16,
-                                                        double *__restrict__ x, int n_pad, int nT) {
-    constexpr int LD = NB + 1, G = 10;
-    extern __shared__ double lds[];
-    double *xs = lds;
-    double *Ls = xs + n_pad;
-    double *part = Ls + NB * LD;
-    double *w = part + 16 * NB;
-    double *Li = w + NB;
-    const int tid = threadIdx.x;
-    const int j = tid % NB, gq = tid / NB;  // G*NB = 960 threads busy in the tall reduction
-    if (tid < NB) xs[(nT - 1) * NB + tid] = x[(nT - 1) * NB + tid];   // the last tile was solved by k_ldl_diag
+                                                        const double *__restrict__ Dfac, double *__restrict__ x, int n_pad, int nT,
+                                                        int32_t *__restrict__ flag, int epoch) {
+    constexpr int LD = NB + 2, G = 10, RPT = (NB + G - 1) / G;
+    extern __shared__ __align__(16) double lds[];
+    double *Ls = lds;
+    double *xs = Ls + NB * LD;
+    double *w = xs + NB;
+    double *part = w + NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = nT - 2 - (int)blockIdx.x;   // the head of the chain is dispatched first
+    const int r0 = s * NB;
+    const int j = tid % NB, gq = tid / NB;    // G*NB = 960 threads in the block products
+    const double *dd = Dfac + (size_t)s * NB * NB;
+    {
+        constexpr int NL = NB * NB / 1024;
+        double vl[NL];
+#pragma unroll
+        for (int u = 0; u < NL; u++) {   // strictly lower part only; the diagonal (D) and above stay zero in LDS
+            const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
+            vl[u] = (jj < i) ? dd[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
+            Ls[i * LD + jj] = vl[u];
+        }
+    }
+    double acc = 0.0;
+    for (int t = nT - 1; t > s; t--) {
+        double a[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {   // block (t, s), before x_t is needed
+            const int i = gq + G * k;
+            a[k] = (gq < G && i < NB) ? S[(size_t)(t * NB + i) * n_pad + r0 + j] : 0.0;
+        }
+        if (t < nT - 1) {   // x_{nT-1} comes from the previous kernel; the others from the workgroup next door
+            if (tid == 0) {
+                while (__hip_atomic_load(flag + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+            }
+            __syncthreads();
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        if (tid < NB) xs[tid] = __hip_atomic_load(x + t * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            const int i = gq + G * k;
+            if (i < NB) acc = fma(a[k], xs[i], acc);
+        }
+        __syncthreads();
+    }
+    if (gq < G) part[gq * NB + j] = acc;
     __syncthreads();
-    for (int s = nT - 2; s >= 0; s--) {
-        const int r0 = s * NB;
-        const double *dd = Dfac + (size_t)s * NB * NB;
-        {
-            constexpr int NL = NB * NB / 1024;
-            double vl[NL], vi[2];
+    if (tid < NB) {
+        double v = rhs[r0 + tid];
 #pragma unroll
-            for (int u = 0; u < NL; u++) {   // strictly lower part only
-                const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
-                vl[u] = (jj < i) ? dd[e] : 0.0;
-            }
+        for (int g = 0; g < G; g++) v -= part[g * NB + tid];
+        w[tid] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {   // L_ss^T x = w: lane l keeps rows l and l + 64; row j of L against x_j, from the last column up
+        const int i0 = lane, i1 = lane + 64;
+        const bool h1 = i1 < NB;
+        double b0 = w[i0], b1 = h1 ? w[i1] : 0.0;
+        const int i1c = h1 ? i1 : 0;
 #pragma unroll
-            for (int u = 0; u < 2; u++) vi[u] = (tid + 1024 * u < NSB * SBK * SBK) ? Linv16[(size_t)s * NSB * SBK * SBK + tid + 1024 * u] : 0.0;
-#pragma unroll
-            for (int u = 0; u < NL; u++) {
-                const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
-                Ls[i * LD + jj] = vl[u];
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int e = tid + 1024 * u;
-                if (e < NSB * SBK * SBK) Li[((e / (SBK * SBK)) * SBK + (e / SBK) % SBK) * 17 + e % SBK] = vi[u];
-            }
+        for (int jj = NB - 1; jj > 0; jj--) {
+            const double v = jj < 64 ? b0 : b1;
+            const int lo = __builtin_amdgcn_readlane(__double2loint(v), jj & 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), jj & 63);
+            const double xj = __hiloint2double(hi, lo);
+            b0 = fma(-Ls[jj * LD + i0], xj, b0);
+            if (jj > 64) b1 = fma(-Ls[jj * LD + i1c], xj, b1);
         }
-        if (gq < G) {
-            double acc = 0.0;
-            int i = (s + 1) * NB + gq;
-            for (; i + 3 * G < n_pad; i += 4 * G) {  // four independent loads in flight
-                const double a0 = S[(size_t)i * n_pad + r0 + j], a1 = S[(size_t)(i + G) * n_pad + r0 + j];
-                const double a2 = S[(size_t)(i + 2 * G) * n_pad + r0 + j], a3 = S[(size_t)(i + 3 * G) * n_pad + r0 + j];
-                acc += a0 * xs[i] + a1 * xs[i + G] + a2 * xs[i + 2 * G] + a3 * xs[i + 3 * G];
-            }
-            for (; i < n_pad; i += G) acc += S[(size_t)i * n_pad + r0 + j] * xs[i];
-            part[gq * NB + j] = acc;
-        }
-        __syncthreads();
-        if (tid < NB) {
-            double a = rhs[r0 + tid];
-#pragma unroll
-            for (int g = 0; g < G; g++) a -= part[g * NB + tid];
-            w[tid] = a;
-        }
-        __syncthreads();
-        // blocked back-substitution inside the tile: x_q = inv(L_qq)^T (w_q - sum_{i >= 16(q+1)} L[i][16q + c] x_i)
-        const int c = tid & 15, pr = tid >> 4;  // 64 partial-sum groups of 16 columns
-        for (int q = NSB - 1; q >= 0; q--) {
-            double acc = 0.0;
-            for (int i = (q + 1) * SBK + pr; i < NB; i += 64) acc += Ls[i * LD + q * SBK + c] * xs[r0 + i];
-            if (pr < 16) part[pr * NB + c] = 0.0;
-            __syncthreads();
-            if (acc != 0.0) atomicAdd(&part[(pr & 15) * NB + c], acc);
-            __syncthreads();
-            if (tid < SBK) {
-                double v = w[q * SBK + tid];
-#pragma unroll
-                for (int g = 0; g < 16; g++) v -= part[g * NB + tid];
-                part[15 * NB + 32 + tid] = v;  // v_q
-            }
-            __syncthreads();
-            if (tid < SBK) {
-                double xv = 0.0;
-#pragma unroll
-                for (int pp = 0; pp < SBK; pp++) xv = fma(Li[(q * SBK + pp) * 17 + tid], part[15 * NB + 32 + pp], xv);  // sum_p inv(L)[p][c] v_p
-                xs[r0 + q * SBK + tid] = xv;
-                x[r0 + q * SBK + tid] = xv;
-            }
-            __syncthreads();
-        }
+        __hip_atomic_store(x + r0 + i0, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h1) __hip_atomic_store(x + r0 + i1, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        if (lane == 0) __hip_atomic_store(flag + s, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1010,9 +1010,13 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
             { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
         }
     }
-    const size_t lds = ((size_t)P.n_pad + NB * (NB + 1) + 16 * NB + NB + NSB * SBK * 17) * sizeof(double);
-    allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_backsolve), lds, g_bs);
-    if (P.nT > 1) { HookScope _h(P, KID_LDL_BACKSOLVE); hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.Linv16, P.delta_s, P.n_pad, P.nT); }
+    if (P.nT > 1) {
+        const size_t lds = ((size_t)NB * (NB + 2) + 2 * NB + 10 * NB) * sizeof(double);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_backsolve), lds, g_bs);
+        P.bs_epoch++;
+        HookScope _h(P, KID_LDL_BACKSOLVE);
+        hipLaunchKernelGGL(k_ldl_backsolve, dim3(P.nT - 1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.delta_s, P.n_pad, P.nT, P.bs_flags, P.bs_epoch);
+    }
 }
 
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) {
