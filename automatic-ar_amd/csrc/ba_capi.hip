@@ -48,6 +48,11 @@ constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;
 
 int load_nccl() {
     if (g_nccl.ok) return AAR_OK;
+    // One node, one process per GPU over xGMI: the bootstrap sockets can stay on loopback and there is no InfiniBand to
+    // probe.  On hosts whose name does not resolve the default interface discovery has been seen to take minutes.
+    // Both are only defaults: a caller's own environment wins.
+    setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+    setenv("NCCL_IB_DISABLE", "1", 0);
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
         g_nccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);

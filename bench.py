@@ -132,6 +132,7 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # single node: rendezvous over loopback, no host-name lookups
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
     import numpy as np
