@@ -275,17 +275,15 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
 // their own: S(i,j) -> S(i,j) + mu [i == j] on free rows; rows / columns of fixed entities (root camera, root marker,
 // non-optimised groups) and of the padding -> identity with zero rhs, i.e. delta = 0; rhs -> g0 + (Schur part).
 //
-// Step s = three launches:
-//   k_ldl_diag    ONE workgroup factors the diagonal tile: the serial part, walked in 6x6 block pivots (see the kernel).
-//                 Epilogue: inverses of the six 16x16 diagonal sub-blocks of L_ss, which turn every triangular solve
-//                 below into small matrix products.
+// Step s = three launches (one for the last tile):
+//   k_ldl_diag    ONE workgroup factors the diagonal tile: the serial part, walked in 6x6 block pivots with the trailing
+//                 matrix in fp64 MFMA accumulators (see the kernel).  Epilogue: inverses of the six 16x16 diagonal
+//                 sub-blocks of L_ss, which turn the panel solve below into small matrix products.  For the last tile it
+//                 also solves the right-hand side, forward and backward.
 //   k_ldl_trsm    every 48-row slab of block column s (and the right-hand side as a 1-row slab): X = A L_ss^-T by
-//                 blocked substitution over 16-column blocks, then L_ts = X D^-1.
+//                 blocked substitution over 16-column blocks on the matrix pipes, then L_ts = X D^-1.
 //   k_ldl_update  trailing tiles: S(I,J) -= L_Is D_s L_Js^T, rhs rows likewise.
 // ------------------------------------------------------------------------------------------------
-#ifndef AAR_CVAR
-#define AAR_CVAR 0
-#endif
 #ifdef AAR_STAMPS  // diagnostic build only (scripts/probe): cycle stamps of one workgroup, never compiled into libaar.so
 __device__ unsigned long long g_stamps[64];
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
