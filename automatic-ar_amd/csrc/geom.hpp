@@ -75,8 +75,11 @@ __device__ __forceinline__ void make_ent_row(const double *__restrict__ v, doubl
         A = 0.5 - t2 * (1.0 / 24.0) + t2 * t2 * (1.0 / 720.0);
         B = (1.0 / 6.0) - t2 * (1.0 / 120.0) + t2 * t2 * (1.0 / 5040.0);
     } else {
-        A = (1.0 - cos(th)) / t2;
-        B = (th - sin(th)) / (t2 * th);
+        double s, c;          // the same sincos as above (the compiler merges the two calls)
+        sincos(th, &s, &c);
+        const double it2 = 1.0 / t2;
+        A = (1.0 - c) * it2;
+        B = (th - s) * it2 / th;
     }
     double J[9];
     // [w]x^2 = w w^T - |w|^2 I
@@ -221,7 +224,7 @@ __device__ __forceinline__ bool spd6_inverse(double a[6][6], double out[36]) {
         for (int p = 0; p < k; p++) d -= a[k][p] * a[k][p];
         if (!(d > 0.0)) { ok = false; d = 1.0; }
         const double l = sqrt(d), il = 1.0 / l;
-        a[k][k] = l;
+        a[k][k] = il;   // the reciprocal is what the substitutions below need (no divisions there)
 #pragma unroll
         for (int i = k + 1; i < 6; i++) {
             double s = a[i][k];
@@ -239,7 +242,7 @@ __device__ __forceinline__ bool spd6_inverse(double a[6][6], double out[36]) {
             double s = (i == c) ? 1.0 : 0.0;
 #pragma unroll
             for (int p = c; p < i; p++) s -= a[i][p] * li[p][c];
-            li[i][c] = s / a[i][i];
+            li[i][c] = s * a[i][i];
         }
 #pragma unroll
     for (int i = 0; i < 6; i++)
