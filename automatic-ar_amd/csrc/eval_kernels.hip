@@ -120,7 +120,9 @@ struct PassAArgs {
     int32_t *flags;
 };
 
-template <int BLOCK>
+// CPL = corners per lane: 4 = one lane per observation; 2 / 1 = two / four lanes per observation for frames with few
+// observations (the wavefront's instruction stream gets that much shorter; the sums over lanes do not care)
+template <int BLOCK, int CPL>
 __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
     extern __shared__ double lds[];
     double *Wl = lds;                                   // [kf][36]
@@ -169,12 +171,11 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
             stride++;
         }
     }
-    for (int it = tid; it < nobs; it += BLOCK) {
+    constexpr int LPO = 4 / CPL;   // lanes per observation
+    for (int t = tid; t < nobs * LPO; t += BLOCK) {
+        const int it = t / LPO, part = t - it * LPO;
         const int o = o0 + (int)(((int64_t)it * stride) % nobs);
         const ObsIdx id = a.idx[o];
-        const float4 uv0 = reinterpret_cast<const float4 *>(a.uv)[2 * (int64_t)o];
-        const float4 uv1 = reinterpret_cast<const float4 *>(a.uv)[2 * (int64_t)o + 1];
-        const float ou[8] = {uv0.x, uv0.y, uv0.z, uv0.w, uv1.x, uv1.y, uv1.z, uv1.w};
         const int sc = id.slots & 0xffff, sm = (id.slots >> 16) & 0xffff;
         Ent ec, em;
         load_ent_lds(entl + (size_t)sc * ENT_STRIDE, ec);
@@ -186,11 +187,13 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
 #pragma unroll
         for (int i = 0; i < 36; i++) { Wc[i] = 0.0; Wm[i] = 0.0; }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int kk = 0; kk < CPL; kk++) {
+            const int k = part * CPL + kk;
+            const float2 ouv = reinterpret_cast<const float2 *>(a.uv)[4 * (int64_t)o + k];
             CornerGeom g;
             project_corner(ec, em, ef, K, a.h, k, g);
             double r[2];
-            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, a.res_f32, a.huber, r[0], r[1]);
+            corner_residual(ouv.x, ouv.y, g.u, g.v, a.res_f32, a.huber, r[0], r[1]);
             double Gc[2][6], Gm[2][6], Gf[2][6];
             corner_jacobian<true, true, true>(ec, em, ef, K, g, Gc, Gm, Gf);
 #pragma unroll
@@ -360,12 +363,12 @@ void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream
 
 int residual_blocks(const DeviceProblem &P) { return (int)((P.N + 255) / 256); }
 
-template <int B>
+template <int B, int CPL>
 static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, hipStream_t st) {
     const size_t lds = ((size_t)P.max_kf * 36 + 32 + (size_t)(P.max_kf + 1) * ENT_STRIDE + (B / 64) * 2048) * sizeof(double);
     static size_t granted = 48 * 1024;
-    allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B>), lds, granted);
-    { HookScope _h(P, KID_PASSA); hipLaunchKernelGGL(k_passA<B>, dim3(P.F), dim3(B), lds, st, a); }
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B, CPL>), lds, granted);
+    { HookScope _h(P, KID_PASSA); hipLaunchKernelGGL((k_passA<B, CPL>), dim3(P.F), dim3(B), lds, st, a); }
 }
 
 size_t passA_lds_bytes(int max_kf, int block) {
@@ -390,11 +393,13 @@ void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_bl
         a.zero2 = zb.g0; a.zero2_n = P.n_pad;
     }
     a.flags = P.flags;
-    // block = 32 lanes for sparse frames (a 64-wide wave would be half empty at ~25 observations per frame), one wave up
-    // to ~96, four waves above
+    // one wavefront per frame up to ~96 observations per frame (four / two lanes per observation while they fit in it),
+    // four wavefronts above
     const double avg = (double)P.N / (double)P.F;
-    if (avg <= 96) launch_passA_t<64>(P, a, st);
-    else launch_passA_t<256>(P, a, st);
+    if (avg <= 14) launch_passA_t<64, 1>(P, a, st);
+    else if (avg <= 30) launch_passA_t<64, 2>(P, a, st);
+    else if (avg <= 96) launch_passA_t<64, 4>(P, a, st);
+    else launch_passA_t<256, 4>(P, a, st);
 }
 
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
