@@ -671,7 +671,8 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     std::vector<std::vector<std::pair<int32_t, int32_t>>> inc(A);
     for (int f = 0; f < F; f++)
         for (int s = fslot_start[f]; s < fslot_start[f + 1]; s++) inc[fslot_ent[s]].push_back({f, s});
-    std::vector<int32_t> pair_frame, pair_slot, sw_ent, sw_begin, sw_end;
+    std::vector<int4> pair_rec;
+    std::vector<int32_t> sw_ent, sw_begin, sw_end;
     const int64_t total_pairs = P.total_slots;
     // (entity, frame) pairs per workgroup: measured optimum 16 (config 3) ... 64 (configs 4, 5); every workgroup ends with
     // an atomic flush of its row panel, so fewer, longer items win once the grid is large enough to fill the chip
@@ -679,8 +680,8 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     per_item = (per_item + 3) / 4 * 4;
     if (const char *e = getenv("AAR_SCHUR_ITEM")) per_item = std::max(4, atoi(e));  // tuning knob (pairs per workgroup)
     for (int a = 0; a < A; a++) {
-        const int base = (int)pair_frame.size();
-        for (auto &pr : inc[a]) { pair_frame.push_back(pr.first); pair_slot.push_back(pr.second); }
+        const int base = (int)pair_rec.size();
+        for (auto &pr : inc[a]) pair_rec.push_back(make_int4(pr.first, pr.second, fslot_start[pr.first], 0));
         const int cnt = (int)inc[a].size();
         for (int s = 0; s < cnt; s += per_item) {
             sw_ent.push_back(a);
@@ -732,7 +733,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     UP(K, Kh); UP(a_idx, a_idx); UP(a_uv, a_uv); UP(frame_obs_start, frame_obs_start);
     UP(fslot_start, fslot_start); UP(fslot_ent, fslot_ent); UP(b_idx, b_idx); UP(b_uv, b_uv);
     UP(chunk_start, chunk_start); UP(ent_fixed, ent_fixed);
-    UP(sw_ent, sw_ent); UP(sw_begin, sw_begin); UP(sw_end, sw_end); UP(pair_frame, pair_frame); UP(pair_slot, pair_slot);
+    UP(sw_ent, sw_ent); UP(sw_begin, sw_begin); UP(sw_end, sw_end); UP(pair_rec, pair_rec);
     if (P.n_smwork) { UP(sm_ga, sm_ga); UP(sm_gb, sm_gb); UP(sm_fb, sm_fb); UP(sm_fe, sm_fe); UP(slot_of, slot_of); UP(slot_frame, slot_frame); }
 #undef UP
 #define AL(field, count) if ((rc = dev_alloc(pb, &P.field, (size_t)(count)))) return fail(rc)

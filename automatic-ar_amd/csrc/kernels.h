@@ -49,7 +49,7 @@ struct DeviceProblem {
     int frames_fixed = 0;
     // Schur work list: item w handles pairs [sw_begin[w], sw_end[w]) of entity sw_ent[w]
     int32_t *sw_ent = nullptr, *sw_begin = nullptr, *sw_end = nullptr;
-    int32_t *pair_frame = nullptr, *pair_slot = nullptr;  // (entity, frame) incidence, grouped by entity
+    int4 *pair_rec = nullptr;             // (entity, frame) incidence, grouped by entity: {frame, W block, first W block of the frame, 0}
     // Schur work list of the MFMA kernel (many shared entities): item w = block (16 entities sm_ga[w]) x (32 entities sm_gb[w])
     // of S over frames [sm_fb[w], sm_fe[w])
     int n_smwork = 0;

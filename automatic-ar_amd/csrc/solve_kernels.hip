@@ -54,9 +54,11 @@ __global__ void __launch_bounds__(256) k_frame_inv(const double *__restrict__ V,
 // traffic stays in L2/LDS.  Only the lower triangle of S is produced.
 // LDS: [A*36] panel | [8] rhs rows | [4][48] per-wave Y scratch
 // ------------------------------------------------------------------------------------------------
+// PRE = passes of the frame's slot list (10 slots each) whose W rows are fetched up front, before Y is formed: pays at
+// config 5 (HBM-bound, -9 %), costs registers / occupancy at configs 3-4, where 0 is used
+template <int PRE>
 __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_ent, const int32_t *__restrict__ sw_begin,
-                                               const int32_t *__restrict__ sw_end, const int32_t *__restrict__ pair_frame,
-                                               const int32_t *__restrict__ pair_slot, const int32_t *__restrict__ fslot_start,
+                                               const int32_t *__restrict__ sw_end, const int4 *__restrict__ pair_rec,
                                                const int32_t *__restrict__ fslot_ent, const double *__restrict__ W,
                                                const double *__restrict__ Vinv, const double *__restrict__ hf, int A,
                                                int n_pad, double sign, double *__restrict__ S, double *__restrict__ rhs) {
@@ -70,41 +72,108 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
     if (tid < 8) pg[tid] = 0.0;
     __syncthreads();
     double *ys = ysc + wave * 48;
-    for (int p = pb + wave; p < pe; p += 4) {
-        const int f = pair_frame[p], sg = pair_slot[p];
-        const int s0 = fslot_start[f], sa = sg - s0;
-        const double *Wa = W + (size_t)sg * 36;
-        if (lane < 36) {
-            const int i = lane / 6, j = lane % 6;
-            double y = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) y += Wa[i * 6 + k] * Vinv[(size_t)f * 36 + k * 6 + j];
-            ys[lane] = y;
-        } else if (lane < 42) {
-            const int i = lane - 36;
-            double y = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) y += Wa[i * 6 + k] * hf[(size_t)f * 6 + k];
-            atomicAdd(pg + i, y);
+    if constexpr (PRE == 0) {
+        for (int p = pb + wave; p < pe; p += 4) {
+            const int4 rec = pair_rec[p];
+            const int f = rec.x, sg = rec.y, s0 = rec.z, sa = sg - s0;
+            const double *Wa = W + (size_t)sg * 36;
+            if (lane < 36) {
+                const int i = lane / 6, j = lane % 6;
+                double y = 0.0;
+    #pragma unroll
+                for (int k = 0; k < 6; k++) y += Wa[i * 6 + k] * Vinv[(size_t)f * 36 + k * 6 + j];
+                ys[lane] = y;
+            } else if (lane < 42) {
+                const int i = lane - 36;
+                double y = 0.0;
+    #pragma unroll
+                for (int k = 0; k < 6; k++) y += Wa[i * 6 + k] * hf[(size_t)f * 6 + k];
+                atomicAdd(pg + i, y);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double Y[36];
+    #pragma unroll
+            for (int i = 0; i < 36; i++) Y[i] = ys[i];
+            __builtin_amdgcn_wave_barrier();
+            const int sl = lane / 6, j = lane % 6;
+            if (lane < 60) {
+                for (int sb = sl; sb <= sa; sb += 10) {
+                    const int b = fslot_ent[s0 + sb];
+                    const double2 *wr = reinterpret_cast<const double2 *>(W + (size_t)(s0 + sb) * 36 + j * 6);
+                    const double2 w0 = wr[0], w1 = wr[1], w2 = wr[2];
+                    double *dst = panel + b * 36 + j;
+    #pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        const double v = Y[i * 6] * w0.x + Y[i * 6 + 1] * w0.y + Y[i * 6 + 2] * w1.x + Y[i * 6 + 3] * w1.y +
+                                         Y[i * 6 + 4] * w2.x + Y[i * 6 + 5] * w2.y;
+                        atomicAdd(dst + i * 6, v);
+                    }
+                }
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        double Y[36];
-#pragma unroll
-        for (int i = 0; i < 36; i++) Y[i] = ys[i];
-        __builtin_amdgcn_wave_barrier();
+    } else {
+        // Every global load of a pair is issued before the first use (the chain pair -> frame -> slot -> W row used to be four
+        // dependent round trips per pair), and the next pair's record is fetched one pair ahead.
         const int sl = lane / 6, j = lane % 6;
-        if (lane < 60) {
-            for (int sb = sl; sb <= sa; sb += 10) {
-                const int b = fslot_ent[s0 + sb];
-                const double2 *wr = reinterpret_cast<const double2 *>(W + (size_t)(s0 + sb) * 36 + j * 6);
-                const double2 w0 = wr[0], w1 = wr[1], w2 = wr[2];
+        int4 rec = make_int4(0, 0, 0, 0);
+        if (pb + wave < pe) rec = pair_rec[pb + wave];
+        for (int p = pb + wave; p < pe; p += 4) {
+            const int f = rec.x, sg = rec.y, s0 = rec.z, sa = sg - s0;
+            if (p + 4 < pe) rec = pair_rec[p + 4];
+            const double *Wa = W + (size_t)sg * 36;
+            double wa[6], vv[6];
+            if (lane < 36) {
+                const int i = lane / 6, jj = lane % 6;
+    #pragma unroll
+                for (int k = 0; k < 6; k++) { wa[k] = Wa[i * 6 + k]; vv[k] = Vinv[(size_t)f * 36 + k * 6 + jj]; }
+            } else if (lane < 42) {
+                const int i = lane - 36;
+    #pragma unroll
+                for (int k = 0; k < 6; k++) { wa[k] = Wa[i * 6 + k]; vv[k] = hf[(size_t)f * 6 + k]; }
+            }
+            int bm[PRE > 0 ? PRE : 1];
+            double2 wr[PRE > 0 ? PRE : 1][3];
+    #pragma unroll
+            for (int m = 0; m < PRE; m++) {
+                const int sb = sl + 10 * m;
+                bm[m] = -1;
+                if (lane < 60 && sb <= sa) {
+                    bm[m] = fslot_ent[s0 + sb];
+                    const double2 *q = reinterpret_cast<const double2 *>(W + (size_t)(s0 + sb) * 36 + j * 6);
+                    wr[m][0] = q[0]; wr[m][1] = q[1]; wr[m][2] = q[2];
+                }
+            }
+            if (lane < 42) {
+                double y = 0.0;
+    #pragma unroll
+                for (int k = 0; k < 6; k++) y += wa[k] * vv[k];
+                if (lane < 36) ys[lane] = y;
+                else atomicAdd(pg + (lane - 36), y);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double Y[36];
+    #pragma unroll
+            for (int i = 0; i < 36; i++) Y[i] = ys[i];
+            __builtin_amdgcn_wave_barrier();
+            auto accumulate = [&](int b, const double2 &w0, const double2 &w1, const double2 &w2) {
                 double *dst = panel + b * 36 + j;
-#pragma unroll
+    #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     const double v = Y[i * 6] * w0.x + Y[i * 6 + 1] * w0.y + Y[i * 6 + 2] * w1.x + Y[i * 6 + 3] * w1.y +
                                      Y[i * 6 + 4] * w2.x + Y[i * 6 + 5] * w2.y;
                     atomicAdd(dst + i * 6, v);
+                }
+            };
+    #pragma unroll
+            for (int m = 0; m < PRE; m++)
+                if (bm[m] >= 0) accumulate(bm[m], wr[m][0], wr[m][1], wr[m][2]);
+            if (lane < 60) {
+                for (int sb = sl + 10 * PRE; sb <= sa; sb += 10) {
+                    const int b = fslot_ent[s0 + sb];
+                    const double2 *q = reinterpret_cast<const double2 *>(W + (size_t)(s0 + sb) * 36 + j * 6);
+                    accumulate(b, q[0], q[1], q[2]);
                 }
             }
         }
@@ -986,10 +1055,17 @@ void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
     }
     if (P.n_swork == 0) return;
     const size_t lds = ((size_t)P.A * 36 + 8 + 4 * 48) * sizeof(double);
-    static size_t granted = 48 * 1024;
-    allow_dynamic_lds(reinterpret_cast<const void *>(k_schur), lds, granted);
-    { HookScope _h(P, KID_SCHUR); hipLaunchKernelGGL(k_schur, dim3(P.n_swork), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_frame,
-                       P.pair_slot, P.fslot_start, P.fslot_ent, b.W, b.Vinv, b.hf, P.A, P.n_pad, sign, b.S, b.rhs); }
+    static size_t granted0 = 48 * 1024, granted3 = 48 * 1024;
+    HookScope _h(P, KID_SCHUR);
+    if (P.max_kf > 64) {
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_schur<3>), lds, granted3);
+        hipLaunchKernelGGL(k_schur<3>, dim3(P.n_swork), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_rec, P.fslot_ent, b.W, b.Vinv, b.hf,
+                           P.A, P.n_pad, sign, b.S, b.rhs);
+    } else {
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_schur<0>), lds, granted0);
+        hipLaunchKernelGGL(k_schur<0>, dim3(P.n_swork), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_rec, P.fslot_ent, b.W, b.Vinv, b.hf,
+                           P.A, P.n_pad, sign, b.S, b.rhs);
+    }
 }
 
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
