@@ -114,6 +114,7 @@ struct aar_problem {
     hipStream_t stream2 = nullptr;     // pass B of the trial point runs here, beside the speculative Schur complement
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = false;              // AAR_OVERLAP=1: pass B of the trial point on a second stream beside the Schur complement
+    bool merge_passes = true;          // passes A and B of an evaluation in one launch (AAR_MERGE_PASSES=0: two launches)
     int64_t trial_points = 0, launches = 0;
     aar_stage_times times;
     bool stage_timers = false;
@@ -285,14 +286,20 @@ int zero_block_set(aar_problem *pb, int which) {
 // mu_pred >= 0, (V_f + mu_pred I)^-1; zero_blk >= 0 clears that block set on the way.
 // spec_schur: also subtract the Schur terms for mu_pred right away (they only need pass A's output), on the main stream,
 // while pass B accumulates the shared blocks into the same S on a second stream (both only add into S: they commute).
-int eval_blocks(aar_problem *pb, int which, double mu_pred, int zero_blk, bool spec_schur = false) {
+int eval_blocks(aar_problem *pb, int which, double mu_pred, int zero_blk, bool spec_schur = false, bool ents_ready = false) {
     DeviceProblem &P = pb->P;
+    if (!ents_ready) launch_unpack(P, which, pb->stream);   // {R, t, J_l} rows of z[which]; after a damped try k_backsub has written them
     if (P.F == 0 && zero_blk >= 0) {  // a rank without frames launches no pass A: clear the dead block set here
         int rc = zero_block_set(pb, zero_blk);
         if (rc) return rc;
     }
     {
         StageTimer t(pb, &pb->times.jacobian_normal_eq);
+        if (pb->merge_passes && launch_passAB(P, which, mu_pred, zero_blk, pb->stream)) {
+            if (spec_schur) launch_schur(P, which, 1.0, pb->stream);
+            pb->launches += spec_schur ? 2 : 1;
+            return check_async("normal-equation kernels");
+        }
         launch_passA(P, which, mu_pred, zero_blk, pb->stream);
         if (spec_schur && pb->overlap && !pb->profiling && !pb->stage_timers) {
             HIP_TRY(hipEventRecord(pb->ev_fork, pb->stream));
@@ -401,7 +408,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     pb->blocks_valid = false;  // S of the current point has been eliminated in place
     if (evaluate_trial) {
         // predicted damping of the next step: every accepted step of the reference's rule with gain >= 0.94 gives 0.33 mu
-        int rc = eval_blocks(pb, tr, mu * 0.33, cur, /*spec_schur=*/true);
+        int rc = eval_blocks(pb, tr, mu * 0.33, cur, /*spec_schur=*/true, /*ents_ready=*/true);
         if (rc) return rc;
         pb->trial_points++;
     } else {
@@ -569,6 +576,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         hipEventCreateWithFlags(&pb->ev_join, hipEventDisableTiming) != hipSuccess)
         return fail(set_error(AAR_ERR_HIP, "second stream / events could not be created"));
     { const char *e = getenv("AAR_OVERLAP"); pb->overlap = (e && e[0] == '1'); }  // measured slower than one stream at config 3: off by default
+    { const char *e = getenv("AAR_MERGE_PASSES"); if (e) pb->merge_passes = (e[0] != '0'); }
 
     PoseLayout &L = pb->L;
     L.C = C; L.M = M; L.F = Fg; L.rc = d->root_cam; L.rm = d->root_marker;

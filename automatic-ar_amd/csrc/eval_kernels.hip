@@ -110,12 +110,12 @@ __device__ __forceinline__ void load_ent_lds(const double *row, Ent &e) {
 // LDS: [max_kf*36] W blocks | [32] V,g,err | [(max_kf+1)*24] entity rows | [nwaves*2048] wave-sum scratch
 // ------------------------------------------------------------------------------------------------
 struct PassAArgs {
-    const ObsIdx *idx; const float *uv; const double *z; const double *Kmat;
+    const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat;   // ent: the {R, t, J_l} table of the point (k_backsub / k_unpack)
     const int32_t *frame_obs_start, *fslot_start, *fslot_ent;
     int A, F, res_f32, max_kf, frames_fixed;
     float huber;
     double h, mu_pred;
-    double *ent_out, *V, *gf, *W, *Vinv, *hf, *err_part;
+    double *V, *gf, *W, *Vinv, *hf, *err_part;
     double *zero0; int64_t zero0_n; double *zero1; int64_t zero1_n; double *zero2; int64_t zero2_n;
     int32_t *flags;
 };
@@ -123,33 +123,49 @@ struct PassAArgs {
 // CPL = corners per lane: 4 = one lane per observation; 2 / 1 = two / four lanes per observation for frames with few
 // observations (the wavefront's instruction stream gets that much shorter; the sums over lanes do not care)
 template <int BLOCK, int CPL>
-__global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
-    extern __shared__ double lds[];
+__device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, const int f, const int n_blocks_a) {
     double *Wl = lds;                                   // [kf][36]
     double *acc = lds + (size_t)a.max_kf * 36;            // [32]
     double *entl = acc + 32;                            // [(max_kf+1)][24]
     double *scratch = entl + (size_t)(a.max_kf + 1) * ENT_STRIDE;  // [BLOCK/64][2048]
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int o0 = a.frame_obs_start[f], o1 = a.frame_obs_start[f + 1];
     const int s0 = a.fslot_start[f], kf = a.fslot_start[f + 1] - s0;
     for (int i = tid; i < kf * 36; i += BLOCK) Wl[i] = 0.0;
     for (int t = tid; t < 32; t += BLOCK) acc[t] = 0.0;
-    // entity rows of this frame's slot list (+ the frame itself at row kf), also published to the global table:
-    // the frame row by its own workgroup, shared row e by workgroup e % F
-    for (int t = tid; t <= kf; t += BLOCK) {
-        const int e = (t < kf) ? a.fslot_ent[s0 + t] : a.A + f;
-        make_ent_row(a.z + 6 * (size_t)e, entl + (size_t)t * ENT_STRIDE);
+    // entity rows of this frame's slot list (+ the frame itself at row kf): global table -> LDS in 16-byte pieces, all the
+    // slot-list loads of a batch in flight before the first row load, all row loads before the first LDS store
+    {
+        constexpr int PCS = ENT_STRIDE / 2, UNR = 8;
+        const int npc = (kf + 1) * PCS;
+        for (int base = 0; base < npc; base += UNR * BLOCK) {
+            int e[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int idx = base + u * BLOCK + tid, t = idx / PCS;
+                e[u] = idx < npc ? (t < kf ? a.fslot_ent[s0 + t] : a.A + f) : -1;
+            }
+            double2 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int idx = base + u * BLOCK + tid, c = idx % PCS;
+                if (e[u] >= 0) v[u] = reinterpret_cast<const double2 *>(a.ent + (size_t)e[u] * ENT_STRIDE)[c];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int idx = base + u * BLOCK + tid;
+                if (e[u] >= 0) reinterpret_cast<double2 *>(entl)[idx] = v[u];
+            }
+        }
     }
-    for (int e = f + tid * a.F; e < a.A; e += BLOCK * a.F) make_ent_row(a.z + 6 * (size_t)e, a.ent_out + (size_t)e * ENT_STRIDE);
     // grid-stride clearing of the block set that is dead by now
     {
-        const int64_t gid = (int64_t)blockIdx.x * BLOCK + tid, stride = (int64_t)gridDim.x * BLOCK;
+        const int64_t gid = (int64_t)f * BLOCK + tid, stride = (int64_t)n_blocks_a * BLOCK;
         for (int64_t i = gid; i < a.zero0_n; i += stride) a.zero0[i] = 0.0;
         for (int64_t i = gid; i < a.zero1_n; i += stride) a.zero1[i] = 0.0;
         for (int64_t i = gid; i < a.zero2_n; i += stride) a.zero2[i] = 0.0;
     }
     __syncthreads();
-    for (int t = tid; t < ENT_STRIDE; t += BLOCK) a.ent_out[(size_t)(a.A + f) * ENT_STRIDE + t] = entl[(size_t)kf * ENT_STRIDE + t];
 
     double vals[28];  // 21 V (packed lower), 6 g, 1 err
 #pragma unroll
@@ -259,14 +275,26 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
 // U_cc (21), U_mm (21), W_cm (36), g_c (6), g_m (6) over its observations in registers; one LDS wave sum;
 // one fp64 atomic per value into the dense shared system (lower triangle, row-major, cameras first).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_passB(const ObsIdx *__restrict__ idx, const float *__restrict__ uv,
-                                               const double *__restrict__ ent, const double *__restrict__ Kmat,
-                                               const int32_t *__restrict__ chunk_start, int n_chunks, int A, double h,
-                                               int res_f32, float huber, int n_pad, double *__restrict__ U0,
-                                               double *__restrict__ g0) {  // U0 = blk.S (zeroed), g0 = blk.g0
-    __shared__ double scratch[4 * 2048];
+struct PassBArgs {
+    const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat; const int32_t *chunk_start;
+    int n_chunks, A, res_f32, n_pad;
+    float huber;
+    double h;
+    double *U0, *g0;   // U0 = blk.S (zeroed), g0 = blk.g0
+};
+
+// one wavefront per chunk; `scratch` = 2048 doubles of LDS per wavefront of the workgroup
+__device__ __forceinline__ void passB_body(const PassBArgs &b, double *scratch, const int first_chunk) {
+    const ObsIdx *__restrict__ idx = b.idx;
+    const float *__restrict__ uv = b.uv;
+    const double *__restrict__ ent = b.ent, *__restrict__ Kmat = b.Kmat;
+    const int32_t *__restrict__ chunk_start = b.chunk_start;
+    const int n_chunks = b.n_chunks, A = b.A, res_f32 = b.res_f32, n_pad = b.n_pad;
+    const float huber = b.huber;
+    const double h = b.h;
+    double *__restrict__ U0 = b.U0, *__restrict__ g0 = b.g0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = blockIdx.x * 4 + wave;
+    const int chunk = first_chunk + wave;
     if (chunk >= n_chunks) return;
     const int o0 = chunk_start[chunk], o1 = chunk_start[chunk + 1];
     double vals[90];
@@ -330,6 +358,27 @@ __global__ void __launch_bounds__(256) k_passB(const ObsIdx *__restrict__ idx, c
     });
 }
 
+// The two passes as kernels of their own, and as ONE launch: workgroups [0, F) are pass A's, the rest pass B's.  They
+// are independent once the {R, t, J_l} table exists (k_backsub / k_unpack write it), so the trial evaluation of an LM step
+// runs them side by side; both are latency-bound with one wavefront per SIMD and together still fit the chip at config 3.
+template <int BLOCK, int CPL>
+__global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
+    extern __shared__ double lds[];
+    passA_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
+__global__ void __launch_bounds__(256) k_passB(const PassBArgs b) {
+    __shared__ double scratch[4 * 2048];
+    passB_body(b, scratch, (int)blockIdx.x * 4);
+}
+
+template <int BLOCK, int CPL>
+__global__ void __launch_bounds__(BLOCK) k_passAB(const PassAArgs a, const PassBArgs b) {
+    extern __shared__ double lds[];   // pass A's layout; pass B uses the first (BLOCK / 64) * 2048 doubles
+    if ((int)blockIdx.x < a.F) passA_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, a.F);
+    else passB_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
+}
+
 // ------------------------------------------------------------------------------------------------
 // max over the diagonal of J^T J restricted to free parameters (mu_0 = tau * max, libs/sparselevmarq.h:369-377)
 __global__ void __launch_bounds__(256) k_maxdiag(const double *__restrict__ U0, int n_pad, int A,
@@ -363,28 +412,19 @@ void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream
 
 int residual_blocks(const DeviceProblem &P) { return (int)((P.N + 255) / 256); }
 
-template <int B, int CPL>
-static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, hipStream_t st) {
-    const size_t lds = ((size_t)P.max_kf * 36 + 32 + (size_t)(P.max_kf + 1) * ENT_STRIDE + (B / 64) * 2048) * sizeof(double);
-    static size_t granted = 48 * 1024;
-    allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B, CPL>), lds, granted);
-    { HookScope _h(P, KID_PASSA); hipLaunchKernelGGL((k_passA<B, CPL>), dim3(P.F), dim3(B), lds, st, a); }
-}
-
 size_t passA_lds_bytes(int max_kf, int block) {
     return ((size_t)max_kf * 36 + 32 + (size_t)(max_kf + 1) * ENT_STRIDE + (block / 64) * 2048) * sizeof(double);
 }
 
-void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st) {
-    if (P.F == 0) return;
+static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, int zero_blk) {
     PassAArgs a;
-    a.idx = P.a_idx; a.uv = P.a_uv; a.z = P.z[which]; a.Kmat = P.K;
+    a.idx = P.a_idx; a.uv = P.a_uv; a.ent = P.ent[which]; a.Kmat = P.K;
     a.frame_obs_start = P.frame_obs_start; a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent;
     a.A = P.A; a.F = P.F; a.res_f32 = P.res_f32; a.max_kf = P.max_kf; a.frames_fixed = P.frames_fixed;
     a.huber = P.huber;
     a.h = P.half_size; a.mu_pred = mu_pred;
     const DeviceProblem::Blocks &b = P.blk[which];
-    a.ent_out = P.ent[which]; a.V = b.V; a.gf = b.gf; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf; a.err_part = P.err_part;
+    a.V = b.V; a.gf = b.gf; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf; a.err_part = P.err_part;
     a.zero0 = a.zero1 = a.zero2 = nullptr; a.zero0_n = a.zero1_n = a.zero2_n = 0;
     if (zero_blk >= 0) {
         const DeviceProblem::Blocks &zb = P.blk[zero_blk];
@@ -393,19 +433,57 @@ void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_bl
         a.zero2 = zb.g0; a.zero2_n = P.n_pad;
     }
     a.flags = P.flags;
+    return a;
+}
+
+static PassBArgs passB_args(const DeviceProblem &P, int which) {
+    PassBArgs b;
+    b.idx = P.b_idx; b.uv = P.b_uv; b.ent = P.ent[which]; b.Kmat = P.K; b.chunk_start = P.chunk_start;
+    b.n_chunks = P.n_chunks; b.A = P.A; b.res_f32 = P.res_f32; b.n_pad = P.n_pad; b.huber = P.huber; b.h = P.half_size;
+    b.U0 = P.blk[which].S; b.g0 = P.blk[which].g0;
+    return b;
+}
+
+// with_b: pass B's chunks ride in the same launch (the caller must not launch pass B again)
+template <int B, int CPL>
+static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, const PassBArgs *pbargs, hipStream_t st) {
+    const size_t lds = passA_lds_bytes(P.max_kf, B);
+    static size_t granted = 48 * 1024, granted_ab = 48 * 1024;
+    HookScope _h(P, KID_PASSA);
+    if (pbargs) {
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB<B, CPL>), lds, granted_ab);
+        hipLaunchKernelGGL((k_passAB<B, CPL>), dim3(P.F + (P.n_chunks + B / 64 - 1) / (B / 64)), dim3(B), lds, st, a, *pbargs);
+    } else {
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B, CPL>), lds, granted);
+        hipLaunchKernelGGL((k_passA<B, CPL>), dim3(P.F), dim3(B), lds, st, a);
+    }
+}
+
+static void launch_passA_any(const DeviceProblem &P, const PassAArgs &a, const PassBArgs *pbargs, hipStream_t st) {
     // one wavefront per frame up to ~96 observations per frame (four / two lanes per observation while they fit in it),
     // four wavefronts above
     const double avg = (double)P.N / (double)P.F;
-    if (avg <= 14) launch_passA_t<64, 1>(P, a, st);
-    else if (avg <= 30) launch_passA_t<64, 2>(P, a, st);
-    else if (avg <= 96) launch_passA_t<64, 4>(P, a, st);
-    else launch_passA_t<256, 4>(P, a, st);
+    if (avg <= 14) launch_passA_t<64, 1>(P, a, pbargs, st);
+    else if (avg <= 30) launch_passA_t<64, 2>(P, a, pbargs, st);
+    else if (avg <= 96) launch_passA_t<64, 4>(P, a, pbargs, st);
+    else launch_passA_t<256, 4>(P, a, pbargs, st);
+}
+
+void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st) {
+    if (P.F == 0) return;
+    launch_passA_any(P, passA_args(P, which, mu_pred, zero_blk), nullptr, st);
 }
 
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
     if (P.n_chunks == 0) return;
-    { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, P.b_idx, P.b_uv, P.ent[which], P.K,
-                       P.chunk_start, P.n_chunks, P.A, P.half_size, P.res_f32, P.huber, P.n_pad, P.blk[which].S, P.blk[which].g0); }
+    { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which)); }
+}
+
+bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st) {
+    if (P.F == 0 || P.n_chunks == 0) return false;   // nothing to merge: the caller launches what there is
+    const PassBArgs b = passB_args(P, which);
+    launch_passA_any(P, passA_args(P, which, mu_pred, zero_blk), &b, st);
+    return true;
 }
 
 void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st) {

@@ -106,6 +106,8 @@ void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream
 // damping; zero_blk >= 0 clears S, rhs, g0 of that block set (they are dead / about to be rebuilt)
 void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st);
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st);              // accumulates into blk[which].S, .g0 (must be zero)
+// both passes in one launch (they only share the entity table ent[which], which must be complete); false = nothing launched
+bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st);
 void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st);            // scal[4] = max free diagonal
 void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st);
 void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st);   // S -= sign * W (V+mu I)^-1 W^T (sign -1 takes it back)

@@ -924,7 +924,7 @@ __global__ void __launch_bounds__(256) k_backsub(const int32_t *__restrict__ fsl
                                                  const double *__restrict__ gf, const double *__restrict__ g0,
                                                  const double *__restrict__ delta_s, const double *__restrict__ zc,
                                                  double *__restrict__ zt, int A, int F, int n_frame_blocks,
-                                                 double *__restrict__ lin_part) {
+                                                 double *__restrict__ lin_part, double *__restrict__ ent_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x == n_frame_blocks) {  // shared part
         double d2 = 0.0, dg = 0.0;
@@ -943,6 +943,11 @@ __global__ void __launch_bounds__(256) k_backsub(const int32_t *__restrict__ fsl
             lin_part[2 * (size_t)F] = red[0] + red[1] + red[2] + red[3];
             lin_part[2 * (size_t)F + 1] = red[4] + red[5] + red[6] + red[7];
         }
+        // {R, t, J_l} rows of the shared entities at the trial point: both observation passes of the trial evaluation read
+        // them from this table (so they need not run one after the other)
+        __threadfence_block();
+        __syncthreads();
+        for (int e = tid; e < A; e += 256) make_ent_row(zt + 6 * (size_t)e, ent_out + (size_t)e * ENT_STRIDE);
         return;
     }
     const int f = blockIdx.x * 4 + wave;
@@ -975,6 +980,13 @@ __global__ void __launch_bounds__(256) k_backsub(const int32_t *__restrict__ fsl
         for (int k = 0; k < 6; k++) d += Vinv[(size_t)f * 36 + lane * 6 + k] * vv[k];
         const size_t zi = (size_t)6 * (A + f) + lane;
         zt[zi] = zc[zi] + d;
+    }
+    {   // the frame's own {R, t, J_l} row at the trial point (lane 0; the six new parameters come from lanes 0..5)
+        const double zn = (lane < 6) ? zc[(size_t)6 * (A + f) + lane] + d : 0.0;
+        double zv[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) zv[i] = __shfl(zn, i);
+        if (lane == 0) make_ent_row(zv, ent_out + (size_t)(A + f) * ENT_STRIDE);
     }
     double d2 = (lane < 6) ? d * d : 0.0;
     double dgv = 0.0;
@@ -1097,7 +1109,7 @@ void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) 
     const DeviceProblem::Blocks &b = P.blk[cur];
     const int nfb = (P.F + 3) / 4;
     { HookScope _h(P, KID_BACKSUB); hipLaunchKernelGGL(k_backsub, dim3(nfb + 1), dim3(256), 0, st, P.fslot_start, P.fslot_ent, b.W, b.Vinv, b.gf, b.g0,
-                       P.delta_s, P.z[cur], P.z[trial], P.A, P.F, nfb, P.lin_part); }
+                       P.delta_s, P.z[cur], P.z[trial], P.A, P.F, nfb, P.lin_part, P.ent[trial]); }
 }
 
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st) {
