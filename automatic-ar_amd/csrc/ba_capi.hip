@@ -344,7 +344,8 @@ int wait_result(aar_problem *pb) {
     return AAR_OK;
 }
 
-int read_scalars(aar_problem *pb, int n_err) {
+// queue the reduction of the step's scalars and their publication to the host record (no wait)
+int launch_scalars(aar_problem *pb, int n_err) {
     DeviceProblem &P = pb->P;
     pb->seq++;
     {
@@ -358,7 +359,11 @@ int read_scalars(aar_problem *pb, int n_err) {
         if (rc) return rc;
         launch_publish(P, pb->seq, pb->stream);
     }
-    int rc = check_async("kernel launch");
+    return check_async("kernel launch");
+}
+
+int read_scalars(aar_problem *pb, int n_err) {
+    int rc = launch_scalars(pb, n_err);
     if (rc) return rc;
     return wait_result(pb);
 }
@@ -408,14 +413,22 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     pb->blocks_valid = false;  // S of the current point has been eliminated in place
     if (evaluate_trial) {
         // predicted damping of the next step: every accepted step of the reference's rule with gain >= 0.94 gives 0.33 mu
-        int rc = eval_blocks(pb, tr, mu * 0.33, cur, /*spec_schur=*/true, /*ents_ready=*/true);
+        int rc = eval_blocks(pb, tr, mu * 0.33, cur, /*spec_schur=*/false, /*ents_ready=*/true);
         if (rc) return rc;
         pb->trial_points++;
     } else {
         HIP_TRY(hipMemsetAsync(P.err_part, 0, sizeof(double) * (size_t)std::max(P.F, 1), pb->stream));
     }
-    int rc = read_scalars(pb, P.F);
+    // The scalars go to the host BEFORE the speculative Schur complement of the trial point is queued: the host takes its
+    // accept / reject decision and queues the next factorisation while that kernel runs, instead of after it.
+    int rc = launch_scalars(pb, P.F);
     if (rc) return rc;
+    if (evaluate_trial) {
+        StageTimer t(pb, &pb->times.schur);
+        launch_schur(P, tr, 1.0, pb->stream);
+        pb->launches += 1;
+    }
+    if ((rc = wait_result(pb))) return rc;
     if (pb->h_flags[0]) {
         (void)hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream);
         return set_error(AAR_ERR_NUMERIC, "non-positive pivot (flags=%d) at mu=%g", pb->h_flags[0], mu);
