@@ -421,13 +421,24 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     }
     // The scalars go to the host BEFORE the speculative Schur complement of the trial point is queued: the host takes its
     // accept / reject decision and queues the next factorisation while that kernel runs, instead of after it.
-    int rc = launch_scalars(pb, P.F);
-    if (rc) return rc;
-    if (evaluate_trial) {
+    // On one GPU the reduction does not even get a launch of its own: it rides as one more workgroup of that kernel.
+    int rc = AAR_OK;
+    bool rode = false;
+    if (evaluate_trial && !pb->comm) {
         StageTimer t(pb, &pb->times.schur);
-        launch_schur(P, tr, 1.0, pb->stream);
+        rode = launch_schur(P, tr, 1.0, pb->stream, pb->seq + 1, P.F);
         pb->launches += 1;
+        if (rode) pb->seq++;
+        else if ((rc = launch_scalars(pb, P.F))) return rc;   // (queued after the Schur kernel: the MFMA variant has no rider)
+    } else {
+        if ((rc = launch_scalars(pb, P.F))) return rc;
+        if (evaluate_trial) {
+            StageTimer t(pb, &pb->times.schur);
+            launch_schur(P, tr, 1.0, pb->stream);
+            pb->launches += 1;
+        }
     }
+    if ((rc = check_async("kernel launch"))) return rc;
     if ((rc = wait_result(pb))) return rc;
     if (pb->h_flags[0]) {
         (void)hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream);

@@ -110,7 +110,9 @@ void launch_passB(const DeviceProblem &P, int which, hipStream_t st);           
 bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st);
 void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st);            // scal[4] = max free diagonal
 void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st);
-void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st);   // S -= sign * W (V+mu I)^-1 W^T (sign -1 takes it back)
+// S -= sign * W (V+mu I)^-1 W^T (sign -1 takes it back).  ride_seq != 0: the reduction of the step's scalars rides in the same
+// launch (true is returned if it did)
+bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq = 0, int ride_n_err = 0);
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st);    // damping + LDL^T + both substitutions -> delta_s
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st);  // scal[0..2], scal[5..6]

@@ -46,6 +46,53 @@ __global__ void __launch_bounds__(256) k_frame_inv(const double *__restrict__ V,
     }
 }
 
+__device__ __forceinline__ void publish_host(const double *__restrict__ scal, const int32_t *__restrict__ flags,
+                                             double *__restrict__ host, unsigned long long seq) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) host[i] = scal[i];
+    reinterpret_cast<long long *>(host)[8] = (long long)(flags[0] | flags[1] | flags[2] | flags[3]);
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(host) + 9, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_publish(const double *__restrict__ scal, const int32_t *__restrict__ flags, double *__restrict__ host,
+                          unsigned long long seq) {
+    if (threadIdx.x == 0) publish_host(scal, flags, host, seq);
+}
+
+
+struct ReduceArgs {   // the step's scalars: [sum r^2, sum |delta_f|^2, sum delta.g] -> scal -> (publish_seq != 0) mapped host record
+    const double *err_part; int n_err; const double *lin_part; int F; int fold_shared;
+    double *scal; const int32_t *flags; double *host; unsigned long long publish_seq;
+};
+
+__device__ __forceinline__ void reduce_scalars_body(const ReduceArgs &r) {   // 256 threads, fixed summation order
+    __shared__ double red[3][256];
+    const int tid = threadIdx.x;
+    double e = 0.0, d2 = 0.0, dg = 0.0;
+    for (int i = tid; i < r.n_err; i += 256) e += r.err_part[i];
+    for (int i = tid; i < r.F; i += 256) { d2 += r.lin_part[2 * (size_t)i]; dg += r.lin_part[2 * (size_t)i + 1]; }
+    red[0][tid] = e; red[1][tid] = d2; red[2][tid] = dg;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            red[0][tid] += red[0][tid + off];
+            red[1][tid] += red[1][tid + off];
+            red[2][tid] += red[2][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        r.scal[0] = red[0][0]; r.scal[1] = red[1][0];
+        // multi-GPU: delta_s . g0 uses this rank's piece of the shared gradient, so it joins the rank sum
+        r.scal[2] = red[2][0] + (r.fold_shared ? r.lin_part[2 * (size_t)r.F + 1] : 0.0);
+        r.scal[5] = r.lin_part[2 * (size_t)r.F]; r.scal[6] = r.lin_part[2 * (size_t)r.F + 1];
+        if (r.publish_seq) publish_host(r.scal, r.flags, r.host, r.publish_seq);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_reduce_scalars(const ReduceArgs r) { reduce_scalars_body(r); }
+
 // ------------------------------------------------------------------------------------------------
 // Schur complement, output-stationary: work item = (shared entity a, a range of the frames that see a).
 // The workgroup keeps row panel [S(a, b)]_{b <= a} (6 x 6(a+1)) and the rhs rows of a in LDS, its four
@@ -61,12 +108,17 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
                                                const int32_t *__restrict__ sw_end, const int4 *__restrict__ pair_rec,
                                                const int32_t *__restrict__ fslot_ent, const double *__restrict__ W,
                                                const double *__restrict__ Vinv, const double *__restrict__ hf, int A,
-                                               int n_pad, double sign, double *__restrict__ S, double *__restrict__ rhs) {
+                                               int n_pad, double sign, double *__restrict__ S, double *__restrict__ rhs,
+                                               int rider, const ReduceArgs red) {
+    if (rider && blockIdx.x == 0) {   // rider (dispatched first): the step's scalars go to the host from here, beside the Schur workgroups
+        reduce_scalars_body(red);
+        return;
+    }
     extern __shared__ double lds[];
     double *panel = lds;
     double *pg = lds + (size_t)A * 36;
     double *ysc = pg + 8;
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = (int)blockIdx.x - rider, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int a = sw_ent[w], pb = sw_begin[w], pe = sw_end[w];
     for (int i = tid; i < (a + 1) * 36; i += 256) panel[i] = 0.0;
     if (tid < 8) pg[tid] = 0.0;
@@ -1004,47 +1056,6 @@ __global__ void __launch_bounds__(256) k_backsub(const int32_t *__restrict__ fsl
 //   and delta_s.g0 (folded into scal[2] when fold_shared, because g0 is a per-rank partial sum)
 // ------------------------------------------------------------------------------------------------
 // publish the scalars and the error flags to the mapped host record; the sequence number goes last, system scope
-__device__ __forceinline__ void publish_host(const double *__restrict__ scal, const int32_t *__restrict__ flags,
-                                             double *__restrict__ host, unsigned long long seq) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) host[i] = scal[i];
-    reinterpret_cast<long long *>(host)[8] = (long long)(flags[0] | flags[1] | flags[2] | flags[3]);
-    __threadfence_system();
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(host) + 9, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ void k_publish(const double *__restrict__ scal, const int32_t *__restrict__ flags, double *__restrict__ host,
-                          unsigned long long seq) {
-    if (threadIdx.x == 0) publish_host(scal, flags, host, seq);
-}
-
-__global__ void __launch_bounds__(256) k_reduce_scalars(const double *__restrict__ err_part, int n_err,
-                                                        const double *__restrict__ lin_part, int F, int fold_shared,
-                                                        double *__restrict__ scal, const int32_t *__restrict__ flags,
-                                                        double *__restrict__ host, unsigned long long publish_seq) {
-    __shared__ double red[3][256];
-    const int tid = threadIdx.x;
-    double e = 0.0, d2 = 0.0, dg = 0.0;
-    for (int i = tid; i < n_err; i += 256) e += err_part[i];
-    for (int i = tid; i < F; i += 256) { d2 += lin_part[2 * (size_t)i]; dg += lin_part[2 * (size_t)i + 1]; }
-    red[0][tid] = e; red[1][tid] = d2; red[2][tid] = dg;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) {
-            red[0][tid] += red[0][tid + off];
-            red[1][tid] += red[1][tid + off];
-            red[2][tid] += red[2][tid + off];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        scal[0] = red[0][0]; scal[1] = red[1][0];
-        // multi-GPU: delta_s . g0 uses this rank's piece of the shared gradient, so it joins the rank sum
-        scal[2] = red[2][0] + (fold_shared ? lin_part[2 * (size_t)F + 1] : 0.0);
-        scal[5] = lin_part[2 * (size_t)F]; scal[6] = lin_part[2 * (size_t)F + 1];
-        if (publish_seq) publish_host(scal, flags, host, publish_seq);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st) {
@@ -1053,7 +1064,17 @@ void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t 
     { HookScope _h(P, KID_FRAME_INV); hipLaunchKernelGGL(k_frame_inv, dim3((P.F + 255) / 256), dim3(256), 0, st, b.V, b.gf, P.F, mu, P.frames_fixed, b.Vinv, b.hf, P.flags); }
 }
 
-void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st) {
+static ReduceArgs reduce_args(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq) {
+    ReduceArgs r;
+    r.err_part = P.err_part; r.n_err = n_err; r.lin_part = P.lin_part; r.F = P.F; r.fold_shared = fold_shared ? 1 : 0;
+    r.scal = P.scal; r.flags = P.flags; r.host = P.host_result; r.publish_seq = publish_seq;
+    return r;
+}
+
+// ride_seq != 0: one extra workgroup of the launch reduces the step's scalars (ride_n_err partial sums of r^2) and publishes
+// them under that sequence number -- the speculative Schur complement and that reduction only depend on the passes before
+// them, not on each other.  Returns false if the scalars did not ride (the caller launches k_reduce_scalars).
+bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq, int ride_n_err) {
     const DeviceProblem::Blocks &b = P.blk[which];
     if (P.n_smwork > 0) {   // many shared entities: block-of-S-stationary MFMA kernel
         const size_t lds = (size_t)2 * SM_ROWS * SM_PS * sizeof(double);
@@ -1063,21 +1084,24 @@ void launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
         hipLaunchKernelGGL(k_schur_y, dim3((unsigned)(((int64_t)P.total_slots * 6 + 255) / 256)), dim3(256), 0, st, P.slot_frame, b.W, b.Vinv, P.total_slots, P.Yw);
         hipLaunchKernelGGL(k_schur_mfma, dim3(P.n_smwork), dim3(512), lds, st, P.sm_ga, P.sm_gb, P.sm_fb, P.sm_fe, P.slot_of, P.fslot_start, b.W, P.Yw, b.gf,
                            P.A, P.n_pad, sign, b.S, b.rhs);
-        return;
+        return false;
     }
-    if (P.n_swork == 0) return;
+    if (P.n_swork == 0) return false;
     const size_t lds = ((size_t)P.A * 36 + 8 + 4 * 48) * sizeof(double);
     static size_t granted0 = 48 * 1024, granted3 = 48 * 1024;
+    const ReduceArgs red = reduce_args(P, ride_n_err, false, ride_seq);
+    const int extra = ride_seq ? 1 : 0;
     HookScope _h(P, KID_SCHUR);
     if (P.max_kf > 64) {
         allow_dynamic_lds(reinterpret_cast<const void *>(k_schur<3>), lds, granted3);
-        hipLaunchKernelGGL(k_schur<3>, dim3(P.n_swork), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_rec, P.fslot_ent, b.W, b.Vinv, b.hf,
-                           P.A, P.n_pad, sign, b.S, b.rhs);
+        hipLaunchKernelGGL(k_schur<3>, dim3(P.n_swork + extra), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_rec, P.fslot_ent, b.W, b.Vinv, b.hf,
+                           P.A, P.n_pad, sign, b.S, b.rhs, extra, red);
     } else {
         allow_dynamic_lds(reinterpret_cast<const void *>(k_schur<0>), lds, granted0);
-        hipLaunchKernelGGL(k_schur<0>, dim3(P.n_swork), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_rec, P.fslot_ent, b.W, b.Vinv, b.hf,
-                           P.A, P.n_pad, sign, b.S, b.rhs);
+        hipLaunchKernelGGL(k_schur<0>, dim3(P.n_swork + extra), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_rec, P.fslot_ent, b.W, b.Vinv, b.hf,
+                           P.A, P.n_pad, sign, b.S, b.rhs, extra, red);
     }
+    return ride_seq != 0;
 }
 
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
@@ -1113,8 +1137,7 @@ void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) 
 }
 
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st) {
-    { HookScope _h(P, KID_REDUCE); hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, P.err_part, n_err, P.lin_part, P.F,
-                       fold_shared ? 1 : 0, P.scal, P.flags, P.host_result, publish_seq); }
+    { HookScope _h(P, KID_REDUCE); hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, reduce_args(P, n_err, fold_shared, publish_seq)); }
 }
 
 void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st) {
