@@ -481,6 +481,11 @@ void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
 
 bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st) {
     if (P.F == 0 || P.n_chunks == 0) return false;   // nothing to merge: the caller launches what there is
+    // Side by side pays while the two passes together are a few wavefronts per SIMD (configs 2-4: -45 % / -11 % of their
+    // summed time at configs 3 / 4); once either fills the chip on its own (config 5: +7 %, pass B's workgroups then carry
+    // pass A's LDS allocation) they go one after the other
+    const int64_t waves = (int64_t)P.F * ((double)P.N / (double)P.F <= 96 ? 1 : 4) + P.n_chunks;
+    if (waves > 4096) return false;
     const PassBArgs b = passB_args(P, which);
     launch_passA_any(P, passA_args(P, which, mu_pred, zero_blk), &b, st);
     return true;
