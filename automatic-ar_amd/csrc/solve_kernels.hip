@@ -664,30 +664,53 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
         xout[r0 + i0] = b0;
         if (h1) xout[r0 + i1] = b1;
     }
-    {   // factored tile -> Dfac (not back into S: other workgroups may still be reading it)
+    if (s == nT - 1) { STAMP(9); STAMP(10); TL_DUMP; return; }   // nobody reads the last tile's factor: its solve is done
+    {   // factored tile -> Dfac (not back into S: other workgroups may still be reading it); only the lower part is ever read
         double *outp = Dfac + (size_t)s * NB * NB;
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
-            outp[idx] = (i == j) ? dsave[i] : T[i * LD + j];
+            if (j <= i) outp[idx] = (i == j) ? dsave[i] : T[i * LD + j];
         }
     }
     STAMP(9);
-    // inverses of the unit-lower 16x16 diagonal sub-blocks: lane c < 16 of a wave solves L x = e_c
-    if (wave < NSB && lane < SBK) {
-        const int q = wave, c = lane, o = q * SBK;
-        double x[SBK];
+    // inverses of the unit-lower 16x16 diagonal sub-blocks, one wavefront each, by halves:
+    //   [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1]: the two 8x8 inverses column by column on 16 lanes (28 fma deep instead of
+    //   120), then the two 8x8x8 products on all 64 lanes, through a wave-private LDS scratch (T is zero on and above the diagonal)
+    if (wave < NSB) {
+        const int q = wave, o = q * SBK;
+        double *sc = Yn + 128 + wave * 192;   // Ai [8][8] | Ci [8][8] | B Ai [8][8]   (the panel is free by now; dsave = Yn[0..NB))
+        if (lane < 16) {
+            const int half = lane >> 3, c = lane & 7, ob = o + 8 * half;
+            double x[8];
 #pragma unroll
-        for (int i = 0; i < SBK; i++) {
-            // x_p = 0 for p < c, so the full row can be used: the L loads are lane-uniform and independent of x
-            double acc2 = (i == c) ? 1.0 : 0.0;
+            for (int i = 0; i < 8; i++) {
+                // x_p = 0 for p < c, so the full row can be used: the L loads are lane-uniform per half and independent of x
+                double a2 = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int pp = 0; pp < i; pp++) acc2 = fma(-T[(o + i) * LD + o + pp], x[pp], acc2);
-            x[i] = acc2;
+                for (int pp = 0; pp < i; pp++) a2 = fma(-T[(ob + i) * LD + ob + pp], x[pp], a2);
+                x[i] = a2;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) sc[half * 64 + i * 8 + c] = x[i];
         }
-        double *li = Linv16 + ((size_t)s * NSB + q) * SBK * SBK;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int r = lane >> 3, c = lane & 7;
+        double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < SBK; i++) li[i * SBK + c] = x[i];
+        for (int pp = 0; pp < 8; pp++) t = fma(T[(o + 8 + r) * LD + o + pp], sc[pp * 8 + c], t);
+        sc[128 + r * 8 + c] = t;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double v = 0.0;
+#pragma unroll
+        for (int pp = 0; pp < 8; pp++) v = fma(-sc[64 + r * 8 + pp], sc[128 + pp * 8 + c], v);
+        double *li = Linv16 + ((size_t)s * NSB + q) * SBK * SBK;
+        li[r * SBK + c] = sc[r * 8 + c];
+        li[r * SBK + 8 + c] = 0.0;
+        li[(8 + r) * SBK + c] = v;
+        li[(8 + r) * SBK + 8 + c] = sc[64 + r * 8 + c];
     }
     STAMP(10);
     TL_DUMP;
