@@ -396,9 +396,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     pb->schur_mu = -1;
     if (pb->comm) {
         StageTimer t(pb, &pb->times.allreduce);
-        int rc = allreduce(pb, P.blk[cur].S, (size_t)P.n_pad * P.n_pad, NCCL_SUM);
-        if (rc) return rc;
-        rc = allreduce(pb, P.blk[cur].rhs, (size_t)P.n_pad, NCCL_SUM);
+        int rc = allreduce(pb, P.blk[cur].S, (size_t)P.n_pad * P.n_pad + P.n_pad, NCCL_SUM);   // S and rhs (contiguous)
         if (rc) return rc;
     }
     {
@@ -774,7 +772,8 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     for (int w = 0; w < 2; w++) {
         AL(blk[w].V, (size_t)F * 36); AL(blk[w].gf, (size_t)F * 6); AL(blk[w].W, (size_t)P.total_slots * 36);
         AL(blk[w].Vinv, (size_t)F * 36); AL(blk[w].hf, (size_t)F * 6);
-        AL(blk[w].S, (size_t)P.n_pad * P.n_pad); AL(blk[w].rhs, P.n_pad); AL(blk[w].g0, P.n_pad);
+        // rhs lives right behind S: one all-reduce covers both on the multi-GPU path
+        AL(blk[w].S, (size_t)P.n_pad * P.n_pad + P.n_pad); P.blk[w].rhs = P.blk[w].S + (size_t)P.n_pad * P.n_pad; AL(blk[w].g0, P.n_pad);
     }
     if (P.n_smwork) AL(Yw, (size_t)P.total_slots * 36);
     AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad); AL(bs_flags, (size_t)P.nT + 1);
