@@ -333,12 +333,12 @@ def test_schur_mfma_kernel_forced_on_small_problems(name, split, monkeypatch):
         np.testing.assert_allclose(x, g["analytic_x"], atol=1e-7)
 
 
-@pytest.mark.parametrize("mfma", ["0", "1"])
-def test_many_entities_schur_against_oracle(mfma, monkeypatch):
+@pytest.mark.parametrize("mfma,cams,markers,frames", [("0", 4, 62, 40), ("1", 4, 62, 40), ("0", 4, 20, 60), ("0", 3, 29, 50)])
+def test_tile_counts_and_schur_kernels_against_oracle(mfma, cams, markers, frames, monkeypatch):
     # 4 cameras / 62 markers / 40 frames: A = 66 shared entities (5 entity groups of 16, a partial last one), 5 tiles of the
-    # reduced system, both Schur kernels
+    # reduced system, both Schur kernels; 4 / 20 / 60: exactly two tiles (A = 24, n = 144); 3 / 29 / 50: two full tiles (n = 192)
     monkeypatch.setenv("AAR_SCHUR_MFMA", mfma)
-    ds = aar.synth(3, num_cams=4, num_markers=62, num_frames=40)
+    ds = aar.synth(3, num_cams=cams, num_markers=markers, num_frames=frames)
     o = ol.Oracle(ds)
     with aar.Problem(ds) as p:
         r, ss = p.eval_residuals(ds.x_full)
@@ -349,7 +349,7 @@ def test_many_entities_schur_against_oracle(mfma, monkeypatch):
             assert np.abs(d - do).max() / np.abs(do).max() < 1e-8, mu
         x, rep = p.lm_solve(ds.x_full)
         rmse, _ = p.reproj_stats(x)
-        assert rep["iterations"] < 40 and abs(rmse - 0.3 * np.sqrt(2)) < 0.03
+        assert rep["iterations"] < 40 and abs(rmse - 0.3 * np.sqrt(2)) < 0.05   # (few observations per unknown: the fit absorbs some noise)
 
 
 def test_single_rank_communicator_path():
