@@ -709,14 +709,41 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     int per_item = (int)std::min<int64_t>(64, std::max<int64_t>(16, total_pairs / 1024));
     per_item = (per_item + 3) / 4 * 4;
     if (const char *e = getenv("AAR_SCHUR_ITEM")) per_item = std::max(4, atoi(e));  // tuning knob (pairs per workgroup)
+    std::vector<int> pair_base(A + 1, 0);
     for (int a = 0; a < A; a++) {
-        const int base = (int)pair_rec.size();
+        pair_base[a] = (int)pair_rec.size();
         for (auto &pr : inc[a]) pair_rec.push_back(make_int4(pr.first, pr.second, fslot_start[pr.first], 0));
-        const int cnt = (int)inc[a].size();
-        for (int s = 0; s < cnt; s += per_item) {
-            sw_ent.push_back(a);
-            sw_begin.push_back(base + s);
-            sw_end.push_back(base + std::min(cnt, s + per_item));
+    }
+    pair_base[A] = (int)pair_rec.size();
+    // Large problems (the kernel is then bound by re-reading W blocks): items are cut by FRAME WINDOW and ordered window-major,
+    // so that the workgroups in flight at any time walk the same frames and find each other's W blocks in L2 / MALL.
+    // Small problems: plain runs of per_item pairs, entity-major (fewer, fuller workgroups).
+    int window = 0;
+    if (total_pairs >= 262144) window = 64;
+    if (const char *e = getenv("AAR_SCHUR_WINDOW")) window = std::max(0, atoi(e));
+    if (window > 0) {
+        std::vector<int> cursor(A, 0);
+        for (int f0 = 0; f0 < F; f0 += window)
+            for (int a = 0; a < A; a++) {
+                int c = cursor[a];
+                const int cnt = (int)inc[a].size();
+                int e = c;
+                while (e < cnt && inc[a][e].first < f0 + window) e++;
+                if (e > c) {
+                    sw_ent.push_back(a);
+                    sw_begin.push_back(pair_base[a] + c);
+                    sw_end.push_back(pair_base[a] + e);
+                }
+                cursor[a] = e;
+            }
+    } else {
+        for (int a = 0; a < A; a++) {
+            const int cnt = (int)inc[a].size();
+            for (int s = 0; s < cnt; s += per_item) {
+                sw_ent.push_back(a);
+                sw_begin.push_back(pair_base[a] + s);
+                sw_end.push_back(pair_base[a] + std::min(cnt, s + per_item));
+            }
         }
     }
     P.n_swork = (int)sw_ent.size();
