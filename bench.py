@@ -57,7 +57,7 @@ def algorithmic_bytes(kernel, N, A, F, n_pad):
         "k_residual": rec + 8 * P,
         "k_unpack": 8 * P,
         "k_schur": 8 * (n_pad * n_pad // 2 + n_pad),  # frame-owned W/V traffic is overhead, not algorithmic
-        "k_ldl_diag": 2 * tile,                       # diagonal tile in, factor out
+        "k_ldl_diag": tile,                           # lower triangle of the diagonal tile in, lower triangle of its factor out
         "k_ldl_trsm": 2 * tile * (avg_rows - 1) + tile,             # the block column below the diagonal in/out + L_ss
         "k_ldl_update": 2 * 8 * (n_pad * n_pad // 2) / max(1, nT - 1) if nT > 1 else 0,   # trailing matrix, amortised over the steps
         "k_ldl_backsolve": 8 * (n_pad * n_pad // 2 + 2 * n_pad),
