@@ -440,7 +440,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     if ((rc = wait_result(pb))) return rc;
     if (pb->h_flags[0]) {
         (void)hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream);
-        return set_error(AAR_ERR_NUMERIC, "non-positive pivot (flags=%d) at mu=%g", pb->h_flags[0], mu);
+        return set_error(AAR_ERR_NUMERIC, "device flags %d at mu=%g (1: a frame block is not positive definite, 2: non-positive pivot of the reduced system, 4: back-substitution chain timed out)", pb->h_flags[0], mu);
     }
     return AAR_OK;
 }

@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
 // LDS (dynamic): Ls [NB][NB+2] | xs [NB] | w [NB] | part [10][NB]
 __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict__ S, const double *__restrict__ rhs,
                                                         const double *__restrict__ Dfac, double *__restrict__ x, int n_pad, int nT,
-                                                        int32_t *__restrict__ flag, int epoch) {
+                                                        int32_t *__restrict__ flag, int epoch, int32_t *__restrict__ err_flags) {
     constexpr int LD = NB + 2, G = 10, RPT = (NB + G - 1) / G;
     extern __shared__ __align__(16) double lds[];
     double *Ls = lds;
@@ -946,7 +946,13 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
         }
         if (t < nT - 1) {   // x_{nT-1} comes from the previous kernel; the others from the workgroup next door
             if (tid == 0) {
-                while (__hip_atomic_load(flag + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+                // bounded: a chain that cannot complete (it always can: a workgroup only waits for ones dispatched before it)
+                // must end in an error flag on the host, never in a hung device
+                long spins = 0;
+                while (__hip_atomic_load(flag + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1L << 24)) { atomicOr(err_flags, 4); break; }
+                }
             }
             __syncthreads();
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -1148,7 +1154,7 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
         allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_backsolve), lds, g_bs);
         P.bs_epoch++;
         HookScope _h(P, KID_LDL_BACKSOLVE);
-        hipLaunchKernelGGL(k_ldl_backsolve, dim3(P.nT - 1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.delta_s, P.n_pad, P.nT, P.bs_flags, P.bs_epoch);
+        hipLaunchKernelGGL(k_ldl_backsolve, dim3(P.nT - 1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.delta_s, P.n_pad, P.nT, P.bs_flags, P.bs_epoch, P.flags);
     }
 }
 
