@@ -28,7 +28,8 @@ SYMBOLS = [
     "aar_eval_normal_equations", "aar_eval_damped_step", "aar_lm_default_params", "aar_lm_init", "aar_lm_step",
     "aar_lm_get_solution", "aar_lm_solve", "aar_get_stage_times", "aar_reproj_stats", "aar_device_count",
     "aar_device_synchronize", "aar_set_kernel_profiling", "aar_get_kernel_times", "aar_kernel_name",
-    "aar_problem_set_huber_delta", "aar_problem_get_huber_delta", "aar_track",
+    "aar_problem_set_huber_delta", "aar_problem_get_huber_delta", "aar_track", "aar_cam_config_read",
+    "aar_undistort_points",
 ]
 NUM_KERNELS = 13
 
@@ -154,6 +155,8 @@ def lib():
     L.aar_kernel_name.argtypes = [C.c_int]
     L.aar_kernel_name.restype = C.c_char_p
     L.aar_track.argtypes = [C.c_void_p, dp, C.POINTER(CLmParams), C.POINTER(C.c_int32), dp]
+    L.aar_cam_config_read.argtypes = [C.c_char_p, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.aar_undistort_points.argtypes = [dp, dp, C.c_int32, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]
     L.aar_problem_set_huber_delta.argtypes = [C.c_void_p, C.c_float]
     L.aar_problem_get_huber_delta.argtypes = [C.c_void_p]
     L.aar_problem_get_huber_delta.restype = C.c_float
@@ -303,6 +306,30 @@ def rodrigues_mat2vec(R):
     w = np.zeros(3)
     lib().aar_rodrigues_mat2vec(_dptr(R), _dptr(w))
     return w
+
+
+MAX_DIST = 12
+
+
+def cam_config_read(path):
+    """calib.{xml,yml,yaml} of one camera -> (K 3x3, dist (n,), (width, height)) -- libs/cam_config.cpp:52-80."""
+    K = np.zeros(9)
+    dist = np.zeros(MAX_DIST)
+    n, w, h = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _check(lib().aar_cam_config_read(path.encode(), _dptr(K), _dptr(dist), C.byref(n), C.byref(w), C.byref(h)))
+    return K.reshape(3, 3), dist[: n.value].copy(), (w.value, h.value)
+
+
+def undistort_points(K, dist, uv, device=0):
+    """MultiCamMapper::remove_distortions for one camera's corners (libs/multicam_mapper.cpp:554-578) on the GPU."""
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    dist = np.ascontiguousarray(dist, dtype=np.float64).reshape(-1)
+    uv = np.ascontiguousarray(uv, dtype=np.float32)
+    out = np.empty_like(uv)
+    fp = C.POINTER(C.c_float)
+    _check(lib().aar_undistort_points(_dptr(K), _dptr(dist) if len(dist) else None, len(dist), uv.size // 2,
+                                      uv.ctypes.data_as(fp), out.ctypes.data_as(fp), device))
+    return out
 
 
 def plan_shards(obs_per_frame, world):

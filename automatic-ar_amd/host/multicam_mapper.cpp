@@ -222,6 +222,23 @@ MultiCamMapper::MatArrays MultiCamMapper::get_mat_arrays() {
 size_t MultiCamMapper::get_root_cam() { return data_ ? (size_t)data_->cam_ids[data_->root_cam] : 0; }
 size_t MultiCamMapper::get_root_marker() { return data_ ? (size_t)data_->marker_ids[data_->root_marker] : 0; }
 double MultiCamMapper::get_marker_size() { return data_ ? data_->marker_size : 0; }
+void MultiCamMapper::remove_distortions() {
+    if (!data_) return;
+    aar_dataset *d = data_;
+    for (int c = 0; c < d->num_cams; c++) {
+        std::vector<int64_t> idx;
+        for (int64_t o = 0; o < d->num_obs; o++)
+            if (d->obs_cam[o] == c) idx.push_back(o);
+        if (idx.empty()) continue;
+        std::vector<float> pts(8 * idx.size());
+        for (size_t k = 0; k < idx.size(); k++) memcpy(&pts[8 * k], d->obs_uv + 8 * idx[k], 8 * sizeof(float));
+        if (aar_undistort_points(d->cam_mats + 9 * c, d->dist_coeffs + 5 * c, 5, (int64_t)(4 * idx.size()), pts.data(), pts.data(), device_id))
+            throw std::runtime_error(aar_last_error());
+        for (size_t k = 0; k < idx.size(); k++) memcpy(d->obs_uv + 8 * idx[k], &pts[8 * k], 8 * sizeof(float));
+    }
+    drop_problem();   // the device copy of the observations is stale now
+}
+
 std::vector<std::array<int, 2>> MultiCamMapper::get_image_sizes() {
     std::vector<std::array<int, 2>> r;
     if (data_)

@@ -69,6 +69,10 @@ class MultiCamMapper {
     bool write_solution_file(std::string path);                 // :1053-1099
     bool read_solution_file(std::string path);                  // :1124-1205
     void write_text_solution_file(std::string text_path);       // :1233-1268
+    // :554-578: cv::undistortPoints(corners, K, dist, noArray(), P = K) on every detection, camera by camera, on the device.
+    // The reference runs it inside init() on raw detections; `.solution` files already hold undistorted corners, so here it is
+    // an explicit call for data sets built from raw `aruco.detections` + calib files.  Throws std::runtime_error on failure.
+    void remove_distortions();
 
     MatArrays get_mat_arrays();
     size_t get_root_cam();     // ids, as in the reference

@@ -90,6 +90,20 @@ int aar_solution_write(const char *path, const aar_dataset *);
 int aar_solution_write_yaml(const char *path, const aar_dataset *);
 int aar_detections_write(const char *path, const aar_dataset *);
 
+/* Camera calibration file <dir>/<cam>/calib.{xml,yml,yaml}: the four keys CamConfig::read_from_file takes from a
+ * cv::FileStorage (libs/cam_config.cpp:52-80): image_width, image_height, camera_matrix (3x3), distortion_coefficients
+ * (up to AAR_MAX_DIST values in OpenCV's order k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4; the rest of dist is zero-filled).
+ * XML and YAML 1.0 dialects of cv::FileStorage. */
+#define AAR_MAX_DIST 12
+int aar_cam_config_read(const char *path, double K[9], double dist[AAR_MAX_DIST], int32_t *n_dist, int32_t *width, int32_t *height);
+
+/* MultiCamMapper::remove_distortions for the corners of ONE camera (libs/multicam_mapper.cpp:554-578):
+ * cv::undistortPoints(points, out, K, dist, noArray(), P = K) -- the fixed-point inversion of the distortion model (five
+ * iterations, as OpenCV 3.2 does for a coefficient vector) followed by re-projection with K; float in, float out, fp64
+ * inside.  Runs on the device (uv_in / uv_out are host pointers, [n_points][2]); uv_out may alias uv_in. */
+int aar_undistort_points(const double K[9], const double *dist, int32_t n_dist, int64_t n_points, const float *uv_in,
+                         float *uv_out, int32_t device_id);
+
 /* cv::Rodrigues as used at libs/multicam_mapper.cpp:470,478 (R row-major 3x3) */
 void aar_rodrigues_vec2mat(const double w[3], double R[9]);
 void aar_rodrigues_mat2vec(const double R[9], double w[3]);

@@ -885,3 +885,39 @@ void orc_reproj_stats(const orc_problem *p, const double *x_full, const double *
 }
 
 }  // extern "C"
+
+// ---- cv::undistortPoints restatement (see ba_oracle.h) ----
+extern "C" void orc_undistort_points(const double K[9], const double *dist, int n_dist, int64_t n, const float *in, float *out) {
+    double k[12];
+    for (int i = 0; i < 12; i++) k[i] = (i < n_dist) ? dist[i] : 0.0;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5], ifx = 1.0 / fx, ify = 1.0 / fy;
+    for (int64_t i = 0; i < n; i++) {
+        double x = ((double)in[2 * i] - cx) * ifx, y = ((double)in[2 * i + 1] - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int it = 0; it < 5; it++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1.0 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1.0 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double dx = 2.0 * k[2] * x * y + k[3] * (r2 + 2.0 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double dy = k[2] * (r2 + 2.0 * y * y) + 2.0 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - dx) * icdist;
+            y = (y0 - dy) * icdist;
+        }
+        const double xx = K[0] * x + K[1] * y + K[2], yy = K[3] * x + K[4] * y + K[5], ww = 1.0 / (K[6] * x + K[7] * y + K[8]);
+        out[2 * i] = (float)(xx * ww);
+        out[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+extern "C" void orc_distort_points(const double K[9], const double *dist, int n_dist, int64_t n, const double *in, double *out) {
+    double k[12];
+    for (int i = 0; i < 12; i++) k[i] = (i < n_dist) ? dist[i] : 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        const double x = (in[2 * i] - K[2]) / K[0], y = (in[2 * i + 1] - K[5]) / K[4];
+        const double r2 = x * x + y * y;
+        const double cdist = (1.0 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2) / (1.0 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2);
+        const double xd = x * cdist + 2.0 * k[2] * x * y + k[3] * (r2 + 2.0 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double yd = y * cdist + k[2] * (r2 + 2.0 * y * y) + 2.0 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        out[2 * i] = K[0] * xd + K[2];
+        out[2 * i + 1] = K[4] * yd + K[5];
+    }
+}

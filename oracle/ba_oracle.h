@@ -97,6 +97,16 @@ double orc_lm_solve(const orc_problem *p, const double *x_full, double *z_inout,
 void orc_reproj_stats(const orc_problem *p, const double *x_full, const double *z, double *rmse,
                       double *mean_dist, double *sum_sq);
 
+/* MultiCamMapper::remove_distortions for one camera: cv::undistortPoints(src, dst, K, dist, noArray(), P = K)
+ * (libs/multicam_mapper.cpp:570).  OpenCV is not in the reference tree (third-party, tested version 3.2.0, README.md:11): this
+ * restates the published algorithm of that version's cvUndistortPoints -- normalise with K, five fixed-point iterations of
+ * the inverse distortion model (k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4), re-project with P = K; fp64 inside, float in / out.
+ * PARITY UNPINNED against OpenCV itself.  in / out: [n][2]. */
+void orc_undistort_points(const double K[9], const double *dist, int n_dist, int64_t n, const float *in, float *out);
+/* The forward model (what cv::projectPoints applies to a normalised point): ideal pixel -> distorted pixel, in fp64.  Test
+ * helper for the round trip distort(undistort(p)) = p. */
+void orc_distort_points(const double K[9], const double *dist, int n_dist, int64_t n, const double *in, double *out);
+
 #ifdef __cplusplus
 }
 #endif

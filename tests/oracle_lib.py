@@ -77,6 +77,9 @@ def oracle():
         L.orc_lm_solve.argtypes = [pp, _dp, _dp, C.POINTER(OrcLmParams), C.c_int, C.c_int, C.POINTER(OrcLmIter),
                                    C.c_int32, C.POINTER(C.c_int32), C.c_int32]
         L.orc_reproj_stats.argtypes = [pp, _dp, _dp, _dp, _dp, _dp]
+        _fp = C.POINTER(C.c_float)
+        L.orc_undistort_points.argtypes = [_dp, _dp, C.c_int, C.c_int64, _fp, _fp]
+        L.orc_distort_points.argtypes = [_dp, _dp, C.c_int, C.c_int64, _dp, _dp]
         _orc = L
     return _orc
 
@@ -290,3 +293,26 @@ def rodrigues_mat2vec(R):
     w = np.zeros(3)
     oracle().orc_rodrigues_mat2vec(_d(R), _d(w))
     return w
+
+
+def undistort_points(K, dist, uv):
+    """oracle restatement of cv::undistortPoints(.., K, dist, noArray(), P = K) (float in / out)"""
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    dist = np.ascontiguousarray(dist, dtype=np.float64).reshape(-1)
+    uv = np.ascontiguousarray(uv, dtype=np.float32)
+    out = np.empty_like(uv)
+    fp = C.POINTER(C.c_float)
+    oracle().orc_undistort_points(K.ctypes.data_as(_dp), dist.ctypes.data_as(_dp), len(dist), uv.size // 2,
+                                  uv.ctypes.data_as(fp), out.ctypes.data_as(fp))
+    return out
+
+
+def distort_points(K, dist, uv):
+    """forward distortion model, fp64 (ideal pixel -> distorted pixel)"""
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    dist = np.ascontiguousarray(dist, dtype=np.float64).reshape(-1)
+    uv = np.ascontiguousarray(uv, dtype=np.float64)
+    out = np.empty_like(uv)
+    oracle().orc_distort_points(K.ctypes.data_as(_dp), dist.ctypes.data_as(_dp), len(dist), uv.size // 2,
+                                uv.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
+    return out

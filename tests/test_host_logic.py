@@ -169,3 +169,81 @@ def test_find_solution_driver_file_contract(tmp_path):
         run = subprocess.run([exe, folder, "0.05"], capture_output=True, text=True)
         assert run.returncode != 0 and "no HIP device" in (run.stderr + run.stdout)
         assert not os.path.exists(os.path.join(folder, "final.solution"))
+
+
+# ---- calibration files and remove_distortions ----
+CALIB_XML = """<?xml version="1.0"?>
+<opencv_storage>
+<calibration_time>"Mon Feb 18 10:00:00 2019"</calibration_time>
+<image_width>1920</image_width>
+<image_height>1080</image_height>
+<camera_matrix type_id="opencv-matrix">
+  <rows>3</rows>
+  <cols>3</cols>
+  <dt>d</dt>
+  <data>
+    1.4321e+03 0. 9.61e+02 0. 1.4298e+03 5.395e+02 0. 0. 1.</data></camera_matrix>
+<distortion_coefficients type_id="opencv-matrix">
+  <rows>1</rows>
+  <cols>5</cols>
+  <dt>d</dt>
+  <data>
+    -1.1e-01 8.5e-02 1.2e-03 -7.e-04 -1.9e-02</data></distortion_coefficients>
+<avg_reprojection_error>3.1e-01</avg_reprojection_error>
+</opencv_storage>
+"""
+
+CALIB_YAML = """%YAML:1.0
+---
+image_width: 1280
+image_height: 720
+camera_matrix: !!opencv-matrix
+   rows: 3
+   cols: 3
+   dt: d
+   data: [ 9.5e+02, 0., 6.4e+02, 0., 9.52e+02,
+       3.6e+02, 0., 0., 1. ]
+distortion_coefficients: !!opencv-matrix
+   rows: 8
+   cols: 1
+   dt: d
+   data: [ 0.2, -0.1, 0.001, 0.002, 0.01, 0.3, -0.05, 0.004 ]
+"""
+
+
+def test_cam_config_reader_xml_and_yaml(tmp_path):
+    # the four keys CamConfig::read_from_file takes (libs/cam_config.cpp:52-80), both cv::FileStorage dialects
+    px = tmp_path / "calib.xml"
+    px.write_text(CALIB_XML)
+    K, dist, size = aar.cam_config_read(str(px))
+    assert size == (1920, 1080)
+    np.testing.assert_array_equal(K, [[1432.1, 0, 961.0], [0, 1429.8, 539.5], [0, 0, 1]])
+    np.testing.assert_array_equal(dist, [-0.11, 0.085, 0.0012, -0.0007, -0.019])
+    py = tmp_path / "calib.yml"
+    py.write_text(CALIB_YAML)
+    K, dist, size = aar.cam_config_read(str(py))
+    assert size == (1280, 720)
+    np.testing.assert_array_equal(K, [[950.0, 0, 640.0], [0, 952.0, 360.0], [0, 0, 1]])
+    np.testing.assert_array_equal(dist, [0.2, -0.1, 0.001, 0.002, 0.01, 0.3, -0.05, 0.004])
+    # a file that lacks one of the keys is refused, as the reference does (:57-77); so is a missing file
+    bad = tmp_path / "bad.yml"
+    bad.write_text(CALIB_YAML.replace("image_height", "image_heigth"))
+    with pytest.raises(aar.AarError):
+        aar.cam_config_read(str(bad))
+    with pytest.raises(aar.AarError):
+        aar.cam_config_read(str(tmp_path / "nope.xml"))
+
+
+def test_oracle_undistort_inverts_the_distortion_model():
+    # distort(undistort(p)) = p: the fixed-point inversion against the forward model, 5- and 8-coefficient vectors
+    rng = np.random.default_rng(7)
+    K = np.array([[1432.1, 0, 961.0], [0, 1429.8, 539.5], [0, 0, 1]])
+    for dist in ([-0.11, 0.085, 0.0012, -0.0007, -0.019], [0.2, -0.1, 0.001, 0.002, 0.01, 0.3, -0.05, 0.004], []):
+        uv = np.stack([rng.uniform(100, 1820, 4000), rng.uniform(60, 1020, 4000)], axis=1).astype(np.float32)
+        und = ol.undistort_points(K, dist, uv)
+        back = ol.distort_points(K, dist, und.astype(np.float64))
+        # float output of undistortPoints (~6e-5 px at 1000 px) + what five iterations of the contraction leave at the image
+        # corners (2.5e-3 px for the strong rational model)
+        assert np.abs(back - uv).max() < (5e-3 if len(dist) > 5 else 2e-3), (dist, np.abs(back - uv).max())
+        if len(dist) == 0:
+            np.testing.assert_allclose(und, uv, atol=1.3e-4)   # no distortion: K^-1 then K, rounded to float
