@@ -29,7 +29,7 @@ SYMBOLS = [
     "aar_lm_get_solution", "aar_lm_solve", "aar_get_stage_times", "aar_reproj_stats", "aar_device_count",
     "aar_device_synchronize", "aar_set_kernel_profiling", "aar_get_kernel_times", "aar_kernel_name",
     "aar_problem_set_huber_delta", "aar_problem_get_huber_delta", "aar_track", "aar_cam_config_read",
-    "aar_undistort_points",
+    "aar_undistort_points", "aar_local_group_create", "aar_local_group_destroy", "aar_comm_create_local",
 ]
 NUM_KERNELS = 13
 
@@ -155,6 +155,10 @@ def lib():
     L.aar_kernel_name.argtypes = [C.c_int]
     L.aar_kernel_name.restype = C.c_char_p
     L.aar_track.argtypes = [C.c_void_p, dp, C.POINTER(CLmParams), C.POINTER(C.c_int32), dp]
+    L.aar_local_group_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+    L.aar_local_group_destroy.argtypes = [C.c_void_p]
+    L.aar_local_group_destroy.restype = None
+    L.aar_comm_create_local.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.aar_cam_config_read.argtypes = [C.c_char_p, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.aar_undistort_points.argtypes = [dp, dp, C.c_int32, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]
     L.aar_problem_set_huber_delta.argtypes = [C.c_void_p, C.c_float]
@@ -366,9 +370,32 @@ class Comm:
         self.world, self.rank = world, rank
         _check(lib().aar_comm_create(uid, world, rank, device, C.byref(self.handle)))
 
+    @classmethod
+    def local(cls, group, rank, device=0):
+        """Rank `rank` of an in-process LocalGroup (all ranks on one GPU, one host thread each)."""
+        self = cls.__new__(cls)
+        self.handle = C.c_void_p()
+        self.world, self.rank = group.world, rank
+        _check(lib().aar_comm_create_local(group.handle, rank, device, C.byref(self.handle)))
+        return self
+
     def close(self):
         if self.handle:
             lib().aar_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class LocalGroup:
+    """aar_local_group: the in-process stand-in for an RCCL communicator (tests / bring-up on a 1-GPU box)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.handle = C.c_void_p()
+        _check(lib().aar_local_group_create(world, C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            lib().aar_local_group_destroy(self.handle)
             self.handle = C.c_void_p()
 
 

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 #include "../host/internal.h"
@@ -71,10 +73,42 @@ int load_nccl() {
 }
 }  // namespace
 
+// In-process stand-in for a communicator (bring-up / tests): `world` host threads of ONE process, each with its own
+// aar_problem on the SAME GPU, exchange through this group instead of RCCL.  Every rule of the sharded path (frame ranges,
+// the all-reduces of S | rhs, of the step's scalars, of the initial diagonal, the final gather) runs unchanged; only the
+// transport differs.  Lets the multi-rank logic be checked on a 1-GPU box.
+struct aar_local_group {
+    int world = 1;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long gen = 0;
+    std::vector<const double *> ptrs;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned long long g = gen;
+        if (++arrived == world) { arrived = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
 struct aar_comm {
     NcclComm comm = nullptr;
     int world = 1, rank = 0, device = 0;
+    aar_local_group *local = nullptr;   // non-null: in-process group instead of RCCL
+    double *tmp = nullptr;              // local transport: reduction scratch on the device
+    size_t tmp_count = 0;
 };
+
+namespace {
+__global__ void k_local_reduce(double *__restrict__ out, const double *const *__restrict__ in, int world, size_t count, int is_max) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double v = in[0][i];
+    for (int r = 1; r < world; r++) v = is_max ? fmax(v, in[r][i]) : v + in[r][i];   // fixed rank order: every rank gets the same bits
+    out[i] = v;
+}
+}  // namespace
 
 #define NCCL_TRY(expr)                                                                                          \
     do {                                                                                                        \
@@ -182,6 +216,25 @@ int upload_z(aar_problem *pb, const double *x_full, int which) {
 
 int allreduce(aar_problem *pb, double *buf, size_t count, int op) {
     if (!pb->comm) return AAR_OK;
+    if (aar_local_group *g = pb->comm->local) {   // in-process transport (see aar_local_group)
+        aar_comm *c = pb->comm;
+        if (c->tmp_count < count + (size_t)g->world) {
+            if (c->tmp) (void)hipFree(c->tmp);
+            c->tmp_count = count + (size_t)g->world;
+            HIP_TRY(hipMalloc((void **)&c->tmp, c->tmp_count * sizeof(double)));
+        }
+        HIP_TRY(hipStreamSynchronize(pb->stream));            // my contribution is complete
+        g->ptrs[c->rank] = buf;
+        g->barrier();                                         // ... and so is everybody else's
+        const double **d_ptrs = reinterpret_cast<const double **>(c->tmp + count);
+        HIP_TRY(hipMemcpyAsync(d_ptrs, g->ptrs.data(), sizeof(double *) * g->world, hipMemcpyHostToDevice, pb->stream));
+        hipLaunchKernelGGL(k_local_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, pb->stream, c->tmp, d_ptrs, g->world, count,
+                           op == NCCL_MAX ? 1 : 0);
+        HIP_TRY(hipStreamSynchronize(pb->stream));
+        g->barrier();                                         // everyone has read everyone's buffer: it may be overwritten now
+        HIP_TRY(hipMemcpyAsync(buf, c->tmp, count * sizeof(double), hipMemcpyDeviceToDevice, pb->stream));
+        return AAR_OK;
+    }
     NCCL_TRY(g_nccl.AllReduce(buf, buf, count, NCCL_FLOAT64, op, pb->comm->comm, pb->stream));
     return AAR_OK;
 }
@@ -350,7 +403,7 @@ int launch_scalars(aar_problem *pb, int n_err) {
     pb->seq++;
     {
         StageTimer t(pb, &pb->times.control);
-        launch_reduce_scalars(P, n_err, pb->comm != nullptr, pb->comm ? 0ull : pb->seq, pb->stream);
+        launch_reduce_scalars(P, n_err, false, pb->comm ? 0ull : pb->seq, pb->stream);
         pb->launches += 1;
     }
     if (pb->comm) {
@@ -396,7 +449,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     pb->schur_mu = -1;
     if (pb->comm) {
         StageTimer t(pb, &pb->times.allreduce);
-        int rc = allreduce(pb, P.blk[cur].S, (size_t)P.n_pad * P.n_pad + P.n_pad, NCCL_SUM);   // S and rhs (contiguous)
+        int rc = allreduce(pb, P.blk[cur].S, (size_t)P.n_pad * P.n_pad + 2 * (size_t)P.n_pad, NCCL_SUM);   // S | rhs | g0 (contiguous)
         if (rc) return rc;
     }
     {
@@ -534,7 +587,29 @@ int aar_comm_create(const char id[AAR_COMM_ID_BYTES], int32_t world_size, int32_
 void aar_comm_destroy(aar_comm *c) {
     if (!c) return;
     if (c->comm && g_nccl.ok) g_nccl.CommDestroy(c->comm);
+    if (c->tmp) (void)hipFree(c->tmp);
     delete c;
+}
+
+int aar_local_group_create(int32_t world_size, aar_local_group **out) {
+    if (!out || world_size < 1 || world_size > 64) return set_error(AAR_ERR_INVALID, "aar_local_group_create: bad arguments");
+    aar_local_group *g = new aar_local_group();
+    g->world = world_size;
+    g->ptrs.assign(world_size, nullptr);
+    *out = g;
+    return AAR_OK;
+}
+
+void aar_local_group_destroy(aar_local_group *g) { delete g; }
+
+int aar_comm_create_local(aar_local_group *group, int32_t rank, int32_t device_id, aar_comm **out) {
+    if (!group || !out || rank < 0 || rank >= group->world) return set_error(AAR_ERR_INVALID, "aar_comm_create_local: bad arguments");
+    int rc = ensure_device(device_id);
+    if (rc) return rc;
+    aar_comm *c = new aar_comm();
+    c->world = group->world; c->rank = rank; c->device = device_id; c->local = group;
+    *out = c;
+    return AAR_OK;
 }
 
 void aar_lm_default_params(aar_lm_params *p) {  // libs/multicam_mapper.cpp:326-330 over libs/sparselevmarq.h:41-49
@@ -799,8 +874,11 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     for (int w = 0; w < 2; w++) {
         AL(blk[w].V, (size_t)F * 36); AL(blk[w].gf, (size_t)F * 6); AL(blk[w].W, (size_t)P.total_slots * 36);
         AL(blk[w].Vinv, (size_t)F * 36); AL(blk[w].hf, (size_t)F * 6);
-        // rhs lives right behind S: one all-reduce covers both on the multi-GPU path
-        AL(blk[w].S, (size_t)P.n_pad * P.n_pad + P.n_pad); P.blk[w].rhs = P.blk[w].S + (size_t)P.n_pad * P.n_pad; AL(blk[w].g0, P.n_pad);
+        // rhs and g0 live right behind S: ONE all-reduce makes all three global on the multi-GPU path (g0, the shared part of
+        // B = -J^T r, is added to the right-hand side on first touch and enters delta.B, so every rank needs all of it)
+        AL(blk[w].S, (size_t)P.n_pad * P.n_pad + 2 * (size_t)P.n_pad);
+        P.blk[w].rhs = P.blk[w].S + (size_t)P.n_pad * P.n_pad;
+        P.blk[w].g0 = P.blk[w].rhs + P.n_pad;
     }
     if (P.n_smwork) AL(Yw, (size_t)P.total_slots * 36);
     AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad); AL(bs_flags, (size_t)P.nT + 1);
@@ -1027,10 +1105,10 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
         if ((rc = damped_try(pb, mu_used, true))) return rc;
         const double *sc = pb->h_scal;
         const double err = sc[0];
-        // L = 0.5 * delta^T (mu*delta - B) (:406); frame pieces were summed over ranks, the shared-parameter
-        // |delta|^2 is replicated and counted once, its delta.g piece is part of the rank sum
+        // L = 0.5 * delta^T (mu*delta - B) (:406); frame pieces were summed over ranks; the shared-parameter pieces
+        // |delta_s|^2 and delta_s . g0 are computed from replicated data (g0 was all-reduced with S) and counted once
         const double d2 = sc[1] + sc[5];
-        const double dg = pb->comm ? sc[2] : sc[2] + sc[6];
+        const double dg = sc[2] + sc[6];
         const double Lq = 0.5 * (mu_used * d2 - dg);
         dnorm = std::sqrt(d2);
         gain = (err - pb->prevErr) / Lq;

@@ -122,6 +122,14 @@ int aar_comm_make_id(char id[AAR_COMM_ID_BYTES]);
 int aar_comm_create(const char id[AAR_COMM_ID_BYTES], int32_t world_size, int32_t rank, int32_t device_id,
                     aar_comm **out);
 void aar_comm_destroy(aar_comm *);
+/* In-process stand-in for a communicator (bring-up and tests on a 1-GPU box): `world_size` host threads of one process,
+ * each with its own aar_problem on the same GPU, exchange through the group instead of RCCL; the sharded path itself
+ * (frame ranges, every all-reduce, the final gather) is unchanged.  Every rank's calls must be made concurrently, one
+ * thread per rank, exactly as separate processes would. */
+typedef struct aar_local_group aar_local_group;
+int aar_local_group_create(int32_t world_size, aar_local_group **out);
+void aar_local_group_destroy(aar_local_group *);
+int aar_comm_create_local(aar_local_group *group, int32_t rank, int32_t device_id, aar_comm **out);
 
 /* ---------------------------------------------------------------------------------------------
  * The problem on the device.

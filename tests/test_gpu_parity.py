@@ -378,3 +378,41 @@ def test_remove_distortions_kernel_equals_oracle():
         ref = ol.undistort_points(K, dist, uv)
         assert np.array_equal(got, ref), dist
     assert aar.undistort_points(K, [0.1], uv[:0]).shape == (0, 2)
+
+
+def _run_rank(group, rank, ds, out, with_huber=False):
+    comm = aar.Comm.local(group, rank, 0)
+    try:
+        with aar.Problem(ds, comm=comm, with_huber=with_huber) as p:
+            x, rep = p.lm_solve(ds.x_full)
+            out[rank] = (x, rep, p.local_obs)
+    except Exception as e:   # a rank that dies would leave the others waiting at a barrier: report, do not hang the test
+        out[rank] = e
+    finally:
+        comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_lm_on_one_gpu_through_the_local_group(world):
+    # The multi-rank path -- frame-range shards, all-reduces of S | rhs, of the step's scalars and of the initial diagonal,
+    # the final gather -- with `world` ranks as host threads on ONE GPU (the in-process transport replaces RCCL, nothing else
+    # changes): every rank must return the single-GPU trace and the full pose vector
+    import threading
+    ds, g = load_golden("g1_cfg2")
+    group = aar.LocalGroup(world)
+    out = [None] * world
+    th = [threading.Thread(target=_run_rank, args=(group, r, ds, out)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a rank is stuck"
+    group.close()
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+        x, rep, nloc = out[r]
+        np.testing.assert_allclose([t["err"] for t in rep["trace"]], g["analytic_err"], rtol=1e-7)
+        np.testing.assert_allclose(x, g["analytic_x"], atol=1e-7)
+    assert sum(o[2] for o in out) == ds.num_obs
+    assert all(np.array_equal(out[0][0], o[0]) for o in out[1:])   # fixed reduction order: identical bits on every rank
