@@ -393,13 +393,13 @@ def _run_rank(group, rank, ds, out, with_huber=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_sharded_lm_on_one_gpu_through_the_local_group(world):
+@pytest.mark.parametrize("world,name", [(2, "g1_cfg2"), (3, "g1_cfg2"), (8, "g1_cfg2"), (4, "g1_cfg3_cut")])
+def test_sharded_lm_on_one_gpu_through_the_local_group(world, name):
     # The multi-rank path -- frame-range shards, all-reduces of S | rhs, of the step's scalars and of the initial diagonal,
     # the final gather -- with `world` ranks as host threads on ONE GPU (the in-process transport replaces RCCL, nothing else
     # changes): every rank must return the single-GPU trace and the full pose vector
     import threading
-    ds, g = load_golden("g1_cfg2")
+    ds, g = load_golden(name)
     group = aar.LocalGroup(world)
     out = [None] * world
     th = [threading.Thread(target=_run_rank, args=(group, r, ds, out)) for r in range(world)]
