@@ -40,6 +40,24 @@ class OrcLmIter(C.Structure):
                 ("accepted", C.c_int32), ("tries", C.c_int32)]
 
 
+class OrcCamModel(C.Structure):
+    _fields_ = [("K", C.c_double * 9), ("dist", C.c_double * 12), ("n_dist", C.c_int32)]
+
+
+def cam_models(Ks, dists):
+    """array of orc_cam_model from per-camera K (3x3) and distortion vectors"""
+    arr = (OrcCamModel * len(Ks))()
+    for i, (K, d) in enumerate(zip(Ks, dists)):
+        K = np.asarray(K, dtype=np.float64).reshape(9)
+        d = np.asarray(d, dtype=np.float64).reshape(-1)
+        for j in range(9):
+            arr[i].K[j] = K[j]
+        for j in range(12):
+            arr[i].dist[j] = d[j] if j < len(d) else 0.0
+        arr[i].n_dist = len(d)
+    return arr
+
+
 def build_oracle(with_ref=True):
     """Compile the checker (gcc, seconds).  The _ref target needs /root/reference and is skipped without it."""
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"])
@@ -80,6 +98,18 @@ def oracle():
         _fp = C.POINTER(C.c_float)
         L.orc_undistort_points.argtypes = [_dp, _dp, C.c_int, C.c_int64, _fp, _fp]
         L.orc_distort_points.argtypes = [_dp, _dp, C.c_int, C.c_int64, _dp, _dp]
+        cm = C.POINTER(OrcCamModel)
+        L.orc_undistort_normalized.argtypes = [cm, C.c_int64, _fp, _fp]
+        L.orc_ippe_square.argtypes = [C.c_float, cm, C.c_int64, _fp, _dp, _dp, _dp, _dp]
+        L.orc_vote.restype = C.c_int64
+        L.orc_vote.argtypes = [C.c_double, C.c_int64, _dp, _dp, _dp, _dp, _dp]
+        L.orc_inv4.argtypes = [_dp, _dp]
+        L.orc_init_run.restype = C.c_void_p
+        L.orc_init_run.argtypes = [C.c_int32, C.c_int32, C.c_int64, _ip, _ip, _ip, _fp, C.c_double, cm, _ip, C.c_int32,
+                                   C.c_double, C.c_int32]
+        L.orc_init_counts.argtypes = [C.c_void_p, _ip]
+        L.orc_init_get.argtypes = [C.c_void_p, _ip, _dp, _ip, _dp, _ip, _dp, _ip]
+        L.orc_init_free.argtypes = [C.c_void_p]
         _orc = L
     return _orc
 
@@ -316,3 +346,60 @@ def distort_points(K, dist, uv):
     oracle().orc_distort_points(K.ctypes.data_as(_dp), dist.ctypes.data_as(_dp), len(dist), uv.size // 2,
                                 uv.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
     return out
+
+
+# ---- Initializer / IPPE restatement (oracle/init_oracle.cpp; parity unpinned, see its header) ----
+def ippe_square(marker_size, K, dist, uv):
+    """aruco::solvePnP_ for n markers of one camera: (T1[n,4,4], e1[n], T2[n,4,4], e2[n])"""
+    uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 8)
+    n = len(uv)
+    cams = cam_models([K], [dist])
+    T1 = np.zeros((n, 16)); T2 = np.zeros((n, 16)); e1 = np.zeros(n); e2 = np.zeros(n)
+    fp = C.POINTER(C.c_float)
+    oracle().orc_ippe_square(float(marker_size), cams, n, uv.ctypes.data_as(fp), _d(T1), _d(e1), _d(T2), _d(e2))
+    return T1.reshape(n, 4, 4), e1, T2.reshape(n, 4, 4), e2
+
+
+def vote(marker_size, T, T1inv, T2inv):
+    """Initializer::find_best_transformation on one set: (best index, weight, cost[n])"""
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(-1, 16)
+    A = np.ascontiguousarray(T1inv, dtype=np.float64).reshape(-1, 16)
+    B = np.ascontiguousarray(T2inv, dtype=np.float64).reshape(-1, 16)
+    n = len(T)
+    cost = np.zeros(max(n, 1)); w = C.c_double(0)
+    best = oracle().orc_vote(float(marker_size), n, _d(T), _d(A), _d(B), _d(cost), C.byref(w))
+    return int(best), w.value, cost[:n]
+
+
+def inv4(A):
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(16)
+    out = np.zeros(16)
+    oracle().orc_inv4(_d(A), _d(out))
+    return out.reshape(4, 4)
+
+
+def init_run(num_cam_slots, num_frames, det_frame, det_cam, det_id, det_uv, marker_size, Ks, dists, excluded=(),
+             threshold=2.0, min_detections=2):
+    """Initializer(detections, marker_size, cam_configs, excluded_cams): dict of ids and 4x4 transforms"""
+    df = np.ascontiguousarray(det_frame, dtype=np.int32); dc = np.ascontiguousarray(det_cam, dtype=np.int32)
+    di = np.ascontiguousarray(det_id, dtype=np.int32); uv = np.ascontiguousarray(det_uv, dtype=np.float32).reshape(-1, 8)
+    ex = np.ascontiguousarray(list(excluded), dtype=np.int32)
+    cams = cam_models(Ks, dists)
+    L = oracle()
+    ip = lambda a: a.ctypes.data_as(_ip)
+    h = L.orc_init_run(num_cam_slots, num_frames, len(df), ip(df), ip(dc), ip(di), uv.ctypes.data_as(C.POINTER(C.c_float)),
+                       float(marker_size), cams, ip(ex), len(ex), float(threshold), int(min_detections))
+    try:
+        cnt = np.zeros(6, dtype=np.int32)
+        L.orc_init_counts(h, ip(cnt))
+        c, m, f, kept = (int(v) for v in cnt[:4])
+        cam_ids = np.zeros(max(c, 1), dtype=np.int32); T_cam = np.zeros((max(c, 1), 16))
+        marker_ids = np.zeros(max(m, 1), dtype=np.int32); T_marker = np.zeros((max(m, 1), 16))
+        frame_ids = np.zeros(max(f, 1), dtype=np.int32); T_object = np.zeros((max(f, 1), 16))
+        kept_ids = np.zeros(max(kept, 1), dtype=np.int32)
+        L.orc_init_get(h, ip(cam_ids), _d(T_cam), ip(marker_ids), _d(T_marker), ip(frame_ids), _d(T_object), ip(kept_ids))
+    finally:
+        L.orc_init_free(h)
+    return dict(cam_ids=cam_ids[:c], T_cam=T_cam[:c].reshape(c, 4, 4), marker_ids=marker_ids[:m],
+                T_marker=T_marker[:m].reshape(m, 4, 4), frame_ids=frame_ids[:f], T_object=T_object[:f].reshape(f, 4, 4),
+                kept_frame_ids=kept_ids[:kept], root_cam=int(cnt[4]), root_marker=int(cnt[5]))
