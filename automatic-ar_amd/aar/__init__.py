@@ -30,6 +30,8 @@ SYMBOLS = [
     "aar_device_synchronize", "aar_set_kernel_profiling", "aar_get_kernel_times", "aar_kernel_name",
     "aar_problem_set_huber_delta", "aar_problem_get_huber_delta", "aar_track", "aar_cam_config_read",
     "aar_undistort_points", "aar_local_group_create", "aar_local_group_destroy", "aar_comm_create_local",
+    "aar_cam_configs_read", "aar_detections_read", "aar_detections_free", "aar_subseqs_read", "aar_ippe_square",
+    "aar_vote_transforms", "aar_init_default_params", "aar_initializer_run",
 ]
 NUM_KERNELS = 13
 
@@ -102,6 +104,22 @@ class CStageTimes(C.Structure):
 _lib = None
 
 
+class CCamModel(C.Structure):
+    _fields_ = [("K", C.c_double * 9), ("dist", C.c_double * 12), ("n_dist", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32)]
+
+
+class CDetections(C.Structure):
+    _fields_ = [("num_cams", C.c_int32), ("num_frames", C.c_int32), ("num_det", C.c_int64),
+                ("det_frame", C.POINTER(C.c_int32)), ("det_cam", C.POINTER(C.c_int32)), ("det_id", C.POINTER(C.c_int32)),
+                ("det_uv", C.POINTER(C.c_float))]
+
+
+class CInitParams(C.Structure):
+    _fields_ = [("marker_size", C.c_double), ("threshold", C.c_double), ("min_detections", C.c_int32),
+                ("n_excluded", C.c_int32), ("excluded_cams", C.POINTER(C.c_int32)), ("device_id", C.c_int32)]
+
+
 def lib():
     """Load libaar.so (built by __graft_entry__.build() / `make -C automatic-ar_amd`).  Fails loudly when missing."""
     global _lib
@@ -161,6 +179,18 @@ def lib():
     L.aar_comm_create_local.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.aar_cam_config_read.argtypes = [C.c_char_p, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.aar_undistort_points.argtypes = [dp, dp, C.c_int32, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]
+    ip, lp, fp = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float)
+    L.aar_cam_configs_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(CCamModel)), ip]
+    L.aar_detections_read.argtypes = [C.c_char_p, ip, C.c_int32, C.POINTER(C.POINTER(CDetections))]
+    L.aar_detections_free.argtypes = [C.POINTER(CDetections)]
+    L.aar_detections_free.restype = None
+    L.aar_subseqs_read.argtypes = [C.c_char_p, C.POINTER(ip), ip]
+    L.aar_ippe_square.argtypes = [C.c_double, C.POINTER(CCamModel), C.c_int64, fp, dp, dp, dp, dp, C.c_int32]
+    L.aar_vote_transforms.argtypes = [C.c_double, C.c_int64, lp, dp, dp, dp, lp, dp, dp, C.c_int32]
+    L.aar_init_default_params.argtypes = [C.POINTER(CInitParams)]
+    L.aar_init_default_params.restype = None
+    L.aar_initializer_run.argtypes = [C.POINTER(CDetections), C.POINTER(CCamModel), C.c_int32, C.POINTER(CInitParams),
+                                      C.POINTER(C.POINTER(CDataset))]
     L.aar_problem_set_huber_delta.argtypes = [C.c_void_p, C.c_float]
     L.aar_problem_get_huber_delta.argtypes = [C.c_void_p]
     L.aar_problem_get_huber_delta.restype = C.c_float
@@ -334,6 +364,125 @@ def undistort_points(K, dist, uv, device=0):
     _check(lib().aar_undistort_points(_dptr(K), _dptr(dist) if len(dist) else None, len(dist), uv.size // 2,
                                       uv.ctypes.data_as(fp), out.ctypes.data_as(fp), device))
     return out
+
+
+# ---- Initializer (libs/initializer.cpp) ----
+def cam_models(Ks, dists, sizes=None):
+    """array of aar_cam_model, one per camera slot"""
+    arr = (CCamModel * max(len(Ks), 1))()
+    for i, (K, d) in enumerate(zip(Ks, dists)):
+        K = np.asarray(K, dtype=np.float64).reshape(9)
+        d = np.asarray(d, dtype=np.float64).reshape(-1)
+        for j in range(9):
+            arr[i].K[j] = K[j]
+        for j in range(MAX_DIST):
+            arr[i].dist[j] = d[j] if j < len(d) else 0.0
+        arr[i].n_dist = len(d)
+        if sizes is not None:
+            arr[i].width, arr[i].height = int(sizes[i][0]), int(sizes[i][1])
+    return arr
+
+
+def cam_configs_read(folder):
+    """CamConfig::read_cam_configs: list of (K 3x3, dist, (w, h)) in ascending sub-directory order"""
+    p = C.POINTER(CCamModel)()
+    n = C.c_int32(0)
+    _check(lib().aar_cam_configs_read(folder.encode(), C.byref(p), C.byref(n)))
+    out = []
+    for i in range(n.value):
+        m = p[i]
+        out.append((np.array(m.K[:]).reshape(3, 3), np.array(m.dist[: m.n_dist]), (m.width, m.height)))
+    C.CDLL(None).free(p)
+    return out
+
+
+class Detections:
+    """numpy copy of an aar_detections (the content of an aruco.detections file)"""
+
+    def __init__(self, num_cams, num_frames, det_frame, det_cam, det_id, det_uv):
+        self.num_cams, self.num_frames = int(num_cams), int(num_frames)
+        self.det_frame = np.ascontiguousarray(det_frame, dtype=np.int32)
+        self.det_cam = np.ascontiguousarray(det_cam, dtype=np.int32)
+        self.det_id = np.ascontiguousarray(det_id, dtype=np.int32)
+        self.det_uv = np.ascontiguousarray(det_uv, dtype=np.float32).reshape(-1, 8)
+
+    def as_c(self):
+        c = CDetections()
+        c.num_cams, c.num_frames, c.num_det = self.num_cams, self.num_frames, len(self.det_frame)
+        ip = C.POINTER(C.c_int32)
+        c.det_frame = self.det_frame.ctypes.data_as(ip)
+        c.det_cam = self.det_cam.ctypes.data_as(ip)
+        c.det_id = self.det_id.ctypes.data_as(ip)
+        c.det_uv = self.det_uv.ctypes.data_as(C.POINTER(C.c_float))
+        return c
+
+
+def detections_read(path, subseqs=None):
+    """Initializer::read_detections_file (libs/initializer.cpp:316-362)"""
+    p = C.POINTER(CDetections)()
+    ss = np.ascontiguousarray(subseqs if subseqs is not None else [], dtype=np.int32)
+    _check(lib().aar_detections_read(path.encode(), ss.ctypes.data_as(C.POINTER(C.c_int32)) if len(ss) else None, len(ss),
+                                     C.byref(p)))
+    try:
+        d = p.contents
+        n = d.num_det
+        return Detections(d.num_cams, d.num_frames, _np(d.det_frame, n, np.int32), _np(d.det_cam, n, np.int32),
+                          _np(d.det_id, n, np.int32), _np(d.det_uv, 8 * n, np.float32))
+    finally:
+        lib().aar_detections_free(p)
+
+
+def subseqs_read(path):
+    p = C.POINTER(C.c_int32)()
+    n = C.c_int32(0)
+    _check(lib().aar_subseqs_read(path.encode(), C.byref(p), C.byref(n)))
+    out = _np(p, n.value, np.int32)
+    C.CDLL(None).free(p)
+    return out
+
+
+def ippe_square(marker_size, K, dist, uv, device=0):
+    """aruco::solvePnP_ for n markers of one camera on the GPU: (T1[n,4,4], e1[n], T2[n,4,4], e2[n])"""
+    uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 8)
+    n = len(uv)
+    cams = cam_models([K], [dist])
+    T1 = np.zeros((max(n, 1), 16)); T2 = np.zeros((max(n, 1), 16)); e1 = np.zeros(max(n, 1)); e2 = np.zeros(max(n, 1))
+    _check(lib().aar_ippe_square(float(marker_size), cams, n, uv.ctypes.data_as(C.POINTER(C.c_float)), _dptr(T1), _dptr(e1),
+                                 _dptr(T2), _dptr(e2), device))
+    return T1[:n].reshape(n, 4, 4), e1[:n], T2[:n].reshape(n, 4, 4), e2[:n]
+
+
+def vote_transforms(marker_size, set_begin, T, T1inv, T2inv, device=0):
+    """Initializer::find_best_transformation for several candidate sets on the GPU: (best[s], weight[s], cost[n])"""
+    sb = np.ascontiguousarray(set_begin, dtype=np.int64)
+    ns = len(sb) - 1
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(-1, 16)
+    A = np.ascontiguousarray(T1inv, dtype=np.float64).reshape(-1, 16)
+    B = np.ascontiguousarray(T2inv, dtype=np.float64).reshape(-1, 16)
+    n = len(T)
+    best = np.zeros(max(ns, 1), dtype=np.int64); weight = np.zeros(max(ns, 1)); cost = np.zeros(max(n, 1))
+    lp = C.POINTER(C.c_int64)
+    _check(lib().aar_vote_transforms(float(marker_size), ns, sb.ctypes.data_as(lp), _dptr(T), _dptr(A), _dptr(B),
+                                     best.ctypes.data_as(lp), _dptr(weight), _dptr(cost), device))
+    return best[:ns], weight[:ns], cost[:n]
+
+
+def initializer_run(det, Ks, dists, marker_size, sizes=None, excluded=(), threshold=2.0, min_detections=2, device=0):
+    """Initializer(...) + MultiCamMapper(Initializer&): the data set the reference writes as initial.solution"""
+    prm = CInitParams()
+    lib().aar_init_default_params(C.byref(prm))
+    prm.marker_size, prm.threshold, prm.min_detections, prm.device_id = marker_size, threshold, min_detections, device
+    ex = np.ascontiguousarray(list(excluded), dtype=np.int32)
+    prm.n_excluded = len(ex)
+    prm.excluded_cams = ex.ctypes.data_as(C.POINTER(C.c_int32)) if len(ex) else None
+    cams = cam_models(Ks, dists, sizes)
+    c = det.as_c()
+    p = C.POINTER(CDataset)()
+    _check(lib().aar_initializer_run(C.byref(c), cams, len(Ks), C.byref(prm), C.byref(p)))
+    try:
+        return Dataset(p)
+    finally:
+        lib().aar_dataset_free(p)
 
 
 def plan_shards(obs_per_frame, world):

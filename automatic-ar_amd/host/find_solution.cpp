@@ -2,11 +2,11 @@
 //
 //   aar_find_solution <data_folder> <marker_size> [ignored] [-subseqs] [-exclude-cams ...] [-with-huber] [-thresh t]
 //
-// File contract kept from the reference: reads <folder>/initial<suffix>.solution, writes
-// <folder>/final<suffix>.solution and .yaml, prints "The algorithm took: ..." (:45,99-100,162-163,175-177).
-// The step that PRODUCES initial.solution in the reference -- Initializer (IPPE votes + MST,
-// libs/initializer.cpp) -- is outside this path (SURVEY.md 8f "next" #1): run the reference's find_solution
-// once (it writes initial.solution before solve(), :146) or generate a synthetic folder with
+// File contract kept from the reference (:45,99-100,146-147,162-163,175-177): reads <folder>/aruco.detections and
+// <folder>/<cam>/calib.{xml,yml,yaml}, runs the Initializer (IPPE poses, votes, spanning trees -- on the GPU, aar_initializer_run),
+// writes <folder>/initial<suffix>.solution(.yaml), solves, writes <folder>/final<suffix>.solution(.yaml) and prints
+// "The algorithm took: ...".  With -from-initial, or when the folder holds no calibration, it starts from an existing
+// initial<suffix>.solution instead (e.g. one the reference wrote).  A synthetic folder in the reference's formats:
 //   aar_find_solution --synth <config 1..5> <out_folder>
 #include <sys/stat.h>
 
@@ -17,14 +17,16 @@
 #include <cstring>
 #include <iostream>
 #include <set>
+#include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "multicam_mapper.h"
 
 using namespace std;
 
 static int print_usage(const char *a0) {
-    cout << "Usage: " << a0 << " <data_folder_path> <marker_size> [-subseqs] [-exclude-cams <cam_id> ...] [-with-huber] [-thresh <t>]" << endl;
+    cout << "Usage: " << a0 << " <data_folder_path> <marker_size> [ignored] [-subseqs] [-exclude-cams <cam_id> ...] [-with-huber] [-thresh <t>] [-from-initial]" << endl;
     cout << "       " << a0 << " --synth <config 1..5> <out_folder>   (write a synthetic data set in the reference's file formats)" << endl;
     return -1;
 }
@@ -36,6 +38,19 @@ static int synth(int cfg, const string &folder) {
     if (aar_synth_generate(&sd, &d)) { cerr << aar_last_error() << endl; return 1; }
     mkdir(folder.c_str(), 0755);
     int rc = aar_detections_write((folder + "/aruco.detections").c_str(), d);
+    for (int c = 0; c < d->num_cams && !rc; c++) {  // one calib.yml per camera slot, cv::FileStorage YAML dialect
+        char dir[64];
+        snprintf(dir, sizeof dir, "/cam_%03d", d->cam_ids[c]);
+        mkdir((folder + dir).c_str(), 0755);
+        FILE *f = fopen((folder + dir + "/calib.yml").c_str(), "w");
+        if (!f) { rc = 1; break; }
+        const double *K = d->cam_mats + 9 * c;
+        fprintf(f, "%%YAML:1.0\n---\nimage_width: %d\nimage_height: %d\ncamera_matrix: !!opencv-matrix\n   rows: 3\n   cols: 3\n   dt: d\n   data: [ ",
+                d->image_sizes[2 * c], d->image_sizes[2 * c + 1]);
+        for (int i = 0; i < 9; i++) fprintf(f, "%.17g%s", K[i], i < 8 ? ", " : " ]\n");
+        fprintf(f, "distortion_coefficients: !!opencv-matrix\n   rows: 1\n   cols: 5\n   dt: d\n   data: [ 0., 0., 0., 0., 0. ]\n");
+        fclose(f);
+    }
     rc |= aar_solution_write((folder + "/initial.solution").c_str(), d);
     rc |= aar_solution_write_yaml((folder + "/initial.solution.yaml").c_str(), d);
     if (rc) cerr << aar_last_error() << endl;
@@ -50,7 +65,7 @@ int main(int argc, char *argv[]) {
     if (argc < 3) return print_usage(argv[0]);
     const string folder_path = argv[1];
     const double marker_size = stod(argv[2]);
-    bool use_subseqs = false, with_huber = false, set_threshold = false;
+    bool use_subseqs = false, with_huber = false, set_threshold = false, from_initial = false;
     double threshold = 2.0;
     set<int> excluded_cams;
     enum ArgFlag { NONE, ExcludeCams, Threshold } arg_flag = NONE;
@@ -59,6 +74,7 @@ int main(int argc, char *argv[]) {
         if (a == "-subseqs") use_subseqs = true;
         else if (a == "-exclude-cams") arg_flag = ExcludeCams;
         else if (a == "-with-huber") { with_huber = true; arg_flag = NONE; }
+        else if (a == "-from-initial") { from_initial = true; arg_flag = NONE; }
         else if (a == "-thresh") { set_threshold = true; arg_flag = Threshold; }
         else if (arg_flag == ExcludeCams) excluded_cams.insert(stoi(a));
         else if (arg_flag == Threshold) { threshold = stod(a); arg_flag = NONE; }
@@ -78,9 +94,48 @@ int main(int argc, char *argv[]) {
     name += ".solution";
     const string initial_path = folder_path + "/initial" + name, final_path = folder_path + "/final" + name;
 
-    aar::MultiCamMapper mcm;
-    if (!mcm.read_solution_file(initial_path)) {
-        cerr << "No " << initial_path << ": this driver starts from the initial solution the reference's Initializer writes." << endl;
+    // Initializer (apps/find_solution.cpp:101-113,142-147).  `-thresh` only names the files in the reference (the value never
+    // reaches the Initializer, whose threshold stays 2.0, libs/initializer.h:52); kept that way.
+    aar_cam_model *cams = nullptr;
+    int32_t n_cams = 0;
+    if (!from_initial && aar_cam_configs_read(folder_path.c_str(), &cams, &n_cams) != AAR_OK) n_cams = 0;
+    aar_dataset *init = nullptr;
+    if (!from_initial && n_cams > 0) {
+        try {
+            vector<int> subseqs;
+            if (use_subseqs) {
+                int32_t *ss = nullptr, n_sub = 0;
+                if (aar_subseqs_read((folder_path + "/subseqs.txt").c_str(), &ss, &n_sub)) throw runtime_error(aar_last_error());
+                subseqs.assign(ss, ss + n_sub);
+                free(ss);
+            }
+            aar_detections *detections = aar::Initializer::read_detections_file(folder_path + "/aruco.detections", subseqs);
+            const long long n_det = detections->num_det;
+            const auto t0 = chrono::system_clock::now();
+            try {
+                aar::Initializer initializer(detections, marker_size, vector<aar_cam_model>(cams, cams + n_cams), excluded_cams);
+                init = initializer.release();
+            } catch (...) {
+                aar_detections_free(detections);
+                throw;
+            }
+            aar_detections_free(detections);
+            const chrono::duration<double> di = chrono::system_clock::now() - t0;
+            cout << "Initializer: " << n_det << " detections -> " << init->num_cams << " cameras, " << init->num_markers << " markers, "
+                 << init->num_frames << " frames in " << di.count() << " s" << endl;
+        } catch (const exception &e) {
+            cerr << "Initializer failed: " << e.what() << endl;
+            free(cams);
+            return 1;
+        }
+    }
+    free(cams);
+    aar::MultiCamMapper mcm(init);
+    if (init) {
+        mcm.write_solution_file(initial_path);
+        mcm.write_text_solution_file(initial_path + ".yaml");
+    } else if (!mcm.read_solution_file(initial_path)) {
+        cerr << "No calibration folders under " << folder_path << " and no " << initial_path << endl;
         return 1;
     }
     if (fabs(mcm.get_marker_size() - (double)(float)marker_size) > 1e-9)

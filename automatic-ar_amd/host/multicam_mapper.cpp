@@ -30,6 +30,8 @@ MultiCamMapper::MultiCamMapper(aar_dataset *dataset) : MultiCamMapper() {
     }
 }
 
+MultiCamMapper::MultiCamMapper(Initializer &initializer) : MultiCamMapper(initializer.release()) {}
+
 MultiCamMapper::~MultiCamMapper() {
     drop_problem();
     aar_dataset_free(data_);
@@ -217,6 +219,62 @@ MultiCamMapper::MatArrays MultiCamMapper::get_mat_arrays() {
         ma.transforms_to_root_marker[data_->marker_ids[m]] = to44(m == L.rm ? Rigid::identity() : pose_to_rigid(data_->x_full + L.full_mk0() + 6LL * L.mk_slot(m)));
     for (int f = 0; f < L.F; f++) ma.object_to_global[data_->frame_ids[f]] = to44(pose_to_rigid(data_->x_full + L.full_fr0() + 6LL * f));
     return ma;
+}
+
+// ---- Initializer mirror (libs/initializer.h) ----
+Initializer::Initializer(const aar_detections *dts, double marker_s, const std::vector<aar_cam_model> &cam_c,
+                         const std::set<int> &excluded_cs, int device_id) {
+    aar_init_params prm;
+    aar_init_default_params(&prm);
+    prm.marker_size = marker_s;
+    prm.device_id = device_id;
+    std::vector<int32_t> ex(excluded_cs.begin(), excluded_cs.end());
+    prm.n_excluded = (int32_t)ex.size();
+    prm.excluded_cams = ex.data();
+    if (aar_initializer_run(dts, cam_c.data(), (int32_t)cam_c.size(), &prm, &data_)) throw std::runtime_error(aar_last_error());
+}
+Initializer::~Initializer() { aar_dataset_free(data_); }
+aar_dataset *Initializer::release() {
+    aar_dataset *d = data_;
+    data_ = nullptr;
+    return d;
+}
+aar_detections *Initializer::read_detections_file(std::string path, const std::vector<int> &subseqs) {
+    aar_detections *d = nullptr;
+    std::vector<int32_t> ss(subseqs.begin(), subseqs.end());
+    if (aar_detections_read(path.c_str(), ss.data(), (int32_t)ss.size(), &d)) throw std::runtime_error(aar_last_error());
+    return d;
+}
+std::set<int> Initializer::get_marker_ids() { return data_ ? std::set<int>(data_->marker_ids, data_->marker_ids + data_->num_markers) : std::set<int>(); }
+std::set<int> Initializer::get_cam_ids() { return data_ ? std::set<int>(data_->cam_ids, data_->cam_ids + data_->num_cams) : std::set<int>(); }
+int Initializer::get_root_cam() { return data_ ? data_->cam_ids[data_->root_cam] : -1; }
+int Initializer::get_root_marker() { return data_ ? data_->marker_ids[data_->root_marker] : -1; }
+double Initializer::get_marker_size() { return data_ ? data_->marker_size : 0; }
+std::map<int, Mat44> Initializer::get_transforms_to_root_cam() {
+    std::map<int, Mat44> r;
+    if (!data_) return r;
+    PoseLayout L;
+    L.C = data_->num_cams; L.M = data_->num_markers; L.F = data_->num_frames; L.rc = data_->root_cam; L.rm = data_->root_marker;
+    for (int c = 0; c < L.C; c++)
+        r[data_->cam_ids[c]] = to44(c == L.rc ? Rigid::identity() : pose_to_rigid(data_->x_full + L.full_cam0() + 6LL * L.cam_slot(c)));
+    return r;
+}
+std::map<int, Mat44> Initializer::get_transforms_to_root_marker() {
+    std::map<int, Mat44> r;
+    if (!data_) return r;
+    PoseLayout L;
+    L.C = data_->num_cams; L.M = data_->num_markers; L.F = data_->num_frames; L.rc = data_->root_cam; L.rm = data_->root_marker;
+    for (int m = 0; m < L.M; m++)
+        r[data_->marker_ids[m]] = to44(m == L.rm ? Rigid::identity() : pose_to_rigid(data_->x_full + L.full_mk0() + 6LL * L.mk_slot(m)));
+    return r;
+}
+std::map<int, Mat44> Initializer::get_object_transforms() {
+    std::map<int, Mat44> r;
+    if (!data_) return r;
+    PoseLayout L;
+    L.C = data_->num_cams; L.M = data_->num_markers; L.F = data_->num_frames; L.rc = data_->root_cam; L.rm = data_->root_marker;
+    for (int f = 0; f < L.F; f++) r[data_->frame_ids[f]] = to44(pose_to_rigid(data_->x_full + L.full_fr0() + 6LL * f));
+    return r;
 }
 
 size_t MultiCamMapper::get_root_cam() { return data_ ? (size_t)data_->cam_ids[data_->root_cam] : 0; }

@@ -6,6 +6,7 @@
 #pragma once
 #include <array>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,34 @@ struct SparseLevMarq {
 
 typedef std::array<double, 16> Mat44;  // row-major 4x4, the reference's CV_64F cv::Mat transforms
 
+// Mirror of the reference's Initializer (libs/initializer.h:9-43) over aar_initializer_run: the constructor runs
+// obtain_pose_estimations + init_transforms (IPPE, candidate sets and votes on the device) and throws std::runtime_error
+// on failure; the getters return what the reference's return (ids, id -> 4x4 transform maps).
+class Initializer {
+   public:
+    Initializer(const aar_detections *dts, double marker_s, const std::vector<aar_cam_model> &cam_c,
+                const std::set<int> &excluded_cs = std::set<int>(), int device_id = 0);
+    ~Initializer();
+    Initializer(const Initializer &) = delete;
+    Initializer &operator=(const Initializer &) = delete;
+    // throws std::runtime_error when the file cannot be opened, as the reference does (libs/initializer.cpp:319-320);
+    // free the result with aar_detections_free
+    static aar_detections *read_detections_file(std::string path, const std::vector<int> &subseqs = std::vector<int>());
+    std::set<int> get_marker_ids();
+    std::set<int> get_cam_ids();
+    int get_root_cam();
+    int get_root_marker();
+    std::map<int, Mat44> get_transforms_to_root_cam();
+    std::map<int, Mat44> get_transforms_to_root_marker();
+    std::map<int, Mat44> get_object_transforms();
+    double get_marker_size();
+    const aar_dataset *dataset() const { return data_; }
+    aar_dataset *release();   // hands the data set to MultiCamMapper(Initializer&)
+
+   private:
+    aar_dataset *data_ = nullptr;
+};
+
 class MultiCamMapper {
    public:
     typedef SparseLevMarq<double>::eVector eVector;
@@ -51,6 +80,7 @@ class MultiCamMapper {
     // Takes ownership of a data set produced by aar_solution_read / aar_synth_generate: the state the
     // reference's MultiCamMapper(Initializer&) constructor ends with (libs/multicam_mapper.cpp:252-335).
     explicit MultiCamMapper(aar_dataset *dataset);
+    explicit MultiCamMapper(Initializer &initializer);   // libs/multicam_mapper.cpp:252-254; takes the initializer's data set
     ~MultiCamMapper();
     MultiCamMapper(const MultiCamMapper &) = delete;
     MultiCamMapper &operator=(const MultiCamMapper &) = delete;

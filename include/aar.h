@@ -104,6 +104,65 @@ int aar_cam_config_read(const char *path, double K[9], double dist[AAR_MAX_DIST]
 int aar_undistort_points(const double K[9], const double *dist, int32_t n_dist, int64_t n_points, const float *uv_in,
                          float *uv_out, int32_t device_id);
 
+/* ---------------------------------------------------------------------------------------------
+ * Initializer (libs/initializer.cpp): raw detections + calibrations -> the initial solution MultiCamMapper(Initializer&)
+ * holds before solve() (apps/find_solution.cpp:118-147).  The pose solver, the candidate sets and the n^2 votes run on the
+ * device; the spanning trees (a handful of nodes) on the host.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct aar_cam_model {       /* CamConfig (libs/cam_config.h)                                          */
+    double K[9];                     /* camera_matrix, row-major                                                */
+    double dist[AAR_MAX_DIST];       /* distortion_coefficients, OpenCV order, zero-filled                      */
+    int32_t n_dist;
+    int32_t width, height;
+} aar_cam_model;
+/* CamConfig::read_cam_configs (libs/cam_config.cpp:80-95): <folder>/<dir>/calib.{xml,yml,yaml} for every sub-directory;
+ * camera index = position of the directory in ASCENDING NAME order (the reference takes readdir order).  Free with free(). */
+int aar_cam_configs_read(const char *folder, aar_cam_model **out, int32_t *n_cams);
+
+typedef struct aar_detections {      /* content of an `aruco.detections` file                                   */
+    int32_t num_cams;                /* camera slots per frame record                                           */
+    int32_t num_frames;              /* frame records                                                           */
+    int64_t num_det;
+    int32_t *det_frame, *det_cam, *det_id;   /* [num_det], file order: frame, camera slot, detection            */
+    float *det_uv;                   /* [num_det][8] RAW (distorted) corners                                    */
+} aar_detections;
+/* Initializer::read_detections_file (libs/initializer.cpp:316-362).  subseqs = first,last frame pairs
+ * (MultiCamMapper::read_subseqs); frames before/between the sub-sequences are emptied, as the reference does. */
+int aar_detections_read(const char *path, const int32_t *subseqs, int32_t n_subseqs, aar_detections **out);
+void aar_detections_free(aar_detections *);
+/* <folder>/subseqs.txt: whitespace-separated frame numbers (libs/multicam_mapper.cpp read_subseqs).  Free with free(). */
+int aar_subseqs_read(const char *path, int32_t **out, int32_t *n);
+
+/* aruco::solvePnP_(size, corners, K, dist) (3rdparty/aruco/aruco/ippe.cpp:118-223) for n markers of one camera, on the
+ * device: T1 / T2 [n][16] = the two 4x4 marker->camera poses rounded to float as getRTMatrix(.., CV_32F) does, err1 <= err2
+ * the float reprojection errors in normalised image units.  uv: [n][8] raw corners (host). */
+int aar_ippe_square(double marker_size, const aar_cam_model *cam, int64_t n, const float *uv, double *T1, double *err1,
+                    double *T2, double *err2, int32_t device_id);
+
+/* Initializer::find_best_transformation (libs/initializer.cpp:151-193) for n_sets candidate sets at once, on the device.
+ * Candidates of set s are [set_begin[s], set_begin[s+1]) of T / T1inv / T2inv ([n][16] row-major 4x4, host).
+ * best[s] = index inside the set of the first minimum (-1: empty set), weight[s] = its summed corner distance,
+ * cost (optional, [n]) = every candidate's sum. */
+int aar_vote_transforms(double marker_size, int64_t n_sets, const int64_t *set_begin, const double *T, const double *T1inv,
+                        const double *T2inv, int64_t *best, double *weight, double *cost, int32_t device_id);
+
+typedef struct aar_init_params {
+    double marker_size;              /* metres                                                                  */
+    double threshold;                /* second IPPE pose kept when err2/err1 < threshold (2.0, initializer.h:52)  */
+    int32_t min_detections;          /* frames with fewer detections are dropped (2, initializer.h:51)           */
+    int32_t n_excluded;
+    const int32_t *excluded_cams;    /* camera slots to ignore (-exclude-cams)                                   */
+    int32_t device_id;
+} aar_init_params;
+void aar_init_default_params(aar_init_params *);
+/* Initializer(detections, marker_size, cam_configs, excluded_cams) followed by MultiCamMapper(Initializer&)
+ * (libs/initializer.cpp:64-71, libs/multicam_mapper.cpp:252-254,281-331): the data set the reference writes as
+ * initial.solution -- ids, intrinsics, corners undistorted with P = K, and the initial pose vector.  cams[i] belongs to
+ * camera slot i.  Fails (AAR_ERR_INVALID) when a camera or marker is not connected to the root by co-visibility, where
+ * the reference runs into std::map::at. */
+int aar_initializer_run(const aar_detections *, const aar_cam_model *cams, int32_t n_cams, const aar_init_params *,
+                        aar_dataset **out);
+
 /* cv::Rodrigues as used at libs/multicam_mapper.cpp:470,478 (R row-major 3x3) */
 void aar_rodrigues_vec2mat(const double w[3], double R[9]);
 void aar_rodrigues_mat2vec(const double R[9], double w[3]);
