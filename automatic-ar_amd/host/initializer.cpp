@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <limits>
@@ -297,7 +298,14 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
     if (prm->n_excluded < 0 || (prm->n_excluded > 0 && !prm->excluded_cams)) return set_error(AAR_ERR_INVALID, "aar_initializer_run: bad excluded_cams");
     const int64_t nd = det->num_det;
     const int S = det->num_cams, NF = det->num_frames;
-    const bool verbose = getenv("AAR_INIT_VERBOSE") != nullptr;   // stage sizes on stderr (scripts/init_bench.py)
+    const bool verbose = getenv("AAR_INIT_VERBOSE") != nullptr;   // stage sizes and times on stderr (scripts/init_bench.py)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto lap = [&](const char *what) {
+        const double t = now();
+        if (verbose) fprintf(stderr, "[aar init] %-28s %8.3f ms\n", what, 1e3 * (t - t_mark));
+        t_mark = t;
+    };
     std::set<int> excl(prm->excluded_cams, prm->excluded_cams + prm->n_excluded);
     for (int64_t i = 0; i < nd; i++) {
         if (det->det_frame[i] < 0 || det->det_frame[i] >= NF || det->det_cam[i] < 0 || det->det_cam[i] >= S)
@@ -325,6 +333,7 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
     for (int64_t u = 0; u < U; u++) { cam_set.insert(det->det_cam[used[u]]); mk_set.insert(det->det_id[used[u]]); }
     const std::vector<int32_t> cam_ids(cam_set.begin(), cam_set.end()), marker_ids(mk_set.begin(), mk_set.end());
     const int C = (int)cam_ids.size(), M = (int)marker_ids.size(), F = (int)kept_frames.size();
+    if (M > 46340 || C > 46340) return set_error(AAR_ERR_UNSUPPORTED, "more than 46340 cameras or markers");   // pair keys are int32
     if (cam_ids.back() >= n_cams)
         return set_error(AAR_ERR_INVALID, "camera slot %d has detections but only %d calibrations were given", cam_ids.back(), n_cams);
     std::map<int, int> cam_rank, mk_rank;
@@ -345,6 +354,7 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
     }
     if (int rc = initdev_ippe(G.d, cams, n_cams, (float)prm->marker_size, U, uv.data(), ucam.data(), e1.data(), e2.data(), uvK.data()))
         return rc;
+    lap("ippe (device, incl. copies)");
     std::vector<char> has2((size_t)U);
     for (int64_t u = 0; u < U; u++) has2[u] = ((double)e2[u] / (double)e1[u] < prm->threshold) ? 1 : 0;  // :409
 
@@ -367,10 +377,12 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
         }
         if ((int64_t)cands.size() >= (1LL << 31) - 64) return set_error(AAR_ERR_UNSUPPORTED, "more than 2^31 candidate transforms");
         // group by set, stable: inside a set the reference's push order (frame, outer id, i, j) is kept
-        std::map<int32_t, int32_t> set_of;
-        for (const Cand &c : cands) set_of.emplace(c.key, 0);
-        int32_t ns = 0;
-        for (auto &kv : set_of) kv.second = ns++;
+        std::vector<int32_t> set_of((size_t)n_nodes * (size_t)n_nodes, -1);   // key = rank1 * n_nodes + rank2 -> set
+        for (const Cand &c : cands) set_of[c.key] = 0;
+        std::vector<int32_t> set_key;
+        for (size_t k = 0; k < set_of.size(); k++)
+            if (set_of[k] == 0) { set_of[k] = (int32_t)set_key.size(); set_key.push_back((int32_t)k); }
+        const int32_t ns = (int32_t)set_key.size();
         std::vector<int64_t> begin((size_t)ns + 1, 0);
         for (const Cand &c : cands) begin[set_of[c.key] + 1]++;
         for (int s = 0; s < ns; s++) begin[s + 1] += begin[s];
@@ -380,6 +392,7 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
             const int64_t at = fill[set_of[c.key]]++;
             ca[at] = c.a; cb[at] = c.b;
         }
+        lap(type == 0 ? "camera candidates (host)" : "marker candidates (host)");
         if (verbose) {
             double pairs = 0;
             for (int s = 0; s < ns; s++) pairs += (double)(begin[s + 1] - begin[s]) * (double)(begin[s + 1] - begin[s]);
@@ -390,14 +403,14 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
         if (int rc = initdev_pair_vote(G.d, type, (int64_t)cands.size(), ca.data(), cb.data(), ns, begin.data(), prm->marker_size,
                                        best.data(), weight.data(), bestT.data()))
             return rc;
+        lap(type == 0 ? "camera votes (device)" : "marker votes (device)");
         std::map<int64_t, Edge> edges;
-        for (auto &kv : set_of) {
-            const int s = kv.second;
+        for (int s = 0; s < ns; s++) {
             if (best[s] < 0) continue;  // every candidate of the set is NaN
             Edge e;
             e.weight = weight[s];
             memcpy(e.T.m, &bestT[12 * (size_t)s], sizeof e.T.m);
-            edges[(int64_t)kv.first] = e;   // key = rank1 * n_nodes + rank2, rank1 < rank2
+            edges[(int64_t)set_key[s]] = e;   // key = rank1 * n_nodes + rank2, rank1 < rank2
         }
         int miss = -1;
         if (!spanning_transforms(n_nodes, edges, to_root[type], miss))
@@ -437,6 +450,7 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
     if (int rc = initdev_object_vote(G.d, (int64_t)cpose.size(), cpose.data(), ccam.data(), cmk.data(), C, to_root[0][0].m, M,
                                      to_root[1][0].m, F, fbegin.data(), prm->marker_size, fbest.data(), fweight.data(), fT.data()))
         return rc;
+    lap("frame votes (host + device)");
     for (int f = 0; f < F; f++)
         if (fbest[f] < 0) return set_error(AAR_ERR_NUMERIC, "frame %d: no finite object pose candidate", kept_frames[f]);
 
