@@ -31,7 +31,7 @@ SYMBOLS = [
     "aar_problem_set_huber_delta", "aar_problem_get_huber_delta", "aar_track", "aar_cam_config_read",
     "aar_undistort_points", "aar_local_group_create", "aar_local_group_destroy", "aar_comm_create_local",
     "aar_cam_configs_read", "aar_detections_read", "aar_detections_free", "aar_subseqs_read", "aar_ippe_square",
-    "aar_vote_transforms", "aar_init_default_params", "aar_initializer_run",
+    "aar_vote_transforms", "aar_init_default_params", "aar_initializer_run", "aar_initializer_object_poses",
 ]
 NUM_KERNELS = 13
 
@@ -191,6 +191,8 @@ def lib():
     L.aar_init_default_params.restype = None
     L.aar_initializer_run.argtypes = [C.POINTER(CDetections), C.POINTER(CCamModel), C.c_int32, C.POINTER(CInitParams),
                                       C.POINTER(C.POINTER(CDataset))]
+    L.aar_initializer_object_poses.argtypes = [C.POINTER(CDataset), C.POINTER(CDetections), C.POINTER(CCamModel), C.c_int32,
+                                               C.POINTER(CInitParams), C.POINTER(C.POINTER(CDataset))]
     L.aar_problem_set_huber_delta.argtypes = [C.c_void_p, C.c_float]
     L.aar_problem_get_huber_delta.argtypes = [C.c_void_p]
     L.aar_problem_get_huber_delta.restype = C.c_float
@@ -467,8 +469,11 @@ def vote_transforms(marker_size, set_begin, T, T1inv, T2inv, device=0):
     return best[:ns], weight[:ns], cost[:n]
 
 
-def initializer_run(det, Ks, dists, marker_size, sizes=None, excluded=(), threshold=2.0, min_detections=2, device=0):
-    """Initializer(...) + MultiCamMapper(Initializer&): the data set the reference writes as initial.solution"""
+def initializer_run(det, Ks, dists, marker_size, sizes=None, excluded=(), threshold=2.0, min_detections=2, device=0,
+                    solution=None):
+    """Initializer(...) + MultiCamMapper(Initializer&): the data set the reference writes as initial.solution.
+    With `solution` (a Dataset): apps/track.cpp's use -- its cameras / markers stay fixed, only the object poses of the
+    detections' frames are initialised (aar_initializer_object_poses)."""
     prm = CInitParams()
     lib().aar_init_default_params(C.byref(prm))
     prm.marker_size, prm.threshold, prm.min_detections, prm.device_id = marker_size, threshold, min_detections, device
@@ -478,7 +483,11 @@ def initializer_run(det, Ks, dists, marker_size, sizes=None, excluded=(), thresh
     cams = cam_models(Ks, dists, sizes)
     c = det.as_c()
     p = C.POINTER(CDataset)()
-    _check(lib().aar_initializer_run(C.byref(c), cams, len(Ks), C.byref(prm), C.byref(p)))
+    if solution is None:
+        _check(lib().aar_initializer_run(C.byref(c), cams, len(Ks), C.byref(prm), C.byref(p)))
+    else:
+        sc = solution.as_c()
+        _check(lib().aar_initializer_object_poses(C.byref(sc), C.byref(c), cams, len(Ks), C.byref(prm), C.byref(p)))
     try:
         return Dataset(p)
     finally:

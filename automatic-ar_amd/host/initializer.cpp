@@ -291,8 +291,10 @@ int aar_cam_configs_read(const char *folder, aar_cam_model **out, int32_t *n_cam
     return AAR_OK;
 }
 
-int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, int32_t n_cams, const aar_init_params *prm,
-                        aar_dataset **out) {
+// `fixed` = a solution whose camera and marker transforms are kept (apps/track.cpp:70-89,117-119): only obtain_pose_estimations
+// and init_object_transforms run, on the detections of cameras / markers the solution knows.
+static int run_initializer(const aar_detections *det, const aar_cam_model *cams, int32_t n_cams, const aar_init_params *prm,
+                           const aar_dataset *fixed, aar_dataset **out) {
     if (!det || !prm || !out || n_cams < 0 || (n_cams > 0 && !cams)) return set_error(AAR_ERR_INVALID, "aar_initializer_run: null argument");
     if (!(prm->marker_size > 0)) return set_error(AAR_ERR_INVALID, "aar_initializer_run: marker_size must be positive");
     if (prm->n_excluded < 0 || (prm->n_excluded > 0 && !prm->excluded_cams)) return set_error(AAR_ERR_INVALID, "aar_initializer_run: bad excluded_cams");
@@ -315,15 +317,26 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
             return set_error(AAR_ERR_INVALID, "detections must be ordered by frame, then camera slot");
     }
 
+    std::set<int> known_cams, known_markers;
+    if (fixed) {
+        known_cams.insert(fixed->cam_ids, fixed->cam_ids + fixed->num_cams);
+        known_markers.insert(fixed->marker_ids, fixed->marker_ids + fixed->num_markers);
+    }
+    // with a fixed solution, a detection of a camera / marker it does not hold cannot be placed and is dropped (the reference
+    // substitutes the identity for it in fill_transformation_set and then fails in MatArray::m.at)
+    auto takes_part = [&](int64_t i) {
+        if (excl.count(det->det_cam[i])) return false;
+        return !fixed || (known_cams.count(det->det_cam[i]) && known_markers.count(det->det_id[i]));
+    };
     // ---- frames with at least min_detections detections in the cameras that take part (libs/initializer.cpp:371-380) ----
     std::vector<int64_t> per_frame((size_t)NF, 0);
     for (int64_t i = 0; i < nd; i++)
-        if (!excl.count(det->det_cam[i])) per_frame[det->det_frame[i]]++;
+        if (takes_part(i)) per_frame[det->det_frame[i]]++;
     std::vector<int64_t> used;          // detection indices, file order
     std::vector<int32_t> kept_frames;   // keys of frame_cam_markers
     for (int64_t i = 0; i < nd; i++) {
         const int f = det->det_frame[i];
-        if (excl.count(det->det_cam[i]) || !(per_frame[f] >= prm->min_detections)) continue;
+        if (!takes_part(i) || !(per_frame[f] >= prm->min_detections)) continue;
         if (kept_frames.empty() || kept_frames.back() != f) kept_frames.push_back(f);
         used.push_back(i);
     }
@@ -331,11 +344,13 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
     if (U == 0) return set_error(AAR_ERR_INVALID, "no frame has %d or more detections", prm->min_detections);
     std::set<int> cam_set, mk_set;
     for (int64_t u = 0; u < U; u++) { cam_set.insert(det->det_cam[used[u]]); mk_set.insert(det->det_id[used[u]]); }
+    int max_used_cam = *cam_set.rbegin();
+    if (fixed) { cam_set = known_cams; mk_set = known_markers; }   // the solution's ids, seen or not
     const std::vector<int32_t> cam_ids(cam_set.begin(), cam_set.end()), marker_ids(mk_set.begin(), mk_set.end());
     const int C = (int)cam_ids.size(), M = (int)marker_ids.size(), F = (int)kept_frames.size();
     if (M > 46340 || C > 46340) return set_error(AAR_ERR_UNSUPPORTED, "more than 46340 cameras or markers");   // pair keys are int32
-    if (cam_ids.back() >= n_cams)
-        return set_error(AAR_ERR_INVALID, "camera slot %d has detections but only %d calibrations were given", cam_ids.back(), n_cams);
+    if (max_used_cam >= n_cams)
+        return set_error(AAR_ERR_INVALID, "camera slot %d has detections but only %d calibrations were given", max_used_cam, n_cams);
     std::map<int, int> cam_rank, mk_rank;
     for (int c = 0; c < C; c++) cam_rank[cam_ids[c]] = c;
     for (int m = 0; m < M; m++) mk_rank[marker_ids[m]] = m;
@@ -360,7 +375,26 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
 
     // ---- init_transforms_cam / init_transforms_marker (libs/initializer.cpp:421-451) ----
     std::vector<Aff12> to_root[2];
-    for (int type = 0; type < 2; type++) {
+    PoseLayout L;
+    L.C = C; L.M = M; L.F = F; L.rc = fixed ? fixed->root_cam : 0; L.rm = fixed ? fixed->root_marker : 0;
+    if (fixed) {
+        auto from_pose = [](const double *v) {
+            const Rigid r = pose_to_rigid(v);
+            Aff12 a;
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) a.m[i * 4 + j] = r.R[i * 3 + j];
+                a.m[i * 4 + 3] = r.t[i];
+            }
+            return a;
+        };
+        to_root[0].assign(C, aff_identity());
+        to_root[1].assign(M, aff_identity());
+        for (int c = 0; c < C; c++)
+            if (c != L.rc) to_root[0][c] = from_pose(fixed->x_full + L.full_cam0() + 6LL * L.cam_slot(c));
+        for (int m = 0; m < M; m++)
+            if (m != L.rm) to_root[1][m] = from_pose(fixed->x_full + L.full_mk0() + 6LL * L.mk_slot(m));
+    }
+    for (int type = 0; type < 2 && !fixed; type++) {
         const int n_nodes = type == 0 ? C : M;
         std::vector<Cand> cands;
         std::vector<Ent> ents;
@@ -456,11 +490,17 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
 
     // ---- MultiCamMapper::init (libs/multicam_mapper.cpp:281-331): ids, intrinsics, undistorted corners, pose vector ----
     aar_dataset *d = dataset_alloc(C, M, F, U, false);
-    d->root_cam = 0; d->root_marker = 0;                       // *cam_ids.begin(), *marker_ids.begin()
+    d->root_cam = L.rc; d->root_marker = L.rm;                 // *cam_ids.begin(), *marker_ids.begin() -- or the solution's
     d->marker_size = (double)(float)prm->marker_size;          // float m_size parameter, libs/multicam_mapper.h:20
     for (int c = 0; c < C; c++) {
-        const aar_cam_model &cm = cams[cam_ids[c]];
         d->cam_ids[c] = cam_ids[c];
+        if (fixed) {   // MultiCamMapper keeps its own intrinsics across init(object_poses, fcm), libs/multicam_mapper.cpp:272-279
+            d->image_sizes[2 * c] = fixed->image_sizes[2 * c]; d->image_sizes[2 * c + 1] = fixed->image_sizes[2 * c + 1];
+            memcpy(d->cam_mats + 9 * c, fixed->cam_mats + 9 * c, 9 * sizeof(double));
+            memcpy(d->dist_coeffs + 5 * c, fixed->dist_coeffs + 5 * c, 5 * sizeof(double));
+            continue;
+        }
+        const aar_cam_model &cm = cams[cam_ids[c]];
         d->image_sizes[2 * c] = cm.width; d->image_sizes[2 * c + 1] = cm.height;
         memcpy(d->cam_mats + 9 * c, cm.K, 9 * sizeof(double));
         for (int k = 0; k < 5; k++) d->dist_coeffs[5 * c + k] = k < cm.n_dist ? cm.dist[k] : 0.0;
@@ -475,10 +515,13 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
         }
         memcpy(d->obs_uv, uvK.data(), sizeof(float) * 8 * (size_t)U);
     }
-    PoseLayout L;
-    L.C = C; L.M = M; L.F = F; L.rc = 0; L.rm = 0;
-    for (int c = 1; c < C; c++) aff_to_pose(to_root[0][c], d->x_full + L.full_cam0() + 6LL * L.cam_slot(c));
-    for (int m = 1; m < M; m++) aff_to_pose(to_root[1][m], d->x_full + L.full_mk0() + 6LL * L.mk_slot(m));
+    if (fixed) {
+        memcpy(d->x_full, fixed->x_full, sizeof(double) * (size_t)L.full_fr0());   // cameras | markers, untouched
+        d->optimize_cam_poses = d->optimize_marker_poses = 0;                      // apps/track.cpp:93-95
+    } else {
+        for (int c = 1; c < C; c++) aff_to_pose(to_root[0][c], d->x_full + L.full_cam0() + 6LL * L.cam_slot(c));
+        for (int m = 1; m < M; m++) aff_to_pose(to_root[1][m], d->x_full + L.full_mk0() + 6LL * L.mk_slot(m));
+    }
     for (int f = 0; f < F; f++) {
         Aff12 T;
         memcpy(T.m, &fT[12 * (size_t)f], sizeof T.m);
@@ -486,6 +529,18 @@ int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, in
     }
     *out = d;
     return AAR_OK;
+}
+
+int aar_initializer_run(const aar_detections *det, const aar_cam_model *cams, int32_t n_cams, const aar_init_params *prm,
+                        aar_dataset **out) {
+    return run_initializer(det, cams, n_cams, prm, nullptr, out);
+}
+
+int aar_initializer_object_poses(const aar_dataset *solution, const aar_detections *det, const aar_cam_model *cams, int32_t n_cams,
+                                 const aar_init_params *prm, aar_dataset **out) {
+    if (!solution) return set_error(AAR_ERR_INVALID, "aar_initializer_object_poses: null solution");
+    if (solution->num_cams < 1 || solution->num_markers < 1) return set_error(AAR_ERR_INVALID, "aar_initializer_object_poses: empty solution");
+    return run_initializer(det, cams, n_cams, prm, solution, out);
 }
 
 }  // extern "C"

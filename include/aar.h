@@ -162,6 +162,14 @@ void aar_init_default_params(aar_init_params *);
  * the reference runs into std::map::at. */
 int aar_initializer_run(const aar_detections *, const aar_cam_model *cams, int32_t n_cams, const aar_init_params *,
                         aar_dataset **out);
+/* The Initializer as apps/track.cpp uses it (:70-89,117-120), for a whole recording at once: the camera and marker
+ * transforms of `solution` are GIVEN (set_transforms_to_root_cam / _marker), only obtain_pose_estimations and
+ * init_object_transforms run, and the result is what MultiCamMapper::init(object_poses, fcm) holds (libs/multicam_mapper.cpp:
+ * 272-279): the solution's cameras / markers / intrinsics, the frames with >= min_detections usable detections, their
+ * initial object poses and undistorted corners, optimize flags (0,0,1).  Follow with aar_problem_create + aar_track.
+ * Detections of cameras or markers the solution does not hold are dropped. */
+int aar_initializer_object_poses(const aar_dataset *solution, const aar_detections *, const aar_cam_model *cams, int32_t n_cams,
+                                 const aar_init_params *, aar_dataset **out);
 
 /* cv::Rodrigues as used at libs/multicam_mapper.cpp:470,478 (R row-major 3x3) */
 void aar_rodrigues_vec2mat(const double w[3], double R[9]);

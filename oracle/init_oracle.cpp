@@ -400,10 +400,14 @@ int64_t orc_vote(double marker_size, int64_t n, const double *T, const double *T
     return best;
 }
 
-void *orc_init_run(int32_t num_cam_slots, int32_t num_frames, int64_t n_det, const int32_t *det_frame,
-                   const int32_t *det_cam, const int32_t *det_id, const float *det_uv, double marker_size,
-                   const orc_cam_model *cams, const int32_t *excluded, int32_t n_excluded, double threshold,
-                   int32_t min_detections) {
+struct FixedTransforms {   // apps/track.cpp:70-89: set_transforms_to_root_cam / _marker instead of init_transforms
+    std::map<int, M4> cam, marker;
+};
+
+static void *init_impl(int32_t num_cam_slots, int32_t num_frames, int64_t n_det, const int32_t *det_frame,
+                       const int32_t *det_cam, const int32_t *det_id, const float *det_uv, double marker_size,
+                       const orc_cam_model *cams, const int32_t *excluded, int32_t n_excluded, double threshold,
+                       int32_t min_detections, const FixedTransforms *fixed) {
     InitState *st = new InitState;
     std::set<int> excl(excluded, excluded + n_excluded);
     // detections[frame][cam] = indices into the flat arrays, in file order
@@ -439,8 +443,12 @@ void *orc_init_run(int32_t num_cam_slots, int32_t num_frames, int64_t n_det, con
         frame_poses_marker[f] = est_marker;
     }
 
+    if (fixed) {
+        st->to_root_cam = fixed->cam;
+        st->to_root_marker = fixed->marker;
+    }
     // ---- init_transforms_cam / init_transforms_marker (libs/initializer.cpp:421-451) ----
-    for (int pass = 0; pass < 2; pass++) {
+    for (int pass = 0; pass < 2 && !fixed; pass++) {
         const bool camera = pass == 0;
         std::map<int, PoseMap> &poses = camera ? frame_poses_cam : frame_poses_marker;
         CandSets sets;
@@ -482,6 +490,26 @@ void *orc_init_run(int32_t num_cam_slots, int32_t num_frames, int64_t n_det, con
         if (idx >= 0) st->object_transforms[fr.first] = std::get<0>(set[idx]);
     }
     return st;
+}
+
+void *orc_init_run(int32_t num_cam_slots, int32_t num_frames, int64_t n_det, const int32_t *det_frame,
+                   const int32_t *det_cam, const int32_t *det_id, const float *det_uv, double marker_size,
+                   const orc_cam_model *cams, const int32_t *excluded, int32_t n_excluded, double threshold,
+                   int32_t min_detections) {
+    return init_impl(num_cam_slots, num_frames, n_det, det_frame, det_cam, det_id, det_uv, marker_size, cams, excluded, n_excluded,
+                     threshold, min_detections, nullptr);
+}
+
+void *orc_init_object_poses(int32_t num_cam_slots, int32_t num_frames, int64_t n_det, const int32_t *det_frame,
+                            const int32_t *det_cam, const int32_t *det_id, const float *det_uv, double marker_size,
+                            const orc_cam_model *cams, int32_t n_fixed_cams, const int32_t *cam_ids, const double *T_cam,
+                            int32_t n_fixed_markers, const int32_t *marker_ids, const double *T_marker, double threshold,
+                            int32_t min_detections) {
+    FixedTransforms fx;
+    for (int i = 0; i < n_fixed_cams; i++) std::memcpy(fx.cam[cam_ids[i]].a, T_cam + 16 * i, sizeof(double) * 16);
+    for (int i = 0; i < n_fixed_markers; i++) std::memcpy(fx.marker[marker_ids[i]].a, T_marker + 16 * i, sizeof(double) * 16);
+    return init_impl(num_cam_slots, num_frames, n_det, det_frame, det_cam, det_id, det_uv, marker_size, cams, nullptr, 0, threshold,
+                     min_detections, &fx);
 }
 
 void orc_init_counts(const void *h, int32_t counts[6]) {

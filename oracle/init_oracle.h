@@ -49,6 +49,13 @@ void *orc_init_run(int32_t num_cam_slots, int32_t num_frames, int64_t n_det, con
                    const int32_t *det_cam, const int32_t *det_id, const float *det_uv, double marker_size,
                    const orc_cam_model *cams, const int32_t *excluded, int32_t n_excluded, double threshold,
                    int32_t min_detections);
+/* apps/track.cpp:88-123 per frame: transforms_to_root_cam / _marker are GIVEN (set_transforms_to_root_*), then
+ * obtain_pose_estimations + init_object_transforms.  Same handle as orc_init_run. */
+void *orc_init_object_poses(int32_t num_cam_slots, int32_t num_frames, int64_t n_det, const int32_t *det_frame,
+                            const int32_t *det_cam, const int32_t *det_id, const float *det_uv, double marker_size,
+                            const orc_cam_model *cams, int32_t n_fixed_cams, const int32_t *cam_ids, const double *T_cam,
+                            int32_t n_fixed_markers, const int32_t *marker_ids, const double *T_marker, double threshold,
+                            int32_t min_detections);
 /* counts[0..2] = cameras, markers, frames with a pose; counts[3] = frames kept in frame_cam_markers;
  * counts[4] = root camera id, counts[5] = root marker id */
 void orc_init_counts(const void *h, int32_t counts[6]);

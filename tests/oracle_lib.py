@@ -107,6 +107,9 @@ def oracle():
         L.orc_init_run.restype = C.c_void_p
         L.orc_init_run.argtypes = [C.c_int32, C.c_int32, C.c_int64, _ip, _ip, _ip, _fp, C.c_double, cm, _ip, C.c_int32,
                                    C.c_double, C.c_int32]
+        L.orc_init_object_poses.restype = C.c_void_p
+        L.orc_init_object_poses.argtypes = [C.c_int32, C.c_int32, C.c_int64, _ip, _ip, _ip, _fp, C.c_double, cm, C.c_int32, _ip,
+                                            _dp, C.c_int32, _ip, _dp, C.c_double, C.c_int32]
         L.orc_init_counts.argtypes = [C.c_void_p, _ip]
         L.orc_init_get.argtypes = [C.c_void_p, _ip, _dp, _ip, _dp, _ip, _dp, _ip]
         L.orc_init_free.argtypes = [C.c_void_p]
@@ -379,16 +382,25 @@ def inv4(A):
 
 
 def init_run(num_cam_slots, num_frames, det_frame, det_cam, det_id, det_uv, marker_size, Ks, dists, excluded=(),
-             threshold=2.0, min_detections=2):
-    """Initializer(detections, marker_size, cam_configs, excluded_cams): dict of ids and 4x4 transforms"""
+             threshold=2.0, min_detections=2, fixed=None):
+    """Initializer(detections, marker_size, cam_configs, excluded_cams): dict of ids and 4x4 transforms.
+    fixed = (cam_ids, T_cam[n,4,4], marker_ids, T_marker[n,4,4]): apps/track.cpp's use, the transforms are given and only
+    obtain_pose_estimations + init_object_transforms run."""
     df = np.ascontiguousarray(det_frame, dtype=np.int32); dc = np.ascontiguousarray(det_cam, dtype=np.int32)
     di = np.ascontiguousarray(det_id, dtype=np.int32); uv = np.ascontiguousarray(det_uv, dtype=np.float32).reshape(-1, 8)
     ex = np.ascontiguousarray(list(excluded), dtype=np.int32)
     cams = cam_models(Ks, dists)
     L = oracle()
     ip = lambda a: a.ctypes.data_as(_ip)
-    h = L.orc_init_run(num_cam_slots, num_frames, len(df), ip(df), ip(dc), ip(di), uv.ctypes.data_as(C.POINTER(C.c_float)),
-                       float(marker_size), cams, ip(ex), len(ex), float(threshold), int(min_detections))
+    if fixed is None:
+        h = L.orc_init_run(num_cam_slots, num_frames, len(df), ip(df), ip(dc), ip(di), uv.ctypes.data_as(C.POINTER(C.c_float)),
+                           float(marker_size), cams, ip(ex), len(ex), float(threshold), int(min_detections))
+    else:
+        ci = np.ascontiguousarray(fixed[0], dtype=np.int32); Tc = np.ascontiguousarray(fixed[1], dtype=np.float64).reshape(-1, 16)
+        mi = np.ascontiguousarray(fixed[2], dtype=np.int32); Tm = np.ascontiguousarray(fixed[3], dtype=np.float64).reshape(-1, 16)
+        h = L.orc_init_object_poses(num_cam_slots, num_frames, len(df), ip(df), ip(dc), ip(di),
+                                    uv.ctypes.data_as(C.POINTER(C.c_float)), float(marker_size), cams, len(ci), ip(ci), _d(Tc),
+                                    len(mi), ip(mi), _d(Tm), float(threshold), int(min_detections))
     try:
         cnt = np.zeros(6, dtype=np.int32)
         L.orc_init_counts(h, ip(cnt))

@@ -400,3 +400,45 @@ def test_find_solution_driver_runs_the_initializer_then_the_lm(tmp_path):
     np.testing.assert_allclose(again.x_full, init.x_full, rtol=0, atol=1e-9)   # the file stores matrices: vec -> mat -> vec
     run2 = subprocess.run([exe, folder, "0.05", "x", "-from-initial"], capture_output=True, text=True)
     assert run2.returncode == 0 and "Initializer:" not in run2.stdout
+
+
+@pytest.mark.gpu
+def test_track_app_flow_initial_object_poses_then_track():
+    # apps/track.cpp:68-123 for a whole recording: a solved map (here: the ground truth), NEW detections, the Initializer with
+    # the map's transforms fixed, then MultiCamMapper::track() on every frame
+    ds = scene(noise=0.2, frames=50)
+    K = ds.cam_mats.reshape(-1, 3, 3)
+    dists = [np.zeros(5)] * ds.num_cams
+    det = detections_of(ds)
+    sol = aar.Dataset()
+    sol.__dict__.update(ds.__dict__)
+    sol.x_full = ds.x_truth.copy()
+    out = aar.initializer_run(det, K, dists, MS, solution=sol)
+    C, M = ds.num_cams, ds.num_markers
+    ns = 6 * (C - 1) + 6 * (M - 1)
+    # the map is untouched: all of the solution's cameras / markers (seen or not), their poses and intrinsics
+    np.testing.assert_array_equal(out.cam_ids, ds.cam_ids)
+    np.testing.assert_array_equal(out.marker_ids, ds.marker_ids)
+    np.testing.assert_array_equal(out.x_full[:ns], ds.x_truth[:ns])
+    np.testing.assert_array_equal(out.cam_mats, ds.cam_mats)
+    assert (out.optimize_cam_poses, out.optimize_marker_poses, out.optimize_object_poses) == (False, False, True)
+    np.testing.assert_array_equal(out.frame_ids, ds.frame_ids)
+    # object poses equal the oracle's, given the same fixed transforms
+    cam, mk, fr = truth_transforms(ds)
+    r = oracle_init(det, K, dists, fixed=(ds.cam_ids, np.array(cam), ds.marker_ids, np.array(mk)))
+    np.testing.assert_array_equal(r["frame_ids"], out.frame_ids)
+    np.testing.assert_allclose(out.x_full[ns:], poses_of(r["T_object"]), rtol=0, atol=2e-6)
+    # track(): every frame's 6-DoF LM from those poses lands on the true object pose (0.2 px noise)
+    with aar.Problem(out, optimize=(False, False, True)) as p:
+        x, it, err = p.track(out.x_full)
+    assert np.array_equal(x[:ns], ds.x_truth[:ns]) and np.all(it >= 1)
+    T_true = np.array(fr)
+    T_got = np.array([rigid(x[ns + 6 * f:][:6]) for f in range(out.num_frames)])
+    T_init = np.array([rigid(out.x_full[ns + 6 * f:][:6]) for f in range(out.num_frames)])
+    assert np.abs(T_got - T_true).max() < 0.02
+    assert np.abs(T_got - T_true).mean() < np.abs(T_init - T_true).mean()
+    # detections of a marker the map does not hold are dropped, as are frames that fall below min_detections because of it
+    det2 = detections_of(ds)
+    det2.det_id[det2.det_id == det2.det_id[0]] = 999
+    out2 = aar.initializer_run(det2, K, dists, MS, solution=sol)
+    assert out2.num_obs == int(np.sum(det2.det_id != 999)) and 999 not in out2.marker_ids
