@@ -65,7 +65,7 @@ int main(int argc, char *argv[]) {
     if (argc < 3) return print_usage(argv[0]);
     const string folder_path = argv[1];
     const double marker_size = stod(argv[2]);
-    bool use_subseqs = false, with_huber = false, set_threshold = false, from_initial = false;
+    bool use_subseqs = false, with_huber = false, set_threshold = false, from_initial = false, tracking_only = false;
     double threshold = 2.0;
     set<int> excluded_cams;
     enum ArgFlag { NONE, ExcludeCams, Threshold } arg_flag = NONE;
@@ -75,11 +75,13 @@ int main(int argc, char *argv[]) {
         else if (a == "-exclude-cams") arg_flag = ExcludeCams;
         else if (a == "-with-huber") { with_huber = true; arg_flag = NONE; }
         else if (a == "-from-initial") { from_initial = true; arg_flag = NONE; }
+        else if (a == "-tracking-only") { tracking_only = true; arg_flag = NONE; }   // names the files only, as in the reference (:54-57,76-77)
         else if (a == "-thresh") { set_threshold = true; arg_flag = Threshold; }
         else if (arg_flag == ExcludeCams) excluded_cams.insert(stoi(a));
         else if (arg_flag == Threshold) { threshold = stod(a); arg_flag = NONE; }
     }
     string name = "";
+    if (tracking_only) name += "_tracking_only";
     if (use_subseqs) name += "_subseqs";
     if (with_huber) name += "_with_huber";
     if (!excluded_cams.empty()) {
