@@ -313,6 +313,44 @@ def test_config4_size_against_oracle():
         assert rep["iterations"] < 30 and abs(rmse - 0.3 * np.sqrt(2)) < 0.02
 
 
+def test_full_size_config5_properties():
+    # BASELINE.json configs[4] (16 cameras / 200 markers / 5000 frames, 1.26 M marker observations = 10 M residual rows), the
+    # largest size: the oracle's sparse LDL^T needs minutes and > 15 GB per step here, so parity goes through properties
+    ds = aar.synth(5)
+    assert ds.num_obs > 1_200_000
+    o = ol.Oracle(ds)
+    with aar.Problem(ds) as p:
+        # residual rows bit-exact against the oracle (a pure streaming pass on the CPU)
+        r, ss = p.eval_residuals(ds.x_full)
+        ro = o.residuals(ds.x_full, res_mode=ol.RES_F32)
+        assert np.array_equal(r, ro)
+        np.testing.assert_allclose(ss, float((ro.astype(np.float64) ** 2).sum()), rtol=1e-12)
+        # a damped step from the start is a descent step
+        d = p.eval_damped_step(ds.x_full, 1e3)
+        assert p.eval_residuals(ds.x_full + d, want_vector=False)[1] < ss
+        x, rep = p.lm_solve(ds.x_full)
+        rmse, _ = p.reproj_stats(x)
+        err = [t["err"] for t in rep["trace"]]
+        assert all(b < a for a, b in zip([rep["initial_err"]] + err[:-1], err))
+        assert rep["iterations"] < 40 and abs(rmse - 0.3 * np.sqrt(2)) < 0.01
+        # idempotence at the optimum
+        x2, rep2 = p.lm_solve(x)
+        assert rep2["iterations"] == 1
+        # cameras come out at the ground truth (gauge fixed by the root camera / marker)
+        np.testing.assert_allclose(x[:6 * (ds.num_cams - 1)], ds.x_truth[:6 * (ds.num_cams - 1)], atol=2e-3)
+
+    # the same solve sharded over four ranks (frame ranges, one all-reduce of S | rhs | g0 per try): identical trace
+    def run(comm, rank):
+        with aar.Problem(ds, comm=comm) as q:
+            xs, reps = q.lm_solve(ds.x_full)
+            return xs, reps, q.local_obs
+    out = _run_ranks(4, run)
+    assert sum(o_[2] for o_ in out) == ds.num_obs
+    for xs, reps, _ in out:
+        np.testing.assert_allclose([t["err"] for t in reps["trace"]], err, rtol=1e-9)
+        np.testing.assert_allclose(xs, x, atol=1e-8)
+
+
 @pytest.mark.parametrize("name,split", [("g1_cfg2", "1"), ("g1_cfg3_cut", "3")])
 def test_schur_mfma_kernel_forced_on_small_problems(name, split, monkeypatch):
     # the block-of-S-stationary MFMA Schur kernel (normally A >= 96) forced on the golden problems: odd frame ranges, a
