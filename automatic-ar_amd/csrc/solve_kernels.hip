@@ -830,8 +830,12 @@ __global__ void __launch_bounds__(256) k_ldl_trsm(double *__restrict__ S, double
 __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
                                                     const double *__restrict__ Dfac, int n_pad, int n, int s, int nT,
                                                     double mu, const int32_t *__restrict__ ent_fixed) {
-    constexpr int LD = NB + 1, SB = 32, NSUB = (NB / SB) * (NB / SB);
-    __shared__ double Li[SB * LD], Lj[SB * LD];
+    // Tile part: one wavefront per 16 x 16 block of a trailing tile, S(I,J) -= L_Is (L_Js D_s)^T on the matrix pipe.  Lane (lc, lr)
+    // fetches the contiguous run [24 lr, 24 lr + 24) of row lc of both panels straight from global memory (12 16-byte loads
+    // each); MFMA step t then contracts columns {t, 24 + t, 48 + t, 72 + t} -- the same permutation of k on both operands, so
+    // the 24 steps cover every k once.  No LDS staging, no workgroup barrier on the way to the first MFMA.
+    constexpr int NSUB = 9, RUN = NB / 4;   // 9 workgroups x 4 wavefronts = the 36 blocks of a 96 x 96 tile
+    __shared__ double zs[NB];
     const int m = nT - s - 1, tid = threadIdx.x;
     const int ntile = m * (m + 1) / 2;
     const int r0 = s * NB;
@@ -839,7 +843,6 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
     const double *dd = Dfac + (size_t)s * NB * NB;
     if ((int)blockIdx.x >= ntile * NSUB) {  // rhs entries of row tile t
         const int t = s + 1 + ((int)blockIdx.x - ntile * NSUB);
-        double *zs = Li;
         if (tid < NB) zs[tid] = rhs[r0 + tid] * dd[tid * NB + tid];  // D_s z_s
         __syncthreads();
         if (tid < NB) {
@@ -858,47 +861,45 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
     int ti = 0, rem = tile;  // decode (ti >= tj) from the linear lower-triangular tile index
     while (rem > ti) { rem -= ti + 1; ti++; }
     const int tj = rem;
-    const int si = sub / (NB / SB), sj = sub % (NB / SB);
-    if (ti == tj && sj > si) return;  // above the diagonal
-    const int i0 = (s + 1 + ti) * NB + si * SB, j0 = (s + 1 + tj) * NB + sj * SB;
-    {
-        constexpr int NU = SB * NB / 256;
-        double va[NU], vb[NU], vd[NU];
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane >> 4, lc = lane & 15;
+    const int q = sub * 4 + wave, bi = q / (NB / 16), bj = q % (NB / 16);
+    // D_s for the B operand: the diagonal of the factor tile, through LDS (every wavefront needs all 96 values)
+    double dv = 0.0;
+    if (tid < NB) dv = dd[tid * NB + tid];
+    const bool live = !(ti == tj && bj > bi);   // blocks above the diagonal of a diagonal tile are never read
+    const int i0 = (s + 1 + ti) * NB + 16 * bi, j0 = (s + 1 + tj) * NB + 16 * bj;
+    double2 va[RUN / 2], vb[RUN / 2];
+    double tgt[4];
+    if (live) {
+        const double2 *pa = reinterpret_cast<const double2 *>(S + (size_t)(i0 + lc) * n_pad + r0 + RUN * lr);
+        const double2 *pb = reinterpret_cast<const double2 *>(S + (size_t)(j0 + lc) * n_pad + r0 + RUN * lr);
 #pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int e = tid + 256 * u, i = e / NB, k = e - i * NB;
-            va[u] = S[(size_t)(i0 + i) * n_pad + r0 + k];
-            vb[u] = S[(size_t)(j0 + i) * n_pad + r0 + k];
-            vd[u] = dd[k * NB + k];
-        }
+        for (int u = 0; u < RUN / 2; u++) { va[u] = pa[u]; vb[u] = pb[u]; }
 #pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int e = tid + 256 * u, i = e / NB, k = e - i * NB;
-            Li[i * LD + k] = va[u];
-            Lj[i * LD + k] = vb[u] * vd[u];  // L_Js * D_s
+        for (int r = 0; r < 4; r++) {   // accumulator register r: row lr + 4 r, column lc
+            const int gi = i0 + lr + 4 * r, gj = j0 + lc;
+            tgt[r] = (gj <= gi) ? S[(size_t)gi * n_pad + gj] : 0.0;
         }
     }
+    if (tid < NB) zs[tid] = dv;
     __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-#pragma unroll 8
-    for (int k = 0; k < NB; k++) {
-        const double a0 = Li[ty * LD + k], a1 = Li[(ty + 16) * LD + k];
-        const double c0 = Lj[tx * LD + k], c1 = Lj[(tx + 16) * LD + k];
-        acc[0][0] = fma(a0, c0, acc[0][0]); acc[0][1] = fma(a0, c1, acc[0][1]);
-        acc[1][0] = fma(a1, c0, acc[1][0]); acc[1][1] = fma(a1, c1, acc[1][1]);
+    if (!live) return;
+    dg_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < RUN / 2; u++) {
+        const double d0 = zs[RUN * lr + 2 * u], d1 = zs[RUN * lr + 2 * u + 1];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u].x, vb[u].x * d0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u].y, vb[u].y * d1, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int p = 0; p < 2; p++)
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int gi = i0 + ty + 16 * p, gj = j0 + tx + 16 * q;
-            if (gj <= gi) {
-                double v = S[(size_t)gi * n_pad + gj];
-                if (first) v = xform_first(v, gi, gj, n, mu, ent_fixed);
-                S[(size_t)gi * n_pad + gj] = v - acc[p][q];
-            }
+    for (int r = 0; r < 4; r++) {
+        const int gi = i0 + lr + 4 * r, gj = j0 + lc;
+        if (gj <= gi) {
+            double v = tgt[r];
+            if (first) v = xform_first(v, gi, gj, n, mu, ent_fixed);
+            S[(size_t)gi * n_pad + gj] = v - acc[r];
         }
+    }
 }
 
 // L^T x = z for the tiles above the last one (k_ldl_diag has solved that).  One workgroup per tile column s, all resident at
