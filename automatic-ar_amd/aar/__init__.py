@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libaar.so")
+LIB_PATH = os.environ.get("AAR_LIB") or os.path.join(os.path.dirname(_HERE), "libaar.so")   # AAR_LIB: A/B runs of two builds
 
 AAR_OK = 0
 AAR_ERR_INVALID, AAR_ERR_NO_DEVICE, AAR_ERR_HIP, AAR_ERR_UNSUPPORTED = -1, -2, -3, -4

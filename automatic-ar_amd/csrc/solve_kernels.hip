@@ -401,8 +401,8 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
 //                 matrix in fp64 MFMA accumulators (see the kernel).  Epilogue: inverses of the six 16x16 diagonal
 //                 sub-blocks of L_ss, which turn the panel solve below into small matrix products.  For the last tile it
 //                 also solves the right-hand side, forward and backward.
-//   k_ldl_trsm    every 48-row slab of block column s (and the right-hand side as a 1-row slab): X = A L_ss^-T by
-//                 blocked substitution over 16-column blocks on the matrix pipes, then L_ts = X D^-1.
+//   k_ldl_trsm    every 16-row slab of block column s (and the right-hand side as a 1-row slab), one wavefront each:
+//                 X = A L_ss^-T by blocked substitution over 16-column blocks on the matrix pipes, then L_ts = X D^-1.
 //   k_ldl_update  trailing tiles: S(I,J) -= L_Is D_s L_Js^T, rhs rows likewise.
 // ------------------------------------------------------------------------------------------------
 #ifdef AAR_STAMPS  // diagnostic build only (scripts/probe): cycle stamps of one workgroup, never compiled into libaar.so
@@ -716,113 +716,96 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
     TL_DUMP;
 }
 
-// X = A L_ss^-T D^-1 for one 48-row slab of block column s (blockIdx < 2m), or for the right-hand side (last block),
-// right-looking over 16-column blocks on the matrix pipes.  Wavefront w < 3 owns rows 16w..16w+15 of the slab as six 16x16
-// fp64 MFMA accumulator tiles and never talks to the others: per block q
+// X = A L_ss^-T D^-1 for one 16-row slab of block column s (blockIdx < 6m), or for the right-hand side (last block),
+// right-looking over 16-column blocks on the matrix pipes.  ONE wavefront per slab: its six 16x16 fp64 MFMA accumulator tiles,
+// the fifteen strictly-lower 16x16 blocks of L_ss and the six inverted diagonal blocks all live in registers, fetched straight
+// from global memory up front (no LDS staging of L_ss, no workgroup barrier), so the first block's MFMAs start as soon as ITS
+// operands have landed and the rest of the fetch hides behind the chain.  Per block q
 //   X_q = R_q inv(L_qq)^T        (4 MFMAs; R_q goes through a wave-private LDS tile to become the A operand)
-//   R_q'' -= X_q L(q'', q)^T      for every later block (4 MFMAs each, B straight from the LDS copy of L_ss)
-// and L_ts = X_q D^-1 goes to global memory.  The fourth wavefront only helps to stage L_ss.
-// LDS (dynamic): Ls [NB][NB+2] | Li [NSB][16][18] | dinv [NB] | St [3][16][18]
-__global__ void __launch_bounds__(256) k_ldl_trsm(double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
-                                                  const double *__restrict__ Dfac, const double *__restrict__ Linv16, int n_pad,
-                                                  int n, int s, int nT, double mu, const int32_t *__restrict__ ent_fixed) {
-    constexpr int LD = NB + 2, ROWS = NB / 2, PL = SBK + 2;
-    extern __shared__ __align__(16) double lds[];
-    double *Ls = lds;
-    double *Li = Ls + NB * LD;
-    double *dinv = Li + NSB * SBK * PL;
-    double *Stg = dinv + NB;
-    const int m = nT - s - 1, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+//   R_q'' -= X_q L(q'', q)^T      for every later block (4 MFMAs each)
+// and L_ts = X_q D^-1 goes to global memory.  Lane (lc, lr) holds columns [4 lr, 4 lr + 4) of row lc of every operand block, so
+// MFMA step t contracts columns {t, 4 + t, 8 + t, 12 + t}: the same permutation of k on both operands.
+// LDS (static): St [16][18]
+__global__ void __launch_bounds__(64) k_ldl_trsm(double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
+                                                 const double *__restrict__ Dfac, const double *__restrict__ Linv16, int n_pad,
+                                                 int n, int s, int nT, double mu, const int32_t *__restrict__ ent_fixed) {
+    constexpr int PL = SBK + 2;
+    __shared__ __align__(16) double St[SBK * PL];
+    const int m = nT - s - 1, b = blockIdx.x, lane = threadIdx.x;
     const int r0 = s * NB;
-    const bool first = (s == 0), is_rhs = (b == 2 * m);
-    const int row0 = (s + 1) * NB + b * ROWS + 16 * wave;   // first slab row of this wavefront
+    const bool first = (s == 0), is_rhs = (b == NSB * m);
+    const int row0 = (s + 1) * NB + SBK * b;   // first slab row of this wavefront
     const double *dd = Dfac + (size_t)s * NB * NB;
     const int lr = lane >> 4, lc = lane & 15;
-    STAMP(16);
     dg_acc_t acc[NSB];
-    {   // every global load is issued before the first use
-        constexpr int NL = NB * NB / 256, NI = NSB * SBK * SBK / 256;
-        double vl[NL], vi[NI];
+    double4 li[NSB];                   // inv(L_qq)[lc][4 lr ..]
+    double4 lb[NSB * (NSB - 1) / 2];   // L(16 q2 + lc, 16 q + 4 lr ..), q < q2, in the order they are consumed
+    double dq[NSB];
 #pragma unroll
-        for (int u = 0; u < NL; u++) {   // only the strictly lower part of L_ss is used, so only that is fetched
-            const int e = tid + 256 * u, i = e / NB, j = e - i * NB;
-            vl[u] = (j < i) ? dd[e] : 0.0;
+    for (int q = 0; q < NSB; q++) {   // issue order = use order: block q's operands first
+#pragma unroll
+        for (int r = 0; r < 4; r++) {   // accumulator register r of tile q: slab row lr + 4 r, column 16 q + lc
+            double v = 0.0;
+            if (!is_rhs) v = S[(size_t)(row0 + lr + 4 * r) * n_pad + r0 + 16 * q + lc];
+            else if (lr + 4 * r == 0) v = rhs[r0 + 16 * q + lc];
+            acc[q][r] = v;
         }
+        li[q] = *reinterpret_cast<const double4 *>(Linv16 + ((size_t)s * NSB + q) * SBK * SBK + lc * SBK + 4 * lr);
+        dq[q] = dd[(16 * q + lc) * (NB + 1)];
 #pragma unroll
-        for (int u = 0; u < NI; u++) vi[u] = Linv16[(size_t)s * NSB * SBK * SBK + tid + 256 * u];
-        const double dv = (tid < NB) ? dd[tid * NB + tid] : 1.0;
+        for (int q2 = q + 1; q2 < NSB; q2++)
+            lb[q * NSB - q * (q + 1) / 2 + (q2 - q - 1)] = *reinterpret_cast<const double4 *>(dd + (size_t)(16 * q2 + lc) * NB + 16 * q + 4 * lr);
+    }
+    if (first) {
 #pragma unroll
         for (int q = 0; q < NSB; q++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {   // accumulator register r of tile q: slab row lr + 4 r, column 16 q + lc
-                double v = 0.0;
-                if (wave < 3) {
-                    if (!is_rhs) v = S[(size_t)(row0 + lr + 4 * r) * n_pad + r0 + 16 * q + lc];
-                    else if (wave == 0 && lr + 4 * r == 0) v = rhs[r0 + 16 * q + lc];
-                }
-                acc[q][r] = v;
+            for (int r = 0; r < 4; r++) {
+                const int gj = r0 + 16 * q + lc;
+                if (!is_rhs) acc[q][r] = xform_first(acc[q][r], row0 + lr + 4 * r, gj, n, mu, ent_fixed);
+                else if (lr + 4 * r == 0) acc[q][r] = (gj >= n || ent_fixed[gj / 6]) ? 0.0 : acc[q][r] + g0[gj];  // B = g0 + Schur part
             }
-#pragma unroll
-        for (int u = 0; u < NL; u++) {
-            const int e = tid + 256 * u, i = e / NB, j = e - i * NB;
-            Ls[i * LD + j] = vl[u];
-        }
-#pragma unroll
-        for (int u = 0; u < NI; u++) {
-            const int e = tid + 256 * u, q = e / (SBK * SBK), r = (e / SBK) % SBK, cc = e % SBK;
-            Li[(q * SBK + r) * PL + cc] = vi[u];
-        }
-        if (tid < NB) dinv[tid] = rcp_refined(dv);
-        if (first && wave < 3) {
-#pragma unroll
-            for (int q = 0; q < NSB; q++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int gj = r0 + 16 * q + lc;
-                    if (!is_rhs) acc[q][r] = xform_first(acc[q][r], row0 + lr + 4 * r, gj, n, mu, ent_fixed);
-                    else if (wave == 0 && lr + 4 * r == 0) acc[q][r] = (gj >= n || ent_fixed[gj / 6]) ? 0.0 : acc[q][r] + g0[gj];  // B = g0 + Schur part
-                }
-        }
     }
-    __syncthreads();
-    STAMP(17);
-    if (wave >= 3 || (is_rhs && wave > 0)) return;
-    double *St = Stg + wave * SBK * PL;
 #pragma unroll
     for (int q = 0; q < NSB; q++) {
-        // R_q -> wave-private LDS tile (accumulator layout: row lr + 4 r, column lc), read back as the A operand A[i = lc][k = lr]
+        // R_q -> wave-private LDS tile (accumulator layout: row lr + 4 r, column lc), read back as the A operand: row lc, columns 4 lr ..
 #pragma unroll
         for (int r = 0; r < 4; r++) St[(lr + 4 * r) * PL + lc] = acc[q][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        dg_acc_t x = {0.0, 0.0, 0.0, 0.0};
+        double ar[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++)   // X[r][c] = sum_p R[r][p] inv(L_qq)[c][p]
-            x = __builtin_amdgcn_mfma_f64_16x16x4f64(St[lc * PL + 4 * t + lr], Li[(q * SBK + lc) * PL + 4 * t + lr], x, 0, 0, 0);
+        for (int t = 0; t < 4; t++) ar[t] = St[lc * PL + 4 * lr + t];
+        dg_acc_t x = {0.0, 0.0, 0.0, 0.0};   // X[r][c] = sum_p R[r][p] inv(L_qq)[c][p]
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[0], li[q].x, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[1], li[q].y, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2], li[q].z, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[3], li[q].w, x, 0, 0, 0);
         __builtin_amdgcn_wave_barrier();
-        const double dq = dinv[16 * q + lc];
+        const double dinv = rcp_refined(dq[q]);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             St[(lr + 4 * r) * PL + lc] = -x[r];
-            if (!is_rhs) S[(size_t)(row0 + lr + 4 * r) * n_pad + r0 + 16 * q + lc] = x[r] * dq;
-            else if (lr + 4 * r == 0) rhs[r0 + 16 * q + lc] = x[r] * dq;
+            if (!is_rhs) S[(size_t)(row0 + lr + 4 * r) * n_pad + r0 + 16 * q + lc] = x[r] * dinv;
+            else if (lr + 4 * r == 0) rhs[r0 + 16 * q + lc] = x[r] * dinv;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (q + 1 < NSB) {
             double ax[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) ax[t] = St[lc * PL + 4 * t + lr];   // -X_q as the A operand
+            for (int t = 0; t < 4; t++) ax[t] = St[lc * PL + 4 * lr + t];   // -X_q as the A operand
 #pragma unroll
-            for (int q2 = q + 1; q2 < NSB; q2++)   // R_q2[r][c] -= sum_p X[r][p] L(16 q2 + c, 16 q + p)
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    acc[q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[t], Ls[(16 * q2 + lc) * LD + 16 * q + 4 * t + lr], acc[q2], 0, 0, 0);
+            for (int q2 = q + 1; q2 < NSB; q2++) {   // R_q2[r][c] -= sum_p X[r][p] L(16 q2 + c, 16 q + p)
+                const double4 l4 = lb[q * NSB - q * (q + 1) / 2 + (q2 - q - 1)];
+                acc[q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[0], l4.x, acc[q2], 0, 0, 0);
+                acc[q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[1], l4.y, acc[q2], 0, 0, 0);
+                acc[q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[2], l4.z, acc[q2], 0, 0, 0);
+                acc[q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[3], l4.w, acc[q2], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    STAMP(24);
-    STAMP(25);
 }
 
 // trailing update of step s in 32x32 output sub-tiles: S(I, J) -= L_Is D_s L_Js^T; rhs rows: b_t -= L_ts D_s z_s.
@@ -1137,16 +1120,14 @@ bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];
     const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * 8) * sizeof(double);
-    const size_t lds_trsm = ((size_t)NB * (NB + 2) + NSB * SBK * (SBK + 2) + NB + 3 * SBK * (SBK + 2)) * sizeof(double);
-    static size_t g_diag = 48 * 1024, g_trsm = 48 * 1024, g_bs = 48 * 1024;
+    static size_t g_diag = 48 * 1024, g_bs = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
-    allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_trsm), lds_trsm, g_trsm);
     for (int s = 0; s < P.nT; s++) {
         const int m = P.nT - s - 1;
         { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags,
                                                          P.nT, b.rhs, b.g0, P.delta_s); }
         if (m > 0) {   // the last tile's right-hand side is solved inside k_ldl_diag
-            { HookScope _h(P, KID_LDL_TRSM); hipLaunchKernelGGL(k_ldl_trsm, dim3(2 * m + 1), dim3(256), lds_trsm, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
+            { HookScope _h(P, KID_LDL_TRSM); hipLaunchKernelGGL(k_ldl_trsm, dim3(NSB * m + 1), dim3(64), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
             { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
         }
     }
