@@ -1,9 +1,10 @@
-"""Initializer timing: aar_initializer_run (GPU) against the oracle's restatement of libs/initializer.cpp (one host core).
+"""Initializer timing: wall time of aar_initializer_run (GPU) per scene size.
 
-    python scripts/init_bench.py [--frames 60 200 500 2000] [--oracle-max 200]
+    python scripts/init_bench.py [--frames 60 200 500 2000] [--cams 8] [--markers 40]
 
-The scene is the synthetic 8-camera / 40-marker ring of BASELINE.json configs[2..3] (0.3 px corner noise); candidates per
-camera-pair / marker-pair set grow linearly with the frame count, the vote quadratically.  Prints one JSON line per size.
+The scene is the synthetic camera ring of BASELINE.json's configs (0.3 px corner noise); candidates per camera-pair /
+marker-pair set grow linearly with the frame count, the vote quadratically.  Prints one JSON line per size.  The CPU
+restatement is timed beside it by tests/tools/init_oracle_time.py (only test infrastructure loads oracle/).
 """
 import argparse
 import json
@@ -15,14 +16,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "automatic-ar_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import aar  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, nargs="+", default=[60, 200, 500, 2000])
-    ap.add_argument("--oracle-max", type=int, default=200, help="largest frame count the CPU restatement is timed on")
     ap.add_argument("--cams", type=int, default=8)
     ap.add_argument("--markers", type=int, default=40)
     a = ap.parse_args()
@@ -37,13 +36,6 @@ def main():
         out = aar.initializer_run(det, K, dists, 0.05)
         gpu_s = time.perf_counter() - t0
         line = dict(frames=F, detections=int(ds.num_obs), cams=out.num_cams, markers=out.num_markers, gpu_seconds=gpu_s)
-        if F <= a.oracle_max:
-            import oracle_lib as O  # test infrastructure: the CPU checker, timed beside the product
-
-            t0 = time.perf_counter()
-            r = O.init_run(det.num_cams, det.num_frames, det.det_frame, det.det_cam, det.det_id, det.det_uv, 0.05, K, dists)
-            line["oracle_seconds_1_core"] = time.perf_counter() - t0
-            line["same_ids"] = bool(np.array_equal(r["frame_ids"], out.frame_ids) and np.array_equal(r["marker_ids"], out.marker_ids))
         print(json.dumps(line), flush=True)
 
 

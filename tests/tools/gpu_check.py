@@ -1,6 +1,7 @@
-"""Ad-hoc GPU bring-up check (not a test): HIP path vs oracle on configs 2 and 3."""
+"""Ad-hoc GPU bring-up check (not collected by pytest): HIP path vs oracle on configs 2 and 3.  Lives under tests/ because it
+loads the CPU checker (oracle/), which only test infrastructure may do."""
 import sys, time, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'automatic-ar_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, aar, oracle_lib as ol
 print('devices', aar.device_count())

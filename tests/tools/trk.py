@@ -1,3 +1,4 @@
+"""Ad-hoc check of aar_track against the golden track fixtures (not collected by pytest; run from the repo root)."""
 import sys
 sys.path.insert(0,'automatic-ar_amd'); sys.path.insert(0,'tests')
 import numpy as np, aar, oracle_lib as ol
