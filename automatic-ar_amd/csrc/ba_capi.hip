@@ -145,6 +145,9 @@ struct aar_problem {
     bool blocks_valid = false;         // blk[cur] holds J^T J blocks and B at z[cur], S not yet eliminated
     double vinv_mu = -1;               // damping for which blk[cur].Vinv / hf are valid (< 0: none)
     double schur_mu = -1;              // damping whose Schur terms are already subtracted from blk[cur].S / rhs (< 0: none)
+    bool s_reduced = false;            // multi-GPU: blk[cur].S | rhs | g0 already hold the all-reduced system for schur_mu
+    bool trial_reduced = false;        // ... the same for the trial's block set, until the step is accepted or rejected
+    bool fused_comm = true;            // the step's scalars and the next step's system share ONE all-reduce (AAR_FUSED_COMM=0: two)
     hipStream_t stream2 = nullptr;     // pass B of the trial point runs here, beside the speculative Schur complement
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = false;              // AAR_OVERLAP=1: pass B of the trial point on a second stream beside the Schur complement
@@ -431,7 +434,16 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     const int cur = pb->cur, tr = 1 - cur;
     if (pb->schur_mu != mu) {  // not already done speculatively by the try that produced this point
         StageTimer t(pb, &pb->times.schur);
-        if (pb->schur_mu >= 0) {
+        if (pb->s_reduced) {
+            // multi-GPU, fused collective: S | rhs | g0 of this point already hold the ALL-REDUCED system for the predicted
+            // damping, so the terms cannot be taken back rank by rank.  Rebuild this rank's shared blocks from its observations
+            // (pass B alone: the frame blocks V, W, g_f of pass A are untouched) -- a mispredicted damping is rare.
+            int rc = zero_block_set(pb, cur);
+            if (rc) return rc;
+            launch_passB(P, cur, pb->stream);
+            pb->launches += 1;
+            pb->s_reduced = false;
+        } else if (pb->schur_mu >= 0) {
             // the speculative Schur complement was taken with another damping than the step now needs (gain < 0.94): take it
             // back with the inverses it used (still in Vinv), keeping the blocks -- and the residual they were built from --
             // exactly those of the accepted trial, as the reference's x64 / J are
@@ -447,11 +459,13 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         pb->launches += 1;
     }
     pb->schur_mu = -1;
-    if (pb->comm) {
+    if (pb->comm && !pb->s_reduced) {
         StageTimer t(pb, &pb->times.allreduce);
         int rc = allreduce(pb, P.blk[cur].S, (size_t)P.n_pad * P.n_pad + 2 * (size_t)P.n_pad, NCCL_SUM);   // S | rhs | g0 (contiguous)
         if (rc) return rc;
     }
+    pb->s_reduced = false;      // the factorisation below consumes the system
+    pb->trial_reduced = false;
     {
         StageTimer t(pb, &pb->times.chol);
         launch_chol(P, cur, mu, pb->stream);
@@ -481,6 +495,25 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         pb->launches += 1;
         if (rode) pb->seq++;
         else if ((rc = launch_scalars(pb, P.F))) return rc;   // (queued after the Schur kernel: the MFMA variant has no rider)
+    } else if (evaluate_trial && pb->fused_comm) {
+        // Multi-GPU: this rank's scalars ride in the speculative Schur launch as on one GPU, but into the 8 doubles behind
+        // g0 of the trial's block set, and ONE all-reduce then carries the step's scalars AND the next step's S | rhs | g0:
+        // an accepted step with the predicted damping (the usual case) costs one collective, not two.
+        {
+            StageTimer t(pb, &pb->times.schur);
+            rode = launch_schur(P, tr, 1.0, pb->stream, 0, P.F, P.blk[tr].tail);
+            pb->launches += 1;
+            if (!rode) { launch_reduce_scalars(P, P.F, false, 0ull, pb->stream, P.blk[tr].tail); pb->launches += 1; }
+        }
+        pb->seq++;
+        {
+            StageTimer t(pb, &pb->times.allreduce);
+            // tail[0..2] = sum r^2, sum |delta_f|^2, sum delta_f.g_f are rank sums; tail[5..6] (shared-parameter pieces) are
+            // computed from replicated data on every rank and stay out of the reduction
+            if ((rc = allreduce(pb, P.blk[tr].S, (size_t)P.n_pad * P.n_pad + 2 * (size_t)P.n_pad + 3, NCCL_SUM))) return rc;
+        }
+        launch_publish(P, pb->seq, pb->stream, P.blk[tr].tail);
+        pb->trial_reduced = true;
     } else {
         if ((rc = launch_scalars(pb, P.F))) return rc;
         if (evaluate_trial) {
@@ -508,6 +541,7 @@ int rebuild_current(aar_problem *pb) {
     pb->blocks_valid = true;
     pb->vinv_mu = -1;
     pb->schur_mu = -1;
+    pb->s_reduced = pb->trial_reduced = false;
     return AAR_OK;
 }
 
@@ -674,6 +708,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         return fail(set_error(AAR_ERR_HIP, "second stream / events could not be created"));
     { const char *e = getenv("AAR_OVERLAP"); pb->overlap = (e && e[0] == '1'); }  // measured slower than one stream at config 3: off by default
     { const char *e = getenv("AAR_MERGE_PASSES"); if (e) pb->merge_passes = (e[0] != '0'); }
+    { const char *e = getenv("AAR_FUSED_COMM"); if (e) pb->fused_comm = (e[0] != '0'); }
 
     PoseLayout &L = pb->L;
     L.C = C; L.M = M; L.F = Fg; L.rc = d->root_cam; L.rm = d->root_marker;
@@ -876,9 +911,11 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         AL(blk[w].Vinv, (size_t)F * 36); AL(blk[w].hf, (size_t)F * 6);
         // rhs and g0 live right behind S: ONE all-reduce makes all three global on the multi-GPU path (g0, the shared part of
         // B = -J^T r, is added to the right-hand side on first touch and enters delta.B, so every rank needs all of it)
-        AL(blk[w].S, (size_t)P.n_pad * P.n_pad + 2 * (size_t)P.n_pad);
+        AL(blk[w].S, (size_t)P.n_pad * P.n_pad + 2 * (size_t)P.n_pad + 8);
         P.blk[w].rhs = P.blk[w].S + (size_t)P.n_pad * P.n_pad;
         P.blk[w].g0 = P.blk[w].rhs + P.n_pad;
+        P.blk[w].tail = P.blk[w].g0 + P.n_pad;
+        if (hipMemset(P.blk[w].tail, 0, 8 * sizeof(double)) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "hipMemset failed"));
     }
     if (P.n_smwork) AL(Yw, (size_t)P.total_slots * 36);
     AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad); AL(bs_flags, (size_t)P.nT + 1);
@@ -1046,6 +1083,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     if ((rc = eval_blocks(pb, pb->cur, -1.0, -1))) return rc;
     pb->vinv_mu = -1;
     pb->schur_mu = -1;
+    pb->s_reduced = pb->trial_reduced = false;
     if ((rc = damped_try(pb, mu, false))) return rc;
     pb->lm_ready = false;
     std::vector<double> x0(x_full, x_full + L.full_len()), x1(x0);
@@ -1080,6 +1118,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     pb->blocks_valid = true;
     pb->vinv_mu = -1;
     pb->schur_mu = -1;
+    pb->s_reduced = pb->trial_reduced = false;
     pb->mu = -1;
     pb->v = 2;  // indeterminate in the reference (libs/sparselevmarq.h:133); every accepted step sets 2 (:411)
     pb->lm_ready = true;
@@ -1119,11 +1158,14 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
             pb->cur = 1 - pb->cur;  // curr_z = estimated_z; its blocks were built speculatively by the try
             pb->vinv_mu = mu_used * 0.33;   // what pass A inverted for
             pb->schur_mu = mu_used * 0.33;  // ... and what the speculative Schur complement was taken with
+            pb->s_reduced = pb->trial_reduced;   // multi-GPU: ... and whether it has been all-reduced already
+            pb->trial_reduced = false;
             pb->blocks_valid = true;        // (a damping other than the predicted one is repaired in damped_try)
             accepted = true;
         } else {
             pb->mu = mu_used * pb->v;
             pb->v = pb->v * 5;
+            pb->trial_reduced = false;
         }
     } while (gain <= 0 && ntries++ < 5 && !accepted);
     if (out) {

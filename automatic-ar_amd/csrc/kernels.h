@@ -69,6 +69,8 @@ struct DeviceProblem {
                                               // the Schur terms, then (in place) its LDL^T factor
         double *rhs = nullptr;                // [n_pad] Schur part of the right-hand side, then z = D^-1 L^-1 b
         double *g0 = nullptr;                 // [n_pad] shared part of B = -J^T r (kept for the gain denominator)
+        double *tail = nullptr;               // [8] right behind g0: the step's scalars of THIS rank, so that on the multi-GPU path
+                                              // they travel in the same all-reduce as the next step's S | rhs | g0
     } blk[2];
     double *Dfac = nullptr;               // [nT][NB*NB] factored diagonal tiles (unit L below, D on the diagonal)
     double *Linv16 = nullptr;             // [nT][6][16*16] inverses of the 16x16 diagonal sub-blocks of every L_ss
@@ -112,11 +114,13 @@ void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st);         
 void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st);
 // S -= sign * W (V+mu I)^-1 W^T (sign -1 takes it back).  ride_seq != 0: the reduction of the step's scalars rides in the same
 // launch (true is returned if it did)
-bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq = 0, int ride_n_err = 0);
+bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq = 0, int ride_n_err = 0,
+                  double *ride_scal = nullptr);   // ride_scal: the rider leaves the scalars there and does not publish
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st);    // damping + LDL^T + both substitutions -> delta_s
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
-void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st);  // scal[0..2], scal[5..6]
-void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st);       // scal/flags -> host record
+void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st,
+                           double *scal_out = nullptr);  // scal[0..2], scal[5..6] (into scal_out instead of P.scal if given)
+void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st, const double *src = nullptr);  // scal/flags -> host record
 int residual_blocks(const DeviceProblem &P);   // entries of err_part written by launch_residual
 // track(): every frame's own 6-DoF LM, whole loop on the device; needs ent[which] rows of the shared entities (launch_unpack)
 void launch_track(const DeviceProblem &P, int which, int max_iters, double min_error, double min_step, double min_avg, double tau,

@@ -1077,17 +1077,17 @@ void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t 
     { HookScope _h(P, KID_FRAME_INV); hipLaunchKernelGGL(k_frame_inv, dim3((P.F + 255) / 256), dim3(256), 0, st, b.V, b.gf, P.F, mu, P.frames_fixed, b.Vinv, b.hf, P.flags); }
 }
 
-static ReduceArgs reduce_args(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq) {
+static ReduceArgs reduce_args(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, double *scal_out = nullptr) {
     ReduceArgs r;
     r.err_part = P.err_part; r.n_err = n_err; r.lin_part = P.lin_part; r.F = P.F; r.fold_shared = fold_shared ? 1 : 0;
-    r.scal = P.scal; r.flags = P.flags; r.host = P.host_result; r.publish_seq = publish_seq;
+    r.scal = scal_out ? scal_out : P.scal; r.flags = P.flags; r.host = P.host_result; r.publish_seq = publish_seq;
     return r;
 }
 
 // ride_seq != 0: one extra workgroup of the launch reduces the step's scalars (ride_n_err partial sums of r^2) and publishes
 // them under that sequence number -- the speculative Schur complement and that reduction only depend on the passes before
 // them, not on each other.  Returns false if the scalars did not ride (the caller launches k_reduce_scalars).
-bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq, int ride_n_err) {
+bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq, int ride_n_err, double *ride_scal) {
     const DeviceProblem::Blocks &b = P.blk[which];
     if (P.n_smwork > 0) {   // many shared entities: block-of-S-stationary MFMA kernel
         const size_t lds = (size_t)2 * SM_ROWS * SM_PS * sizeof(double);
@@ -1102,8 +1102,8 @@ bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
     if (P.n_swork == 0) return false;
     const size_t lds = ((size_t)P.A * 36 + 8 + 4 * 48) * sizeof(double);
     static size_t granted0 = 48 * 1024, granted3 = 48 * 1024;
-    const ReduceArgs red = reduce_args(P, ride_n_err, false, ride_seq);
-    const int extra = ride_seq ? 1 : 0;
+    const ReduceArgs red = reduce_args(P, ride_n_err, false, ride_scal ? 0ull : ride_seq, ride_scal);
+    const int extra = (ride_seq || ride_scal) ? 1 : 0;
     HookScope _h(P, KID_SCHUR);
     if (P.max_kf > 64) {
         allow_dynamic_lds(reinterpret_cast<const void *>(k_schur<3>), lds, granted3);
@@ -1114,7 +1114,7 @@ bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
         hipLaunchKernelGGL(k_schur<0>, dim3(P.n_swork + extra), dim3(256), lds, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_rec, P.fslot_ent, b.W, b.Vinv, b.hf,
                            P.A, P.n_pad, sign, b.S, b.rhs, extra, red);
     }
-    return ride_seq != 0;
+    return extra != 0;
 }
 
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
@@ -1147,12 +1147,12 @@ void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) 
                        P.delta_s, P.z[cur], P.z[trial], P.A, P.F, nfb, P.lin_part, P.ent[trial]); }
 }
 
-void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st) {
-    { HookScope _h(P, KID_REDUCE); hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, reduce_args(P, n_err, fold_shared, publish_seq)); }
+void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st, double *scal_out) {
+    { HookScope _h(P, KID_REDUCE); hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, reduce_args(P, n_err, fold_shared, publish_seq, scal_out)); }
 }
 
-void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st) {
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, P.scal, P.flags, P.host_result, publish_seq);
+void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st, const double *src) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, src ? src : P.scal, P.flags, P.host_result, publish_seq);
 }
 
 }  // namespace aar

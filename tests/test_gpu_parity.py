@@ -6,6 +6,8 @@ step <= 1e-8 relative to Eigen::SimplicialLDLT; LM trace equal to the real Spars
 same (analytic) Jacobian; final reprojection error within 1e-4 px (north-star bar; observed ~1e-7) of the
 reference-faithful CPU run.  Needs a real MI355X.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -510,3 +512,43 @@ def test_sharded_huber_schedule_and_idle_rank():
     for x, rep, _ in outs:
         np.testing.assert_allclose([t["err"] for t in rep["trace"]], [t["err"] for t in reps["trace"]], rtol=1e-8)
         np.testing.assert_allclose(x, xs, atol=1e-8)
+
+
+def test_sharded_retry_and_mispredicted_damping():
+    # (1) far start + tau = 1e-6 (golden retry fixture): rejected tries, the blocks of the current point are rebuilt;
+    # (2) the -with-huber fixture: late in its 505 steps an accepted step has a gain far below 0.94, so its damping is NOT the
+    #     predicted 0.33 mu -- on the multi-GPU path the speculative system of such a step has already been all-reduced together
+    #     with the step's scalars, so the rank's shared blocks are rebuilt from its observations (pass B alone) before the new
+    #     Schur complement.
+    # Three ranks must reproduce the single-GPU trace, try for try, with the fused collective and without it.
+    ds_r, g = load_golden("g1_cfg2_retry")
+    ds_h, gh = load_golden("g1_cfg2_huber")
+    for ds, prm_kw, hub in ((ds_r, dict(tau=float(g["tau"][0])), False), (ds_h, dict(), True)):
+        with aar.Problem(ds, with_huber=hub) as p:
+            x1, rep1 = p.lm_solve(ds.x_full, params=aar.lm_default_params(**prm_kw), trace_cap=600)
+        tries1 = np.array([t["tries"] for t in rep1["trace"]])
+        mu1 = np.array([t["mu"] for t in rep1["trace"]])
+        err1 = np.array([t["err"] for t in rep1["trace"]])
+        if hub:
+            odd = np.nonzero((tries1[1:] == 1) & (np.abs(mu1[1:] / mu1[:-1] - 0.33) > 1e-6))[0]
+            assert len(odd) >= 1                                        # an accepted step with another damping than predicted
+            k = int(odd[0]) + 3
+        else:
+            assert tries1.max() > 1                                     # a rejected try
+            k = 6
+
+        def solve(comm, r):
+            with aar.Problem(ds, comm=comm, with_huber=hub) as q:
+                return q.lm_solve(ds.x_full, params=aar.lm_default_params(**prm_kw), trace_cap=600)
+        for fused in ("1", "0"):
+            os.environ["AAR_FUSED_COMM"] = fused
+            try:
+                outs = _run_ranks(3, solve)
+            finally:
+                del os.environ["AAR_FUSED_COMM"]
+            for x, rep in outs:
+                k = min(k, len(rep["trace"]), len(tries1))
+                assert [t["tries"] for t in rep["trace"]][:k] == tries1[:k].tolist()
+                np.testing.assert_allclose([t["err"] for t in rep["trace"]][:k], err1[:k], rtol=1e-5)
+                np.testing.assert_allclose([t["mu"] for t in rep["trace"]][:k], mu1[:k], rtol=1e-3)
+                assert abs(np.sqrt(rep["final_err"] / (4 * ds.num_obs)) - np.sqrt(rep1["final_err"] / (4 * ds.num_obs))) < 1e-4
