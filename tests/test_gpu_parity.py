@@ -392,6 +392,46 @@ def test_tile_counts_and_schur_kernels_against_oracle(mfma, cams, markers, frame
         assert rep["iterations"] < 40 and abs(rmse - 0.3 * np.sqrt(2)) < 0.05   # (few observations per unknown: the fit absorbs some noise)
 
 
+def test_randomized_shapes_against_oracle():
+    # a sweep over sizes that move every structural parameter at once: camera / marker counts (shared system n from 18 to ~400,
+    # i.e. one to five 96-wide tiles, n not a multiple of 16 or 96), frames from a handful to a few hundred (ragged visibility),
+    # every optimise-flag combination now and then, sharded over 2-3 ranks for every third shape
+    rng = np.random.default_rng(20190219)
+    done = 0
+    for k in range(40):
+        C, M, F = int(rng.integers(3, 11)), int(rng.integers(4, 60)), int(rng.integers(2, 160))
+        try:
+            ds = aar.synth(3, num_cams=C, num_markers=M, num_frames=F, seed=int(rng.integers(1, 2 ** 31)))
+        except aar.AarError:
+            continue                      # no frame with two observations at this size
+        if ds.num_obs < 20:
+            continue
+        opt = [(True, True, True), (True, True, True), (False, True, True), (True, False, True)][k % 4]
+        o = ol.Oracle(ds, optimize=opt)
+        with aar.Problem(ds, optimize=opt) as p:
+            r, ss = p.eval_residuals(ds.x_full)
+            assert np.array_equal(r, o.residuals(ds.x_full, res_mode=ol.RES_F32)), (C, M, F)
+            mu = float(10.0 ** rng.integers(0, 7))
+            d = p.eval_damped_step(ds.x_full, mu)
+            do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+            assert np.abs(d - do).max() / np.abs(do).max() < 1e-7, (C, M, F, mu)
+            x, rep = p.lm_solve(ds.x_full)
+        xo, repo = o.lm_solve(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+        assert abs(rep["iterations"] - repo["iterations"]) <= 1, (C, M, F)
+        np.testing.assert_allclose(rep["final_err"], repo["final_err"], rtol=1e-5, err_msg=str((C, M, F)))
+        if k % 3 == 0 and opt == (True, True, True):
+            def solve(comm, rank, ds=ds):
+                with aar.Problem(ds, comm=comm) as q:
+                    return q.lm_solve(ds.x_full)
+            for xs, reps in _run_ranks(2 + k % 2, solve):
+                assert reps["iterations"] == rep["iterations"], (C, M, F)
+                np.testing.assert_allclose(reps["final_err"], rep["final_err"], rtol=1e-8)
+        done += 1
+        if done >= 9:
+            break
+    assert done >= 7
+
+
 def test_single_rank_communicator_path():
     # world_size 1 through RCCL: exercises the sharded code path (all-reduces of S, rhs, scalars) on one GPU
     ds, g = load_golden("g1_cfg2")
