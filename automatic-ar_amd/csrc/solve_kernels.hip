@@ -906,28 +906,25 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
     const int r0 = s * NB;
     const int j = tid % NB, gq = tid / NB;    // G*NB = 960 threads in the block products
     const double *dd = Dfac + (size_t)s * NB * NB;
-    {
-        constexpr int NL = NB * NB / 1024;
-        double vl[NL];
+    // Fetch order = use order: block (nT-1, s) first -- its product only waits for x_{nT-1}, which the previous kernel left in
+    // memory -- then L_ss, which is not needed before the final substitution and is parked in LDS after that first product.
+    constexpr int NL = NB * NB / 1024;
+    double a[RPT], vl[NL];
+    auto fetch_block = [&](int t) {
 #pragma unroll
-        for (int u = 0; u < NL; u++) {   // strictly lower part only; the diagonal (D) and above stay zero in LDS
-            const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
-            vl[u] = (jj < i) ? dd[e] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < NL; u++) {
-            const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
-            Ls[i * LD + jj] = vl[u];
-        }
-    }
-    double acc = 0.0;
-    for (int t = nT - 1; t > s; t--) {
-        double a[RPT];
-#pragma unroll
-        for (int k = 0; k < RPT; k++) {   // block (t, s), before x_t is needed
+        for (int k = 0; k < RPT; k++) {
             const int i = gq + G * k;
             a[k] = (gq < G && i < NB) ? S[(size_t)(t * NB + i) * n_pad + r0 + j] : 0.0;
         }
+    };
+    fetch_block(nT - 1);
+#pragma unroll
+    for (int u = 0; u < NL; u++) {   // strictly lower part only; the diagonal (D) and above stay zero in LDS
+        const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
+        vl[u] = (jj < i) ? dd[e] : 0.0;
+    }
+    double acc = 0.0;
+    for (int t = nT - 1; t > s; t--) {
         if (t < nT - 1) {   // x_{nT-1} comes from the previous kernel; the others from the workgroup next door
             if (tid == 0) {
                 // bounded: a chain that cannot complete (it always can: a workgroup only waits for ones dispatched before it)
@@ -947,6 +944,14 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
         for (int k = 0; k < RPT; k++) {
             const int i = gq + G * k;
             if (i < NB) acc = fma(a[k], xs[i], acc);
+        }
+        if (t - 1 > s) fetch_block(t - 1);   // block (t-1, s), before x_{t-1} is needed
+        if (t == nT - 1) {
+#pragma unroll
+            for (int u = 0; u < NL; u++) {
+                const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
+                Ls[i * LD + jj] = vl[u];
+            }
         }
         __syncthreads();
     }
