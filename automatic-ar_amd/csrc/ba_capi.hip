@@ -429,6 +429,8 @@ int read_scalars(aar_problem *pb, int n_err) {
 //   -> pass A / pass B at the trial point into blk[1-cur] (speculative: they ARE the next step's Jacobian pass when the
 //      trial is accepted, and the trial's sum r^2 comes out of pass A) -> scalars to the host.
 // blk[cur].S/rhs are consumed; pass A clears them together with blk[cur].g0 on the way.
+constexpr int TRY_NOT_POSITIVE_DEFINITE = 1;   // damped_try: not an error code of the C ABI (those are negative)
+
 int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     DeviceProblem &P = pb->P;
     const int cur = pb->cur, tr = 1 - cur;
@@ -526,7 +528,10 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     if ((rc = wait_result(pb))) return rc;
     if (pb->h_flags[0]) {
         (void)hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream);
-        return set_error(AAR_ERR_NUMERIC, "device flags %d at mu=%g (1: a frame block is not positive definite, 2: non-positive pivot of the reduced system, 4: back-substitution chain timed out)", pb->h_flags[0], mu);
+        set_error(AAR_ERR_NUMERIC, "device flags %d at mu=%g (1: a frame block is not positive definite, 2: non-positive pivot of the reduced system, 4: back-substitution chain timed out)", pb->h_flags[0], mu);
+        // Only the reduced system lost positive definiteness (far from the optimum its Schur complement can, in floating point):
+        // the LM loop takes that as a failed try and raises the damping; every rank sees the same replicated pivots.
+        return pb->h_flags[0] == 2 ? TRY_NOT_POSITIVE_DEFINITE : AAR_ERR_NUMERIC;
     }
     return AAR_OK;
 }
@@ -1084,7 +1089,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     pb->vinv_mu = -1;
     pb->schur_mu = -1;
     pb->s_reduced = pb->trial_reduced = false;
-    if ((rc = damped_try(pb, mu, false))) return rc;
+    if ((rc = damped_try(pb, mu, false))) return rc == TRY_NOT_POSITIVE_DEFINITE ? AAR_ERR_NUMERIC : rc;
     pb->lm_ready = false;
     std::vector<double> x0(x_full, x_full + L.full_len()), x1(x0);
     if ((rc = download_z(pb, 1 - pb->cur, x1.data()))) return rc;
@@ -1141,7 +1146,17 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
     do {
         if (!pb->blocks_valid && (rc = rebuild_current(pb))) return rc;  // a rejected try consumed them
         const double mu_used = pb->mu;
-        if ((rc = damped_try(pb, mu_used, true))) return rc;
+        if ((rc = damped_try(pb, mu_used, true))) {
+            if (rc != TRY_NOT_POSITIVE_DEFINITE) return rc;
+            // J^T J + mu I came out indefinite in floating point: the reference's LDL^T would hand back the stationary point
+            // of an indefinite model and its gain test would reject the trial (libs/sparselevmarq.h:408-419); same outcome here
+            pb->mu = mu_used * pb->v;
+            pb->v = pb->v * 5;
+            pb->trial_reduced = false;
+            pb->blocks_valid = false;
+            gain = -1;
+            continue;
+        }
         const double *sc = pb->h_scal;
         const double err = sc[0];
         // L = 0.5 * delta^T (mu*delta - B) (:406); frame pieces were summed over ranks; the shared-parameter pieces

@@ -400,6 +400,18 @@ def test_find_solution_driver_runs_the_initializer_then_the_lm(tmp_path):
     np.testing.assert_allclose(again.x_full, init.x_full, rtol=0, atol=1e-9)   # the file stores matrices: vec -> mat -> vec
     run2 = subprocess.run([exe, folder, "0.05", "x", "-from-initial"], capture_output=True, text=True)
     assert run2.returncode == 0 and "Initializer:" not in run2.stdout
+    # the reference's options (parsed from argv[4] on, apps/find_solution.cpp:47) name the files the same way (:74-97) and
+    # reach the Initializer: sub-sequences empty the frames outside them, excluded cameras vanish from the solution
+    with open(os.path.join(folder, "subseqs.txt"), "w") as f:
+        f.write("100 299\n")
+    run3 = subprocess.run([exe, folder, "0.05", "x", "-subseqs", "-exclude-cams", "3", "-with-huber", "-thresh", "2.5"],
+                          capture_output=True, text=True)
+    assert run3.returncode == 0, run3.stderr + run3.stdout
+    name = "_subseqs_with_huber_excluded_cams_3_thresh_2.5.solution"
+    sub = aar.solution_read(os.path.join(folder, "initial" + name))
+    assert os.path.exists(os.path.join(folder, "final" + name)) and os.path.exists(os.path.join(folder, "final" + name + ".yaml"))
+    assert 3 not in sub.cam_ids and sub.num_cams == 7
+    assert sub.frame_ids.min() >= 100 and sub.num_frames < init.num_frames   # frames after the last range are kept (:350-359)
 
 
 @pytest.mark.gpu
