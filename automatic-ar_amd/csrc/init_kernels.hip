@@ -8,7 +8,7 @@
 //   k_object_cands  the same for fill_transformation_set (:73-93), the per-frame sets of init_object_transforms.
 //   k_vote          find_best_transformation (:151-193): cost_i = sum_j sum_corners |p - T2inv_j T_i T1inv_j p|.  The n^2 part:
 //                   one wavefront per 64 candidates i of a set, T_i in registers, the j-side (24 doubles) read through the
-//                   scalar cache because it is uniform across the wavefront; ~200 fp64 operations per (i,j): VALU-bound.
+//                   scalar cache because it is uniform across the wavefront; ~160 fp64 operations per (i,j): VALU-bound.
 //
 // All matrices are the 3x4 top of the reference's 4x4 CV_64F matrices (bottom row 0 0 0 1 stays exact under products and
 // inverses), row-major.
@@ -294,6 +294,20 @@ __global__ void __launch_bounds__(256) k_prep_jside(long long n, const double *_
     store_jside(BJ + 24 * k, aff_load(A + 12 * k), aff_load(B + 12 * k), h);
 }
 
+// sqrt for the vote: v_rsq_f64 seed (~2^-26) + one coupled Goldschmidt step + one residual correction = full double accuracy
+// (<= 1 ulp) in 8 instructions, without the range scaling of the library sqrt (the arguments are squared distances of
+// metre-sized scenes, nowhere near the denormals); an exact zero stays an exact zero.
+__device__ __forceinline__ double vote_sqrt(double q) {
+    const double y = __builtin_amdgcn_rsq(q);
+    double g = q * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, q);
+    g = fma(d, h, g);
+    return q == 0.0 ? 0.0 : g;   // (a NaN argument stays NaN: such a candidate must never win the vote)
+}
+
 // work item: candidates [i0, i0+64) of the set [begin, end)
 __global__ void __launch_bounds__(64) k_vote(const int4 *__restrict__ items, const double *__restrict__ Tc,
                                              const double *__restrict__ BJ, double h, double *__restrict__ cost) {
@@ -313,13 +327,14 @@ __global__ void __launch_bounds__(64) k_vote(const int4 *__restrict__ items, con
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const double ax = b[12 + c], ay = b[16 + c], az = b[20 + c];
-            const double rx = T[0] * ax + T[1] * ay + T[2] * az + T[3];
-            const double ry = T[4] * ax + T[5] * ay + T[6] * az + T[7];
-            const double rz = T[8] * ax + T[9] * ay + T[10] * az + T[11];
-            const double dx = px[c] - (b[0] * rx + b[1] * ry + b[2] * rz + b[3]);
-            const double dy = py[c] - (b[4] * rx + b[5] * ry + b[6] * rz + b[7]);
-            const double dz = -(b[8] * rx + b[9] * ry + b[10] * rz + b[11]);
-            s += sqrt(dx * dx + dy * dy + dz * dz);
+            // three-term rows as FMA chains ending in the translation (one instruction per product, none for the additions)
+            const double rx = fma(T[0], ax, fma(T[1], ay, fma(T[2], az, T[3])));
+            const double ry = fma(T[4], ax, fma(T[5], ay, fma(T[6], az, T[7])));
+            const double rz = fma(T[8], ax, fma(T[9], ay, fma(T[10], az, T[11])));
+            const double dx = px[c] - fma(b[0], rx, fma(b[1], ry, fma(b[2], rz, b[3])));
+            const double dy = py[c] - fma(b[4], rx, fma(b[5], ry, fma(b[6], rz, b[7])));
+            const double dz = -fma(b[8], rx, fma(b[9], ry, fma(b[10], rz, b[11])));
+            s += vote_sqrt(fma(dx, dx, fma(dy, dy, dz * dz)));
         }
         acc += s;
     }
