@@ -1,6 +1,6 @@
 export TMPDIR=/tmp
 ROOT=$(pwd)
-python -m pytest tests -q -m gpu -x > gpurun_out/gpu_tests.log 2>&1; tail -3 gpurun_out/gpu_tests.log
+python -m pytest tests/test_initializer.py -q -m gpu -x > gpurun_out/gpu_tests.log 2>&1; grep -E "passed|failed" gpurun_out/gpu_tests.log
 AAR_INIT_VERBOSE=1 python scripts/init_bench.py --frames 500 2000 5000 > gpurun_out/init_bench.log 2>&1
 AAR_INIT_VERBOSE=1 python scripts/init_bench.py --cams 16 --markers 200 --frames 1000 5000 >> gpurun_out/init_bench.log 2>&1
 python tests/tools/init_oracle_time.py --frames 200 500 >> gpurun_out/init_bench.log 2>&1
