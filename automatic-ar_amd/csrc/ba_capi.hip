@@ -84,11 +84,20 @@ struct aar_local_group {
     int arrived = 0;
     unsigned long long gen = 0;
     std::vector<const double *> ptrs;
-    void barrier() {
+    bool broken = false;
+    // false: a rank never arrived (it failed before its collective) -- the group is marked broken and every waiter returns,
+    // as a communicator whose peer died would; a test must fail, not hang
+    bool barrier() {
         std::unique_lock<std::mutex> lk(m);
+        if (broken) return false;
         const unsigned long long g = gen;
-        if (++arrived == world) { arrived = 0; gen++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        if (++arrived == world) { arrived = 0; gen++; cv.notify_all(); return true; }
+        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g || broken; }) || broken) {
+            broken = true;
+            cv.notify_all();
+            return false;
+        }
+        return true;
     }
 };
 
@@ -228,13 +237,13 @@ int allreduce(aar_problem *pb, double *buf, size_t count, int op) {
         }
         HIP_TRY(hipStreamSynchronize(pb->stream));            // my contribution is complete
         g->ptrs[c->rank] = buf;
-        g->barrier();                                         // ... and so is everybody else's
+        if (!g->barrier()) return set_error(AAR_ERR_COMM, "local group: a rank did not reach the collective");   // ... and so is everybody else's
         const double **d_ptrs = reinterpret_cast<const double **>(c->tmp + count);
         HIP_TRY(hipMemcpyAsync(d_ptrs, g->ptrs.data(), sizeof(double *) * g->world, hipMemcpyHostToDevice, pb->stream));
         hipLaunchKernelGGL(k_local_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, pb->stream, c->tmp, d_ptrs, g->world, count,
                            op == NCCL_MAX ? 1 : 0);
         HIP_TRY(hipStreamSynchronize(pb->stream));
-        g->barrier();                                         // everyone has read everyone's buffer: it may be overwritten now
+        if (!g->barrier()) return set_error(AAR_ERR_COMM, "local group: a rank did not reach the collective");   // everyone has read everyone's buffer: it may be overwritten now
         HIP_TRY(hipMemcpyAsync(buf, c->tmp, count * sizeof(double), hipMemcpyDeviceToDevice, pb->stream));
         return AAR_OK;
     }

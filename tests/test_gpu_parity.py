@@ -482,7 +482,7 @@ def test_sharded_lm_on_one_gpu_through_the_local_group(world, name):
     ds, g = load_golden(name)
     group = aar.LocalGroup(world)
     out = [None] * world
-    th = [threading.Thread(target=_run_rank, args=(group, r, ds, out)) for r in range(world)]
+    th = [threading.Thread(target=_run_rank, args=(group, r, ds, out), daemon=True) for r in range(world)]
     for t in th:
         t.start()
     for t in th:
@@ -511,7 +511,7 @@ def _run_ranks(world, fn):
             out[r] = e
         finally:
             comm.close()
-    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    th = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
     for t in th:
         t.start()
     for t in th:
