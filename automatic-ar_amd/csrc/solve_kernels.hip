@@ -808,8 +808,8 @@ __global__ void __launch_bounds__(64) k_ldl_trsm(double *__restrict__ S, double 
     }
 }
 
-// trailing update of step s in 32x32 output sub-tiles: S(I, J) -= L_Is D_s L_Js^T; rhs rows: b_t -= L_ts D_s z_s.
-// grid: [tiles (ti >= tj)] x 9 sub-tiles, then one workgroup per rhs row tile.  LDS: Li [32][NB+1], Ljd [32][NB+1]
+// trailing update of step s in 16x16 output blocks on the matrix pipe: S(I, J) -= L_Is D_s L_Js^T; rhs rows: b_t -= L_ts D_s z_s.
+// grid: [tiles (ti >= tj)] x 9 workgroups of four wavefronts (one 16x16 block each), then one workgroup per rhs row tile.
 __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
                                                     const double *__restrict__ Dfac, int n_pad, int n, int s, int nT,
                                                     double mu, const int32_t *__restrict__ ent_fixed) {
