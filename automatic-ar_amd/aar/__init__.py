@@ -60,7 +60,8 @@ class CSynthDesc(C.Structure):
     _fields_ = [
         ("num_cams", C.c_int32), ("num_markers", C.c_int32), ("num_frames", C.c_int32), ("seed", C.c_uint64),
         ("marker_size", C.c_double), ("noise_px", C.c_double), ("init_rot_sigma", C.c_double),
-        ("init_trans_sigma", C.c_double), ("init_scale", C.c_double),
+        ("init_trans_sigma", C.c_double), ("init_scale", C.c_double), ("cam_arc_deg", C.c_double),
+        ("min_view_cos", C.c_double),
     ]
 
 

@@ -63,7 +63,7 @@ void aar_synth_default(aar_synth_desc *d, int32_t config_index) {
     // BASELINE.json configs (index into the JSON array): 1: 4/12/100, 2: 8/40/500, 3: 8/40/2000, 4: 16/200/5000.
     // SURVEY.md numbers them 2..5; `config_index` here is the SURVEY number.
     switch (config_index) {
-        case 1: d->num_cams = 3;  d->num_markers = 6;   d->num_frames = 60;   break;  // box-like plumbing case
+        case 1: d->num_cams = 3;  d->num_markers = 6;   d->num_frames = 180;  break;  // box-like plumbing case (one full turn; the bottom face is never seen)
         case 2: d->num_cams = 4;  d->num_markers = 12;  d->num_frames = 100;  break;
         case 3: d->num_cams = 8;  d->num_markers = 40;  d->num_frames = 500;  break;
         case 4: d->num_cams = 8;  d->num_markers = 40;  d->num_frames = 2000; break;
@@ -76,6 +76,10 @@ void aar_synth_default(aar_synth_desc *d, int32_t config_index) {
     d->init_rot_sigma = 0.02;
     d->init_trans_sigma = 0.01;
     d->init_scale = 1.0;
+    if (config_index == 1) {   // the "box" case: three cameras side by side looking at one object, faces seen at a slant
+        d->cam_arc_deg = 50.0;
+        d->min_view_cos = 0.35;
+    }
 }
 
 int aar_synth_generate(const aar_synth_desc *sd, aar_dataset **out) {
@@ -85,11 +89,16 @@ int aar_synth_generate(const aar_synth_desc *sd, aar_dataset **out) {
     Rng rng(sd->seed);
     const double PI = 3.14159265358979323846;
     const double centre[3] = {0, 0, 2.0};
+    const double min_cos = sd->min_view_cos > 0 ? sd->min_view_cos : 0.8;
 
     // --- cameras: ring of radius 2 m around the scene centre in camera 0's x-z plane, looking at it ---
     std::vector<Rigid> Tc(C);  // camera i -> camera 0 (= world)
     for (int i = 0; i < C; i++) {
-        const double az = 2 * PI * i / C + (i > 0 ? 0.1 : 0.0);  // offset keeps the opposite camera off theta = pi
+        double az = 2 * PI * i / C + (i > 0 ? 0.1 : 0.0);  // offset keeps the opposite camera off theta = pi
+        if (sd->cam_arc_deg > 0 && C > 1) {   // cameras side by side on an arc centred on camera 0: 0, +s, -s, +2s, ...
+            const double step = sd->cam_arc_deg * PI / 180.0 / (C - 1);
+            az = ((i & 1) ? 1.0 : -1.0) * ((i + 1) / 2) * step;
+        }
         const double pos[3] = {centre[0] + 2.0 * std::sin(az), 0, centre[2] - 2.0 * std::cos(az)};
         double z[3] = {centre[0] - pos[0], centre[1] - pos[1], centre[2] - pos[2]};
         normalize3(z);
@@ -149,7 +158,7 @@ int aar_synth_generate(const aar_synth_desc *sd, aar_dataset **out) {
                 const double nrm[3] = {Wm.R[2], Wm.R[5], Wm.R[8]};
                 double dir[3] = {Tc[c].t[0] - Wm.t[0], Tc[c].t[1] - Wm.t[1], Tc[c].t[2] - Wm.t[2]};
                 normalize3(dir);
-                if (nrm[0] * dir[0] + nrm[1] * dir[1] + nrm[2] * dir[2] < 0.8) continue;
+                if (nrm[0] * dir[0] + nrm[1] * dir[1] + nrm[2] * dir[2] < min_cos) continue;
                 const Rigid Cm = compose(Tci, Wm);  // marker -> camera c
                 double uv[8];
                 bool inside = true;

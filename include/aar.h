@@ -77,8 +77,13 @@ typedef struct aar_synth_desc {
     double init_rot_sigma;      /* rad, perturbation of every rotation-vector component (0.02)         */
     double init_trans_sigma;    /* m, perturbation of every translation component (0.01)               */
     double init_scale;          /* multiplies both sigmas (1.0)                                        */
+    double cam_arc_deg;         /* 0: cameras on a full ring around the scene; > 0: side by side on an arc of that
+                                   many degrees centred on camera 0 (config 1, the box-like case: 50)   */
+    double min_view_cos;        /* a marker is seen when cos(normal, view ray) >= this (0 = default 0.8;
+                                   config 1: 0.35)                                                      */
 } aar_synth_desc;
-void aar_synth_default(aar_synth_desc *, int32_t config_index); /* BASELINE.json configs[1..4] -> 2..5 */
+void aar_synth_default(aar_synth_desc *, int32_t config_index); /* BASELINE.json configs[1..4] -> 2..5; 1 = a 3-camera /
+                                                                   6-marker stand-in for configs[0] (the box data set) */
 int aar_synth_generate(const aar_synth_desc *, aar_dataset **out);
 
 /* File formats of the path.

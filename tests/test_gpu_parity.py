@@ -592,3 +592,62 @@ def test_sharded_retry_and_mispredicted_damping():
                 np.testing.assert_allclose([t["err"] for t in rep["trace"]][:k], err1[:k], rtol=1e-5)
                 np.testing.assert_allclose([t["mu"] for t in rep["trace"]][:k], mu1[:k], rtol=1e-3)
                 assert abs(np.sqrt(rep["final_err"] / (4 * ds.num_obs)) - np.sqrt(rep1["final_err"] / (4 * ds.num_obs))) < 1e-4
+
+
+def test_config1_box_like_find_solution_vs_compiled_reference(tmp_path):
+    # BASELINE.json configs[0] (box data set: 3 cameras / ~6 markers, marker_size 0.05; the data set itself is not in the
+    # container, README.md:55-56 -- `--synth 1` writes a stand-in in the reference's file formats).  The whole find_solution
+    # flow (apps/find_solution.cpp:101-163) on the HIP path -- calib folders + aruco.detections -> Initializer -> initial.solution
+    # -> LM -> final.solution -- against the REAL reference solver (oracle/_ref: libs/sparselevmarq.h + Eigen compiled in place)
+    # started from the very same initial.solution with the reference-faithful residual / central-difference float Jacobian.
+    import subprocess
+    from conftest import PKG
+    exe = os.path.join(PKG, "aar_find_solution")
+    folder = str(tmp_path / "box")
+    assert subprocess.run([exe, "--synth", "1", folder], capture_output=True, text=True).returncode == 0
+    os.remove(os.path.join(folder, "initial.solution"))           # the driver must write its own from the Initializer
+    run = subprocess.run([exe, folder, "0.05"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr + run.stdout
+    assert "Initializer:" in run.stdout and "The algorithm took:" in run.stdout
+    init = aar.solution_read(os.path.join(folder, "initial.solution"))
+    fin = aar.solution_read(os.path.join(folder, "final.solution"))
+    assert init.num_cams == 3 and 5 <= init.num_markers <= 6 and init.num_frames > 100   # (the box's bottom face is never seen)
+    assert fin.num_obs == init.num_obs and np.array_equal(fin.obs_uv, init.obs_uv)
+    o = ol.Oracle(init)
+    solve = o.ref_lm_solve if ol.have_ref() else o.lm_solve
+    x_ref, rep_ref = solve(init.x_full, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32)
+    rmse_ref = o.reproj_stats(x_ref)["rmse"]
+    rmse_gpu = o.reproj_stats(fin.x_full)["rmse"]
+    rmse_init = o.reproj_stats(init.x_full)["rmse"]
+    assert rmse_gpu < rmse_init
+    assert abs(rmse_gpu - rmse_ref) < 1e-4, (rmse_gpu, rmse_ref)        # the north star's bar
+    # the same solve through the C ABI from the file: same iteration count as the driver printed, same final error
+    with aar.Problem(init) as p:
+        x, rep = p.lm_solve(init.x_full)
+        assert ("LM iterations: %d " % rep["iterations"]) in run.stdout
+        assert abs(p.reproj_stats(x)[0] - rmse_gpu) < 1e-7               # final.solution stores vec -> mat -> vec
+        assert abs(rep["iterations"] - rep_ref["iterations"]) <= 2
+
+
+def test_full_size_config3_against_compiled_reference():
+    # BASELINE.json's metric configuration (8 cameras / 40 markers / 500 frames) at FULL size against the real reference solver
+    # (oracle/_ref) on the same detections: one damped step against the oracle's sparse LDL^T of the same analytic system, and
+    # the complete solve: final sum of squares / RMSE of the reference-faithful CPU run (numeric float Jacobian) within the
+    # north star's 1e-4 px.  (~10 s of CPU for the reference solve.)
+    ds = aar.synth(3)
+    o = ol.Oracle(ds)
+    solve = o.ref_lm_solve if ol.have_ref() else o.lm_solve
+    x_ref, rep_ref = solve(ds.x_full, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=min(32, os.cpu_count() or 1))
+    with aar.Problem(ds) as p:
+        mu = 1e5
+        d = p.eval_damped_step(ds.x_full, mu)
+        do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+        assert np.abs(d - do).max() / np.abs(do).max() < 1e-9
+        x, rep = p.lm_solve(ds.x_full)
+        rmse, ss = p.reproj_stats(x)
+    st = o.reproj_stats(x_ref)
+    assert abs(rmse - st["rmse"]) < 1e-4, (rmse, st["rmse"])
+    assert abs(rmse - st["rmse"]) < 1e-6                                   # what is observed: 5e-8 px
+    np.testing.assert_allclose(rep["final_err"], rep_ref["final_err"], rtol=1e-5)   # 8873.4574 vs 8873.4597 in round 1
+    assert abs(rep["iterations"] - rep_ref["iterations"]) <= 1
+    assert np.abs(x - x_ref).max() < 1e-3

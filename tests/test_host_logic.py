@@ -163,7 +163,7 @@ def test_find_solution_driver_file_contract(tmp_path):
     for f in ("aruco.detections", "initial.solution", "initial.solution.yaml"):
         assert os.path.exists(os.path.join(folder, f))
     ds = aar.solution_read(os.path.join(folder, "initial.solution"))
-    assert (ds.num_cams, ds.num_markers) == (3, 6)          # box-like plumbing case (BASELINE.json configs[0])
+    assert (ds.num_cams, ds.num_markers) == (3, 6)          # box-like stand-in for BASELINE.json configs[0]
     if aar.device_count() == 0:
         # no GPU here: the product must fail loudly, not fall back to a CPU path
         run = subprocess.run([exe, folder, "0.05"], capture_output=True, text=True)
