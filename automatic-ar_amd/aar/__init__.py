@@ -32,6 +32,7 @@ SYMBOLS = [
     "aar_undistort_points", "aar_local_group_create", "aar_local_group_destroy", "aar_comm_create_local",
     "aar_cam_configs_read", "aar_detections_read", "aar_detections_free", "aar_subseqs_read", "aar_ippe_square",
     "aar_vote_transforms", "aar_init_default_params", "aar_initializer_run", "aar_initializer_object_poses",
+    "aar_comm_get_stats",
 ]
 NUM_KERNELS = 13
 
@@ -97,6 +98,11 @@ class CLmReport(C.Structure):
     ]
 
 
+class CCommStats(C.Structure):
+    _fields_ = [("world_size", C.c_int32), ("rank", C.c_int32), ("ranks_seen", C.c_int32), ("allreduce_calls", C.c_int64),
+                ("allreduce_bytes", C.c_int64), ("system_allreduce_bytes", C.c_int64)]
+
+
 class CStageTimes(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("unpack", "jacobian_normal_eq", "schur", "chol", "backsub", "residual",
                                           "control", "allreduce", "total")] + [("launches", C.c_int64)]
@@ -148,6 +154,7 @@ def lib():
     L.aar_comm_make_id.argtypes = [C.c_char_p]
     L.aar_comm_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.aar_comm_destroy.argtypes = [C.c_void_p]
+    L.aar_comm_get_stats.argtypes = [C.c_void_p, C.POINTER(CCommStats)]
     L.aar_comm_destroy.restype = None
     L.aar_problem_desc_from_dataset.argtypes = [C.POINTER(CDataset), C.POINTER(CProblemDesc)]
     L.aar_problem_desc_from_dataset.restype = None
@@ -537,6 +544,11 @@ class Comm:
         self.world, self.rank = group.world, rank
         _check(lib().aar_comm_create_local(group.handle, rank, device, C.byref(self.handle)))
         return self
+
+    def stats(self):
+        st = CCommStats()
+        _check(lib().aar_comm_get_stats(self.handle, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in CCommStats._fields_}
 
     def close(self):
         if self.handle:

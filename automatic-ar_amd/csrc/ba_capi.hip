@@ -42,6 +42,7 @@ struct NcclApi {
     int (*CommInitRank)(NcclComm *, int, NcclId, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommCount)(NcclComm, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
@@ -65,6 +66,7 @@ int load_nccl() {
     g_nccl.CommInitRank = (int (*)(NcclComm *, int, NcclId, int))dlsym(g_nccl.lib, "ncclCommInitRank");
     g_nccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, NcclComm, hipStream_t))dlsym(g_nccl.lib, "ncclAllReduce");
     g_nccl.CommDestroy = (int (*)(NcclComm))dlsym(g_nccl.lib, "ncclCommDestroy");
+    g_nccl.CommCount = (int (*)(NcclComm, int *))dlsym(g_nccl.lib, "ncclCommCount");
     g_nccl.GetErrorString = (const char *(*)(int))dlsym(g_nccl.lib, "ncclGetErrorString");
     if (!g_nccl.GetUniqueId || !g_nccl.CommInitRank || !g_nccl.AllReduce || !g_nccl.CommDestroy)
         return set_error(AAR_ERR_COMM, "librccl lacks the expected nccl* symbols");
@@ -107,6 +109,7 @@ struct aar_comm {
     aar_local_group *local = nullptr;   // non-null: in-process group instead of RCCL
     double *tmp = nullptr;              // local transport: reduction scratch on the device
     size_t tmp_count = 0;
+    int64_t allreduce_calls = 0, allreduce_bytes = 0, last_system_bytes = 0;   // aar_comm_get_stats
 };
 
 namespace {
@@ -116,6 +119,22 @@ __global__ void k_local_reduce(double *__restrict__ out, const double *const *__
     double v = in[0][i];
     for (int r = 1; r < world; r++) v = is_max ? fmax(v, in[r][i]) : v + in[r][i];   // fixed rank order: every rank gets the same bits
     out[i] = v;
+}
+
+// The reduced system travels as the PACKED lower triangle (only that half is ever produced or read): row i of S contributes its
+// i + 1 leading entries, then the `extra` doubles that sit right behind S (rhs | g0 | the step's scalars).  grid.y = row
+// (row n_pad = the extra part), dir 0 = pack, 1 = unpack.
+__global__ void __launch_bounds__(256) k_pack_system(double *__restrict__ S, int n_pad, int extra, double *__restrict__ packed, int dir) {
+    const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    const size_t tri = (size_t)n_pad * (n_pad + 1) / 2;
+    if (i < n_pad) {
+        if (j > i) return;
+        double *a = S + (size_t)i * n_pad + j, *b = packed + (size_t)i * (i + 1) / 2 + j;
+        if (dir == 0) *b = *a; else *a = *b;
+    } else if (j < extra) {
+        double *a = S + (size_t)n_pad * n_pad + j, *b = packed + tri + j;
+        if (dir == 0) *b = *a; else *a = *b;
+    }
 }
 }  // namespace
 
@@ -141,6 +160,8 @@ struct aar_problem {
     unsigned long long seq = 0;
     double *d_frames_all = nullptr;  // [6 F_global] gather buffer (multi-GPU)
     double *d_diag = nullptr;        // [n_pad]
+    double *d_pack = nullptr;        // multi-GPU: packed lower triangle of S | rhs | g0 | scalars, the all-reduce payload
+    double *d_status = nullptr;      // multi-GPU: one double for collective status decisions
     std::vector<double> h_z;    // staging [6A + 6F_loc]
     // host copies of the index structure (normal-equation assembly for tests)
     std::vector<int32_t> h_fslot_start, h_fslot_ent;
@@ -228,6 +249,8 @@ int upload_z(aar_problem *pb, const double *x_full, int which) {
 
 int allreduce(aar_problem *pb, double *buf, size_t count, int op) {
     if (!pb->comm) return AAR_OK;
+    pb->comm->allreduce_calls++;
+    pb->comm->allreduce_bytes += (int64_t)(count * sizeof(double));
     if (aar_local_group *g = pb->comm->local) {   // in-process transport (see aar_local_group)
         aar_comm *c = pb->comm;
         if (c->tmp_count < count + (size_t)g->world) {
@@ -248,6 +271,41 @@ int allreduce(aar_problem *pb, double *buf, size_t count, int op) {
         return AAR_OK;
     }
     NCCL_TRY(g_nccl.AllReduce(buf, buf, count, NCCL_FLOAT64, op, pb->comm->comm, pb->stream));
+    return AAR_OK;
+}
+
+// All-reduce of the reduced system of block set `which`: packed lower triangle of S | rhs | g0 (| the first n_tail doubles of
+// the tail: the step's scalars of the fused collective).  n_pad (n_pad + 1) / 2 + 2 n_pad + n_tail doubles instead of the
+// n_pad^2 + ... of the square.
+int allreduce_system(aar_problem *pb, int which, int n_tail) {
+    DeviceProblem &P = pb->P;
+    const int extra = 2 * P.n_pad + n_tail;
+    const size_t count = (size_t)P.n_pad * (P.n_pad + 1) / 2 + (size_t)extra;
+    const dim3 grid((unsigned)((std::max(P.n_pad, extra) + 255) / 256), (unsigned)P.n_pad + 1);
+    hipLaunchKernelGGL(k_pack_system, grid, dim3(256), 0, pb->stream, P.blk[which].S, P.n_pad, extra, pb->d_pack, 0);
+    int rc = allreduce(pb, pb->d_pack, count, NCCL_SUM);
+    if (rc) return rc;
+    pb->comm->last_system_bytes = (int64_t)(count * sizeof(double));
+    hipLaunchKernelGGL(k_pack_system, grid, dim3(256), 0, pb->stream, P.blk[which].S, P.n_pad, extra, pb->d_pack, 1);
+    pb->launches += 2;
+    return AAR_OK;
+}
+
+// The same status on every rank: the most severe (most negative) code any rank holds.  A rank that fails alone would leave
+// the others waiting in their next collective forever (RCCL has no timeout), so rank-local failures that decide control flow
+// are agreed on first.
+int collective_status(aar_problem *pb, int local_rc, int *agreed) {
+    *agreed = local_rc;
+    if (!pb->comm) return AAR_OK;
+    const double v = (double)(-local_rc);
+    HIP_TRY(hipMemcpyAsync(pb->d_status, &v, sizeof v, hipMemcpyHostToDevice, pb->stream));
+    HIP_TRY(hipStreamSynchronize(pb->stream));     // (v is a stack variable)
+    int rc = allreduce(pb, pb->d_status, 1, NCCL_MAX);
+    if (rc) return rc;
+    double w = 0;
+    HIP_TRY(hipMemcpyAsync(&w, pb->d_status, sizeof w, hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    *agreed = -(int)w;
     return AAR_OK;
 }
 
@@ -420,9 +478,9 @@ int launch_scalars(aar_problem *pb, int n_err) {
     }
     if (pb->comm) {
         StageTimer t(pb, &pb->times.allreduce);
-        int rc = allreduce(pb, P.scal, 3, NCCL_SUM);  // [sum r^2, sum |delta_f|^2, sum delta.g]
+        int rc = allreduce(pb, P.scal, 4, NCCL_SUM);  // [sum r^2, sum |delta_f|^2, sum delta.g, every rank's error flags]
         if (rc) return rc;
-        launch_publish(P, pb->seq, pb->stream);
+        launch_publish(P, pb->seq, pb->stream, nullptr, /*flags_reduced=*/true);
     }
     return check_async("kernel launch");
 }
@@ -472,7 +530,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     pb->schur_mu = -1;
     if (pb->comm && !pb->s_reduced) {
         StageTimer t(pb, &pb->times.allreduce);
-        int rc = allreduce(pb, P.blk[cur].S, (size_t)P.n_pad * P.n_pad + 2 * (size_t)P.n_pad, NCCL_SUM);   // S | rhs | g0 (contiguous)
+        int rc = allreduce_system(pb, cur, 0);   // S (lower triangle) | rhs | g0
         if (rc) return rc;
     }
     pb->s_reduced = false;      // the factorisation below consumes the system
@@ -519,11 +577,12 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         pb->seq++;
         {
             StageTimer t(pb, &pb->times.allreduce);
-            // tail[0..2] = sum r^2, sum |delta_f|^2, sum delta_f.g_f are rank sums; tail[5..6] (shared-parameter pieces) are
-            // computed from replicated data on every rank and stay out of the reduction
-            if ((rc = allreduce(pb, P.blk[tr].S, (size_t)P.n_pad * P.n_pad + 2 * (size_t)P.n_pad + 3, NCCL_SUM))) return rc;
+            // tail[0..2] = sum r^2, sum |delta_f|^2, sum delta_f.g_f are rank sums, tail[3] carries every rank's error flags (so that
+            // all ranks take the same branch); tail[5..6] (shared-parameter pieces) are computed from replicated data on every
+            // rank and stay out of the reduction
+            if ((rc = allreduce_system(pb, tr, 4))) return rc;
         }
-        launch_publish(P, pb->seq, pb->stream, P.blk[tr].tail);
+        launch_publish(P, pb->seq, pb->stream, P.blk[tr].tail, /*flags_reduced=*/true);
         pb->trial_reduced = true;
     } else {
         if ((rc = launch_scalars(pb, P.F))) return rc;
@@ -540,7 +599,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         set_error(AAR_ERR_NUMERIC, "device flags %d at mu=%g (1: a frame block is not positive definite, 2: non-positive pivot of the reduced system, 4: back-substitution chain timed out)", pb->h_flags[0], mu);
         // Only the reduced system lost positive definiteness (far from the optimum its Schur complement can, in floating point):
         // the LM loop takes that as a failed try and raises the damping; every rank sees the same replicated pivots.
-        return pb->h_flags[0] == 2 ? TRY_NOT_POSITIVE_DEFINITE : AAR_ERR_NUMERIC;
+        // (a zero or negative pivot fills the trial point with NaNs, which the next pass A reports as flag 1 as well: still a failed try)
+        return (pb->h_flags[0] & 2) ? TRY_NOT_POSITIVE_DEFINITE : AAR_ERR_NUMERIC;
     }
     return AAR_OK;
 }
@@ -629,6 +689,23 @@ int aar_comm_create(const char id[AAR_COMM_ID_BYTES], int32_t world_size, int32_
         return set_error(AAR_ERR_COMM, "ncclCommInitRank failed: %s", g_nccl.GetErrorString ? g_nccl.GetErrorString(r) : "?");
     }
     *out = c;
+    return AAR_OK;
+}
+
+int aar_comm_get_stats(const aar_comm *c, aar_comm_stats *out) {
+    if (!c || !out) return set_error(AAR_ERR_INVALID, "aar_comm_get_stats: null argument");
+    memset(out, 0, sizeof *out);
+    out->world_size = c->world;
+    out->rank = c->rank;
+    out->ranks_seen = c->world;
+    if (c->comm && g_nccl.CommCount) {   // what RCCL itself reports for this communicator
+        int n = 0;
+        NCCL_TRY(g_nccl.CommCount(c->comm, &n));
+        out->ranks_seen = n;
+    }
+    out->allreduce_calls = c->allreduce_calls;
+    out->allreduce_bytes = c->allreduce_bytes;
+    out->system_allreduce_bytes = c->last_system_bytes;
     return AAR_OK;
 }
 
@@ -753,6 +830,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     P.frames_fixed = L.of ? 0 : 1;
     const int A = P.A, F = P.F;
 
+    int local_rc = AAR_OK;   // rank-local limits: decided collectively below
     // ---- ordering A (reference order) + per-frame slot lists ----
     std::vector<int32_t> frame_obs_start(F + 1, 0), fslot_start(F + 1, 0), fslot_ent;
     std::vector<ObsIdx> a_idx(N);
@@ -772,7 +850,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
             }
             std::sort(ents.begin(), ents.end());
             ents.erase(std::unique(ents.begin(), ents.end()), ents.end());
-            if (ents.size() > 65535) return fail(set_error(AAR_ERR_UNSUPPORTED, "frame %d touches more than 65535 entities", f));
+            if (ents.size() > 65535 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "frame %d touches more than 65535 entities", f);
             for (size_t s = 0; s < ents.size(); s++) slot_of[ents[s]] = (int32_t)s;
             for (int64_t k = 0; k < cnt; k++) {
                 const int64_t g = ob + o + k;
@@ -791,8 +869,15 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     }
     P.total_slots = (int)fslot_ent.size();
     const size_t ldsA = ((size_t)P.max_kf * 36 + 32 + (size_t)(P.max_kf + 1) * ENT_STRIDE + 4 * 2048) * sizeof(double);
-    if (ldsA > 160 * 1024) return fail(set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers; the frame-block kernel holds them in LDS (limit ~ %d)", P.max_kf, (160 * 1024 / 8 - 56 - 8192) / 60));
-    if ((size_t)A * 36 * 8 + 2048 > 160 * 1024) return fail(set_error(AAR_ERR_UNSUPPORTED, "%d cameras+markers exceed the Schur row panel held in LDS", A));
+    if (ldsA > 160 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers; the frame-block kernel holds them in LDS (limit ~ %d)", P.max_kf, (160 * 1024 / 8 - 56 - 8192) / 60);
+    if ((size_t)A * 36 * 8 + 2048 > 160 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "%d cameras+markers exceed the Schur row panel held in LDS", A);
+    {   // the limits above depend on the rank's own frames: agree on the outcome before anybody returns (see collective_status)
+        if (pb->comm && (rc = dev_alloc(pb, &pb->d_status, 1))) return fail(rc);
+        int agreed = local_rc;
+        if ((rc = collective_status(pb, local_rc, &agreed))) return fail(rc);
+        if (local_rc) return fail(local_rc);
+        if (agreed) return fail(set_error(agreed, "another rank could not create its shard of the problem (status %d)", agreed));
+    }
 
     // ---- ordering B: (camera, marker, frame) runs cut into wave-sized chunks ----
     std::vector<int32_t> perm(N);
@@ -938,6 +1023,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
 #undef AL
     if ((rc = dev_alloc(pb, &pb->d_diag, P.n_pad))) return fail(rc);
     if (pb->comm && (rc = dev_alloc(pb, &pb->d_frames_all, 6 * (size_t)std::max(Fg, 1)))) return fail(rc);
+    if (pb->comm && (rc = dev_alloc(pb, &pb->d_pack, (size_t)P.n_pad * (P.n_pad + 1) / 2 + 2 * (size_t)P.n_pad + 8))) return fail(rc);
     if (hipHostMalloc((void **)&pb->h_scal, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
         return fail(set_error(AAR_ERR_HIP, "hipHostMalloc failed"));
     memset(pb->h_scal, 0, 16 * sizeof(double));

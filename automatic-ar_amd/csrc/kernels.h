@@ -120,7 +120,8 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st); 
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st,
                            double *scal_out = nullptr);  // scal[0..2], scal[5..6] (into scal_out instead of P.scal if given)
-void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st, const double *src = nullptr);  // scal/flags -> host record
+// scal / flags -> host record; flags_reduced: the flags are decoded from src[3] (every rank's flags, all-reduced) instead of P.flags
+void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st, const double *src = nullptr, bool flags_reduced = false);
 int residual_blocks(const DeviceProblem &P);   // entries of err_part written by launch_residual
 // track(): every frame's own 6-DoF LM, whole loop on the device; needs ent[which] rows of the shared entities (launch_unpack)
 void launch_track(const DeviceProblem &P, int which, int max_iters, double min_error, double min_step, double min_avg, double tau,

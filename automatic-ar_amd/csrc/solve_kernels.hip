@@ -46,18 +46,30 @@ __global__ void __launch_bounds__(256) k_frame_inv(const double *__restrict__ V,
     }
 }
 
+// The error flags of a rank as one double that survives a SUM all-reduce over up to 4095 ranks: bit b set on k ranks adds k 4096^b.
+// Every rank decodes the same value, so every rank takes the same branch (a rank that failed alone would otherwise leave the
+// others waiting in their next collective).
+__device__ __forceinline__ double encode_flags(int f) {
+    return (double)(f & 1) + 4096.0 * (double)((f >> 1) & 1) + 16777216.0 * (double)((f >> 2) & 1);
+}
+__device__ __forceinline__ int decode_flags(double v) {
+    const long long q = (long long)v;
+    return ((q % 4096) ? 1 : 0) | (((q / 4096) % 4096) ? 2 : 0) | ((q / 16777216) ? 4 : 0);
+}
+
+// flags_reduced: the flags come from scal[3] (all ranks' flags, summed by the all-reduce) instead of this rank's flag words
 __device__ __forceinline__ void publish_host(const double *__restrict__ scal, const int32_t *__restrict__ flags,
-                                             double *__restrict__ host, unsigned long long seq) {
+                                             double *__restrict__ host, unsigned long long seq, int flags_reduced = 0) {
 #pragma unroll
     for (int i = 0; i < 8; i++) host[i] = scal[i];
-    reinterpret_cast<long long *>(host)[8] = (long long)(flags[0] | flags[1] | flags[2] | flags[3]);
+    reinterpret_cast<long long *>(host)[8] = flags_reduced ? (long long)decode_flags(scal[3]) : (long long)(flags[0] | flags[1] | flags[2] | flags[3]);
     __threadfence_system();
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(host) + 9, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void k_publish(const double *__restrict__ scal, const int32_t *__restrict__ flags, double *__restrict__ host,
-                          unsigned long long seq) {
-    if (threadIdx.x == 0) publish_host(scal, flags, host, seq);
+                          unsigned long long seq, int flags_reduced) {
+    if (threadIdx.x == 0) publish_host(scal, flags, host, seq, flags_reduced);
 }
 
 
@@ -86,6 +98,7 @@ __device__ __forceinline__ void reduce_scalars_body(const ReduceArgs &r) {   // 
         r.scal[0] = red[0][0]; r.scal[1] = red[1][0];
         // multi-GPU: delta_s . g0 uses this rank's piece of the shared gradient, so it joins the rank sum
         r.scal[2] = red[2][0] + (r.fold_shared ? r.lin_part[2 * (size_t)r.F + 1] : 0.0);
+        r.scal[3] = encode_flags(r.flags[0] | r.flags[1] | r.flags[2] | r.flags[3]);   // multi-GPU: joins the rank sum
         r.scal[5] = r.lin_part[2 * (size_t)r.F]; r.scal[6] = r.lin_part[2 * (size_t)r.F + 1];
         if (r.publish_seq) publish_host(r.scal, r.flags, r.host, r.publish_seq);
     }
@@ -1156,8 +1169,8 @@ void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, 
     { HookScope _h(P, KID_REDUCE); hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, reduce_args(P, n_err, fold_shared, publish_seq, scal_out)); }
 }
 
-void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st, const double *src) {
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, src ? src : P.scal, P.flags, P.host_result, publish_seq);
+void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st, const double *src, bool flags_reduced) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, src ? src : P.scal, P.flags, P.host_result, publish_seq, flags_reduced ? 1 : 0);
 }
 
 }  // namespace aar

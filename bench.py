@@ -3,6 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 2|3|4|5] [--no-cpu-baseline]
 
+`--gpus N` with N > 1 needs nothing else: when the script is not already running under torch.distributed.run (WORLD_SIZE unset)
+it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a
+CHILD process -- before this process has made any HIP call -- relays rank 0's JSON line and exits non-zero if any rank failed.
+
 A "step" is one LM iteration = one step() of ucoslam::SparseLevMarq (libs/sparselevmarq.h:349-430): Jacobian /
 normal-equation build at the current point, >= 1 damped solve, >= 1 trial residual, accept/reject.  The timed region
 runs EXACTLY K steps as back-to-back solve() calls from the same initial guess (a solve takes ~15 steps to stop; the last
@@ -16,6 +20,8 @@ Prints ONE JSON line (rank 0).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -111,6 +117,73 @@ def cpu_baseline(ds, workload, max_threads):
             "err_after_sample": rep["final_err"]}
 
 
+def self_launch(n, argv):
+    """Parent of an N-GPU run: one fresh child process per GPU through torch.distributed.run.  This process never touches the GPU
+    (no `import aar`, no torch.cuda call), so nothing that has initialised HIP is ever re-executed or forked."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["AAR_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line = None
+    for raw in proc.stdout:                       # relay: the one JSON line of rank 0 goes to stdout, anything else to stderr
+        txt = raw.strip()
+        if txt.startswith("{") and '"metric"' in txt:
+            try:
+                json.loads(txt)
+                line = txt
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(raw)
+    rc = proc.wait()
+    if line is not None and rc == 0:
+        print(line)
+        sys.stdout.flush()
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank child run failed (exit code %d)\n" % (n, rc))
+        raise SystemExit(rc if 0 < rc < 256 else 1)
+    if line is None:
+        sys.stderr.write("bench.py: the child run printed no result line\n")
+        raise SystemExit(1)
+
+
+def plumbing_only(args, world, rank, dist):
+    """--plumbing-only: everything of the N-rank path that needs no GPU -- rendezvous, shard plan, the gathers and the
+    max-over-ranks of the timing, the JSON line -- so that the launcher can be tested on a CPU-only machine (tests/test_bench_launcher.py)."""
+    import numpy as np
+
+    import aar
+    ds = aar.synth(args.workload)
+    begin = aar.plan_shards(np.bincount(ds.obs_frame, minlength=ds.num_frames), world)
+    local_obs = int(np.sum((ds.obs_frame >= begin[rank]) & (ds.obs_frame < begin[rank + 1])))
+    fail = os.environ.get("AAR_BENCH_FAIL_RANK")
+    if fail is not None and int(fail) == rank:
+        raise SystemExit(3)                       # test hook: a rank that dies after the rendezvous
+    per_rank, dt = [local_obs], 0.001 * (rank + 1)
+    if dist is not None:
+        import torch
+        dist.barrier()
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, local_obs)
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "LM iterations/sec", "value": None, "unit": "LM iterations/s", "n_gpus": world, "plumbing_only": True,
+                          "ranks_seen": world, "local_obs": per_rank, "max_rank_seconds": dt,
+                          "config": {"workload": WORKLOADS[args.workload], "marker_observations": int(ds.num_obs)}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,13 +192,16 @@ def main():
     ap.add_argument("--workload", type=int, default=3, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--plumbing-only", action="store_true", help="launcher / rendezvous / JSON relay only, no GPU work (CPU test of the N-rank plumbing)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, sys.argv[1:])      # before anything below can touch the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...` (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or leave the launching to bench.py)" % (args.gpus, world, args.gpus))
     dist = None
     if world > 1 or os.environ.get("AAR_FORCE_COMM") == "1":
         # torch.distributed is rendezvous plumbing only (id broadcast, barrier, max over ranks); the data path is RCCL inside libaar
@@ -135,6 +211,8 @@ def main():
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # single node: rendezvous over loopback, no host-name lookups
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+    if args.plumbing_only:
+        return plumbing_only(args, world, rank, dist)
     import numpy as np
 
     import aar
@@ -228,6 +306,11 @@ def main():
         track = {"frames": int(ds.num_frames), "seconds_per_call": dt_tr, "frames_per_s": ds.num_frames / dt_tr,
                  "mean_lm_iterations_per_frame": float(np.mean(it_t)), "max_pose_delta_vs_bundle_solution": float(np.abs(xt[ns:] - x_fin[ns:]).max())}
 
+    per_rank_obs = [int(problem.local_obs)]
+    comm_stats = comm.stats() if comm is not None else None
+    if dist is not None:
+        per_rank_obs = [None] * world
+        dist.all_gather_object(per_rank_obs, int(problem.local_obs))
     if rank != 0:
         problem.close()
         if dist is not None:
@@ -250,6 +333,11 @@ def main():
         "iteration_hbm": {"bytes_per_iteration": b_iter, "achieved": b_iter * done / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                           "frac": b_iter * done / dt / 1e9 / HBM_PEAK_GBPS},
         "roofline": roofline, "kernels": kernels, "track": track,
+        # multi-GPU bookkeeping: ranks RCCL itself reports for the communicator, observations per rank (frame-range shards
+        # balanced by observation count), payload of ONE all-reduce of the reduced system (packed lower triangle | rhs | g0 | scalars)
+        "ranks_seen": comm_stats["ranks_seen"] if comm_stats else 1, "local_obs": per_rank_obs,
+        "allreduce_bytes": comm_stats["system_allreduce_bytes"] if comm_stats else 0,
+        "allreduce_calls": comm_stats["allreduce_calls"] if comm_stats else 0,
     }
     if world == 1 and not args.no_cpu_baseline:
         threads = os.cpu_count() or 1

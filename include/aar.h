@@ -194,6 +194,13 @@ int aar_comm_make_id(char id[AAR_COMM_ID_BYTES]);
 int aar_comm_create(const char id[AAR_COMM_ID_BYTES], int32_t world_size, int32_t rank, int32_t device_id,
                     aar_comm **out);
 void aar_comm_destroy(aar_comm *);
+/* What the communicator has moved so far (bench.py reports it): ranks_seen = ncclCommCount of the RCCL communicator,
+ * system_allreduce_bytes = payload of ONE all-reduce of the reduced system (packed lower triangle of S | rhs | g0 | scalars). */
+typedef struct aar_comm_stats {
+    int32_t world_size, rank, ranks_seen;
+    int64_t allreduce_calls, allreduce_bytes, system_allreduce_bytes;
+} aar_comm_stats;
+int aar_comm_get_stats(const aar_comm *, aar_comm_stats *out);
 /* In-process stand-in for a communicator (bring-up and tests on a 1-GPU box): `world_size` host threads of one process,
  * each with its own aar_problem on the same GPU, exchange through the group instead of RCCL; the sharded path itself
  * (frame ranges, every all-reduce, the final gather) is unchanged.  Every rank's calls must be made concurrently, one
