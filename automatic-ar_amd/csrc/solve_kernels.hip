@@ -448,6 +448,25 @@ __device__ __forceinline__ double xform_first(double v, int gi, int gj, int n, d
     if (fi || fj) return gi == gj ? 1.0 : 0.0;
     return gi == gj ? v + mu : v;
 }
+// the same with the two gauge flags already known
+__device__ __forceinline__ double xform_first_flags(double v, int gi, int gj, bool fi, bool fj, double mu) {
+    if (fi || fj) return gi == gj ? 1.0 : 0.0;
+    return gi == gj ? v + mu : v;
+}
+// Gauge flags of 2 x 16 rows in ONE wave-wide ballot, so that the first-touch transform costs a single early load per wavefront
+// instead of two dependent loads per matrix element: bit l (l < 16) = row base_a + step_a l is a gauge / padding row, bit 16 + l
+// the same for base_b + step_b l.  Not on the first touch: 0, nothing loaded.
+__device__ __forceinline__ unsigned long long gauge_ballot(bool first, const int32_t *__restrict__ ent_fixed, int n, int base_a, int step_a,
+                                                           int base_b, int step_b) {
+    if (!first) return 0ull;
+    const int lane = threadIdx.x & 63;
+    bool f = false;
+    if (lane < 32) {
+        const int g = lane < 16 ? base_a + step_a * lane : base_b + step_b * (lane - 16);
+        f = g >= n || ent_fixed[g / 6] != 0;
+    }
+    return __ballot(f);
+}
 
 // 1/d: v_rcp_f64 is good to 2^-24.4 (scripts/probe/rcp_probe.hip); one cubic step 1/d = x (1 + e + e^2 + ...), e = 1 - d x,
 // leaves 2^-73 and matches the IEEE quotient on 4 M samples -- one instruction less than two Newton steps
@@ -534,6 +553,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
     const int r0 = s * NB;
     const bool first = (s == 0);
     STAMP(0);
+    const unsigned long long gmask = gauge_ballot(first, ent_fixed, n, r0, 6, r0, 6);   // bit e: entity e of this tile is a gauge / padding entity
     {   // tile -> LDS, coalesced; damping / gauge on first touch; zeros above the diagonal
         double v[PER];
 #pragma unroll
@@ -546,7 +566,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
         for (int u = 0; u < PER; u++) {
             const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
             double x = v[u];
-            if (first && j <= i) x = xform_first(x, r0 + i, r0 + j, n, mu, ent_fixed);
+            if (first && j <= i) x = xform_first_flags(x, i, j, (gmask >> (i / 6)) & 1, (gmask >> (j / 6)) & 1, mu);
             T[i * LD + j] = x;
         }
     }
@@ -651,8 +671,8 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
         double b0 = rhs[r0 + i0], b1 = h1 ? rhs[r0 + i1] : 0.0;
         if (first) {   // B = g0 + Schur part on free rows, 0 on gauge / padding rows (as k_ldl_trsm does for its rhs slab)
             const int g0i = r0 + i0, g1i = r0 + i1;
-            b0 = (g0i >= n || ent_fixed[g0i / 6]) ? 0.0 : b0 + g0[g0i];
-            if (h1) b1 = (g1i >= n || ent_fixed[g1i / 6]) ? 0.0 : b1 + g0[g1i];
+            b0 = ((gmask >> (i0 / 6)) & 1) ? 0.0 : b0 + g0[g0i];
+            if (h1) b1 = ((gmask >> (i1 / 6)) & 1) ? 0.0 : b1 + g0[g1i];
         }
         const double *c0p = T + i0 * LD, *c1p = T + (h1 ? i1 : 0) * LD;
         auto bcast = [&](double v0, double v1, int j) -> double {   // entry j of the vector held as (v0: rows 0-63, v1: rows 64-95)
@@ -750,6 +770,7 @@ __global__ void __launch_bounds__(64) k_ldl_trsm(double *__restrict__ S, double 
     const int row0 = (s + 1) * NB + SBK * b;   // first slab row of this wavefront
     const double *dd = Dfac + (size_t)s * NB * NB;
     const int lr = lane >> 4, lc = lane & 15;
+    const unsigned long long gmask = gauge_ballot(first, ent_fixed, n, is_rhs ? r0 : row0, 1, r0, 6);   // bits 0-15: slab rows, 16-31: entities of tile s
     dg_acc_t acc[NSB];
     double4 li[NSB];                   // inv(L_qq)[lc][4 lr ..]
     double4 lb[NSB * (NSB - 1) / 2];   // L(16 q2 + lc, 16 q + 4 lr ..), q < q2, in the order they are consumed
@@ -775,8 +796,9 @@ __global__ void __launch_bounds__(64) k_ldl_trsm(double *__restrict__ S, double 
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int gj = r0 + 16 * q + lc;
-                if (!is_rhs) acc[q][r] = xform_first(acc[q][r], row0 + lr + 4 * r, gj, n, mu, ent_fixed);
-                else if (lr + 4 * r == 0) acc[q][r] = (gj >= n || ent_fixed[gj / 6]) ? 0.0 : acc[q][r] + g0[gj];  // B = g0 + Schur part
+                const bool fj = (gmask >> (16 + (16 * q + lc) / 6)) & 1;
+                if (!is_rhs) acc[q][r] = xform_first_flags(acc[q][r], row0 + lr + 4 * r, gj, (gmask >> (lr + 4 * r)) & 1, fj, mu);
+                else if (lr + 4 * r == 0) acc[q][r] = fj ? 0.0 : acc[q][r] + g0[gj];  // B = g0 + Schur part
             }
     }
 #pragma unroll
@@ -864,6 +886,7 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
     if (tid < NB) dv = dd[tid * NB + tid];
     const bool live = !(ti == tj && bj > bi);   // blocks above the diagonal of a diagonal tile are never read
     const int i0 = (s + 1 + ti) * NB + 16 * bi, j0 = (s + 1 + tj) * NB + 16 * bj;
+    const unsigned long long gmask = gauge_ballot(first, ent_fixed, n, i0, 1, j0, 1);   // bits 0-15: rows of this block, 16-31: its columns
     double2 va[RUN / 2], vb[RUN / 2];
     double tgt[4];
     if (live) {
@@ -892,7 +915,7 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
         const int gi = i0 + lr + 4 * r, gj = j0 + lc;
         if (gj <= gi) {
             double v = tgt[r];
-            if (first) v = xform_first(v, gi, gj, n, mu, ent_fixed);
+            if (first) v = xform_first_flags(v, gi, gj, (gmask >> (lr + 4 * r)) & 1, (gmask >> (16 + lc)) & 1, mu);
             S[(size_t)gi * n_pad + gj] = v - acc[r];
         }
     }
