@@ -32,7 +32,8 @@ SYMBOLS = [
     "aar_undistort_points", "aar_local_group_create", "aar_local_group_destroy", "aar_comm_create_local",
     "aar_cam_configs_read", "aar_detections_read", "aar_detections_free", "aar_subseqs_read", "aar_ippe_square",
     "aar_vote_transforms", "aar_init_default_params", "aar_initializer_run", "aar_initializer_object_poses",
-    "aar_comm_get_stats",
+    "aar_comm_get_stats", "aar_lm_set_step_callback", "aar_lm_set_stop_function", "aar_problem_extract_z", "aar_problem_merge_z",
+    "aar_solution_read_ex", "aar_cam_configs_read_ex",
 ]
 NUM_KERNELS = 13
 
@@ -109,6 +110,8 @@ class CStageTimes(C.Structure):
 
 
 _lib = None
+STEP_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+STOP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
 
 
 class CCamModel(C.Structure):
@@ -144,6 +147,7 @@ def lib():
     L.aar_synth_default.restype = None
     L.aar_synth_generate.argtypes = [C.POINTER(CSynthDesc), C.POINTER(C.POINTER(CDataset))]
     L.aar_solution_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(CDataset))]
+    L.aar_solution_read_ex.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.POINTER(CDataset))]
     for n in ("aar_solution_write", "aar_solution_write_yaml", "aar_detections_write"):
         getattr(L, n).argtypes = [C.c_char_p, C.POINTER(CDataset)]
     L.aar_rodrigues_vec2mat.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -189,6 +193,7 @@ def lib():
     L.aar_undistort_points.argtypes = [dp, dp, C.c_int32, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]
     ip, lp, fp = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float)
     L.aar_cam_configs_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(CCamModel)), ip]
+    L.aar_cam_configs_read_ex.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.POINTER(CCamModel)), ip]
     L.aar_detections_read.argtypes = [C.c_char_p, ip, C.c_int32, C.POINTER(C.POINTER(CDetections))]
     L.aar_detections_free.argtypes = [C.POINTER(CDetections)]
     L.aar_detections_free.restype = None
@@ -201,6 +206,10 @@ def lib():
                                       C.POINTER(C.POINTER(CDataset))]
     L.aar_initializer_object_poses.argtypes = [C.POINTER(CDataset), C.POINTER(CDetections), C.POINTER(CCamModel), C.c_int32,
                                                C.POINTER(CInitParams), C.POINTER(C.POINTER(CDataset))]
+    L.aar_lm_set_step_callback.argtypes = [C.c_void_p, STEP_CB, C.c_void_p, C.c_int32]
+    L.aar_lm_set_stop_function.argtypes = [C.c_void_p, STOP_FN, C.c_void_p]
+    L.aar_problem_extract_z.argtypes = [C.c_void_p, dp, dp]
+    L.aar_problem_merge_z.argtypes = [C.c_void_p, dp, dp]
     L.aar_problem_set_huber_delta.argtypes = [C.c_void_p, C.c_float]
     L.aar_problem_get_huber_delta.argtypes = [C.c_void_p]
     L.aar_problem_get_huber_delta.restype = C.c_float
@@ -314,9 +323,9 @@ def synth(config_index, **over):
         lib().aar_dataset_free(p)
 
 
-def solution_read(path):
+def solution_read(path, reference_indexing=False):
     p = C.POINTER(CDataset)()
-    _check(lib().aar_solution_read(path.encode(), C.byref(p)))
+    _check(lib().aar_solution_read_ex(path.encode(), 1 if reference_indexing else 0, C.byref(p)))
     try:
         return Dataset(p)
     finally:
@@ -393,11 +402,11 @@ def cam_models(Ks, dists, sizes=None):
     return arr
 
 
-def cam_configs_read(folder):
-    """CamConfig::read_cam_configs: list of (K 3x3, dist, (w, h)) in ascending sub-directory order"""
+def cam_configs_read(folder, readdir_order=False):
+    """CamConfig::read_cam_configs: list of (K 3x3, dist, (w, h)) in ascending sub-directory order (or readdir order, as the reference)"""
     p = C.POINTER(CCamModel)()
     n = C.c_int32(0)
-    _check(lib().aar_cam_configs_read(folder.encode(), C.byref(p), C.byref(n)))
+    _check(lib().aar_cam_configs_read_ex(folder.encode(), 1 if readdir_order else 0, C.byref(p), C.byref(n)))
     out = []
     for i in range(n.value):
         m = p[i]
@@ -672,6 +681,34 @@ class Problem:
         _check(lib().aar_track(self.handle, _dptr(x), C.byref(params) if params is not None else None,
                                it.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(err)))
         return x, it, err
+
+    def set_step_callback(self, fn, want_z=True):
+        """SparseLevMarq::setStepCallBackFunc: fn(z) after every step (z = numpy copy of curr_z, or None when want_z is False)."""
+        if fn is None:
+            self._step_cb = None
+            _check(lib().aar_lm_set_step_callback(self.handle, C.cast(None, STEP_CB), None, 0))
+            return
+        def tramp(ctx, zp, n):
+            fn(np.ctypeslib.as_array(zp, shape=(n,)).copy() if zp else None)
+        self._step_cb = STEP_CB(tramp)          # keep the trampoline alive
+        _check(lib().aar_lm_set_step_callback(self.handle, self._step_cb, None, int(want_z)))
+
+    def set_stop_function(self, fn):
+        """SparseLevMarq::setStopFunction: fn(z) -> True stops the loop (no iteration cap while it is set)."""
+        if fn is None:
+            self._stop_fn = None
+            _check(lib().aar_lm_set_stop_function(self.handle, C.cast(None, STOP_FN), None))
+            return
+        def tramp(ctx, zp, n):
+            return 1 if fn(np.ctypeslib.as_array(zp, shape=(n,)).copy()) else 0
+        self._stop_fn = STOP_FN(tramp)
+        _check(lib().aar_lm_set_stop_function(self.handle, self._stop_fn, None))
+
+    def extract_z(self, x_full):
+        x = self._x(x_full)
+        z = np.zeros(self.num_vars)
+        _check(lib().aar_problem_extract_z(self.handle, _dptr(x), _dptr(z)))
+        return z
 
     def set_huber_delta(self, delta):
         _check(lib().aar_problem_set_huber_delta(self.handle, float(delta)))

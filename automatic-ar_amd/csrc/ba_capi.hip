@@ -172,6 +172,14 @@ struct aar_problem {
     bool lm_ready = false;
     bool with_huber = false;
     float hubber_delta = 2.5f;         // MultiCamMapper::hubberDelta (libs/multicam_mapper.h:41)
+    // SparseLevMarq::_step_callback / _stopFunction (libs/sparselevmarq.h:135-136)
+    aar_lm_step_callback step_cb = nullptr;
+    void *step_ctx = nullptr;
+    bool step_want_z = false;
+    aar_lm_stop_function stop_fn = nullptr;
+    void *stop_ctx = nullptr;
+    std::vector<double> cb_x, cb_z;    // staging of curr_z for the callbacks
+    float huber_of_blocks = -1.f;      // Huber delta the residual behind blk[cur]'s B = -J^T r was weighted with (x64 of libs/sparselevmarq.h:367)
     bool blocks_valid = false;         // blk[cur] holds J^T J blocks and B at z[cur], S not yet eliminated
     double vinv_mu = -1;               // damping for which blk[cur].Vinv / hf are valid (< 0: none)
     double schur_mu = -1;              // damping whose Schur terms are already subtracted from blk[cur].S / rhs (< 0: none)
@@ -611,11 +619,41 @@ int rebuild_current(aar_problem *pb) {
     int rc = zero_block_set(pb, pb->cur);
     if (rc) return rc;
     if ((rc = zero_block_set(pb, 1 - pb->cur))) return rc;
-    if ((rc = eval_blocks(pb, pb->cur, -1.0, -1))) return rc;
+    // B = -J^T x64 of the reference is computed ONCE per step(), from the residual of the last accepted evaluation
+    // (libs/sparselevmarq.h:367), i.e. with the Huber delta in force THEN -- the step callback may have moved it since
+    const float huber_now = pb->P.huber;
+    if (pb->with_huber && pb->huber_of_blocks > 0.f) pb->P.huber = pb->huber_of_blocks;
+    rc = eval_blocks(pb, pb->cur, -1.0, -1);
+    pb->P.huber = huber_now;
+    if (rc) return rc;
     pb->blocks_valid = true;
     pb->vinv_mu = -1;
     pb->schur_mu = -1;
     pb->s_reduced = pb->trial_reduced = false;
+    return AAR_OK;
+}
+
+// x_full -> z of the reference for the problem's Config (mats2eVec order: cameras | markers | frames), and back
+void extract_z(const PoseLayout &L, const double *x_full, double *z) {
+    int64_t k = 0;
+    if (L.oc) for (int64_t i = 0; i < 6LL * (L.C - 1); i++) z[k++] = x_full[L.full_cam0() + i];
+    if (L.om) for (int64_t i = 0; i < 6LL * (L.M - 1); i++) z[k++] = x_full[L.full_mk0() + i];
+    if (L.of) for (int64_t i = 0; i < 6LL * L.F; i++) z[k++] = x_full[L.full_fr0() + i];
+}
+void merge_z(const PoseLayout &L, const double *z, double *x_full) {
+    int64_t k = 0;
+    if (L.oc) for (int64_t i = 0; i < 6LL * (L.C - 1); i++) x_full[L.full_cam0() + i] = z[k++];
+    if (L.om) for (int64_t i = 0; i < 6LL * (L.M - 1); i++) x_full[L.full_mk0() + i] = z[k++];
+    if (L.of) for (int64_t i = 0; i < 6LL * L.F; i++) x_full[L.full_fr0() + i] = z[k++];
+}
+
+// curr_z on the host for a callback (a device -> host copy per call: only made when a callback asked for it)
+int current_z_for_callbacks(aar_problem *pb, const double *x_start) {
+    pb->cb_x.assign(x_start, x_start + pb->L.full_len());
+    int rc = download_z(pb, pb->cur, pb->cb_x.data());
+    if (rc) return rc;
+    pb->cb_z.resize((size_t)std::max<int64_t>(pb->L.z_len(), 1));
+    extract_z(pb->L, pb->cb_x.data(), pb->cb_z.data());
     return AAR_OK;
 }
 
@@ -1212,6 +1250,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     if ((rc = zero_block_set(pb, 0))) return rc;
     if ((rc = zero_block_set(pb, 1))) return rc;
     if ((rc = eval_blocks(pb, 0, -1.0, -1))) return rc;
+    pb->huber_of_blocks = P.huber;
     HIP_TRY(hipMemsetAsync(P.lin_part, 0, 2 * (size_t)(P.F + 1) * sizeof(double), pb->stream));
     if ((rc = read_scalars(pb, P.F))) return rc;
     pb->currErr = pb->prevErr = pb->h_scal[0];
@@ -1266,6 +1305,7 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
             pb->v = 2.f;
             pb->currErr = err;
             pb->cur = 1 - pb->cur;  // curr_z = estimated_z; its blocks were built speculatively by the try
+            pb->huber_of_blocks = pb->P.huber;
             pb->vinv_mu = mu_used * 0.33;   // what pass A inverted for
             pb->schur_mu = mu_used * 0.33;  // ... and what the speculative Schur complement was taken with
             pb->s_reduced = pb->trial_reduced;   // multi-GPU: ... and whether it has been all-reduced already
@@ -1297,10 +1337,14 @@ int aar_lm_get_solution(aar_problem *pb, double *x_full, double *err) {
     return download_z(pb, pb->cur, x_full);
 }
 
-// SparseLevMarq::solve(z, f, J), libs/sparselevmarq.h:440-472 (no stop function on this path)
+// SparseLevMarq::solve(z, f, J), libs/sparselevmarq.h:440-472
 int aar_lm_solve(aar_problem *pb, double *x_full, const aar_lm_params *prm, aar_lm_report *rep) {
     if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_lm_solve: null argument");
-    if (pb->with_huber) {  // MultiCamMapper::solve sets hubberDelta = 10 before solver.solve (libs/multicam_mapper.cpp:425)
+    // MultiCamMapper::solve sets hubberDelta = 10 before solver.solve (libs/multicam_mapper.cpp:425) and installs optCallBack as
+    // the step callback (:422).  A with_huber problem WITHOUT a caller's step callback gets exactly that pair here; a caller
+    // that installs its own callback (aar::MultiCamMapper does) owns both the start value and the schedule.
+    const bool own_schedule = pb->with_huber && !pb->step_cb;
+    if (own_schedule) {
         pb->hubber_delta = 10;
         pb->P.huber = pb->hubber_delta;
     }
@@ -1310,21 +1354,41 @@ int aar_lm_solve(aar_problem *pb, double *x_full, const aar_lm_params *prm, aar_
     const double rows = 8.0 * (double)pb->N_global;
     const double initial = pb->currErr;
     int mustExit = 0, iters = 0;
-    for (int i = 0; i < pb->prm.max_iters && !mustExit; i++) {
-        aar_lm_iter it;
-        if ((rc = aar_lm_step(pb, &it))) return rc;
-        if (pb->currErr < pb->prm.min_error) mustExit = 1;
-        if (std::fabs(pb->prevErr - pb->currErr) <= pb->prm.min_step_error_diff ||
-            std::fabs((pb->prevErr - pb->currErr) / rows) <= pb->prm.min_average_step_error_diff || !it.accepted)
-            mustExit = 2;
-        if (pb->currErr > pb->prevErr) mustExit = 3;
+    auto after_step = [&](const aar_lm_iter &it) -> int {   // _step_callback(curr_z), :449 / :463
         if (rep && rep->trace && iters < rep->trace_cap) rep->trace[iters] = it;
         iters++;
-        if (pb->with_huber && pb->hubber_delta > 2.5) {  // optCallBack, libs/multicam_mapper.cpp:412-417 (float -= double)
+        if (pb->step_cb) {
+            if (pb->step_want_z && (rc = current_z_for_callbacks(pb, x_full))) return rc;
+            pb->step_cb(pb->step_ctx, pb->step_want_z ? pb->cb_z.data() : nullptr, pb->L.z_len());
+        } else if (own_schedule && pb->hubber_delta > 2.5) {  // optCallBack, libs/multicam_mapper.cpp:412-417 (float -= double)
             pb->hubber_delta = (float)((double)pb->hubber_delta - 7.5 / 500);
             pb->P.huber = pb->hubber_delta;
         }
-        pb->prevErr = pb->currErr;
+        return AAR_OK;
+    };
+    if (pb->stop_fn) {   // :444-450: do { step; callback } while (!stop(curr_z)) -- no iteration cap, no error-based exit
+        bool stop = false;
+        do {
+            aar_lm_iter it;
+            if ((rc = aar_lm_step(pb, &it))) return rc;
+            if ((rc = after_step(it))) return rc;
+            // (prevErr is NOT advanced on this branch of the reference: every gain test keeps comparing with the error of the
+            //  start point, libs/sparselevmarq.h:444-450 against :464)
+            if ((rc = current_z_for_callbacks(pb, x_full))) return rc;
+            stop = pb->stop_fn(pb->stop_ctx, pb->cb_z.data(), pb->L.z_len()) != 0;
+        } while (!stop);
+    } else {
+        for (int i = 0; i < pb->prm.max_iters && !mustExit; i++) {
+            aar_lm_iter it;
+            if ((rc = aar_lm_step(pb, &it))) return rc;
+            if (pb->currErr < pb->prm.min_error) mustExit = 1;
+            if (std::fabs(pb->prevErr - pb->currErr) <= pb->prm.min_step_error_diff ||
+                std::fabs((pb->prevErr - pb->currErr) / rows) <= pb->prm.min_average_step_error_diff || !it.accepted)
+                mustExit = 2;
+            if (pb->currErr > pb->prevErr) mustExit = 3;
+            if ((rc = after_step(it))) return rc;
+            pb->prevErr = pb->currErr;
+        }
     }
     HIP_TRY(hipStreamSynchronize(pb->stream));
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1340,6 +1404,33 @@ int aar_lm_solve(aar_problem *pb, double *x_full, const aar_lm_params *prm, aar_
         rep->solve_seconds = secs;
         rep->trial_points = pb->trial_points;
     }
+    return AAR_OK;
+}
+
+int aar_lm_set_step_callback(aar_problem *pb, aar_lm_step_callback fn, void *ctx, int32_t want_z) {
+    if (!pb) return set_error(AAR_ERR_INVALID, "aar_lm_set_step_callback: null argument");
+    pb->step_cb = fn;
+    pb->step_ctx = ctx;
+    pb->step_want_z = fn && want_z;
+    return AAR_OK;
+}
+
+int aar_lm_set_stop_function(aar_problem *pb, aar_lm_stop_function fn, void *ctx) {
+    if (!pb) return set_error(AAR_ERR_INVALID, "aar_lm_set_stop_function: null argument");
+    pb->stop_fn = fn;
+    pb->stop_ctx = ctx;
+    return AAR_OK;
+}
+
+int aar_problem_extract_z(const aar_problem *pb, const double *x_full, double *z) {
+    if (!pb || !x_full || !z) return set_error(AAR_ERR_INVALID, "aar_problem_extract_z: null argument");
+    extract_z(pb->L, x_full, z);
+    return AAR_OK;
+}
+
+int aar_problem_merge_z(const aar_problem *pb, const double *z, double *x_full) {
+    if (!pb || !x_full || !z) return set_error(AAR_ERR_INVALID, "aar_problem_merge_z: null argument");
+    merge_z(pb->L, z, x_full);
     return AAR_OK;
 }
 

@@ -262,18 +262,25 @@ int aar_subseqs_read(const char *path, int32_t **out, int32_t *n) {
 }
 
 int aar_cam_configs_read(const char *folder, aar_cam_model **out, int32_t *n_cams) {
+    return aar_cam_configs_read_ex(folder, AAR_DIR_ORDER_NAME, out, n_cams);
+}
+
+int aar_cam_configs_read_ex(const char *folder, int32_t dir_order, aar_cam_model **out, int32_t *n_cams) {
     if (!folder || !out || !n_cams) return set_error(AAR_ERR_INVALID, "aar_cam_configs_read: null argument");
+    if (dir_order != AAR_DIR_ORDER_NAME && dir_order != AAR_DIR_ORDER_READDIR) return set_error(AAR_ERR_INVALID, "aar_cam_configs_read_ex: bad dir_order");
     DIR *dir = opendir(folder);
     if (!dir) return set_error(AAR_ERR_IO, "could not open folder %s", folder);
     std::vector<std::string> dirs;
     for (dirent *e = readdir(dir); e; e = readdir(dir)) {
         const std::string name = e->d_name;
-        if (name == "." || name == "..") continue;
+        // the reference's get_dirs_list keeps "." and ".." (libs/filesystem.cpp:9-12): a calib file in the data folder itself
+        // or in its parent would become a camera slot there; kept out in name order, kept in in readdir order
+        if (dir_order == AAR_DIR_ORDER_NAME && (name == "." || name == "..")) continue;
         struct stat st;
         if (stat((std::string(folder) + "/" + name).c_str(), &st) == 0 && S_ISDIR(st.st_mode)) dirs.push_back(name);
     }
     closedir(dir);
-    std::sort(dirs.begin(), dirs.end());
+    if (dir_order == AAR_DIR_ORDER_NAME) std::sort(dirs.begin(), dirs.end());   // AAR_DIR_ORDER_READDIR: as the file system lists them (libs/cam_config.cpp:80-95)
     std::vector<aar_cam_model> cams;
     const char *exts[3] = {"xml", "yml", "yaml"};
     for (const std::string &dn : dirs)

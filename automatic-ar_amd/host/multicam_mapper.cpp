@@ -4,8 +4,10 @@
 
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <iostream>
 #include <stdexcept>
+#include <string>
 
 #include "internal.h"
 #include "se3.h"
@@ -31,6 +33,135 @@ MultiCamMapper::MultiCamMapper(aar_dataset *dataset) : MultiCamMapper() {
 }
 
 MultiCamMapper::MultiCamMapper(Initializer &initializer) : MultiCamMapper(initializer.release()) {}
+
+static Rigid from44(const Mat44 &m) {
+    Rigid T;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T.R[r * 3 + c] = m[r * 4 + c];
+        T.t[r] = m[r * 4 + 3];
+    }
+    return T;
+}
+
+MultiCamMapper::MultiCamMapper(size_t root_c, const std::map<int, Mat44> &T_to_root_cam, size_t root_m, const std::map<int, Mat44> &T_to_root_marker,
+                               const std::map<int, Mat44> &obj_transforms, const FrameCamMarkers &fcm, float m_size,
+                               std::vector<aar_cam_model> &cam_confs)
+    : MultiCamMapper() {
+    init(root_c, T_to_root_cam, root_m, T_to_root_marker, obj_transforms, fcm, m_size, cam_confs);
+}
+
+// frames (ascending id), their poses, and the detections in the reference's residual order -- frame, camera, detection order
+// (libs/multicam_mapper.cpp:1001-1007) -- minus what fill_iteration_arrays erases: cameras / markers without a transform (:356-367)
+void MultiCamMapper::load_frames(const std::map<int, Mat44> &object_poses, const FrameCamMarkers &fcm) {
+    aar_dataset *old = data_;
+    std::map<int, int> cam_index, marker_index, frame_index;
+    for (int c = 0; c < old->num_cams; c++) cam_index[old->cam_ids[c]] = c;
+    for (int m = 0; m < old->num_markers; m++) marker_index[old->marker_ids[m]] = m;
+    int fi = 0;
+    for (const auto &kv : object_poses) frame_index[kv.first] = fi++;
+    struct O { int f, c, m; const float *uv; };
+    std::vector<O> obs;
+    for (const auto &fr : fcm) {
+        auto f = frame_index.find(fr.first);
+        if (f == frame_index.end()) throw std::runtime_error("MultiCamMapper::init: detections of frame " + std::to_string(fr.first) + " without an object pose");   // the reference: std::map::at
+        for (const auto &cm : fr.second) {
+            auto c = cam_index.find(cm.first);
+            if (c == cam_index.end()) continue;
+            for (const Marker &mk : cm.second) {
+                auto m = marker_index.find(mk.id);
+                if (m == marker_index.end()) continue;
+                obs.push_back({f->second, c->second, m->second, mk.corners});
+            }
+        }
+    }
+    const int C = old->num_cams, M = old->num_markers, F = (int)object_poses.size();
+    aar_dataset *d = dataset_alloc(C, M, F, (int64_t)obs.size(), false);
+    memcpy(d->cam_ids, old->cam_ids, sizeof(int32_t) * C);
+    memcpy(d->marker_ids, old->marker_ids, sizeof(int32_t) * M);
+    memcpy(d->image_sizes, old->image_sizes, sizeof(int32_t) * 2 * C);
+    memcpy(d->cam_mats, old->cam_mats, sizeof(double) * 9 * C);
+    memcpy(d->dist_coeffs, old->dist_coeffs, sizeof(double) * 5 * C);
+    d->root_cam = old->root_cam; d->root_marker = old->root_marker; d->marker_size = old->marker_size;
+    d->optimize_cam_poses = old->optimize_cam_poses; d->optimize_marker_poses = old->optimize_marker_poses;
+    d->optimize_object_poses = old->optimize_object_poses; d->optimize_cam_intrinsics = old->optimize_cam_intrinsics;
+    const int64_t shared = 6LL * (C - 1) + 6LL * (M - 1);
+    memcpy(d->x_full, old->x_full, sizeof(double) * shared);
+    fi = 0;
+    for (const auto &kv : object_poses) {
+        d->frame_ids[fi] = kv.first;
+        rigid_to_pose(from44(kv.second), d->x_full + shared + 6LL * fi);
+        fi++;
+    }
+    for (size_t i = 0; i < obs.size(); i++) {
+        d->obs_frame[i] = obs[i].f; d->obs_cam[i] = obs[i].c; d->obs_marker[i] = obs[i].m;
+        memcpy(d->obs_uv + 8 * i, obs[i].uv, sizeof(float) * 8);
+    }
+    drop_problem();
+    aar_dataset_free(old);
+    data_ = d;
+    remove_distortions();
+    mats2eVec();
+}
+
+void MultiCamMapper::init(const std::map<int, Mat44> &object_poses, const FrameCamMarkers &fcm) {   // libs/multicam_mapper.cpp:272-279
+    if (!data_) throw std::runtime_error("MultiCamMapper::init(object_poses, fcm): the mapper holds no cameras / markers yet");
+    load_frames(object_poses, fcm);
+}
+
+void MultiCamMapper::init(size_t root_c, const std::map<int, Mat44> &T_to_root_cam, size_t root_m, const std::map<int, Mat44> &T_to_root_marker,
+                          const std::map<int, Mat44> &object_poses, const FrameCamMarkers &fcm, float m_size,
+                          const std::vector<aar_cam_model> &cam_confs) {   // libs/multicam_mapper.cpp:281-335
+    if (T_to_root_cam.empty() || T_to_root_marker.empty()) throw std::runtime_error("MultiCamMapper::init: no cameras / markers");
+    if (!T_to_root_cam.count((int)root_c) || !T_to_root_marker.count((int)root_m)) throw std::runtime_error("MultiCamMapper::init: root id without a transform");
+    const int C = (int)T_to_root_cam.size(), M = (int)T_to_root_marker.size();
+    aar_dataset *d = dataset_alloc(C, M, 0, 0, false);
+    cam_models_.assign(C, aar_cam_model());
+    int i = 0;
+    for (const auto &kv : T_to_root_cam) {   // ascending id = MatArray order (libs/multicam_mapper.h:95-105)
+        const int id = kv.first;
+        if (id < 0 || id >= (int)cam_confs.size()) { aar_dataset_free(d); throw std::runtime_error("MultiCamMapper::init: no calibration for camera id " + std::to_string(id)); }   // cam_configs[cam_id], :314
+        d->cam_ids[i] = id;
+        if (id == (int)root_c) d->root_cam = i;
+        const aar_cam_model &cc = cam_confs[id];
+        memcpy(d->cam_mats + 9 * i, cc.K, sizeof cc.K);
+        for (int j = 0; j < 5; j++) d->dist_coeffs[5 * i + j] = cc.dist[j];
+        d->image_sizes[2 * i] = cc.width; d->image_sizes[2 * i + 1] = cc.height;
+        cam_models_[i] = cc;
+        i++;
+    }
+    i = 0;
+    for (const auto &kv : T_to_root_marker) {
+        d->marker_ids[i] = kv.first;
+        if (kv.first == (int)root_m) d->root_marker = i;
+        i++;
+    }
+    PoseLayout L;
+    L.C = C; L.M = M; L.F = 0; L.rc = d->root_cam; L.rm = d->root_marker;
+    i = 0;
+    for (const auto &kv : T_to_root_cam) { if (i != L.rc) rigid_to_pose(from44(kv.second), d->x_full + L.full_cam0() + 6LL * L.cam_slot(i)); i++; }
+    i = 0;
+    for (const auto &kv : T_to_root_marker) { if (i != L.rm) rigid_to_pose(from44(kv.second), d->x_full + L.full_mk0() + 6LL * L.mk_slot(i)); i++; }
+    d->marker_size = (double)m_size;   // float parameter, libs/multicam_mapper.h:20
+    d->optimize_cam_intrinsics = 1;    // a fresh mapper holds the default Config (libs/multicam_mapper.h:75-81)
+    drop_problem();
+    aar_dataset_free(data_);
+    data_ = d;
+    config_ = Config();
+    solver_params = SparseLevMarq<double>::Params();   // :326-330
+    solver_params.verbose = true;
+    solver_params.maxIters = 10000;
+    solver_params.min_average_step_error_diff = 1e-4;
+    load_frames(object_poses, fcm);
+    // eval_curr_solution + "the very initial error" (:331-333); the pose groups only, as error_function evaluates them
+    const Config keep = config_;
+    config_.optimize_cam_intrinsics = false;
+    if (ensure_problem()) { config_ = keep; throw std::runtime_error(aar_last_error()); }
+    double e0 = 0;
+    const int rc = aar_eval_residuals(problem_, data_->x_full, nullptr, &e0);
+    config_ = keep;
+    if (rc) throw std::runtime_error(aar_last_error());
+    std::cout << "the very initial error: " << e0 << std::endl;
+}
 
 MultiCamMapper::~MultiCamMapper() {
     drop_problem();
@@ -118,28 +249,29 @@ void MultiCamMapper::error_function(const eVector &input, eVector &error) {
     if (rc) throw std::runtime_error(aar_last_error());
 }
 
-void MultiCamMapper::solve() {
+// optCallBack, libs/multicam_mapper.cpp:412-417: the Huber delta schedule, driven by the solver's step callback
+void MultiCamMapper::optCallBack(const eVector &) {
+    if (hubberDelta > 2.5) hubberDelta -= 7.5 / 500;
+    if (with_huber_ && problem_ && aar_problem_set_huber_delta(problem_, hubberDelta)) throw std::runtime_error(aar_last_error());
+}
+
+void MultiCamMapper::solve() {   // libs/multicam_mapper.cpp:419-428
     if (!data_) throw std::runtime_error("MultiCamMapper::solve: no data set");
     if (config_.optimize_cam_intrinsics)
         throw std::runtime_error("MultiCamMapper::solve: optimize_cam_intrinsics is not on the accelerated path (call set_optmize_flag_cam_intrinsics(false) as find_solution does)");
     if (ensure_problem()) throw std::runtime_error(aar_last_error());
     mats2eVec();
+    solver.attach(problem_, data_->x_full);
+    solver.setParams(solver_params);
+    solver.setStepCallBackFunc(std::bind(&MultiCamMapper::optCallBack, this, std::placeholders::_1), /*needs_z=*/false);
     double e0 = 0;
     if (aar_eval_residuals(problem_, data_->x_full, nullptr, &e0)) throw std::runtime_error(aar_last_error());
     std::cout << "initial_error: " << e0 << "error size: " << 8 * data_->num_obs << std::endl;  // :424
     hubberDelta = 10;
-    aar_lm_params p;
-    aar_lm_default_params(&p);
-    p.max_iters = solver_params.maxIters;
-    p.min_error = solver_params.minError;
-    p.min_step_error_diff = solver_params.min_step_error_diff;
-    p.min_average_step_error_diff = solver_params.min_average_step_error_diff;
-    p.tau = solver_params.tau;
-    p.verbose = solver_params.verbose ? 1 : 0;
-    memset(&last_report, 0, sizeof last_report);
-    if (aar_lm_solve(problem_, data_->x_full, &p, &last_report)) throw std::runtime_error(aar_last_error());
-    if (with_huber_) hubberDelta = aar_problem_get_huber_delta(problem_);  // where optCallBack's schedule left it
-    mats2eVec();  // io_vec holds the solution, as after solver.solve(io_vec, ...) in the reference
+    if (with_huber_ && aar_problem_set_huber_delta(problem_, hubberDelta)) throw std::runtime_error(aar_last_error());
+    solver.solve(io_vec);
+    last_report = solver.report;
+    eVec2Mats(io_vec);
 }
 
 // track(): the reference refines ONE frame per call (apps/track.cpp:127-131 re-inits the mapper with the frame's detections
@@ -185,6 +317,7 @@ bool MultiCamMapper::read_solution_file(std::string path) {
     drop_problem();
     aar_dataset_free(data_);
     data_ = d;
+    cam_models_.clear();
     config_.optimize_cam_poses = d->optimize_cam_poses != 0;
     config_.optimize_marker_poses = d->optimize_marker_poses != 0;
     config_.optimize_object_poses = d->optimize_object_poses != 0;
@@ -290,7 +423,9 @@ void MultiCamMapper::remove_distortions() {
         if (idx.empty()) continue;
         std::vector<float> pts(8 * idx.size());
         for (size_t k = 0; k < idx.size(); k++) memcpy(&pts[8 * k], d->obs_uv + 8 * idx[k], 8 * sizeof(float));
-        if (aar_undistort_points(d->cam_mats + 9 * c, d->dist_coeffs + 5 * c, 5, (int64_t)(4 * idx.size()), pts.data(), pts.data(), device_id))
+        const bool full = (int)cam_models_.size() == d->num_cams;   // built from calibrations: all of distortion_coefficients
+        if (aar_undistort_points(d->cam_mats + 9 * c, full ? cam_models_[c].dist : d->dist_coeffs + 5 * c, full ? cam_models_[c].n_dist : 5,
+                                 (int64_t)(4 * idx.size()), pts.data(), pts.data(), device_id))
             throw std::runtime_error(aar_last_error());
         for (size_t k = 0; k < idx.size(); k++) memcpy(d->obs_uv + 8 * idx[k], &pts[8 * k], 8 * sizeof(float));
     }

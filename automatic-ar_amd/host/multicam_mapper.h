@@ -5,7 +5,11 @@
 // include/aar.h (HIP kernels); there is no CPU arithmetic path behind this class.
 #pragma once
 #include <array>
+#include <cstring>
+#include <functional>
 #include <map>
+#include <stdexcept>
+#include <type_traits>
 #include <set>
 #include <string>
 #include <vector>
@@ -14,9 +18,16 @@
 
 namespace aar {
 
-// ucoslam::SparseLevMarq<T>::Params, libs/sparselevmarq.h:30-50 (field names kept)
+// ucoslam::SparseLevMarq<T> (libs/sparselevmarq.h:26-141) over the C ABI: Params with the reference's field names, setParams,
+// init / step / getCurrentSolution, solve, setStepCallBackFunc, setStopFunction.  The evaluation functions f (error_function) and
+// J (jacobian_function) are the MAPPER'S OWN -- the HIP kernels of the attached aar_problem; solve(z, f, J) with arbitrary host
+// callbacks is not offered (a host-callback Jacobian cannot run on the device and a CPU loop would be a fallback path).
+// z is the reference's parameter vector for the problem's Config (mats2eVec order).
 template <typename T>
-struct SparseLevMarq {
+class SparseLevMarq {
+    static_assert(std::is_same<T, double>::value, "the accelerated path computes in double, as the reference's instantiation does");
+
+   public:
     struct Params {
         int maxIters = 100;
         T minError = 1e-5;
@@ -29,9 +40,96 @@ struct SparseLevMarq {
         bool verbose = false;
     };
     typedef std::vector<T> eVector;
+
+    // the device problem whose kernels stand for f and J; x_full supplies the groups the Config keeps fixed
+    void attach(aar_problem *problem, const double *x_full) {
+        problem_ = problem;
+        x_.assign(x_full, x_full + aar_problem_full_len(problem));
+    }
+    void setParams(const Params &p) { _params = p; }
+    T solve(eVector &z) {   // :440-472
+        need();
+        install();
+        if (aar_problem_merge_z(problem_, z.data(), x_.data())) fail();
+        const aar_lm_params p = c_params();
+        std::memset(&report, 0, sizeof report);
+        if (aar_lm_solve(problem_, x_.data(), &p, &report)) fail();
+        if (aar_problem_extract_z(problem_, x_.data(), z.data())) fail();
+        return report.final_err;
+    }
+    void init(eVector &z) {   // :238-249
+        need();
+        if (aar_problem_merge_z(problem_, z.data(), x_.data())) fail();
+        const aar_lm_params p = c_params();
+        if (aar_lm_init(problem_, x_.data(), &p)) fail();
+    }
+    bool step() {   // :349-430; the step callback is solve()'s business in the reference too
+        need();
+        aar_lm_iter it;
+        if (aar_lm_step(problem_, &it)) fail();
+        last_iter = it;
+        return it.accepted != 0;
+    }
+    T getCurrentSolution(eVector &z) {   // :432-437
+        need();
+        double err = 0;
+        if (aar_lm_get_solution(problem_, x_.data(), &err)) fail();
+        z.resize((size_t)aar_problem_num_vars(problem_));
+        if (aar_problem_extract_z(problem_, x_.data(), z.data())) fail();
+        return err;
+    }
+    // needs_z = false spares the device -> host copy of curr_z for callbacks that ignore their argument (it is then empty)
+    void setStepCallBackFunc(std::function<void(const eVector &)> callback, bool needs_z = true) { step_cb_ = callback; step_needs_z_ = needs_z; }
+    void setStopFunction(std::function<bool(const eVector &)> stop_function) { stop_fn_ = stop_function; }
+
+    Params _params;
+    aar_lm_report report;     // of the last solve()
+    aar_lm_iter last_iter;    // of the last step()
+
+   private:
+    void need() const { if (!problem_) throw std::runtime_error("SparseLevMarq: no problem attached"); }
+    [[noreturn]] static void fail() { throw std::runtime_error(aar_last_error()); }
+    aar_lm_params c_params() const {
+        aar_lm_params p;
+        aar_lm_default_params(&p);
+        p.max_iters = _params.maxIters;
+        p.min_error = _params.minError;
+        p.min_step_error_diff = _params.min_step_error_diff;
+        p.min_average_step_error_diff = _params.min_average_step_error_diff;
+        p.tau = _params.tau;
+        p.verbose = _params.verbose ? 1 : 0;
+        return p;
+    }
+    static void step_tramp(void *ctx, const double *z, int64_t n) {
+        SparseLevMarq *self = static_cast<SparseLevMarq *>(ctx);
+        if (z) self->zbuf_.assign(z, z + n); else self->zbuf_.clear();
+        self->step_cb_(self->zbuf_);
+    }
+    static int stop_tramp(void *ctx, const double *z, int64_t n) {
+        SparseLevMarq *self = static_cast<SparseLevMarq *>(ctx);
+        self->zbuf_.assign(z, z + n);
+        return self->stop_fn_(self->zbuf_) ? 1 : 0;
+    }
+    void install() {
+        if (aar_lm_set_step_callback(problem_, step_cb_ ? &step_tramp : nullptr, this, step_needs_z_ ? 1 : 0)) fail();
+        if (aar_lm_set_stop_function(problem_, stop_fn_ ? &stop_tramp : nullptr, this)) fail();
+    }
+    aar_problem *problem_ = nullptr;
+    std::vector<double> x_;
+    eVector zbuf_;
+    std::function<void(const eVector &)> step_cb_;
+    std::function<bool(const eVector &)> stop_fn_;
+    bool step_needs_z_ = true;
 };
 
 typedef std::array<double, 16> Mat44;  // row-major 4x4, the reference's CV_64F cv::Mat transforms
+
+// aruco::Marker as the path uses it (3rdparty/aruco/aruco/marker.h:46-58): an id and four image corners x0 y0 .. x3 y3
+struct Marker {
+    int id = 0;
+    float corners[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+typedef std::map<int, std::map<int, std::vector<Marker>>> FrameCamMarkers;   // frame id -> camera id -> detections, as the reference's fcm
 
 // Mirror of the reference's Initializer (libs/initializer.h:9-43) over aar_initializer_run: the constructor runs
 // obtain_pose_estimations + init_transforms (IPPE, candidate sets and votes on the device) and throws std::runtime_error
@@ -81,6 +179,16 @@ class MultiCamMapper {
     // reference's MultiCamMapper(Initializer&) constructor ends with (libs/multicam_mapper.cpp:252-335).
     explicit MultiCamMapper(aar_dataset *dataset);
     explicit MultiCamMapper(Initializer &initializer);   // libs/multicam_mapper.cpp:252-254; takes the initializer's data set
+    // libs/multicam_mapper.h:17 / multicam_mapper.cpp:256-259: root ids, id -> 4x4 transform maps (camera -> root camera, marker ->
+    // root marker, root marker -> root camera per frame), RAW detections per frame and camera, marker size, calibrations
+    // indexed by camera id.  Runs init(): observation order and dropping of unknown cameras / markers as fill_iteration_arrays
+    // (:345-377), remove_distortions on the device, "the very initial error" printed -- so it needs a GPU, like the rest.
+    MultiCamMapper(size_t root_c, const std::map<int, Mat44> &T_to_root_cam, size_t root_m, const std::map<int, Mat44> &T_to_root_marker,
+                   const std::map<int, Mat44> &obj_transforms, const FrameCamMarkers &fcm, float m_size, std::vector<aar_cam_model> &cam_confs);
+    void init(size_t root_c, const std::map<int, Mat44> &T_to_root_cam, size_t root_m, const std::map<int, Mat44> &T_to_root_marker,
+              const std::map<int, Mat44> &object_poses, const FrameCamMarkers &fcm, float m_size, const std::vector<aar_cam_model> &cam_confs);   // :281-335
+    // :272-279, apps/track.cpp:127-131: new frames and RAW detections for a mapper that keeps its cameras, markers and intrinsics
+    void init(const std::map<int, Mat44> &object_poses, const FrameCamMarkers &fcm);
     ~MultiCamMapper();
     MultiCamMapper(const MultiCamMapper &) = delete;
     MultiCamMapper &operator=(const MultiCamMapper &) = delete;
@@ -112,6 +220,7 @@ class MultiCamMapper {
 
     eVector io_vec;           // packed parameters for the current Config (mats2eVec, :445-461)
     float hubberDelta = 2.5;
+    SparseLevMarq<double> solver;                 // libs/multicam_mapper.h:198; solve() drives it as the reference does (:419-428)
     SparseLevMarq<double>::Params solver_params;  // what MultiCamMapper::init installs (:326-330)
     aar_lm_report last_report;                    // iterations, errors and timing of the last solve()
     std::vector<int32_t> track_iterations;        // per frame, after track()
@@ -122,13 +231,16 @@ class MultiCamMapper {
     const aar_dataset *dataset() const { return data_; }
 
    private:
+    void optCallBack(const eVector &v);   // :412-417
     void mats2eVec();
     void eVec2Mats(const eVector &v);
     int ensure_problem();
     void drop_problem();
 
+    void load_frames(const std::map<int, Mat44> &object_poses, const FrameCamMarkers &fcm);
     aar_dataset *data_ = nullptr;
     aar_problem *problem_ = nullptr;
+    std::vector<aar_cam_model> cam_models_;   // per camera INDEX, when the mapper was built from calibrations (full distortion vectors)
     Config config_;
     bool with_huber_ = false;
 };

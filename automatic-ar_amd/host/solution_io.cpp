@@ -100,18 +100,21 @@ int aar_solution_write(const char *path, const aar_dataset *d) {
     w.put<size_t>((size_t)F);
     for (int i = 0; i < F; i++) {
         w.put<int32_t>(d->frame_ids[i]);
-        std::vector<std::pair<int, std::pair<int64_t, int64_t>>> runs;  // cam -> [b,e)
+        // one record per camera of the data set, empty ones included: that is what the reference writes after its Initializer
+        // (read_detections_file gives every frame an entry per camera slot, libs/initializer.cpp:333-347), and what its reader
+        // needs -- it takes the c-th record of a frame for camera id c (:1117-1119)
+        std::vector<std::pair<int64_t, int64_t>> run(C, {0, 0});  // camera index -> [b,e)
         for (int64_t o = fstart[i]; o < fstart[i + 1];) {
             int64_t e = o;
             while (e < fstart[i + 1] && d->obs_cam[e] == d->obs_cam[o]) e++;
-            runs.push_back({d->obs_cam[o], {o, e}});
+            run[d->obs_cam[o]] = {o, e};
             o = e;
         }
-        w.put<size_t>(runs.size());
-        for (auto &r : runs) {
-            w.put<int32_t>(d->cam_ids[r.first]);
-            w.put<size_t>((size_t)(r.second.second - r.second.first));
-            for (int64_t o = r.second.first; o < r.second.second; o++)
+        w.put<size_t>((size_t)C);
+        for (int c = 0; c < C; c++) {
+            w.put<int32_t>(d->cam_ids[c]);
+            w.put<size_t>((size_t)(run[c].second - run[c].first));
+            for (int64_t o = run[c].first; o < run[c].second; o++)
                 write_marker(w, d->marker_ids[d->obs_marker[o]], d->obs_uv + 8 * o);
         }
     }
@@ -124,8 +127,11 @@ int aar_solution_write(const char *path, const aar_dataset *d) {
     return good ? AAR_OK : set_error(AAR_ERR_IO, "write error on %s", path);
 }
 
-int aar_solution_read(const char *path, aar_dataset **out) {
+int aar_solution_read(const char *path, aar_dataset **out) { return aar_solution_read_ex(path, 0, out); }
+
+int aar_solution_read_ex(const char *path, int32_t read_flags, aar_dataset **out) {
     if (!path || !out) return set_error(AAR_ERR_INVALID, "aar_solution_read: null argument");
+    const bool ref_index = (read_flags & AAR_SOLUTION_REFERENCE_INDEXING) != 0;
     FILE *f = fopen(path, "rb");
     if (!f) return set_error(AAR_ERR_IO, "Could not open a file in: %s for reading.", path);
     Reader r{f};
@@ -157,16 +163,22 @@ int aar_solution_read(const char *path, aar_dataset **out) {
     for (size_t i = 0; i < F; i++) frame_index[frame_ids[i]] = (int)i;
 
     // deserialize_frame_cam_markers (:1101-1122).  The reference re-indexes frames and cameras by loop
-    // counter and ignores the stored ids (:1117-1119); this reader honours the ids,
+    // counter and ignores the stored ids (:1117-1119); by default this reader honours the ids,
     // which is identical whenever ids are 0..n-1 and every frame lists every camera, and correct otherwise.
+    // AAR_SOLUTION_REFERENCE_INDEXING reproduces the reference: the f-th frame record is filed under frame id f and the
+    // c-th camera record of a frame under camera id c, whatever ids the file stores; fill_iteration_arrays (:345-377) then
+    // drops the observations of a camera id it does not know, and an unknown frame id is what the reference would hand to
+    // MatArray::operator[] (libs/multicam_mapper.h:118-123: a silent std::map insertion / an out_of_range) -- an error here.
     struct O { int f, c, m; float uv[8]; };
     std::vector<O> obs;
     const size_t num_f = r.get<size_t>();
     for (size_t i = 0; i < num_f && r.ok; i++) {
-        const int32_t fid = r.get<int32_t>();
+        int32_t fid = r.get<int32_t>();
+        if (ref_index) fid = (int32_t)i;
         const size_t num_c = r.get<size_t>();
         for (size_t j = 0; j < num_c && r.ok; j++) {
-            const int32_t cid = r.get<int32_t>();
+            int32_t cid = r.get<int32_t>();
+            if (ref_index) cid = (int32_t)j;
             const size_t num_m = r.get<size_t>();
             for (size_t k = 0; k < num_m && r.ok; k++) {
                 O o;
@@ -175,6 +187,10 @@ int aar_solution_read(const char *path, aar_dataset **out) {
                 auto fi = frame_index.find(fid);
                 auto ci = cam_index.find(cid);
                 auto mi = marker_index.find(mid);
+                if (ref_index && fi == frame_index.end()) {
+                    fclose(f);
+                    return set_error(AAR_ERR_INVALID, "%s: with the reference's re-indexing frame record %zu becomes frame id %d, which the file does not list", path, i, fid);
+                }
                 // fill_iteration_arrays drops observations of unknown cameras / markers (:356-367)
                 if (fi == frame_index.end() || ci == cam_index.end() || mi == marker_index.end()) continue;
                 o.f = fi->second; o.c = ci->second; o.m = mi->second;

@@ -91,6 +91,13 @@ int aar_synth_generate(const aar_synth_desc *, aar_dataset **out);
  *  .solution.yaml     libs/multicam_mapper.cpp:1233-1268  (cv::FileStorage YAML 1.0 dialect)
  *  aruco.detections   libs/multicam_mapper.cpp:216-237, libs/initializer.cpp:316-348               */
 int aar_solution_read(const char *path, aar_dataset **out);
+/* flags: AAR_SOLUTION_REFERENCE_INDEXING files the detections as the reference's deserialize_frame_cam_markers does
+ * (libs/multicam_mapper.cpp:1101-1122): the f-th frame record under frame id f and the c-th camera record of a frame under
+ * camera id c -- the LOOP COUNTERS, not the ids the file stores (:1117-1119).  Same result as the default (ids honoured) when
+ * frame / camera ids are 0..n-1 and every frame lists every camera; on `-subseqs` or `-exclude-cams` solutions it is what the
+ * reference's track / overlay would see.  A frame counter that is not a stored frame id is AAR_ERR_INVALID. */
+#define AAR_SOLUTION_REFERENCE_INDEXING 1
+int aar_solution_read_ex(const char *path, int32_t flags, aar_dataset **out);
 int aar_solution_write(const char *path, const aar_dataset *);
 int aar_solution_write_yaml(const char *path, const aar_dataset *);
 int aar_detections_write(const char *path, const aar_dataset *);
@@ -123,6 +130,10 @@ typedef struct aar_cam_model {       /* CamConfig (libs/cam_config.h)           
 /* CamConfig::read_cam_configs (libs/cam_config.cpp:80-95): <folder>/<dir>/calib.{xml,yml,yaml} for every sub-directory;
  * camera index = position of the directory in ASCENDING NAME order (the reference takes readdir order).  Free with free(). */
 int aar_cam_configs_read(const char *folder, aar_cam_model **out, int32_t *n_cams);
+/* dir_order: AAR_DIR_ORDER_NAME (ascending name, "." / ".." skipped: the default above) or AAR_DIR_ORDER_READDIR -- the order
+ * readdir lists the sub-directories in, "." and ".." included, exactly as the reference's get_dirs_list (libs/filesystem.cpp:5-17). */
+enum { AAR_DIR_ORDER_NAME = 0, AAR_DIR_ORDER_READDIR = 1 };
+int aar_cam_configs_read_ex(const char *folder, int32_t dir_order, aar_cam_model **out, int32_t *n_cams);
 
 typedef struct aar_detections {      /* content of an `aruco.detections` file                                   */
     int32_t num_cams;                /* camera slots per frame record                                           */
@@ -292,8 +303,27 @@ typedef struct aar_lm_report {
 int aar_lm_init(aar_problem *, const double *x_full, const aar_lm_params *);
 int aar_lm_step(aar_problem *, aar_lm_iter *out);
 int aar_lm_get_solution(aar_problem *, double *x_full, double *err);
-/* SparseLevMarq::solve(z, f, J) (libs/sparselevmarq.h:440-472): x_full in/out */
+/* SparseLevMarq::solve(z, f, J) (libs/sparselevmarq.h:440-472): x_full in/out.  The step callback and the stop function below
+ * are honoured exactly where the reference calls them (:446-451, :463). */
 int aar_lm_solve(aar_problem *, double *x_full, const aar_lm_params *, aar_lm_report *);
+
+/* The solver seam of ucoslam::SparseLevMarq<T> (libs/sparselevmarq.h:118-123).
+ *  setStepCallBackFunc: called on the host after every step() with curr_z -- the reference's z for the problem's Config
+ *    (mats2eVec order, aar_problem_num_vars doubles).  want_z = 0 spares the device -> host copy of curr_z for callbacks that
+ *    ignore it, as MultiCamMapper::optCallBack does (libs/multicam_mapper.cpp:412-417); z is then NULL.
+ *  setStopFunction: when set, solve() runs do { step(); callback; } while (!stop(curr_z)) with NO iteration cap and none of the
+ *    error-based exits (:444-450); nonzero = stop.
+ * NULL clears.  A with_huber problem without a step callback runs the mapper's own pair -- hubberDelta = 10 at the start of
+ * solve(), optCallBack's schedule per step; a caller that installs a callback owns both (aar_problem_set_huber_delta).
+ * On a sharded problem every rank must install the same kind of callback (fetching curr_z is a collective). */
+typedef void (*aar_lm_step_callback)(void *ctx, const double *z, int64_t num_vars);
+typedef int (*aar_lm_stop_function)(void *ctx, const double *z, int64_t num_vars);
+int aar_lm_set_step_callback(aar_problem *, aar_lm_step_callback fn, void *ctx, int32_t want_z);
+int aar_lm_set_stop_function(aar_problem *, aar_lm_stop_function fn, void *ctx);
+/* z <-> x_full for the problem's Config (mats2eVec / eVec2Mats, libs/multicam_mapper.cpp:445-461,595-606): extract copies the
+ * optimised groups of x_full into z; merge writes z back into x_full and leaves the fixed groups alone. */
+int aar_problem_extract_z(const aar_problem *, const double *x_full, double *z);
+int aar_problem_merge_z(const aar_problem *, const double *z, double *x_full);
 
 /* MultiCamMapper::track() (libs/multicam_mapper.cpp:430-443) for every frame of the problem at once: cameras and markers
  * stay at their x_full values, each frame's object pose is refined on its own by the LM of SparseLevMarq::solve(z, f)

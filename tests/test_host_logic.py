@@ -66,8 +66,9 @@ def test_solution_file_round_trip_and_layout(tmp_path):
     assert struct.unpack_from("<Q", raw, off)[0] == F     # serialize_frame_cam_markers
     assert raw[-4:] == bytes([1, 1, 1, 0])                # Config flags as 4 bools, intrinsics off
     n_marker_records = ds.num_obs
-    n_cam_runs = len(set(zip(ds.obs_frame.tolist(), ds.obs_cam.tolist())))
-    assert len(raw) == off + 8 + F * (4 + 8) + n_cam_runs * (4 + 8) + n_marker_records * 36 + 4
+    # every frame carries one record per camera, empty ones included (what the reference writes after read_detections_file,
+    # libs/initializer.cpp:333-347, and what its loop-counter reader needs, libs/multicam_mapper.cpp:1117-1119)
+    assert len(raw) == off + 8 + F * (4 + 8) + F * C * (4 + 8) + n_marker_records * 36 + 4
 
 
 def test_solution_reader_honours_ids_and_drops_unknown(tmp_path):
@@ -247,3 +248,61 @@ def test_oracle_undistort_inverts_the_distortion_model():
         assert np.abs(back - uv).max() < (5e-3 if len(dist) > 5 else 2e-3), (dist, np.abs(back - uv).max())
         if len(dist) == 0:
             np.testing.assert_allclose(und, uv, atol=1.3e-4)   # no distortion: K^-1 then K, rounded to float
+
+
+def test_solution_reader_reference_indexing(tmp_path):
+    # libs/multicam_mapper.cpp:1101-1122: the reference files the f-th frame record under frame id f and the c-th camera record
+    # of a frame under camera id c (loop counters).  Default reader: the stored ids.  The writer emits one record per camera
+    # and frame (empty ones included) as the reference does after its Initializer, so the two views agree whenever camera and
+    # frame ids are 0..n-1 -- which is what lets the reference's own track / overlay read a final.solution written here.
+    ds = aar.synth(2)
+    assert np.array_equal(ds.frame_ids, np.arange(ds.num_frames)) and np.array_equal(ds.cam_ids, np.arange(ds.num_cams))
+    p = str(tmp_path / "a.solution")
+    aar.solution_write(p, ds)
+    a, b = aar.solution_read(p), aar.solution_read(p, reference_indexing=True)
+    for k in ("obs_frame", "obs_cam", "obs_marker", "obs_uv", "frame_ids", "cam_ids"):
+        assert np.array_equal(getattr(a, k), getattr(ds, k)) and np.array_equal(getattr(b, k), getattr(ds, k)), k
+    # a solution without camera 1 (-exclude-cams): the c-th record is no longer camera c; the reference's view shifts camera 2's
+    # detections to "camera 1" (unknown: dropped by fill_iteration_arrays, :356-360) and camera 3's to camera 2
+    ex = aar.Dataset()
+    ex.__dict__.update(ds.__dict__)
+    keep = ds.obs_cam != 1
+    ex.num_cams, ex.cam_ids = 3, np.array([0, 2, 3], dtype=np.int32)
+    ex.image_sizes, ex.cam_mats, ex.dist_coeffs = ds.image_sizes[[0, 2, 3]], ds.cam_mats[[0, 2, 3]], ds.dist_coeffs[[0, 2, 3]]
+    remap = np.array([0, -1, 1, 2])
+    ex.obs_frame, ex.obs_marker, ex.obs_uv = ds.obs_frame[keep], ds.obs_marker[keep], ds.obs_uv[keep]
+    ex.obs_cam = remap[ds.obs_cam[keep]].astype(np.int32)
+    ex.num_obs = int(keep.sum())
+    ex.x_full = np.concatenate([ds.x_full[6:18], ds.x_full[18:]])
+    q = str(tmp_path / "ex.solution")
+    aar.solution_write(q, ex)
+    a, b = aar.solution_read(q), aar.solution_read(q, reference_indexing=True)
+    assert np.array_equal(a.obs_cam, ex.obs_cam) and a.num_obs == ex.num_obs
+    n0, n2, n3 = (int(np.sum(ex.cam_ids[ex.obs_cam] == c)) for c in (0, 2, 3))
+    assert b.num_obs == n0 + n3                                    # records 0, 1, 2 = "cameras 0, 1, 2": 1 is unknown, 3's land on 2
+    assert int(np.sum(b.cam_ids[b.obs_cam] == 2)) == n3 and int(np.sum(b.cam_ids[b.obs_cam] == 3)) == 0
+    # a solution whose frame ids do not start at 0 (the -subseqs case): frame record 0 would be frame id 0, which does not exist
+    sub = aar.Dataset()
+    sub.__dict__.update(ds.__dict__)
+    sub.frame_ids = ds.frame_ids + 100
+    q = str(tmp_path / "b.solution")
+    aar.solution_write(q, sub)
+    assert np.array_equal(aar.solution_read(q).frame_ids, sub.frame_ids)
+    with pytest.raises(aar.AarError) as e:
+        aar.solution_read(q, reference_indexing=True)
+    assert e.value.code == aar.AAR_ERR_INVALID and "re-indexing" in str(e.value)
+
+
+def test_cam_configs_in_readdir_order(tmp_path):
+    # libs/cam_config.cpp:80-95 takes the sub-directories in readdir order; the default here is ascending name
+    import ctypes
+    folder = tmp_path / "seq"
+    for name, w in (("cam_b", 1920), ("cam_a", 1280), ("cam_c", 640)):
+        (folder / name).mkdir(parents=True)
+        (folder / name / "calib.yml").write_text(CALIB_YAML.replace("image_width: 1280", "image_width: %d" % w))
+    by_name = [c[2][0] for c in aar.cam_configs_read(str(folder))]
+    assert by_name == [1280, 1920, 640]
+    listed = [n for n in os.listdir(str(folder))]                    # os.listdir = readdir order minus "." and ".."
+    by_readdir = [c[2][0] for c in aar.cam_configs_read(str(folder), readdir_order=True)]
+    assert by_readdir == [{"cam_a": 1280, "cam_b": 1920, "cam_c": 640}[n] for n in listed]
+    assert sorted(by_readdir) == sorted(by_name)
