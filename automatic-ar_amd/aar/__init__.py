@@ -75,6 +75,7 @@ class CProblemDesc(C.Structure):
         ("obs_frame", C.POINTER(C.c_int32)), ("obs_cam", C.POINTER(C.c_int32)), ("obs_marker", C.POINTER(C.c_int32)),
         ("obs_uv", C.POINTER(C.c_float)),
         ("optimize_cam_poses", C.c_int32), ("optimize_marker_poses", C.c_int32), ("optimize_object_poses", C.c_int32),
+        ("optimize_cam_intrinsics", C.c_int32),
         ("residual_mode", C.c_int32), ("with_huber", C.c_int32), ("device_id", C.c_int32), ("comm", C.c_void_p),
     ]
 
@@ -582,13 +583,15 @@ class LocalGroup:
 class Problem:
     """aar_problem: the bundle-adjustment problem resident on one GPU."""
 
-    def __init__(self, ds, residual_mode=RES_F32, device=0, comm=None, optimize=None, with_huber=False):
+    def __init__(self, ds, residual_mode=RES_F32, device=0, comm=None, optimize=None, with_huber=False, intrinsics=False):
+        """intrinsics=True: Config::optimize_cam_intrinsics -- every vector ends with 9 per camera (x_with_intrinsics builds one)"""
         self.ds = ds
         self._cds = ds.as_c()
         d = CProblemDesc()
         lib().aar_problem_desc_from_dataset(C.byref(self._cds), C.byref(d))
         if optimize is not None:
             d.optimize_cam_poses, d.optimize_marker_poses, d.optimize_object_poses = [int(b) for b in optimize]
+        d.optimize_cam_intrinsics = int(intrinsics)
         d.residual_mode = residual_mode
         d.with_huber = int(with_huber)
         d.device_id = device
@@ -614,6 +617,13 @@ class Problem:
         x = np.ascontiguousarray(x_full, dtype=np.float64)
         assert x.shape == (self.full_len,)
         return x
+
+    def x_with_intrinsics(self, x_pose):
+        """pose vector + the data set's (fx cx fy cy d0..d4) per camera: the `.solution` vector (libs/multicam_mapper.cpp:1085-1089)"""
+        K = np.asarray(self.ds.cam_mats, dtype=np.float64).reshape(-1, 9)
+        d = np.asarray(self.ds.dist_coeffs, dtype=np.float64).reshape(-1, 5)
+        intr = np.concatenate([np.stack([K[:, 0], K[:, 2], K[:, 4], K[:, 5]], axis=1), d], axis=1).reshape(-1)
+        return np.concatenate([np.asarray(x_pose, dtype=np.float64), intr])
 
     def eval_residuals(self, x_full, want_vector=True):
         x = self._x(x_full)

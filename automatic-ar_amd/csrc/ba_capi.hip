@@ -245,6 +245,8 @@ void pack_z(const aar_problem *pb, const double *x_full, std::vector<double> &z)
     for (int m = 0; m < L.M; m++)
         if (m != L.rm) memcpy(&z[6 * (size_t)(L.C + m)], x_full + L.full_mk0() + 6LL * L.mk_slot(m), 6 * sizeof(double));
     if (F) memcpy(&z[6 * (size_t)A], x_full + L.full_fr0() + 6LL * pb->f_begin, (size_t)6 * F * sizeof(double));
+    if (L.oi)   // intrinsics entity of camera c: (fx, cx, fy, cy, -, -); the distortion entries d0..d4 never reach the projection
+        for (int c = 0; c < L.C; c++) memcpy(&z[6 * (size_t)(L.C + L.M + c)], x_full + L.full_intr0() + 9LL * c, 4 * sizeof(double));
 }
 
 int upload_z(aar_problem *pb, const double *x_full, int which) {
@@ -331,6 +333,8 @@ int download_z(aar_problem *pb, int which, double *x_full) {
     if (L.om)
         for (int m = 0; m < L.M; m++)
             if (m != L.rm) memcpy(x_full + L.full_mk0() + 6LL * L.mk_slot(m), &z[6 * (size_t)(L.C + m)], 6 * sizeof(double));
+    if (L.oi)
+        for (int c = 0; c < L.C; c++) memcpy(x_full + L.full_intr0() + 9LL * c, &z[6 * (size_t)(L.C + L.M + c)], 4 * sizeof(double));
     if (L.of) {
         if (!pb->comm) {
             if (F) memcpy(x_full + L.full_fr0(), &z[6 * (size_t)A], (size_t)6 * F * sizeof(double));
@@ -639,12 +643,14 @@ void extract_z(const PoseLayout &L, const double *x_full, double *z) {
     if (L.oc) for (int64_t i = 0; i < 6LL * (L.C - 1); i++) z[k++] = x_full[L.full_cam0() + i];
     if (L.om) for (int64_t i = 0; i < 6LL * (L.M - 1); i++) z[k++] = x_full[L.full_mk0() + i];
     if (L.of) for (int64_t i = 0; i < 6LL * L.F; i++) z[k++] = x_full[L.full_fr0() + i];
+    if (L.oi) for (int64_t i = 0; i < 9LL * L.C; i++) z[k++] = x_full[L.full_intr0() + i];
 }
 void merge_z(const PoseLayout &L, const double *z, double *x_full) {
     int64_t k = 0;
     if (L.oc) for (int64_t i = 0; i < 6LL * (L.C - 1); i++) x_full[L.full_cam0() + i] = z[k++];
     if (L.om) for (int64_t i = 0; i < 6LL * (L.M - 1); i++) x_full[L.full_mk0() + i] = z[k++];
     if (L.of) for (int64_t i = 0; i < 6LL * L.F; i++) x_full[L.full_fr0() + i] = z[k++];
+    if (L.oi) for (int64_t i = 0; i < 9LL * L.C; i++) x_full[L.full_intr0() + i] = z[k++];
 }
 
 // curr_z on the host for a callback (a device -> host copy per call: only made when a callback asked for it)
@@ -842,6 +848,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     PoseLayout &L = pb->L;
     L.C = C; L.M = M; L.F = Fg; L.rc = d->root_cam; L.rm = d->root_marker;
     L.oc = d->optimize_cam_poses != 0; L.om = d->optimize_marker_poses != 0; L.of = d->optimize_object_poses != 0;
+    L.oi = d->optimize_cam_intrinsics != 0;
     pb->N_global = Ng;
 
     // ---- shard by frame range ----
@@ -857,7 +864,9 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     pb->o_begin = ob;
 
     DeviceProblem &P = pb->P;
-    P.C = C; P.M = M; P.A = C + M; P.F = pb->f_end - pb->f_begin; P.N = N;
+    // optimize_cam_intrinsics: one more shared entity per camera (fx, cx, fy, cy and two idle slots), after cameras and markers
+    P.intr = L.oi ? 1 : 0;
+    P.C = C; P.M = M; P.A = C + M + (L.oi ? C : 0); P.F = pb->f_end - pb->f_begin; P.N = N;
     P.n = 6 * P.A;
     P.nT = (P.n + CHOL_NB - 1) / CHOL_NB;
     P.n_pad = P.nT * CHOL_NB;
@@ -885,16 +894,17 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
                 const int64_t g = ob + o + k;
                 ents.push_back(d->obs_cam[g]);
                 ents.push_back(C + d->obs_marker[g]);
+                if (L.oi) ents.push_back(C + M + d->obs_cam[g]);
             }
             std::sort(ents.begin(), ents.end());
             ents.erase(std::unique(ents.begin(), ents.end()), ents.end());
-            if (ents.size() > 65535 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "frame %d touches more than 65535 entities", f);
+            if (ents.size() >= (1u << SLOT_C_BITS) && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "frame %d touches %zu entities (limit %d)", f, ents.size(), (1 << SLOT_C_BITS) - 1);
             for (size_t s = 0; s < ents.size(); s++) slot_of[ents[s]] = (int32_t)s;
             for (int64_t k = 0; k < cnt; k++) {
                 const int64_t g = ob + o + k;
                 ObsIdx id;
                 id.frame = f; id.cam = d->obs_cam[g]; id.marker = C + d->obs_marker[g];
-                id.slots = slot_of[id.cam] | (slot_of[id.marker] << 16);
+                id.slots = pack_slots(slot_of[id.cam], slot_of[id.marker], L.oi ? slot_of[C + M + id.cam] : 0);
                 a_idx[o + k] = id;
             }
             fslot_start[f] = (int32_t)fslot_ent.size();
@@ -1030,6 +1040,8 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     std::vector<int32_t> ent_fixed(A, 0);
     for (int c = 0; c < C; c++) ent_fixed[c] = (c == L.rc || !L.oc) ? 1 : 0;
     for (int m = 0; m < M; m++) ent_fixed[C + m] = (m == L.rm || !L.om) ? 1 : 0;
+    // (intrinsics entities are free, root camera included: fill_io_vec_cam_intrinsics covers ALL cameras, libs/multicam_mapper.cpp:488-498;
+    //  their two idle parameters have zero rows and columns and get mu on the diagonal, like the reference's five distortion columns)
     std::vector<double> Kh(d->cam_mats, d->cam_mats + 9 * (size_t)C);
 
     // ---- upload ----
@@ -1151,54 +1163,51 @@ int aar_eval_normal_equations(aar_problem *pb, const double *x_full, double *JtJ
     }
     HIP_TRY(hipStreamSynchronize(pb->stream));
     pb->lm_ready = false;
-    // reference column of each device parameter (or -1): roots and non-optimised groups have none
+    // reference column of each device parameter (or -1): roots, non-optimised groups and the two idle parameters of an
+    // intrinsics entity have none
     const int64_t Pz = L.z_len();
-    auto ent_col = [&](int a) -> int64_t {
-        if (a < L.C) { const int s = L.cam_slot(a); return (s < 0 || !L.oc) ? -1 : L.z_cam0() + 6LL * s; }
-        const int s = L.mk_slot(a - L.C);
-        return (s < 0 || !L.om) ? -1 : L.z_mk0() + 6LL * s;
+    auto par_col = [&](int a, int i) -> int64_t {
+        if (a < L.C) { const int s = L.cam_slot(a); return (s < 0 || !L.oc) ? -1 : L.z_cam0() + 6LL * s + i; }
+        if (a < L.C + L.M) { const int s = L.mk_slot(a - L.C); return (s < 0 || !L.om) ? -1 : L.z_mk0() + 6LL * s + i; }
+        return i < 4 ? L.z_intr0() + 9LL * (a - L.C - L.M) + i : -1;   // fx cx fy cy; the d0..d4 columns stay zero
     };
     if (JtJ) {
         std::fill(JtJ, JtJ + Pz * Pz, 0.0);
-        for (int a = 0; a < A; a++) {
-            const int64_t ca = ent_col(a);
-            if (ca < 0) continue;
-            for (int b = 0; b <= a; b++) {
-                const int64_t cb = ent_col(b);
-                if (cb < 0) continue;
+        for (int a = 0; a < A; a++)
+            for (int b = 0; b <= a; b++)
                 for (int i = 0; i < 6; i++)
                     for (int j = 0; j < 6; j++) {
                         if (a == b && j > i) continue;
+                        const int64_t ca = par_col(a, i), cb = par_col(b, j);
+                        if (ca < 0 || cb < 0) continue;
                         const double v = U0[(size_t)(6 * a + i) * np + 6 * b + j];
-                        JtJ[(ca + i) * Pz + cb + j] = v;
-                        JtJ[(cb + j) * Pz + ca + i] = v;
+                        JtJ[ca * Pz + cb] = v;
+                        JtJ[cb * Pz + ca] = v;
                     }
-            }
-        }
         if (L.of)
             for (int f = 0; f < F; f++) {
                 const int64_t cf = L.z_fr0() + 6LL * f;
                 for (int i = 0; i < 6; i++)
                     for (int j = 0; j < 6; j++) JtJ[(cf + i) * Pz + cf + j] = V[(size_t)f * 36 + i * 6 + j];
-                for (int s = pb->h_fslot_start[f]; s < pb->h_fslot_start[f + 1]; s++) {
-                    const int64_t ca = ent_col(pb->h_fslot_ent[s]);
-                    if (ca < 0) continue;
-                    for (int i = 0; i < 6; i++)
+                for (int s = pb->h_fslot_start[f]; s < pb->h_fslot_start[f + 1]; s++)
+                    for (int i = 0; i < 6; i++) {
+                        const int64_t ca = par_col(pb->h_fslot_ent[s], i);
+                        if (ca < 0) continue;
                         for (int j = 0; j < 6; j++) {
                             const double v = W[(size_t)s * 36 + i * 6 + j];
-                            JtJ[(ca + i) * Pz + cf + j] = v;
-                            JtJ[(cf + j) * Pz + ca + i] = v;
+                            JtJ[ca * Pz + cf + j] = v;
+                            JtJ[(cf + j) * Pz + ca] = v;
                         }
-                }
+                    }
             }
     }
     if (B) {
         std::fill(B, B + Pz, 0.0);
-        for (int a = 0; a < A; a++) {
-            const int64_t ca = ent_col(a);
-            if (ca < 0) continue;
-            for (int i = 0; i < 6; i++) B[ca + i] = g0[6 * (size_t)a + i];
-        }
+        for (int a = 0; a < A; a++)
+            for (int i = 0; i < 6; i++) {
+                const int64_t ca = par_col(a, i);
+                if (ca >= 0) B[ca] = g0[6 * (size_t)a + i];
+            }
         if (L.of)
             for (int f = 0; f < F; f++)
                 for (int i = 0; i < 6; i++) B[L.z_fr0() + 6LL * f + i] = gf[(size_t)f * 6 + i];
@@ -1227,10 +1236,10 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     std::vector<double> x0(x_full, x_full + L.full_len()), x1(x0);
     if ((rc = download_z(pb, 1 - pb->cur, x1.data()))) return rc;
     // z ordering of the Config
-    int64_t k = 0;
-    if (L.oc) for (int64_t i = 0; i < 6LL * (L.C - 1); i++) delta[k++] = x1[L.full_cam0() + i] - x0[L.full_cam0() + i];
-    if (L.om) for (int64_t i = 0; i < 6LL * (L.M - 1); i++) delta[k++] = x1[L.full_mk0() + i] - x0[L.full_mk0() + i];
-    if (L.of) for (int64_t i = 0; i < 6LL * L.F; i++) delta[k++] = x1[L.full_fr0() + i] - x0[L.full_fr0() + i];
+    std::vector<double> z0((size_t)std::max<int64_t>(L.z_len(), 1)), z1(z0);
+    extract_z(L, x0.data(), z0.data());
+    extract_z(L, x1.data(), z1.data());
+    for (int64_t i = 0; i < L.z_len(); i++) delta[i] = z1[i] - z0[i];
     return AAR_OK;
 }
 
@@ -1493,6 +1502,7 @@ int aar_set_kernel_profiling(aar_problem *pb, int on) {
 int aar_get_kernel_times(aar_problem *pb, double seconds[AAR_NUM_KERNELS], int64_t launches[AAR_NUM_KERNELS]) {
     if (!pb || !seconds || !launches) return set_error(AAR_ERR_INVALID, "aar_get_kernel_times: null argument");
     static_assert(AAR_NUM_KERNELS == KID_COUNT, "kernel id table out of sync with include/aar.h");
+    static_assert(ENT_STRIDE == ENT_STRIDE_H, "entity row stride");
     HIP_TRY(hipSetDevice(pb->device));
     HIP_TRY(hipStreamSynchronize(pb->stream));
     prof_harvest(pb);

@@ -43,15 +43,17 @@ __device__ __forceinline__ void wave_sum_lds(const double (&vals)[NV], double *_
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void k_unpack(const double *__restrict__ z, double *__restrict__ ent, int n_ent) {
+__global__ void k_unpack(const double *__restrict__ z, double *__restrict__ ent, int n_ent, int k0, int k1) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < n_ent) make_ent_row(z + 6 * gid, ent + gid * ENT_STRIDE);
+    if (gid >= n_ent) return;
+    if (gid >= k0 && gid < k1) make_k_row(z + 6 * gid, ent + gid * ENT_STRIDE);   // intrinsics entities [k0, k1)
+    else make_ent_row(z + 6 * gid, ent + gid * ENT_STRIDE);
 }
 
 // ------------------------------------------------------------------------------------------------
 // one thread per observation; per-frame partial sums are not needed here, so per-block partials
 __global__ void __launch_bounds__(256) k_residual(const ObsIdx *__restrict__ idx, const float *__restrict__ uv,
-                                                  const double *__restrict__ ent, const double *__restrict__ Kmat,
+                                                  const double *__restrict__ ent, const double *__restrict__ Kmat, int kstride,
                                                   int64_t N, int A, double h, int res_f32, float huber, double *__restrict__ r_out,
                                                   double *__restrict__ err_part) {
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,7 +69,7 @@ __global__ void __launch_bounds__(256) k_residual(const ObsIdx *__restrict__ idx
         load_ent_rt(ent, A + id.frame, ef);
         double K[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) K[i] = Kmat[9 * id.cam + i];
+        for (int i = 0; i < 9; i++) K[i] = Kmat[kstride * id.cam + i];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             CornerGeom g;
@@ -111,6 +113,7 @@ __device__ __forceinline__ void load_ent_lds(const double *row, Ent &e) {
 // ------------------------------------------------------------------------------------------------
 struct PassAArgs {
     const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat;   // ent: the {R, t, J_l} table of the point (k_backsub / k_unpack)
+    int kstride;                                                                 // Kmat[kstride * camera + i]
     const int32_t *frame_obs_start, *fslot_start, *fslot_ent;
     int A, F, res_f32, max_kf, frames_fixed;
     float huber;
@@ -122,7 +125,9 @@ struct PassAArgs {
 
 // CPL = corners per lane: 4 = one lane per observation; 2 / 1 = two / four lanes per observation for frames with few
 // observations (the wavefront's instruction stream gets that much shorter; the sums over lanes do not care)
-template <int BLOCK, int CPL>
+// INTR: camera intrinsics are optimised -- every observation also feeds W_kf, the block of its camera's intrinsics entity
+// (four live rows: fx, cx, fy, cy) against the frame, at that entity's frame-local slot
+template <int BLOCK, int CPL, bool INTR = false>
 __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, const int f, const int n_blocks_a) {
     double *Wl = lds;                                   // [kf][36]
     double *acc = lds + (size_t)a.max_kf * 36;            // [32]
@@ -192,16 +197,21 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
         const int it = t / LPO, part = t - it * LPO;
         const int o = o0 + (int)(((int64_t)it * stride) % nobs);
         const ObsIdx id = a.idx[o];
-        const int sc = id.slots & 0xffff, sm = (id.slots >> 16) & 0xffff;
+        const int sc = id.slots & ((1 << SLOT_C_BITS) - 1), sm = (id.slots >> SLOT_C_BITS) & ((1 << SLOT_M_BITS) - 1);
+        const int sk = (id.slots >> (SLOT_C_BITS + SLOT_M_BITS)) & ((1 << SLOT_M_BITS) - 1);
         Ent ec, em;
         load_ent_lds(entl + (size_t)sc * ENT_STRIDE, ec);
         load_ent_lds(entl + (size_t)sm * ENT_STRIDE, em);
         double K[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) K[i] = a.Kmat[9 * id.cam + i];
-        double Wc[36], Wm[36];
+        for (int i = 0; i < 9; i++) K[i] = a.Kmat[a.kstride * id.cam + i];
+        double Wc[36], Wm[36], Wk[INTR ? 24 : 1];
 #pragma unroll
         for (int i = 0; i < 36; i++) { Wc[i] = 0.0; Wm[i] = 0.0; }
+        if (INTR) {
+#pragma unroll
+            for (int i = 0; i < 24; i++) Wk[i] = 0.0;
+        }
 #pragma unroll
         for (int kk = 0; kk < CPL; kk++) {
             const int k = part * CPL + kk;
@@ -212,6 +222,16 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
             corner_residual(ouv.x, ouv.y, g.u, g.v, a.res_f32, a.huber, r[0], r[1]);
             double Gc[2][6], Gm[2][6], Gf[2][6];
             corner_jacobian<true, true, true>(ec, em, ef, K, g, Gc, Gm, Gf);
+            if (INTR) {
+                double Gk[2][4];
+                corner_jacobian_intr(g, Gk);
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 6; j++) Wk[i * 6 + j] += Gk[rr][i] * Gf[rr][j];
+            }
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
                 vals[27] += r[rr] * r[rr];
@@ -234,6 +254,11 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
         for (int i = 0; i < 36; i++) atomicAdd(wc + i, Wc[i]);
 #pragma unroll
         for (int i = 0; i < 36; i++) atomicAdd(wm + i, Wm[i]);
+        if (INTR) {
+            double *wk = Wl + sk * 36;
+#pragma unroll
+            for (int i = 0; i < 24; i++) atomicAdd(wk + i, Wk[i]);
+        }
     }
     // V, g, err: wave sums, then one LDS add per wave and value
     wave_sum_lds<28>(vals, scratch + wave * 2048, lane, [&](int i, double s) { atomicAdd(acc + i, s); });
@@ -277,6 +302,7 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
 // ------------------------------------------------------------------------------------------------
 struct PassBArgs {
     const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat; const int32_t *chunk_start;
+    int kstride, k_ent0;   // Kmat[kstride * camera + i]; first intrinsics entity (C + M) for the intrinsics variant
     int n_chunks, A, res_f32, n_pad;
     float huber;
     double h;
@@ -306,7 +332,7 @@ __device__ __forceinline__ void passB_body(const PassBArgs &b, double *scratch, 
     load_ent(ent, head.marker, em);
     double K[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) K[i] = Kmat[9 * head.cam + i];
+    for (int i = 0; i < 9; i++) K[i] = Kmat[b.kstride * head.cam + i];
     for (int o = o0 + lane; o < o1; o += 64) {
         const ObsIdx id = idx[o];
         const float4 uv0 = reinterpret_cast<const float4 *>(uv)[2 * (int64_t)o];
@@ -372,6 +398,86 @@ __global__ void __launch_bounds__(256) k_passB(const PassBArgs b) {
     passB_body(b, scratch, (int)blockIdx.x * 4);
 }
 
+// Pass B for the intrinsics entities (optimize_cam_intrinsics): same chunks, the 62 values of U_kk (4x4, packed lower), W_kc
+// (4x6: intrinsics x the camera's own pose), W_km (4x6: intrinsics x marker) and g_k; rows of entity k_ent0 + camera.
+__device__ __forceinline__ void passB_intr_body(const PassBArgs &b, double *scratch, const int first_chunk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = first_chunk + wave;
+    if (chunk >= b.n_chunks) return;
+    const int o0 = b.chunk_start[chunk], o1 = b.chunk_start[chunk + 1];
+    double vals[62];
+#pragma unroll
+    for (int i = 0; i < 62; i++) vals[i] = 0.0;
+    const ObsIdx head = b.idx[o0];
+    Ent ec, em;
+    load_ent(b.ent, head.cam, ec);
+    load_ent(b.ent, head.marker, em);
+    double K[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) K[i] = b.Kmat[b.kstride * head.cam + i];
+    for (int o = o0 + lane; o < o1; o += 64) {
+        const ObsIdx id = b.idx[o];
+        const float4 uv0 = reinterpret_cast<const float4 *>(b.uv)[2 * (int64_t)o];
+        const float4 uv1 = reinterpret_cast<const float4 *>(b.uv)[2 * (int64_t)o + 1];
+        const float ou[8] = {uv0.x, uv0.y, uv0.z, uv0.w, uv1.x, uv1.y, uv1.z, uv1.w};
+        Ent ef;
+        load_ent(b.ent, b.A + id.frame, ef);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            CornerGeom g;
+            project_corner(ec, em, ef, K, b.h, k, g);
+            double r[2];
+            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, b.res_f32, b.huber, r[0], r[1]);
+            double Gc[2][6], Gm[2][6], Gf[2][6], Gk[2][4];
+            corner_jacobian<true, true, false>(ec, em, ef, K, g, Gc, Gm, Gf);
+            corner_jacobian_intr(g, Gk);
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    vals[58 + i] += Gk[rr][i] * r[rr];
+#pragma unroll
+                    for (int j = 0; j <= i; j++) vals[i * (i + 1) / 2 + j] += Gk[rr][i] * Gk[rr][j];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        vals[10 + i * 6 + j] += Gk[rr][i] * Gc[rr][j];
+                        vals[34 + i * 6 + j] += Gk[rr][i] * Gm[rr][j];
+                    }
+                }
+        }
+    }
+    const int rc = 6 * head.cam, rm = 6 * head.marker, rk = 6 * (b.k_ent0 + head.cam);
+    double *__restrict__ U0 = b.U0, *__restrict__ g0 = b.g0;
+    const int n_pad = b.n_pad;
+    wave_sum_lds<62>(vals, scratch + wave * 2048, lane, [&](int v, double s) {
+        if (v < 10) {
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= v) i++;
+            const int j = v - i * (i + 1) / 2;
+            atomicAdd(U0 + (size_t)(rk + i) * n_pad + rk + j, s);
+        } else if (v < 34) {   // the intrinsics rows lie below cameras and markers: (k, c) and (k, m) are lower-triangle blocks
+            const int i = (v - 10) / 6, j = (v - 10) % 6;
+            atomicAdd(U0 + (size_t)(rk + i) * n_pad + rc + j, s);
+        } else if (v < 58) {
+            const int i = (v - 34) / 6, j = (v - 34) % 6;
+            atomicAdd(U0 + (size_t)(rk + i) * n_pad + rm + j, s);
+        } else {
+            atomicAdd(g0 + rk + (v - 58), s);
+        }
+    });
+}
+
+__global__ void __launch_bounds__(256) k_passB_intr(const PassBArgs b) {
+    __shared__ double scratch[4 * 2048];
+    passB_intr_body(b, scratch, (int)blockIdx.x * 4);
+}
+
+template <int BLOCK, int CPL, bool INTR>
+__global__ void __launch_bounds__(BLOCK) k_passA_intr(const PassAArgs a) {
+    extern __shared__ double lds[];
+    passA_body<BLOCK, CPL, INTR>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
 template <int BLOCK, int CPL>
 __global__ void __launch_bounds__(BLOCK) k_passAB(const PassAArgs a, const PassBArgs b) {
     extern __shared__ double lds[];   // pass A's layout; pass B uses the first (BLOCK / 64) * 2048 doubles
@@ -400,13 +506,15 @@ __global__ void __launch_bounds__(256) k_maxdiag(const double *__restrict__ U0, 
 // ------------------------------------------------------------------------------------------------
 void launch_unpack(const DeviceProblem &P, int which, hipStream_t st) {
     const int n_ent = P.A + P.F;
-    { HookScope _h(P, KID_UNPACK); hipLaunchKernelGGL(k_unpack, dim3((n_ent + 255) / 256), dim3(256), 0, st, P.z[which], P.ent[which], n_ent); }
+    { HookScope _h(P, KID_UNPACK); hipLaunchKernelGGL(k_unpack, dim3((n_ent + 255) / 256), dim3(256), 0, st, P.z[which], P.ent[which], n_ent,
+                                                      P.C + P.M, P.intr ? P.C + P.M + P.C : P.C + P.M); }
 }
 
 void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream_t st) {
     const int blocks = (int)((P.N + 255) / 256);
     if (blocks == 0) return;
-    { HookScope _h(P, KID_RESIDUAL); hipLaunchKernelGGL(k_residual, dim3(blocks), dim3(256), 0, st, P.a_idx, P.a_uv, P.ent[which], P.K, P.N, P.A,
+    const KTable kt = k_table(P, which);
+    { HookScope _h(P, KID_RESIDUAL); hipLaunchKernelGGL(k_residual, dim3(blocks), dim3(256), 0, st, P.a_idx, P.a_uv, P.ent[which], kt.base, kt.stride, P.N, P.A,
                        P.half_size, P.res_f32, P.huber, r_out, P.err_part); }
 }
 
@@ -418,7 +526,8 @@ size_t passA_lds_bytes(int max_kf, int block) {
 
 static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, int zero_blk) {
     PassAArgs a;
-    a.idx = P.a_idx; a.uv = P.a_uv; a.ent = P.ent[which]; a.Kmat = P.K;
+    a.idx = P.a_idx; a.uv = P.a_uv; a.ent = P.ent[which];
+    { const KTable kt = k_table(P, which); a.Kmat = kt.base; a.kstride = kt.stride; }
     a.frame_obs_start = P.frame_obs_start; a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent;
     a.A = P.A; a.F = P.F; a.res_f32 = P.res_f32; a.max_kf = P.max_kf; a.frames_fixed = P.frames_fixed;
     a.huber = P.huber;
@@ -438,7 +547,9 @@ static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, i
 
 static PassBArgs passB_args(const DeviceProblem &P, int which) {
     PassBArgs b;
-    b.idx = P.b_idx; b.uv = P.b_uv; b.ent = P.ent[which]; b.Kmat = P.K; b.chunk_start = P.chunk_start;
+    b.idx = P.b_idx; b.uv = P.b_uv; b.ent = P.ent[which]; b.chunk_start = P.chunk_start;
+    { const KTable kt = k_table(P, which); b.Kmat = kt.base; b.kstride = kt.stride; }
+    b.k_ent0 = P.C + P.M;
     b.n_chunks = P.n_chunks; b.A = P.A; b.res_f32 = P.res_f32; b.n_pad = P.n_pad; b.huber = P.huber; b.h = P.half_size;
     b.U0 = P.blk[which].S; b.g0 = P.blk[which].g0;
     return b;
@@ -450,7 +561,11 @@ static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, const Pas
     const size_t lds = passA_lds_bytes(P.max_kf, B);
     static size_t granted = 48 * 1024, granted_ab = 48 * 1024;
     HookScope _h(P, KID_PASSA);
-    if (pbargs) {
+    if (P.intr) {   // (never merged with pass B: launch_passAB declines)
+        static size_t granted_i = 48 * 1024;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passA_intr<B, CPL, true>), lds, granted_i);
+        hipLaunchKernelGGL((k_passA_intr<B, CPL, true>), dim3(P.F), dim3(B), lds, st, a);
+    } else if (pbargs) {
         allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB<B, CPL>), lds, granted_ab);
         hipLaunchKernelGGL((k_passAB<B, CPL>), dim3(P.F + (P.n_chunks + B / 64 - 1) / (B / 64)), dim3(B), lds, st, a, *pbargs);
     } else {
@@ -477,10 +592,11 @@ void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_bl
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
     if (P.n_chunks == 0) return;
     { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which)); }
+    if (P.intr) { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB_intr, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which)); }
 }
 
 bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st) {
-    if (P.F == 0 || P.n_chunks == 0) return false;   // nothing to merge: the caller launches what there is
+    if (P.F == 0 || P.n_chunks == 0 || P.intr) return false;   // nothing to merge (or the intrinsics variants): the caller launches what there is
     // Side by side pays while the two passes together are a few wavefronts per SIMD (configs 2-4: -45 % / -11 % of their
     // summed time at configs 3 / 4); once either fills the chip on its own (config 5: +7 %, pass B's workgroups then carry
     // pass A's LDS allocation) they go one after the other
@@ -517,6 +633,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 struct TrackArgs {
     const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat; const int32_t *frame_obs_start;
+    int kstride;
     int A, F; float huber; double h;
     int max_iters; double min_error, min_step_error_diff, min_average_step_error_diff, tau;
     double *z;            // [6(A+F)]: frame poses in/out
@@ -548,7 +665,7 @@ __device__ __forceinline__ double track_eval(const TrackArgs &a, int f, const do
         load_ent(a.ent, id.marker, em);
         double K[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) K[i] = a.Kmat[9 * id.cam + i];
+        for (int i = 0; i < 9; i++) K[i] = a.Kmat[a.kstride * id.cam + i];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             CornerGeom gm;
@@ -676,7 +793,8 @@ void launch_track(const DeviceProblem &P, int which, int max_iters, double min_e
                   int32_t *iters_out, double *err_out, hipStream_t st) {
     if (P.F == 0) return;
     TrackArgs a;
-    a.idx = P.a_idx; a.uv = P.a_uv; a.ent = P.ent[which]; a.Kmat = P.K; a.frame_obs_start = P.frame_obs_start;
+    a.idx = P.a_idx; a.uv = P.a_uv; a.ent = P.ent[which]; a.frame_obs_start = P.frame_obs_start;
+    { const KTable kt = k_table(P, which); a.Kmat = kt.base; a.kstride = kt.stride; }
     a.A = P.A; a.F = P.F; a.huber = P.huber; a.h = P.half_size;
     a.max_iters = max_iters; a.min_error = min_error; a.min_step_error_diff = min_step; a.min_average_step_error_diff = min_avg; a.tau = tau;
     a.z = P.z[which]; a.iters_out = iters_out; a.err_out = err_out;

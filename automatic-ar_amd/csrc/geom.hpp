@@ -94,6 +94,17 @@ __device__ __forceinline__ void make_ent_row(const double *__restrict__ v, doubl
     row[21] = 0; row[22] = 0; row[23] = 0;
 }
 
+// Row of an INTRINSICS entity (optimize_cam_intrinsics): the pinhole matrix intrinsics_vec2mats rebuilds from
+// (fx, cx, fy, cy) -- cv::Mat::eye with those four entries, libs/multicam_mapper.cpp:580-593 -- in the first nine doubles,
+// so that the kernels read K from the entity table exactly as they read it from the constant table otherwise.
+__device__ __forceinline__ void make_k_row(const double *__restrict__ v, double *__restrict__ row) {
+    row[0] = v[0]; row[1] = 0; row[2] = v[1];
+    row[3] = 0; row[4] = v[2]; row[5] = v[3];
+    row[6] = 0; row[7] = 0; row[8] = 1;
+#pragma unroll
+    for (int i = 9; i < ENT_STRIDE; i++) row[i] = 0;
+}
+
 // corner k of the marker model: (-h,h,0) (h,h,0) (h,-h,0) (-h,-h,0)  (aruco marker.cpp:358-367)
 __device__ __forceinline__ double corner_sx(int k) { return (k == 1 || k == 2) ? 1.0 : -1.0; }
 __device__ __forceinline__ double corner_sy(int k) { return (k < 2) ? 1.0 : -1.0; }
@@ -165,6 +176,12 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
 
 // Jacobian rows of (u,v) for corner geometry g: Gc/Gm/Gf are [2][6] (row 0 = u, row 1 = v);
 // d r/d theta = -G, so J^T J = G^T G and B = -J^T r = G^T r.
+// d(u,v)/d(fx, cx, fy, cy) for the pinhole matrix [fx 0 cx; 0 fy cy; 0 0 1] of an intrinsics entity: u = fx x/w + cx
+__device__ __forceinline__ void corner_jacobian_intr(const CornerGeom &g, double Gk[2][4]) {
+    Gk[0][0] = g.pc[0] * g.iw; Gk[0][1] = 1.0; Gk[0][2] = 0.0; Gk[0][3] = 0.0;
+    Gk[1][0] = 0.0; Gk[1][1] = 0.0; Gk[1][2] = g.pc[1] * g.iw; Gk[1][3] = 1.0;
+}
+
 template <bool WANT_C, bool WANT_M, bool WANT_F>
 __device__ __forceinline__ void corner_jacobian(const Ent &ec, const Ent &em, const Ent &ef,
                                                 const double *__restrict__ K, const CornerGeom &g, double Gc[2][6],

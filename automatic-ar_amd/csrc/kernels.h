@@ -19,14 +19,15 @@ struct LaunchHook {  // called around every kernel launch when profiling is on
     void *ctx = nullptr;
 };
 
-// Per-observation record of an ordering: {frame (local), camera, marker, slot_c | slot_m << 16}
+// Per-observation record of an ordering: {frame (local), camera, marker, frame-local W slots: camera | marker << 10 | intrinsics << 21}
 struct ObsIdx {
     int32_t frame, cam, marker, slots;
 };
 
 struct DeviceProblem {
     // sizes
-    int C = 0, M = 0, A = 0;          // cameras, markers, shared entities A = C + M
+    int C = 0, M = 0, A = 0;          // cameras, markers, shared entities A = C + M (+ C intrinsics entities when intr)
+    int intr = 0;                     // optimize_cam_intrinsics: entity C + M + c = (fx, cx, fy, cy, -, -) of camera c, its row = K
     int F = 0;                        // local frames
     int64_t N = 0;                    // local observations
     int n = 0, n_pad = 0, nT = 0;     // reduced system: n = 6A, padded to a multiple of CHOL_NB, tiles
@@ -95,6 +96,16 @@ inline void allow_dynamic_lds(const void *kernel, size_t bytes, size_t &granted)
     }
 }
 
+// camera matrices: the constant table, or -- intrinsics being optimised -- the rows of the intrinsics entities of pose buffer `which`
+struct KTable { const double *base; int stride; };
+constexpr int ENT_STRIDE_H = 24;   // = geom.hpp's ENT_STRIDE
+inline KTable k_table(const DeviceProblem &P, int which) {
+    if (P.intr) return KTable{P.ent[which] + (size_t)(P.C + P.M) * ENT_STRIDE_H, ENT_STRIDE_H};
+    return KTable{P.K, 9};
+}
+constexpr int SLOT_C_BITS = 10, SLOT_M_BITS = 11;   // ObsIdx::slots
+inline int pack_slots(int sc, int sm, int sk) { return sc | (sm << SLOT_C_BITS) | (sk << (SLOT_C_BITS + SLOT_M_BITS)); }
+
 struct HookScope {  // RAII: pre/post around one launch
     const DeviceProblem &P;
     int kid;
@@ -107,7 +118,7 @@ void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream
 // pass A at z[which]: entity table, V, g_f, W, per-frame sum r^2 (err_part[f]); mu_pred >= 0 also gives Vinv, h_f for that
 // damping; zero_blk >= 0 clears S, rhs, g0 of that block set (they are dead / about to be rebuilt)
 void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st);
-void launch_passB(const DeviceProblem &P, int which, hipStream_t st);              // accumulates into blk[which].S, .g0 (must be zero)
+void launch_passB(const DeviceProblem &P, int which, hipStream_t st);              // accumulates into blk[which].S, .g0 (must be zero); with intrinsics: their shared blocks too
 // both passes in one launch (they only share the entity table ent[which], which must be complete); false = nothing launched
 bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st);
 void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st);            // scal[4] = max free diagonal

@@ -1030,7 +1030,7 @@ __global__ void __launch_bounds__(256) k_backsub(const int32_t *__restrict__ fsl
                                                  const double *__restrict__ gf, const double *__restrict__ g0,
                                                  const double *__restrict__ delta_s, const double *__restrict__ zc,
                                                  double *__restrict__ zt, int A, int F, int n_frame_blocks,
-                                                 double *__restrict__ lin_part, double *__restrict__ ent_out) {
+                                                 double *__restrict__ lin_part, double *__restrict__ ent_out, int k_ent0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x == n_frame_blocks) {  // shared part
         double d2 = 0.0, dg = 0.0;
@@ -1053,7 +1053,10 @@ __global__ void __launch_bounds__(256) k_backsub(const int32_t *__restrict__ fsl
         // them from this table (so they need not run one after the other)
         __threadfence_block();
         __syncthreads();
-        for (int e = tid; e < A; e += 256) make_ent_row(zt + 6 * (size_t)e, ent_out + (size_t)e * ENT_STRIDE);
+        for (int e = tid; e < A; e += 256) {   // entities from k_ent0 on are intrinsics entities: their row is the camera matrix
+            if (e >= k_ent0) make_k_row(zt + 6 * (size_t)e, ent_out + (size_t)e * ENT_STRIDE);
+            else make_ent_row(zt + 6 * (size_t)e, ent_out + (size_t)e * ENT_STRIDE);
+        }
         return;
     }
     const int f = blockIdx.x * 4 + wave;
@@ -1185,7 +1188,7 @@ void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) 
     const DeviceProblem::Blocks &b = P.blk[cur];
     const int nfb = (P.F + 3) / 4;
     { HookScope _h(P, KID_BACKSUB); hipLaunchKernelGGL(k_backsub, dim3(nfb + 1), dim3(256), 0, st, P.fslot_start, P.fslot_ent, b.W, b.Vinv, b.gf, b.g0,
-                       P.delta_s, P.z[cur], P.z[trial], P.A, P.F, nfb, P.lin_part, P.ent[trial]); }
+                       P.delta_s, P.z[cur], P.z[trial], P.A, P.F, nfb, P.lin_part, P.ent[trial], P.intr ? P.C + P.M : P.A); }
 }
 
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st, double *scal_out) {

@@ -155,10 +155,12 @@ void MultiCamMapper::init(size_t root_c, const std::map<int, Mat44> &T_to_root_c
     // eval_curr_solution + "the very initial error" (:331-333); the pose groups only, as error_function evaluates them
     const Config keep = config_;
     config_.optimize_cam_intrinsics = false;
+    drop_problem();
     if (ensure_problem()) { config_ = keep; throw std::runtime_error(aar_last_error()); }
     double e0 = 0;
     const int rc = aar_eval_residuals(problem_, data_->x_full, nullptr, &e0);
     config_ = keep;
+    drop_problem();   // (built for the pose groups only)
     if (rc) throw std::runtime_error(aar_last_error());
     std::cout << "the very initial error: " << e0 << std::endl;
 }
@@ -176,7 +178,7 @@ void MultiCamMapper::drop_problem() {
 void MultiCamMapper::set_optmize_flag_cam_poses(bool f) { config_.optimize_cam_poses = f; drop_problem(); }
 void MultiCamMapper::set_optmize_flag_marker_poses(bool f) { config_.optimize_marker_poses = f; drop_problem(); }
 void MultiCamMapper::set_optmize_flag_object_poses(bool f) { config_.optimize_object_poses = f; drop_problem(); }
-void MultiCamMapper::set_optmize_flag_cam_intrinsics(bool f) { config_.optimize_cam_intrinsics = f; }
+void MultiCamMapper::set_optmize_flag_cam_intrinsics(bool f) { config_.optimize_cam_intrinsics = f; drop_problem(); }
 void MultiCamMapper::set_with_huber(bool wh) { with_huber_ = wh; drop_problem(); }
 void MultiCamMapper::set_config(Config &conf) { config_ = conf; drop_problem(); }
 
@@ -218,6 +220,25 @@ void MultiCamMapper::eVec2Mats(const eVector &v) {
     if (config_.optimize_cam_poses) copy(L.full_cam0(), 6LL * (L.C - 1));
     if (config_.optimize_marker_poses) copy(L.full_mk0(), 6LL * (L.M - 1));
     if (config_.optimize_object_poses) copy(L.full_fr0(), 6LL * L.F);
+    if (config_.optimize_cam_intrinsics)
+        for (int c = 0; c < L.C; c++) {  // intrinsics_vec2mats, :580-593: cv::Mat::eye with fx, cx, fy, cy (a skew is gone), then d0..d4
+            double *K = data_->cam_mats + 9 * c;
+            K[0] = v[k++]; K[1] = 0; K[2] = v[k++]; K[3] = 0; K[4] = v[k++]; K[5] = v[k++]; K[6] = 0; K[7] = 0; K[8] = 1;
+            for (int j = 0; j < 5; j++) data_->dist_coeffs[5 * c + j] = v[k++];
+        }
+}
+
+// x_full of the device problem for the current Config: the pose vector, followed -- with optimize_cam_intrinsics -- by
+// fx cx fy cy d0..d4 per camera (fill_io_vec_cam_intrinsics, :488-498), i.e. the `.solution` vector
+std::vector<double> MultiCamMapper::problem_vector() {
+    std::vector<double> x(data_->x_full, data_->x_full + aar_dataset_full_len(data_));
+    if (config_.optimize_cam_intrinsics)
+        for (int c = 0; c < data_->num_cams; c++) {
+            const double *K = data_->cam_mats + 9 * c;
+            x.push_back(K[0]); x.push_back(K[2]); x.push_back(K[4]); x.push_back(K[5]);
+            for (int j = 0; j < 5; j++) x.push_back(data_->dist_coeffs[5 * c + j]);
+        }
+    return x;
 }
 
 int MultiCamMapper::ensure_problem() {
@@ -227,6 +248,7 @@ int MultiCamMapper::ensure_problem() {
     d.optimize_cam_poses = config_.optimize_cam_poses;
     d.optimize_marker_poses = config_.optimize_marker_poses;
     d.optimize_object_poses = config_.optimize_object_poses;
+    d.optimize_cam_intrinsics = config_.optimize_cam_intrinsics;
     d.residual_mode = residual_mode;
     d.with_huber = with_huber_ ? 1 : 0;
     d.device_id = device_id;
@@ -237,16 +259,13 @@ int MultiCamMapper::ensure_problem() {
 
 void MultiCamMapper::error_function(const eVector &input, eVector &error) {
     if (!data_) throw std::runtime_error("MultiCamMapper::error_function: no data set");
-    if (input.size() != get_num_vars(config_) || config_.optimize_cam_intrinsics)
-        throw std::runtime_error("MultiCamMapper::error_function: configuration outside the accelerated path");
+    if (input.size() != get_num_vars(config_)) throw std::runtime_error("MultiCamMapper::error_function: input has not the Config's number of variables");
     if (ensure_problem()) throw std::runtime_error(aar_last_error());
     if (with_huber_ && aar_problem_set_huber_delta(problem_, hubberDelta)) throw std::runtime_error(aar_last_error());
-    std::vector<double> keep(data_->x_full, data_->x_full + aar_dataset_full_len(data_));
-    eVec2Mats(input);
+    std::vector<double> x = problem_vector();
+    if (aar_problem_merge_z(problem_, input.data(), x.data())) throw std::runtime_error(aar_last_error());
     error.assign(8 * (size_t)data_->num_obs, 0.0);
-    const int rc = aar_eval_residuals(problem_, data_->x_full, error.data(), nullptr);
-    memcpy(data_->x_full, keep.data(), keep.size() * sizeof(double));
-    if (rc) throw std::runtime_error(aar_last_error());
+    if (aar_eval_residuals(problem_, x.data(), error.data(), nullptr)) throw std::runtime_error(aar_last_error());
 }
 
 // optCallBack, libs/multicam_mapper.cpp:412-417: the Huber delta schedule, driven by the solver's step callback
@@ -257,15 +276,14 @@ void MultiCamMapper::optCallBack(const eVector &) {
 
 void MultiCamMapper::solve() {   // libs/multicam_mapper.cpp:419-428
     if (!data_) throw std::runtime_error("MultiCamMapper::solve: no data set");
-    if (config_.optimize_cam_intrinsics)
-        throw std::runtime_error("MultiCamMapper::solve: optimize_cam_intrinsics is not on the accelerated path (call set_optmize_flag_cam_intrinsics(false) as find_solution does)");
     if (ensure_problem()) throw std::runtime_error(aar_last_error());
     mats2eVec();
-    solver.attach(problem_, data_->x_full);
+    const std::vector<double> x_start = problem_vector();
+    solver.attach(problem_, x_start.data());
     solver.setParams(solver_params);
     solver.setStepCallBackFunc(std::bind(&MultiCamMapper::optCallBack, this, std::placeholders::_1), /*needs_z=*/false);
     double e0 = 0;
-    if (aar_eval_residuals(problem_, data_->x_full, nullptr, &e0)) throw std::runtime_error(aar_last_error());
+    if (aar_eval_residuals(problem_, x_start.data(), nullptr, &e0)) throw std::runtime_error(aar_last_error());
     std::cout << "initial_error: " << e0 << "error size: " << 8 * data_->num_obs << std::endl;  // :424
     hubberDelta = 10;
     if (with_huber_ && aar_problem_set_huber_delta(problem_, hubberDelta)) throw std::runtime_error(aar_last_error());
@@ -290,7 +308,9 @@ void MultiCamMapper::track() {
     p.tau = solver_params.tau;
     track_iterations.assign(data_->num_frames, 0);
     track_errors.assign(data_->num_frames, 0.0);
-    if (aar_track(problem_, data_->x_full, &p, track_iterations.data(), track_errors.data())) throw std::runtime_error(aar_last_error());
+    std::vector<double> x = problem_vector();
+    if (aar_track(problem_, x.data(), &p, track_iterations.data(), track_errors.data())) throw std::runtime_error(aar_last_error());
+    memcpy(data_->x_full, x.data(), sizeof(double) * aar_dataset_full_len(data_));   // (only the frame poses have moved)
     mats2eVec();
 }
 

@@ -196,7 +196,7 @@ class MultiCamMapper {
     void set_optmize_flag_cam_poses(bool);       // sic: the reference spells it "optmize"
     void set_optmize_flag_marker_poses(bool);
     void set_optmize_flag_object_poses(bool);
-    void set_optmize_flag_cam_intrinsics(bool);  // true is rejected at solve(): outside this path (apps/find_solution.cpp:140)
+    void set_optmize_flag_cam_intrinsics(bool);  // fx cx fy cy (+ the five idle distortion entries) per camera join z (:488-498)
     void set_with_huber(bool);                   // Huber-weighted residual rows + optCallBack's delta schedule (:412-417)
     void set_config(Config &conf);
     size_t get_num_vars(const Config &conf);
@@ -232,6 +232,7 @@ class MultiCamMapper {
 
    private:
     void optCallBack(const eVector &v);   // :412-417
+    std::vector<double> problem_vector();
     void mats2eVec();
     void eVec2Mats(const eVector &v);
     int ensure_problem();

@@ -19,7 +19,8 @@
  * (fill_io_vec_cams/markers/object_poses, libs/multicam_mapper.cpp:500-522: ascending index, root camera
  * and root marker skipped) i.e. the pose part of the `.solution` vector (:1085-1089).  Which groups are
  * optimised is a flag (MultiCamMapper::Config, libs/multicam_mapper.h:75-81); fixed groups keep their
- * values.  Camera intrinsics are never optimised on this path (apps/find_solution.cpp:140).
+ * values.  With optimize_cam_intrinsics (off in find_solution, apps/find_solution.cpp:140; on in the reference's default
+ * Config) the vectors carry the 9-per-camera intrinsics block behind the poses: see aar_problem_desc.
  */
 #ifndef AAR_H
 #define AAR_H
@@ -239,6 +240,13 @@ typedef struct aar_problem_desc {
     const int32_t *obs_frame, *obs_cam, *obs_marker;  /* frame-nondecreasing (reference order)      */
     const float *obs_uv;                      /* [N][8]                                             */
     int32_t optimize_cam_poses, optimize_marker_poses, optimize_object_poses;
+    int32_t optimize_cam_intrinsics;          /* MultiCamMapper::Config's fourth flag (libs/multicam_mapper.h:75-81): every vector of this
+                                                 problem -- x_full, z, delta -- then ENDS with 9 entries per camera, fx cx fy cy d0..d4
+                                                 (fill_io_vec_cam_intrinsics, libs/multicam_mapper.cpp:488-498: all cameras, the root too), i.e.
+                                                 x_full is the whole `.solution` vector (:1085-1089); cam_mats then only supplies nothing but
+                                                 its shape -- the projection uses the pinhole matrix intrinsics_vec2mats rebuilds from those
+                                                 four numbers (:580-593, no skew), the five distortion entries are carried along untouched
+                                                 (their Jacobian columns are exact zeros in the reference: project_marker ignores them)     */
     int32_t residual_mode;                    /* AAR_RES_F32 | AAR_RES_F64                          */
     int32_t with_huber;                       /* MultiCamMapper::set_with_huber (libs/multicam_mapper.cpp:31-33,1014-1019): residual
                                                  rows scaled by sqrt(rho(e)/e); aar_lm_solve then also runs optCallBack's delta
@@ -251,7 +259,7 @@ typedef struct aar_problem_desc {
 void aar_problem_desc_from_dataset(const aar_dataset *, aar_problem_desc *);
 int aar_problem_create(const aar_problem_desc *, aar_problem **out);
 void aar_problem_destroy(aar_problem *);
-int64_t aar_problem_full_len(const aar_problem *);    /* length of x_full                            */
+int64_t aar_problem_full_len(const aar_problem *);    /* length of x_full (+ 9 per camera with optimize_cam_intrinsics) */
 int64_t aar_problem_num_vars(const aar_problem *);    /* length of the reference's z for the Config  */
 int64_t aar_problem_local_obs(const aar_problem *);   /* observations owned by this rank             */
 /* MultiCamMapper::hubberDelta: the delta the next residual evaluations use (only meaningful with with_huber) */

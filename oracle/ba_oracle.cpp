@@ -161,7 +161,8 @@ Mat4 pose_to_mat(const double *v) {
 struct Layout {  // offsets into x_full and into z (libs/multicam_mapper.cpp:445-461)
     int C, M, F, rc, rm;
     int64_t full_cam0, full_mk0, full_fr0, full_len;
-    int64_t z_cam0, z_mk0, z_fr0, z_len;  // -1 when the group is not optimised
+    int64_t z_cam0, z_mk0, z_fr0, z_intr0, z_len;  // -1 when the group is not optimised
+    int jac_slab;                                  // triplet slots per observation: 8 x 18 (+ 8 x 9 with intrinsics)
     explicit Layout(const orc_problem *p) {
         C = p->num_cams; M = p->num_markers; F = p->num_frames; rc = p->root_cam; rm = p->root_marker;
         full_cam0 = 0; full_mk0 = 6LL * (C - 1); full_fr0 = full_mk0 + 6LL * (M - 1);
@@ -171,7 +172,10 @@ struct Layout {  // offsets into x_full and into z (libs/multicam_mapper.cpp:445
         if (p->opt_cams) { z_cam0 = o; o += 6LL * (C - 1); }
         if (p->opt_markers) { z_mk0 = o; o += 6LL * (M - 1); }
         if (p->opt_frames) { z_fr0 = o; o += 6LL * F; }
+        z_intr0 = -1;
+        if (p->opt_intrinsics) { z_intr0 = o; o += 9LL * C; }   // fill_io_vec_cam_intrinsics: ALL cameras, the root too (:488-498)
         z_len = o;
+        jac_slab = 144 + (p->opt_intrinsics ? 72 : 0);
     }
     // position of entity within its (root-skipping) group, -1 for the root
     int cam_slot(int c) const { return c == rc ? -1 : (c < rc ? c : c - 1); }
@@ -202,14 +206,24 @@ void build_mats(const Layout &L, const std::vector<double> &x, Mats &ma) {
     for (int f = 0; f < L.F; f++) ma.fr[f] = pose_to_mat(&x[L.full_fr0 + 6LL * f]);
 }
 
+// camera matrix of camera c: the data set's, or -- with the intrinsics in z -- what intrinsics_vec2mats builds from it
+// (libs/multicam_mapper.cpp:580-593: cv::Mat::eye with fx, cx, fy, cy; any skew of the calibration is gone)
+void cam_matrix(const orc_problem *p, const Layout &L, const double *z, int c, double K[9]) {
+    if (z && L.z_intr0 >= 0) {
+        const double *q = z + L.z_intr0 + 9LL * c;
+        K[0] = q[0]; K[1] = 0; K[2] = q[1]; K[3] = 0; K[4] = q[2]; K[5] = q[3]; K[6] = 0; K[7] = 0; K[8] = 1;
+    } else {
+        std::memcpy(K, p->K + 9 * c, sizeof(double) * 9);
+    }
+}
+
 // project_marker: libs/multicam_mapper.cpp:608-649.  out = 4 corners (x,y) in double, before the
 // cv::Point2f store.
 void project_marker(const orc_problem *p, const Layout &L, const Mat4 &Tc, const Mat4 &Tf, const Mat4 &Tm, int c,
-                    int m, double out[8]) {
+                    int m, const double *K, double out[8]) {
     Mat4 T = Tf;
     if (c != L.rc) T = mul(inv_lu(Tc), T);
     if (m != L.rm) T = mul(T, Tm);
-    const double *K = p->K + 9 * c;
     double KT[12];  // cam_mat * transform.rowRange(0,3)
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 4; j++) {
@@ -313,9 +327,9 @@ inline void matTvec(const double *A, const double *x, double *y) {
 
 // d(u,v)/d(params) for one observation: Gc, Gm, Gf are 8x6 row-major (rows = 2*corner + {x,y});
 // also the double-precision projection. dr/dparam = -G.
-void analytic_blocks(const orc_problem *p, const Ent &ec, const Ent &em, const Ent &ef, int c, double proj[8],
-                     double Gc[48], double Gm[48], double Gf[48]) {
-    const double *K = p->K + 9 * c;
+// Gk (8x4, optional): d(u,v)/d(fx, cx, fy, cy) of the pinhole matrix [fx 0 cx; 0 fy cy; 0 0 1]
+void analytic_blocks(const orc_problem *p, const Ent &ec, const Ent &em, const Ent &ef, const double *K, double proj[8],
+                     double Gc[48], double Gm[48], double Gf[48], double *Gk = nullptr) {
     float hs = (float)p->marker_size / 2.f;
     double h = (double)hs;
     const double X[4][3] = {{-h, h, 0}, {h, h, 0}, {h, -h, 0}, {-h, -h, 0}};
@@ -331,6 +345,11 @@ void analytic_blocks(const orc_problem *p, const Ent &ec, const Ent &em, const E
         matvec(K, pc, hx);
         double iw = 1.0 / hx[2], u = hx[0] * iw, v = hx[1] * iw;
         proj[2 * k] = u; proj[2 * k + 1] = v;
+        if (Gk) {   // u = fx x/w + cx, v = fy y/w + cy
+            double *g = Gk + 8 * k;
+            g[0] = pc[0] * iw; g[1] = 1; g[2] = 0; g[3] = 0;
+            g[4] = 0; g[5] = 0; g[6] = pc[1] * iw; g[7] = 1;
+        }
         double A[6];  // d(u,v)/dp
         for (int j = 0; j < 3; j++) {
             A[j] = (K[j] - u * K[6 + j]) * iw;
@@ -376,7 +395,8 @@ int64_t jacobian_impl(const orc_problem *p, const double *x_full, const double *
     std::vector<double> x;
     build_full(p, L, x_full, z, x);
     const int64_t N = p->num_obs;
-    // every observation owns a fixed slab of 8*18 triplet slots so threads never collide
+    // every observation owns a fixed slab of 8*18 (+ 8*9) triplet slots so threads never collide
+    const int64_t slab = L.jac_slab;
     std::vector<int64_t> cnt(N, 0);
 
     if (jac_mode == ORC_JAC_ANALYTIC) {
@@ -387,9 +407,10 @@ int64_t jacobian_impl(const orc_problem *p, const double *x_full, const double *
 #pragma omp parallel for schedule(static)
         for (int64_t o = 0; o < N; o++) {
             int c = p->obs_cam[o], m = p->obs_marker[o], f = p->obs_frame[o];
-            double proj[8], Gc[48], Gm[48], Gf[48];
-            analytic_blocks(p, ec[c], em[m], ef[f], c, proj, Gc, Gm, Gf);
-            int64_t base = o * 144, n = 0;
+            double proj[8], Gc[48], Gm[48], Gf[48], Gk[32], Kc[9];
+            cam_matrix(p, L, z, c, Kc);
+            analytic_blocks(p, ec[c], em[m], ef[f], Kc, proj, Gc, Gm, Gf, L.z_intr0 >= 0 ? Gk : nullptr);
+            int64_t base = o * slab, n = 0;
             auto emit = [&](const double *G, int64_t col0) {
                 for (int r = 0; r < 8; r++)
                     for (int j = 0; j < 6; j++) {
@@ -402,6 +423,14 @@ int64_t jacobian_impl(const orc_problem *p, const double *x_full, const double *
             if (L.z_cam0 >= 0 && c != L.rc) emit(Gc, L.z_cam0 + 6LL * L.cam_slot(c));
             if (L.z_mk0 >= 0 && m != L.rm) emit(Gm, L.z_mk0 + 6LL * L.mk_slot(m));
             if (L.z_fr0 >= 0) emit(Gf, L.z_fr0 + 6LL * f);
+            if (L.z_intr0 >= 0)   // 9 columns per camera: 4 live, the 5 distortion columns explicit zeros as in the reference
+                for (int r = 0; r < 8; r++)
+                    for (int j = 0; j < 9; j++) {
+                        rows[base + n] = (int32_t)(8 * o + r);
+                        cols[base + n] = (int32_t)(L.z_intr0 + 9LL * c + j);
+                        vals[base + n] = j < 4 ? -Gk[(r / 2) * 8 + (r % 2) * 4 + j] : 0.0;
+                        n++;
+                    }
             cnt[o] = n;
         }
     } else {
@@ -416,7 +445,34 @@ int64_t jacobian_impl(const orc_problem *p, const double *x_full, const double *
         for (int64_t o = 0; o < N; o++) {
             int c = p->obs_cam[o], m = p->obs_marker[o], f = p->obs_frame[o];
             const float *uv = p->obs_uv + 8 * o;
-            int64_t base = o * 144, n = 0;
+            int64_t base = o * slab, n = 0;
+            double Kc[9];
+            cam_matrix(p, L, z, c, Kc);
+            auto quotient = [&](const double pa[8], const double ps[8], int64_t col) {   // obtain_marker_derivs, :976-994
+                double ra[8], rs[8];
+                if (track) {  // calcDerivates differentiates the whole error function, Huber weights included
+                    obs_residual(p, pa, uv, ORC_RES_F64, ra);
+                    obs_residual(p, ps, uv, ORC_RES_F64, rs);
+                }
+                for (int k = 0; k < 8; k++) {
+                    double ea, es;
+                    if (track) {
+                        ea = ra[k]; es = rs[k];
+                    } else if (f32) {
+                        ea = (double)(uv[k] - (float)pa[k]);
+                        es = (double)(uv[k] - (float)ps[k]);
+                    } else {
+                        ea = (double)uv[k] - pa[k];
+                        es = (double)uv[k] - ps[k];
+                    }
+                    const double dv = (ea - es) / (2 * delta);
+                    if (track && !(std::fabs(dv) > 1e-4)) continue;  // libs/sparselevmarq.h:182,215
+                    rows[base + n] = (int32_t)(8 * o + k);
+                    cols[base + n] = (int32_t)col;
+                    vals[base + n] = dv;
+                    n++;
+                }
+            };
             auto block = [&](int which, const double *pose, int64_t col0) {
                 const Mat4 &T0 = which == 0 ? ma.cam[c] : (which == 1 ? ma.mk[m] : ma.fr[f]);
                 for (int i = 0; i < 6; i++) {
@@ -432,43 +488,32 @@ int64_t jacobian_impl(const orc_problem *p, const double *x_full, const double *
                         Ta(i - 3, 3) += delta; Ts(i - 3, 3) -= delta;
                     }
                     double pa[8], ps[8];
-                    project_marker(p, L, which == 0 ? Ta : ma.cam[c], which == 2 ? Ta : ma.fr[f], which == 1 ? Ta : ma.mk[m], c, m, pa);
-                    project_marker(p, L, which == 0 ? Ts : ma.cam[c], which == 2 ? Ts : ma.fr[f], which == 1 ? Ts : ma.mk[m], c, m, ps);
-                    double ra[8], rs[8];
-                    if (track) {  // calcDerivates differentiates the whole error function, Huber weights included
-                        obs_residual(p, pa, uv, ORC_RES_F64, ra);
-                        obs_residual(p, ps, uv, ORC_RES_F64, rs);
-                    }
-                    for (int k = 0; k < 8; k++) {
-                        double ea, es;
-                        if (track) {
-                            ea = ra[k]; es = rs[k];
-                        } else if (f32) {
-                            ea = (double)(uv[k] - (float)pa[k]);
-                            es = (double)(uv[k] - (float)ps[k]);
-                        } else {
-                            ea = (double)uv[k] - pa[k];
-                            es = (double)uv[k] - ps[k];
-                        }
-                        const double dv = (ea - es) / (2 * delta);
-                        if (track && !(std::fabs(dv) > 1e-4)) continue;  // libs/sparselevmarq.h:182,215
-                        rows[base + n] = (int32_t)(8 * o + k);
-                        cols[base + n] = (int32_t)(col0 + i);
-                        vals[base + n] = dv;
-                        n++;
-                    }
+                    project_marker(p, L, which == 0 ? Ta : ma.cam[c], which == 2 ? Ta : ma.fr[f], which == 1 ? Ta : ma.mk[m], c, m, Kc, pa);
+                    project_marker(p, L, which == 0 ? Ts : ma.cam[c], which == 2 ? Ts : ma.fr[f], which == 1 ? Ts : ma.mk[m], c, m, Kc, ps);
+                    quotient(pa, ps, col0 + i);
                 }
             };
             if (L.z_cam0 >= 0 && c != L.rc) block(0, &x[L.full_cam0 + 6LL * L.cam_slot(c)], L.z_cam0 + 6LL * L.cam_slot(c));
             if (L.z_mk0 >= 0 && m != L.rm) block(1, &x[L.full_mk0 + 6LL * L.mk_slot(m)], L.z_mk0 + 6LL * L.mk_slot(m));
             if (L.z_fr0 >= 0) block(2, &x[L.full_fr0 + 6LL * f], L.z_fr0 + 6LL * f);
+            if (L.z_intr0 >= 0)   // the intrinsics phase of obtain_transformation_derivs, :835-893: fx, cx, fy, cy +- J_delta in the
+                for (int i = 0; i < 9; i++) {   // matrix, d0..d4 +- J_delta in a vector project_marker never reads (:630-640)
+                    double Ka[9], Ks[9];
+                    std::memcpy(Ka, Kc, sizeof Ka); std::memcpy(Ks, Kc, sizeof Ks);
+                    const int at[4] = {0, 2, 4, 5};
+                    if (i < 4) { Ka[at[i]] += delta; Ks[at[i]] -= delta; }
+                    double pa[8], ps[8];
+                    project_marker(p, L, ma.cam[c], ma.fr[f], ma.mk[m], c, m, Ka, pa);
+                    project_marker(p, L, ma.cam[c], ma.fr[f], ma.mk[m], c, m, Ks, ps);
+                    quotient(pa, ps, L.z_intr0 + 9LL * c + i);
+                }
             cnt[o] = n;
         }
     }
     // compact the slabs
     int64_t w = 0;
     for (int64_t o = 0; o < N; o++) {
-        int64_t base = o * 144;
+        int64_t base = o * slab;
         if (w != base) {
             std::memmove(rows + w, rows + base, sizeof(int32_t) * cnt[o]);
             std::memmove(cols + w, cols + base, sizeof(int32_t) * cnt[o]);
@@ -489,8 +534,9 @@ void residual_impl(const orc_problem *p, const double *x_full, const double *z, 
     // result does not depend on the loop schedule.
     for (int64_t o = 0; o < p->num_obs; o++) {
         int c = p->obs_cam[o], m = p->obs_marker[o], f = p->obs_frame[o];
-        double proj[8];
-        project_marker(p, L, ma.cam[c], ma.fr[f], ma.mk[m], c, m, proj);
+        double proj[8], Kc[9];
+        cam_matrix(p, L, z, c, Kc);
+        project_marker(p, L, ma.cam[c], ma.fr[f], ma.mk[m], c, m, Kc, proj);
         obs_residual(p, proj, p->obs_uv + 8 * o, res_mode, r + 8 * o);
     }
 }
@@ -682,6 +728,8 @@ std::vector<int32_t> frames_first_order(const orc_problem *p) {
         for (int64_t i = 0; i < 6LL * (L.C - 1); i++) order.push_back((int32_t)(L.z_cam0 + i));
     if (L.z_mk0 >= 0)
         for (int64_t i = 0; i < 6LL * (L.M - 1); i++) order.push_back((int32_t)(L.z_mk0 + i));
+    if (L.z_intr0 >= 0)
+        for (int64_t i = 0; i < 9LL * L.C; i++) order.push_back((int32_t)(L.z_intr0 + i));
     return order;
 }
 
@@ -713,8 +761,8 @@ struct StepSystem {
 void build_system(const orc_problem *p, const double *x_full, const double *z, int jac_mode, const double *r, StepSystem &S) {
     Layout L(p);
     const int64_t N = p->num_obs;
-    std::vector<int32_t> rows(144 * N), cols(144 * N);
-    std::vector<double> vals(144 * N);
+    std::vector<int32_t> rows(L.jac_slab * N), cols(L.jac_slab * N);
+    std::vector<double> vals(L.jac_slab * N);
     int64_t nnz = jacobian_impl(p, x_full, z, jac_mode, rows.data(), cols.data(), vals.data());
     Csc J = csc_from_triplets((int)(8 * N), (int)L.z_len, rows.data(), cols.data(), vals.data(), nnz);
     Csc Jt = transpose(J);                    // libs/sparselevmarq.h:355
@@ -739,6 +787,24 @@ void orc_extract_z(const orc_problem *p, const double *x_full, double *z) {
     if (L.z_cam0 >= 0) std::memcpy(z + L.z_cam0, x_full + L.full_cam0, sizeof(double) * 6 * (L.C - 1));
     if (L.z_mk0 >= 0) std::memcpy(z + L.z_mk0, x_full + L.full_mk0, sizeof(double) * 6 * (L.M - 1));
     if (L.z_fr0 >= 0) std::memcpy(z + L.z_fr0, x_full + L.full_fr0, sizeof(double) * 6 * L.F);
+    if (L.z_intr0 >= 0)   // fill_io_vec_cam_intrinsics, :488-498
+        for (int c = 0; c < L.C; c++) {
+            double *q = z + L.z_intr0 + 9LL * c;
+            const double *K = p->K + 9 * c;
+            q[0] = K[0]; q[1] = K[2]; q[2] = K[4]; q[3] = K[5];
+            for (int j = 0; j < 5; j++) q[4 + j] = p->dist ? p->dist[5 * c + j] : 0.0;
+        }
+}
+
+int64_t orc_jac_capacity(const orc_problem *p) { return Layout(p).jac_slab * p->num_obs; }
+
+void orc_get_intrinsics(const orc_problem *p, const double *z, double *K_out, double *dist_out) {   // intrinsics_vec2mats, :580-593
+    Layout L(p);
+    for (int c = 0; c < L.C; c++) {
+        cam_matrix(p, L, z, c, K_out + 9 * c);
+        for (int j = 0; j < 5; j++)
+            dist_out[5 * c + j] = (z && L.z_intr0 >= 0) ? z[L.z_intr0 + 9LL * c + 4 + j] : (p->dist ? p->dist[5 * c + j] : 0.0);
+    }
 }
 
 void orc_merge_z(const orc_problem *p, const double *x_full, const double *z, double *x_out) {

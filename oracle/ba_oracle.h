@@ -40,6 +40,11 @@ typedef struct orc_problem {
     int32_t opt_cams, opt_markers, opt_frames;   /* MultiCamMapper::Config (intrinsics off)    */
     int32_t with_huber;                  /* libs/multicam_mapper.cpp:1014-1019                 */
     float huber_delta;
+    int32_t opt_intrinsics;              /* Config::optimize_cam_intrinsics: z ends with 9 per camera -- fx cx fy cy d0..d4
+                                            (fill_io_vec_cam_intrinsics, :488-498); the projection then uses the pinhole matrix
+                                            intrinsics_vec2mats rebuilds from z (:580-593: no skew), the five distortion entries
+                                            never reach project_marker (their Jacobian columns are exact zeros)              */
+    const double *dist;                  /* [num_cams][5] or NULL (zeros): only carried through z                            */
 } orc_problem;
 
 enum { ORC_RES_F32 = 0,   /* reference-faithful: projections rounded to float, float subtraction */
@@ -70,9 +75,13 @@ typedef struct orc_lm_iter {             /* one step() of libs/sparselevmarq.h:3
 int64_t orc_full_len(const orc_problem *p);
 /* length of z for the problem's Config flags */
 int64_t orc_num_vars(const orc_problem *p);
-/* z <-> x_full helpers (optimised groups only, reference order cams|markers|frames) */
+/* z <-> x_full helpers (optimised groups only, reference order cams|markers|frames|intrinsics); the intrinsics part of z comes
+ * from p->K / p->dist on the way in and is read back with orc_get_intrinsics */
 void orc_extract_z(const orc_problem *p, const double *x_full, double *z);
 void orc_merge_z(const orc_problem *p, const double *x_full, const double *z, double *x_out);
+void orc_get_intrinsics(const orc_problem *p, const double *z, double *K_out /* [C][9] */, double *dist_out /* [C][5] */);
+/* triplet capacity orc_jacobian needs: 8 rows x (18 pose + 9 intrinsics columns) per observation */
+int64_t orc_jac_capacity(const orc_problem *p);
 
 /* cv::Rodrigues restatement (call sites libs/multicam_mapper.cpp:470,478) */
 void orc_rodrigues_vec2mat(const double w[3], double R[9]);
@@ -80,7 +89,7 @@ void orc_rodrigues_mat2vec(const double R[9], double w[3]);
 
 /* error_function / eval_curr_solution: libs/multicam_mapper.cpp:731-737,996-1028 */
 void orc_residuals(const orc_problem *p, const double *x_full, const double *z, int res_mode, double *r);
-/* jacobian_function: libs/multicam_mapper.cpp:739-801,803-994. Triplets (row, col, val); capacity 8*18*N. */
+/* jacobian_function: libs/multicam_mapper.cpp:739-801,803-994. Triplets (row, col, val); capacity orc_jac_capacity. */
 int64_t orc_jacobian(const orc_problem *p, const double *x_full, const double *z, int jac_mode,
                      int32_t *rows, int32_t *cols, double *vals);
 /* dense J^T J (P x P, row-major) and B = -J^T r (libs/sparselevmarq.h:355-367); small problems only */

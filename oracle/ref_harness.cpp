@@ -57,8 +57,9 @@ double ref_lm_solve(const orc_problem *p_in, const double *x_full, double *z_ino
         err.resize(8 * N);
         orc_residuals(p, x_full, z.data(), res_mode, err.data());
     };
-    std::vector<int32_t> rows(144 * N), cols(144 * N);
-    std::vector<double> vals(144 * N);
+    const int64_t cap = orc_jac_capacity(p);
+    std::vector<int32_t> rows(cap), cols(cap);
+    std::vector<double> vals(cap);
     auto fJ = [&](const eVector &z, Eigen::SparseMatrix<double> &J) {
         int64_t nnz = orc_jacobian(p, x_full, z.data(), jac_mode, rows.data(), cols.data(), vals.data());
         std::vector<Eigen::Triplet<double>> t;

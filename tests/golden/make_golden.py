@@ -39,9 +39,9 @@ def trace_arrays(rep, prefix):
             prefix + "iterations": np.array([rep["iterations"]]), prefix + "final_err": np.array([rep["final_err"]])}
 
 
-def g1(name, ds, synth_args, tau=1.0, with_huber=False):
+def g1(name, ds, synth_args, tau=1.0, with_huber=False, intrinsics=False):
     """G1: LM trace + final solution of the real solver, reference-faithful callbacks."""
-    o = ol.Oracle(ds, with_huber=with_huber)
+    o = ol.Oracle(ds, with_huber=with_huber, intrinsics=intrinsics)
     prm = ol.mapper_params(tau=tau)
     x_ref, rep = o.ref_lm_solve(ds.x_full, params=prm, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=1, use_omp_mult=True)
     x_acc, rep_acc = o.ref_lm_solve(ds.x_full, params=prm, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32, threads=1, use_omp_mult=True)
@@ -52,10 +52,16 @@ def g1(name, ds, synth_args, tau=1.0, with_huber=False):
     out.update(trace_arrays(rep_acc, "analytic_"))
     out["faithful_x"] = x_ref
     out["analytic_x"] = x_acc
-    st = o.reproj_stats(x_ref)
-    out["faithful_rmse"] = np.array([st["rmse"], st["mean_dist"], st["sum_sq"]])
-    st = o.reproj_stats(x_acc)
-    out["analytic_rmse"] = np.array([st["rmse"], st["mean_dist"], st["sum_sq"]])
+    out["faithful_z"] = rep["z"]          # the whole z: with intrinsics it ends with fx cx fy cy d0..d4 per camera
+    out["analytic_z"] = rep_acc["z"]
+    if intrinsics:   # statistics at the solved intrinsics
+        out["faithful_rmse"] = np.array([np.sqrt(float((o.residuals(x_ref, rep["z"], res_mode=ol.RES_F64) ** 2).sum()) / (4 * ds.num_obs)), 0, 0])
+        out["analytic_rmse"] = np.array([np.sqrt(float((o.residuals(x_acc, rep_acc["z"], res_mode=ol.RES_F64) ** 2).sum()) / (4 * ds.num_obs)), 0, 0])
+    else:
+        st = o.reproj_stats(x_ref)
+        out["faithful_rmse"] = np.array([st["rmse"], st["mean_dist"], st["sum_sq"]])
+        st = o.reproj_stats(x_acc)
+        out["analytic_rmse"] = np.array([st["rmse"], st["mean_dist"], st["sum_sq"]])
     out["r0_f32"] = o.residuals(ds.x_full, res_mode=ol.RES_F32)   # with_huber: weighted with the oracle's delta (10)
     out["with_huber"] = np.array([int(with_huber)])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
@@ -117,6 +123,13 @@ if __name__ == "__main__":
     dsh.obs_uv = dsh.obs_uv.copy()
     dsh.obs_uv[bad] += rng.normal(0, 25, size=(int(bad.sum()), 8)).astype(np.float32)
     g1("g1_cfg2_huber", dsh, [2, 4, 12, 100, 1.0], with_huber=True)
+    # optimize_cam_intrinsics (the reference's default Config): calibrations off by ~1 % / a few pixels, a skew that
+    # intrinsics_vec2mats drops; z ends with 9 per camera
+    dsi = aar.synth(2)
+    dsi.cam_mats = dsi.cam_mats.copy()
+    dsi.cam_mats[:, 0] *= 1.01; dsi.cam_mats[:, 2] += 3.0; dsi.cam_mats[:, 4] *= 0.995; dsi.cam_mats[:, 5] -= 2.0; dsi.cam_mats[:, 1] = 0.4
+    dsi.dist_coeffs = np.tile(np.array([0.01, -0.02, 0.001, 0.002, 0.003]), (dsi.num_cams, 1))
+    g1("g1_cfg2_intr", dsi, [2, 4, 12, 100, 1.0], intrinsics=True)
     g_track("g_track_cfg2", aar.synth(2), False)
     g_track("g_track_cfg2_huber", dsh, True)
     g2("g2_small", aar.synth(2, num_cams=3, num_markers=8, num_frames=20))

@@ -27,6 +27,7 @@ class OrcProblem(C.Structure):
         ("obs_uv", C.POINTER(C.c_float)),
         ("opt_cams", C.c_int32), ("opt_markers", C.c_int32), ("opt_frames", C.c_int32),
         ("with_huber", C.c_int32), ("huber_delta", C.c_float),
+        ("opt_intrinsics", C.c_int32), ("dist", C.POINTER(C.c_double)),
     ]
 
 
@@ -83,6 +84,9 @@ def oracle():
         L.orc_num_vars.restype = C.c_int64
         L.orc_num_vars.argtypes = [pp]
         L.orc_extract_z.argtypes = [pp, _dp, _dp]
+        L.orc_get_intrinsics.argtypes = [pp, _dp, _dp, _dp]
+        L.orc_jac_capacity.restype = C.c_int64
+        L.orc_jac_capacity.argtypes = [pp]
         L.orc_merge_z.argtypes = [pp, _dp, _dp, _dp]
         L.orc_rodrigues_vec2mat.argtypes = [_dp, _dp]
         L.orc_rodrigues_mat2vec.argtypes = [_dp, _dp]
@@ -152,8 +156,9 @@ def mapper_params(**over):
 class Oracle:
     """One problem bound to the oracle.  `ds` is an aar.Dataset-like object (numpy fields)."""
 
-    def __init__(self, ds, optimize=(True, True, True), with_huber=False, huber_delta=10.0):
+    def __init__(self, ds, optimize=(True, True, True), with_huber=False, huber_delta=10.0, intrinsics=False):
         self.ds = ds
+        self.dist = np.ascontiguousarray(getattr(ds, "dist_coeffs", np.zeros((ds.num_cams, 5))), dtype=np.float64).reshape(-1)
         self.K = np.ascontiguousarray(ds.cam_mats, dtype=np.float64).reshape(-1)
         self.of = np.ascontiguousarray(ds.obs_frame, dtype=np.int32)
         self.oc = np.ascontiguousarray(ds.obs_cam, dtype=np.int32)
@@ -172,6 +177,8 @@ class Oracle:
         p.opt_cams, p.opt_markers, p.opt_frames = [int(b) for b in optimize]
         p.with_huber = int(with_huber)
         p.huber_delta = huber_delta
+        p.opt_intrinsics = int(intrinsics)
+        p.dist = _d(self.dist)
         self.p = p
         self.N = int(p.num_obs)
         self.full_len = oracle().orc_full_len(C.byref(p))
@@ -190,6 +197,13 @@ class Oracle:
         oracle().orc_merge_z(C.byref(self.p), _d(x), _d(z), _d(out))
         return out
 
+    def intrinsics(self, z):
+        """(K [C,3,3], dist [C,5]) as intrinsics_vec2mats rebuilds them from z (the data set's when z holds none)"""
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        K = np.zeros(9 * self.ds.num_cams); d = np.zeros(5 * self.ds.num_cams)
+        oracle().orc_get_intrinsics(C.byref(self.p), _d(z), _d(K), _d(d))
+        return K.reshape(-1, 3, 3), d.reshape(-1, 5)
+
     def residuals(self, x_full, z=None, res_mode=RES_F32):
         x = np.ascontiguousarray(x_full, dtype=np.float64)
         z = self.extract_z(x) if z is None else np.ascontiguousarray(z, dtype=np.float64)
@@ -200,7 +214,7 @@ class Oracle:
     def jacobian(self, x_full, z=None, jac_mode=JAC_ANALYTIC):
         x = np.ascontiguousarray(x_full, dtype=np.float64)
         z = self.extract_z(x) if z is None else np.ascontiguousarray(z, dtype=np.float64)
-        cap = 144 * self.N
+        cap = oracle().orc_jac_capacity(C.byref(self.p))
         rows = np.zeros(cap, dtype=np.int32)
         cols = np.zeros(cap, dtype=np.int32)
         vals = np.zeros(cap)
@@ -235,7 +249,7 @@ class Oracle:
         err = fn(C.byref(self.p), _d(x), _d(z), C.byref(prm), jac_mode, res_mode, tr, cap, C.byref(n), threads, *extra)
         trace = [dict(err=tr[i].err, mu=tr[i].mu, gain=tr[i].gain, delta_norm=tr[i].delta_norm,
                       accepted=tr[i].accepted, tries=tr[i].tries) for i in range(min(n.value, cap))]
-        return self.merge_z(x, z), dict(final_err=err, iterations=n.value, trace=trace)
+        return self.merge_z(x, z), dict(final_err=err, iterations=n.value, trace=trace, z=z)
 
     def lm_solve(self, x_full, params=None, jac_mode=JAC_NUMERIC_F32, res_mode=RES_F32, threads=0):
         """The restated LM loop + own sparse LDL^T (the "port")."""

@@ -723,6 +723,11 @@ def test_cpp_mirror_constructor_init_and_solver_seam(tmp_path):
     assert int(kv["seam_steps"]) == 4 and int(kv["seam_callbacks"]) == 4 and int(kv["seam_zlen"]) == ds.full_len
     assert float(kv["seam_final_err"]) <= float(kv["direct_final_err"]) * (1 + 1e-9)
     assert int(kv["track_frames"]) == ds.num_frames and float(kv["track_max_err"]) < 100.0
+    # the default Config (intrinsics on) through the mirror: fx and cy come back from a calibration set 1 % / 2 px off
+    assert int(kv["intr_num_vars"]) == int(kv["intr_io_vec"]) == ds.full_len + 9 * ds.num_cams
+    assert float(kv["intr_final_err"]) < float(kv["intr_initial_err"]) and float(kv["intr_final_err"]) < 1.05 * float(kv["direct_final_err"])
+    assert abs(float(kv["intr_fx0"]) - 1000.0) < 6.0 and abs(float(kv["intr_cy0"]) - 360.0) < 3.0    # (weakly determined by 390 observations: fx 1010 -> 1003.8, cy 358 -> 361.7)
+    np.testing.assert_allclose(float(kv["intr_err_fn"]), float(kv["intr_final_err"]), rtol=1e-12)   # error_function(io_vec) at the solution
 
 
 def test_unsupported_sizes_are_refused_collectively():
@@ -768,3 +773,48 @@ def test_unsupported_sizes_are_refused_collectively():
             return err.code
     out = _run_ranks(2, create)                            # frames 0-1 / 2-3 by observation count: only the last rank holds the wide frame
     assert out == [aar.AAR_ERR_UNSUPPORTED, aar.AAR_ERR_UNSUPPORTED]
+
+
+def test_intrinsics_block_against_oracle_and_real_solver():
+    # MultiCamMapper::Config::optimize_cam_intrinsics (the reference's default Config; libs/multicam_mapper.cpp:488-498,580-593,
+    # 788-798,835-893): 9 more entries per camera at the end of every vector.  Rows bit-exact, J^T J / B of the analytic columns,
+    # damped step, the LM trace of the real solver driven with the same Jacobian; the distortion entries never move
+    ds, g = load_golden("g1_cfg2_intr")
+    o = ol.Oracle(ds, intrinsics=True)
+    i0 = ds.full_len
+    with aar.Problem(ds, intrinsics=True) as p:
+        assert p.full_len == ds.full_len + 9 * ds.num_cams and p.num_vars == o.num_vars
+        x0 = p.x_with_intrinsics(ds.x_full)
+        np.testing.assert_array_equal(p.extract_z(x0), o.extract_z(ds.x_full))
+        r, ss = p.eval_residuals(x0)
+        assert np.array_equal(r, g["r0_f32"])
+        H, B, _ = p.eval_normal_equations(x0)
+        Ho, Bo = o.normal_equations(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+        assert np.abs(H - Ho).max() / np.abs(Ho).max() < 1e-12
+        assert np.abs(B - Bo).max() / np.abs(Bo).max() < 1e-11
+        assert not H[i0:, :].reshape(-1, 9, H.shape[1])[:, 4:, :].any()            # distortion rows / columns: exact zeros
+        for mu in (float(np.diag(Ho).max()), 1e3):
+            d = p.eval_damped_step(x0, mu)
+            do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+            assert np.abs(d - do).max() / np.abs(do).max() < 1e-8, mu
+            assert not d[i0:].reshape(-1, 9)[:, 4:].any()
+        x, rep = p.lm_solve(x0)
+        assert rep["iterations"] == int(g["analytic_iterations"][0])
+        np.testing.assert_allclose([t["err"] for t in rep["trace"]], g["analytic_err"], rtol=1e-7)
+        np.testing.assert_allclose(p.extract_z(x), g["analytic_z"], atol=1e-6)
+        np.testing.assert_array_equal(x[i0:].reshape(-1, 9)[:, 4:], ds.dist_coeffs)
+        assert np.abs(x[i0:].reshape(-1, 9)[:, :4] - x0[i0:].reshape(-1, 9)[:, :4]).max() > 0.5      # the intrinsics did move
+        # reprojection error at the solved intrinsics: below the reference-faithful run's (see tests/test_oracle_golden.py)
+        rmse = np.sqrt(float((o.residuals(ds.x_full, p.extract_z(x), res_mode=ol.RES_F64) ** 2).sum()) / (4 * ds.num_obs))
+        assert abs(rmse - g["analytic_rmse"][0]) < 1e-7 and rmse <= g["faithful_rmse"][0] + 1e-9
+        assert abs(rmse - g["faithful_rmse"][0]) < 1e-3
+
+    def solve(comm, rank):
+        with aar.Problem(ds, intrinsics=True, comm=comm) as q:
+            return q.lm_solve(q.x_with_intrinsics(ds.x_full))
+    for xs, reps in _run_ranks(3, solve):                                           # sharded: intrinsics entities are shared ones
+        np.testing.assert_allclose([t["err"] for t in reps["trace"]], [t["err"] for t in rep["trace"]], rtol=1e-8)
+        np.testing.assert_allclose(xs, x, atol=1e-7)
+    # a fixed-intrinsics problem on the same data keeps the calibration's skew: other rows, other optimum
+    with aar.Problem(ds) as p:
+        assert not np.array_equal(p.eval_residuals(ds.x_full)[0], g["r0_f32"])

@@ -85,6 +85,23 @@ int main(int argc, char **argv) {
         MultiCamMapper::eVector zs = c.io_vec;   // restart from the solution: with a stop function the loop runs until it says so
         const double e = c.solver.solve(zs);
         printf("seam_steps = %d\nseam_callbacks = %d\nseam_zlen = %zu\nseam_final_err = %.17g\n", c.solver.report.iterations, calls, zlen, e);
+        // ---- (5) the reference's DEFAULT Config: optimize_cam_intrinsics on (libs/multicam_mapper.h:75-81)
+        {
+            aar_dataset *d2 = nullptr;
+            if (aar_synth_generate(&sd, &d2)) throw std::runtime_error(aar_last_error());
+            for (int cc = 0; cc < d2->num_cams; cc++) { d2->cam_mats[9 * cc] *= 1.01; d2->cam_mats[9 * cc + 5] -= 2.0; }   // a calibration that is a bit off
+            MultiCamMapper e(d2);
+            e.solver_params.verbose = false;
+            e.set_optmize_flag_cam_intrinsics(true);
+            const size_t nv = e.get_num_vars(MultiCamMapper::Config());
+            e.solve();
+            MultiCamMapper::eVector err1;
+            e.error_function(e.io_vec, err1);   // at the solution, intrinsics part of z included
+            double s1 = 0;
+            for (double v : err1) s1 += v * v;
+            printf("intr_num_vars = %zu\nintr_io_vec = %zu\nintr_initial_err = %.17g\nintr_final_err = %.17g\nintr_err_fn = %.17g\nintr_fx0 = %.9g\nintr_cy0 = %.9g\n", nv,
+                   e.io_vec.size(), e.last_report.initial_err, e.last_report.final_err, s1, e.dataset()->cam_mats[0], e.dataset()->cam_mats[5]);
+        }
         // ---- (4) init(object_poses, fcm) + track(): cameras / markers kept, frames replaced (apps/track.cpp:127-131)
         b.init(Tf, fcm);
         b.set_optmize_flag_cam_poses(false);
