@@ -1006,33 +1006,71 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     P.n_swork = (int)sw_ent.size();
     // many shared entities: the MFMA kernel owns 16 x 32-entity blocks of S and streams frame ranges (solve_kernels.hip);
     // frame ranges are cut so that the grid is a few workgroups per CU
-    std::vector<int32_t> sm_ga, sm_gb, sm_fb, sm_fe, slot_frame;
-    std::vector<uint16_t> slot_of;
-    // Measured at config 5 (A = 216): 1.72 ms against 1.69 ms for the output-stationary kernel -- both sit at the ~3 TB/s this
-    // access pattern gets out of L2 / HBM -- so it is opt-in (AAR_SCHUR_MFMA=1) until its blocks of S are
-    // large enough to cut the re-reads further; tests force it on to keep it correct.
-    bool schur_mfma = false;
+    std::vector<int32_t> sm_ga, sm_gb, sm_fb, sm_fe, slot_frame, slot_dense, dense_ent;
+    // The MFMA kernel works on dense per-frame panels (solve_kernels.hip).  Default: on from 96 shared entities, where the
+    // output-stationary kernel's re-reads of W dominate (config 5); AAR_SCHUR_MFMA=0 / 1 forces it (tests force it on small problems).
+    bool schur_mfma = A >= 96 && F > 0;
     if (const char *e = getenv("AAR_SCHUR_MFMA")) schur_mfma = atoi(e) != 0 && F > 0;
+    std::vector<int32_t> sm_frames;   // frame lists of the blocks, back to back
     if (schur_mfma) {
-        const int nga = (A + 15) / 16;
-        int pairs = 0;
-        for (int ga = 0; ga < nga; ga++) pairs += std::min((16 * ga + 15) / 32, (A - 1) / 32) + 1;
-        int nsplit = std::max(1, std::min(F / 32, (1536 + pairs - 1) / pairs));
-        if (const char *e = getenv("AAR_SCHUR_SPLIT")) nsplit = std::max(1, atoi(e));
-        int flen = ((F + nsplit - 1) / nsplit + 1) / 2 * 2;   // even: frames go through the kernel two at a time
-        // frame range outermost: the workgroups that run at the same time then stream the same frames, so a W / Y row
-        // comes from HBM once and from L2 / MALL for the other blocks of S that need it
-        for (int f0 = 0; f0 < F; f0 += flen)
-            for (int ga = 0; ga < nga; ga++)
-                for (int gb = 0; gb <= std::min((16 * ga + 15) / 32, (A - 1) / 32); gb++) {
-                    sm_ga.push_back(ga); sm_gb.push_back(gb); sm_fb.push_back(f0); sm_fe.push_back(std::min(F, f0 + flen));
-                }
-        slot_of.assign((size_t)F * A, 0xFFFF);
+        // dense entity 0 = the pseudo entity g_f; then the entities that are seen at all, MOST FREQUENT FIRST (ties: ascending):
+        // the often-seen entities form dense groups, the rarely seen ones share groups that whole stretches of frames do not
+        // touch at all -- a block of S then only streams the frames in which both of its entity groups are present
+        std::vector<int32_t> seen;
+        for (int a = 0; a < A; a++)
+            if (!inc[a].empty()) seen.push_back(a);
+        std::stable_sort(seen.begin(), seen.end(), [&](int32_t x, int32_t y) { return inc[x].size() > inc[y].size(); });
+        std::vector<int32_t> dense_of(A, -1);
+        dense_ent.push_back(-1);
+        for (int32_t a : seen) { dense_of[a] = (int32_t)dense_ent.size(); dense_ent.push_back(a); }
+        P.Ad = ((int)dense_ent.size() + 31) / 32 * 32;
+        dense_ent.resize(P.Ad, -1);
+        const int nga = P.Ad / 16, ngb = P.Ad / 32;
+        // frames in which a group of 16 (a side) / 32 (b side) dense entities has anybody present; the pseudo entity is everywhere
+        std::vector<std::vector<uint8_t>> pa(nga, std::vector<uint8_t>(F, 0)), pb(ngb, std::vector<uint8_t>(F, 0));
+        for (int f = 0; f < F; f++) {
+            pa[0][f] = pb[0][f] = 1;
+            for (int s = fslot_start[f]; s < fslot_start[f + 1]; s++) {
+                const int dd = dense_of[fslot_ent[s]];
+                pa[dd / 16][f] = 1;
+                pb[dd / 32][f] = 1;
+            }
+        }
+        struct Blk { int ga, gb; std::vector<int32_t> fr; };
+        std::vector<Blk> blks;
+        int64_t total_steps = 0;
+        for (int ga = 0; ga < nga; ga++)
+            for (int gb = 0; gb <= (16 * ga + 15) / 32; gb++) {
+                Blk bk{ga, gb, {}};
+                for (int f = 0; f < F; f++)
+                    if (pa[ga][f] && pb[gb][f]) bk.fr.push_back(f);
+                if (bk.fr.empty()) continue;
+                total_steps += ((int64_t)bk.fr.size() + 1) / 2;
+                blks.push_back(std::move(bk));
+            }
+        // cut every block's frame list into pieces of about total / target frames (even lengths: two frames per step), pieces of
+        // the same stretch of frames next to each other so that the workgroups in flight share panels in L2
+        int target = 12 * (int)blks.size();   // pieces per block: measured optimum at config 5 (8: -1 %, 24: -9 %); AAR_SCHUR_SPLIT overrides
+        if (const char *e = getenv("AAR_SCHUR_SPLIT")) target = std::max(1, atoi(e)) * (int)blks.size();
+        const int64_t plen = std::max<int64_t>(16, ((2 * total_steps + target - 1) / target + 1) / 2 * 2);
+        struct Piece { int blk; int64_t b, e; int f0; };
+        std::vector<Piece> pieces;
+        for (size_t k = 0; k < blks.size(); k++)
+            for (int64_t b0 = 0; b0 < (int64_t)blks[k].fr.size(); b0 += plen)
+                pieces.push_back({(int)k, b0, std::min<int64_t>(b0 + plen, (int64_t)blks[k].fr.size()), blks[k].fr[b0]});
+        std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.f0 < y.f0; });
+        for (const Piece &pc : pieces) {
+            sm_ga.push_back(blks[pc.blk].ga); sm_gb.push_back(blks[pc.blk].gb);
+            sm_fb.push_back((int32_t)sm_frames.size());
+            sm_frames.insert(sm_frames.end(), blks[pc.blk].fr.begin() + pc.b, blks[pc.blk].fr.begin() + pc.e);
+            sm_fe.push_back((int32_t)sm_frames.size());
+        }
         slot_frame.resize(P.total_slots);
+        slot_dense.resize(P.total_slots);
         for (int f = 0; f < F; f++)
             for (int s = fslot_start[f]; s < fslot_start[f + 1]; s++) {
-                slot_of[(size_t)f * A + fslot_ent[s]] = (uint16_t)(s - fslot_start[f]);
                 slot_frame[s] = f;
+                slot_dense[s] = dense_of[fslot_ent[s]];
             }
         P.n_smwork = (int)sm_ga.size();
     }
@@ -1050,7 +1088,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     UP(fslot_start, fslot_start); UP(fslot_ent, fslot_ent); UP(b_idx, b_idx); UP(b_uv, b_uv);
     UP(chunk_start, chunk_start); UP(ent_fixed, ent_fixed);
     UP(sw_ent, sw_ent); UP(sw_begin, sw_begin); UP(sw_end, sw_end); UP(pair_rec, pair_rec);
-    if (P.n_smwork) { UP(sm_ga, sm_ga); UP(sm_gb, sm_gb); UP(sm_fb, sm_fb); UP(sm_fe, sm_fe); UP(slot_of, slot_of); UP(slot_frame, slot_frame); }
+    if (P.n_smwork) { UP(sm_ga, sm_ga); UP(sm_gb, sm_gb); UP(sm_fb, sm_fb); UP(sm_fe, sm_fe); UP(slot_dense, slot_dense); UP(slot_frame, slot_frame); UP(dense_ent, dense_ent); UP(sm_frames, sm_frames); }
 #undef UP
 #define AL(field, count) if ((rc = dev_alloc(pb, &P.field, (size_t)(count)))) return fail(rc)
     AL(z[0], 6 * (size_t)(A + F)); AL(z[1], 6 * (size_t)(A + F));
@@ -1066,7 +1104,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         P.blk[w].tail = P.blk[w].g0 + P.n_pad;
         if (hipMemset(P.blk[w].tail, 0, 8 * sizeof(double)) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "hipMemset failed"));
     }
-    if (P.n_smwork) AL(Yw, (size_t)P.total_slots * 36);
+    if (P.n_smwork) { AL(Wd, (size_t)F * P.Ad * 36); AL(Yd, (size_t)F * P.Ad * 36); }   // zeroed here, once: absent pairs are never written
     AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad); AL(bs_flags, (size_t)P.nT + 1);
     AL(err_part, std::max<size_t>((size_t)F, (size_t)((N + 255) / 256)) + 1);
     AL(lin_part, 2 * (size_t)(F + 1)); AL(scal, 8); AL(flags, 4);

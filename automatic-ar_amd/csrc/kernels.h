@@ -51,13 +51,19 @@ struct DeviceProblem {
     // Schur work list: item w handles pairs [sw_begin[w], sw_end[w]) of entity sw_ent[w]
     int32_t *sw_ent = nullptr, *sw_begin = nullptr, *sw_end = nullptr;
     int4 *pair_rec = nullptr;             // (entity, frame) incidence, grouped by entity: {frame, W block, first W block of the frame, 0}
-    // Schur work list of the MFMA kernel (many shared entities): item w = block (16 entities sm_ga[w]) x (32 entities sm_gb[w])
-    // of S over frames [sm_fb[w], sm_fe[w])
+    // Schur work list of the MFMA kernel (many shared entities): item w = block (16 dense entities sm_ga[w]) x (32 dense entities
+    // sm_gb[w]) of S over the frames sm_frames[sm_fb[w] .. sm_fe[w])
     int n_smwork = 0;
-    int32_t *sm_ga = nullptr, *sm_gb = nullptr, *sm_fb = nullptr, *sm_fe = nullptr;
-    uint16_t *slot_of = nullptr;          // [F][A] frame-local W slot of an entity, 0xFFFF = not seen in that frame
+    int32_t *sm_ga = nullptr, *sm_gb = nullptr, *sm_fb = nullptr, *sm_fe = nullptr, *sm_frames = nullptr;
+    // ... which reads DENSE per-frame panels: dense entity 0 = the frame's gradient g_f (a pseudo entity whose block row 0 is g_f: its
+    // column of S is the Schur part of the right-hand side), 1.. = the shared entities that are seen at all, ascending; Ad = their
+    // number padded to a multiple of 32.  Blocks of absent (entity, frame) pairs are zero ONCE and for all (the visibility pattern
+    // never changes), k_schur_fill only rewrites the present ones.
+    int Ad = 0;
+    int32_t *slot_dense = nullptr;        // [total_slots] dense entity of every W block
     int32_t *slot_frame = nullptr;        // [total_slots] frame of every W block
-    double *Yw = nullptr;                 // [total_slots][36] W_af (V_f + mu I)^-1
+    int32_t *dense_ent = nullptr;         // [Ad] shared entity of a dense index (-1: the pseudo entity / padding)
+    double *Wd = nullptr, *Yd = nullptr;  // [F][Ad][36] W_af and W_af (V_f + mu I)^-1
     // state: everything that depends on a pose vector exists twice (index 0/1 = the two pose buffers), so that the
     // blocks of a trial point can be built while those of the current point are still needed for a mu retry
     double *z[2] = {nullptr, nullptr};    // [6A + 6F] pose vectors

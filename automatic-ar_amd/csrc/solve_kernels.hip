@@ -255,20 +255,28 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
 }
 
 // ------------------------------------------------------------------------------------------------
-// Schur complement for many shared entities (A >= SM_MIN_A), on the matrix pipes.  The output-stationary kernel above
-// reads every W_bf once per (a, f) pair it meets -- at 216 entities that is 36x the bytes of W from HBM.  Here a workgroup
-// owns a 96 x 192 block of S (16 entities a x 32 entities b) in fp64 MFMA accumulators (8 wavefronts x 9 sub-tiles) and
-// streams a range of frames through LDS two at a time: rows of Y_af = W_af (V_f + mu I)^-1 (k_schur_y) for its a's, rows
-// of W_bf for its b's, absent entities as zero rows; K = 2 frames x 6 = 12 = three v_mfma_f64_16x16x4 per sub-tile, no
-// padding.  Every W / Y row is fetched once per block of S that needs it (at most 14 / 7 times at config 5).
+// Schur complement for many shared entities, on the matrix pipes.  The output-stationary kernel above reads every W_bf once
+// per (a, f) pair it meets -- at 216 entities that is 36x the bytes of W.  Here the frame blocks are first laid out DENSE
+// per frame (k_schur_fill: Wd / Yd [F][Ad][6][6], absent pairs stay zero -- at config 5 a frame sees 122 of the 166 entities
+// that are seen at all, so dense panels cost 36 % more bytes than the sparse lists and make every fetch a contiguous,
+// index-free stream), and a workgroup owns a 96 x 192 block of S (16 x 32 dense entities) in fp64 MFMA accumulators
+// (8 wavefronts x 9 sub-tiles) while it streams a range of frames through LDS two at a time: K = 2 frames x 6 = 12 = three
+// v_mfma_f64_16x16x4 per sub-tile, no padding.  Dense entity 0 is the frame's gradient g_f, so the Schur part of the
+// right-hand side is simply column (entity 0, parameter 0) of the product.
 // LDS (dynamic): stage [2][288][14]
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_schur_y(const int32_t *__restrict__ slot_frame, const double *__restrict__ W,
-                                                 const double *__restrict__ Vinv, int total_slots, double *__restrict__ Yw) {
+__global__ void __launch_bounds__(256) k_schur_fill(const int32_t *__restrict__ slot_frame, const int32_t *__restrict__ slot_dense,
+                                                    const double *__restrict__ W, const double *__restrict__ Vinv,
+                                                    const double *__restrict__ gf, int total_slots, int F, int Ad,
+                                                    double *__restrict__ Wd, double *__restrict__ Yd) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)total_slots * 6) {   // the pseudo entity: row 0 of block (f, 0) = g_f
+        const int64_t q = gid - (int64_t)total_slots * 6;
+        if (q < (int64_t)F * 6) Wd[(q / 6) * Ad * 36 + (q % 6)] = gf[q];
+        return;
+    }
     const int64_t sl = gid / 6;
     const int i = (int)(gid - sl * 6);
-    if (sl >= total_slots) return;
     const int f = slot_frame[sl];
     const double2 *wp = reinterpret_cast<const double2 *>(W + sl * 36 + i * 6);
     const double2 w0 = wp[0], w1 = wp[1], w2 = wp[2];
@@ -281,29 +289,27 @@ __global__ void __launch_bounds__(256) k_schur_y(const int32_t *__restrict__ slo
         y[0] = fma(w[k], v0.x, y[0]); y[1] = fma(w[k], v0.y, y[1]); y[2] = fma(w[k], v1.x, y[2]);
         y[3] = fma(w[k], v1.y, y[3]); y[4] = fma(w[k], v2.x, y[4]); y[5] = fma(w[k], v2.y, y[5]);
     }
-    double2 *yp = reinterpret_cast<double2 *>(Yw + sl * 36 + i * 6);
+    const size_t o = ((size_t)f * Ad + slot_dense[sl]) * 36 + i * 6;
+    double2 *yp = reinterpret_cast<double2 *>(Yd + o), *wd = reinterpret_cast<double2 *>(Wd + o);
     yp[0] = make_double2(y[0], y[1]); yp[1] = make_double2(y[2], y[3]); yp[2] = make_double2(y[4], y[5]);
+    wd[0] = w0; wd[1] = w1; wd[2] = w2;
 }
 
-constexpr int SM_GA = 16, SM_GB = 32, SM_AR = 6 * SM_GA, SM_BR = 6 * SM_GB, SM_ROWS = SM_AR + SM_BR, SM_PS = 14;
+constexpr int SM_GA = 16, SM_GB = 32, SM_AR = 6 * SM_GA, SM_BR = 6 * SM_GB, SM_ROWS = SM_AR + SM_BR, SM_PS = 14, SM_DEPTH = 4;
 __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ w_ga, const int32_t *__restrict__ w_gb,
                                                     const int32_t *__restrict__ w_fb, const int32_t *__restrict__ w_fe,
-                                                    const uint16_t *__restrict__ slot_of, const int32_t *__restrict__ fslot_start,
-                                                    const double *__restrict__ W, const double *__restrict__ Yw,
-                                                    const double *__restrict__ gf, int A, int n_pad, double sign,
+                                                    const int32_t *__restrict__ flist, const int32_t *__restrict__ dense_ent, const double *__restrict__ Wd,
+                                                    const double *__restrict__ Yd, int Ad, int n_pad, double sign,
                                                     double *__restrict__ S, double *__restrict__ rhs) {
     extern __shared__ __align__(16) double stage[];   // [2][SM_ROWS][SM_PS]
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ga = w_ga[w], gb = w_gb[w], fb = w_fb[w], fe = w_fe[w];
     const int lr = lane >> 4, lc = lane & 15;
-    // staging role: thread t < 288 owns row t of the stage: (entity, parameter) of the a side (t < 96) or of the b side
-    const bool isA = tid < SM_AR;
-    const int e = isA ? SM_GA * ga + tid / 6 : SM_GB * gb + (tid - SM_AR) / 6;
-    const int pi = isA ? tid % 6 : (tid - SM_AR) % 6;
-    const bool ev = tid < SM_ROWS && e < A;
-    const bool do_rhs = isA && gb == 0 && ev;
-    const double *src = isA ? Yw : W;
-    double racc = 0.0;
+    // staging role: thread t < 288 owns row t of the stage: (dense entity, parameter) of the a side (t < 96: a row of Y) or of
+    // the b side (a row of W); consecutive threads read consecutive 48-byte rows of one frame's panel
+    const bool isA = tid < SM_AR, stager = tid < SM_ROWS;
+    const double *src = (isA ? Yd + (size_t)SM_GA * ga * 36 + (size_t)tid * 6 : Wd + (size_t)SM_GB * gb * 36 + (size_t)(tid - SM_AR) * 6);
+    const size_t fstride = (size_t)Ad * 36;
     dg_acc_t acc[3][3];
 #pragma unroll
     for (int x = 0; x < 3; x++)
@@ -311,61 +317,29 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
         for (int y = 0; y < 3; y++) acc[x][y] = dg_acc_t{0.0, 0.0, 0.0, 0.0};
     const int rt0 = 3 * (wave & 1), ct0 = 3 * (wave >> 1);
 
-    // two-deep pipeline: slots of step s+2, rows of step s+1, MFMAs of step s
-    auto fetch_slots = [&](int f0, unsigned (&sl)[2], int (&fs)[2]) {   // nothing here waits: the values are used one step later
+    // position k of the block's frame list (frames in which both entity groups are present; two of them per step)
+    auto fetch_rows = [&](int k0, double2 (&v)[6]) {   // nothing here waits: the values are stored steps later
 #pragma unroll
         for (int ff = 0; ff < 2; ff++) {
-            const int f = f0 + ff;
-            sl[ff] = (ev && f < fe) ? (unsigned)slot_of[(size_t)f * A + e] : 0xFFFFu;
-            fs[ff] = f < fe ? fslot_start[f] : 0;
-        }
-    };
-    auto fetch_rows = [&](int f0, const unsigned (&sl)[2], const int (&fs)[2], double (&v)[12], double (&g)[12]) {
-#pragma unroll
-        for (int ff = 0; ff < 2; ff++) {
-            if (sl[ff] != 0xFFFFu) {
-                const double2 *p = reinterpret_cast<const double2 *>(src + ((int64_t)fs[ff] + sl[ff]) * 36 + pi * 6);
-                const double2 a0 = p[0], a1 = p[1], a2 = p[2];
-                v[6 * ff] = a0.x; v[6 * ff + 1] = a0.y; v[6 * ff + 2] = a1.x; v[6 * ff + 3] = a1.y; v[6 * ff + 4] = a2.x; v[6 * ff + 5] = a2.y;
-                if (do_rhs) {
-                    const double2 *q = reinterpret_cast<const double2 *>(gf + (size_t)(f0 + ff) * 6);
-                    const double2 g0 = q[0], g1 = q[1], g2 = q[2];
-                    g[6 * ff] = g0.x; g[6 * ff + 1] = g0.y; g[6 * ff + 2] = g1.x; g[6 * ff + 3] = g1.y; g[6 * ff + 4] = g2.x; g[6 * ff + 5] = g2.y;
-                }
+            if (stager && k0 + ff < fe) {
+                const double2 *p = reinterpret_cast<const double2 *>(src + (size_t)flist[k0 + ff] * fstride);
+                v[3 * ff] = p[0]; v[3 * ff + 1] = p[1]; v[3 * ff + 2] = p[2];
             } else {
-#pragma unroll
-                for (int j = 0; j < 6; j++) { v[6 * ff + j] = 0.0; g[6 * ff + j] = 0.0; }
+                v[3 * ff] = v[3 * ff + 1] = v[3 * ff + 2] = make_double2(0.0, 0.0);
             }
         }
     };
-    auto put_rows = [&](int buf, const double (&v)[12], const double (&g)[12]) {
-        if (tid < SM_ROWS) {
+    auto put_rows = [&](int buf, const double2 (&v)[6]) {
+        if (stager) {
             double2 *d = reinterpret_cast<double2 *>(stage + ((size_t)buf * SM_ROWS + tid) * SM_PS);
 #pragma unroll
-            for (int h = 0; h < 6; h++) d[h] = make_double2(v[2 * h], v[2 * h + 1]);
-        }
-        if (do_rhs) {
-#pragma unroll
-            for (int j = 0; j < 12; j++) racc = fma(v[j], g[j], racc);
+            for (int h = 0; h < 6; h++) d[h] = v[h];
         }
     };
-    unsigned sl_n[2], sl_nn[2];
-    int fs_n[2], fs_nn[2];
-    double v[12], g[12];
-#pragma unroll
-    for (int j = 0; j < 12; j++) g[j] = 0.0;
-    fetch_slots(fb, sl_n, fs_n);
-    fetch_rows(fb, sl_n, fs_n, v, g);
-    fetch_slots(fb + 2, sl_n, fs_n);
-    put_rows(0, v, g);
-    __syncthreads();
-    int buf = 0;
-    for (int f0 = fb; f0 < fe; f0 += 2) {
-        const bool more = f0 + 2 < fe;
-        if (more) {
-            fetch_rows(f0 + 2, sl_n, fs_n, v, g);      // in flight while the matrix pipes work on this step
-            fetch_slots(f0 + 4, sl_nn, fs_nn);
-        }
+    // Register ring SM_DEPTH steps deep: the rows of step s + SM_DEPTH are requested while step s computes -- one step of the matrix
+    // pipes (27 MFMAs per wavefront, ~1.4 us) is shorter than a loaded chip's memory latency, a single step of look-ahead starves
+    double2 v[SM_DEPTH][6];
+    auto compute = [&](int buf) {
         const double *sb = stage + (size_t)buf * SM_ROWS * SM_PS;
         double av[3][3], bv[3][3];
 #pragma unroll
@@ -381,25 +355,45 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
             for (int x = 0; x < 3; x++)
 #pragma unroll
                 for (int y = 0; y < 3; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x][t], bv[y][t], acc[x][y], 0, 0, 0);
-        if (more) {
-            put_rows(buf ^ 1, v, g);
-            sl_n[0] = sl_nn[0]; sl_n[1] = sl_nn[1]; fs_n[0] = fs_nn[0]; fs_n[1] = fs_nn[1];
+    };
+    const int nsteps = (fe - fb + 1) / 2;
+#pragma unroll
+    for (int d = 0; d < SM_DEPTH; d++) fetch_rows(fb + 2 * d, v[d]);     // steps 0 .. SM_DEPTH-1 (beyond the range: zeros, nothing loaded)
+    put_rows(0, v[0]);
+    fetch_rows(fb + 2 * SM_DEPTH, v[0]);
+    __syncthreads();
+    for (int s0 = 0; s0 < nsteps; s0 += SM_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < SM_DEPTH; d++) {
+            const int s = s0 + d;                       // this step's rows sit in stage[s & 1]; step s + 1's in ring slot (d + 1) % SM_DEPTH
+            if (s < nsteps) {
+                compute(s & 1);
+                put_rows((s + 1) & 1, v[(d + 1) % SM_DEPTH]);
+                fetch_rows(fb + 2 * (s + 1 + SM_DEPTH), v[(d + 1) % SM_DEPTH]);
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        buf ^= 1;
     }
-    // S(a rows, b cols) -= sign * acc, lower triangle only; exact zeros (entity pairs never seen together) are skipped
+    // S(a rows, b cols) -= sign * acc, lower triangle only; exact zeros (entity pairs never seen together) are skipped.  Column
+    // (dense entity 0, parameter 0) is Y g: the Schur part of the right-hand side.
 #pragma unroll
     for (int x = 0; x < 3; x++)
 #pragma unroll
         for (int y = 0; y < 3; y++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int row = SM_AR * ga + 16 * (rt0 + x) + lr + 4 * r, col = SM_BR * gb + 16 * (ct0 + y) + lc;
                 const double val = acc[x][y][r];
-                if (val != 0.0 && col <= row && row < 6 * A) atomicAdd(S + (size_t)row * n_pad + col, -sign * val);
+                if (val == 0.0) continue;
+                const int rd = SM_AR * ga + 16 * (rt0 + x) + lr + 4 * r, cd = SM_BR * gb + 16 * (ct0 + y) + lc;
+                const int da = rd / 6, db = cd / 6, pa = rd - 6 * da, pb = cd - 6 * db;
+                if (db > da || (db == da && pb > pa)) continue;      // the lower triangle in DENSE order: every entity pair exactly once
+                const int ea = dense_ent[da], eb = dense_ent[db];
+                if (ea < 0) continue;
+                if (db == 0) { if (pb == 0) atomicAdd(rhs + 6 * ea + pa, -sign * val); continue; }
+                // dense order is by frequency, not by entity: a pair whose real order is the other way round lands transposed
+                const int row = 6 * ea + pa, col = 6 * eb + pb;
+                atomicAdd(S + (row >= col ? (size_t)row * n_pad + col : (size_t)col * n_pad + row), -sign * val);
             }
-    if (do_rhs && racc != 0.0) atomicAdd(rhs + SM_AR * ga + tid, -sign * racc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1133,14 +1127,15 @@ static ReduceArgs reduce_args(const DeviceProblem &P, int n_err, bool fold_share
 // them, not on each other.  Returns false if the scalars did not ride (the caller launches k_reduce_scalars).
 bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq, int ride_n_err, double *ride_scal) {
     const DeviceProblem::Blocks &b = P.blk[which];
-    if (P.n_smwork > 0) {   // many shared entities: block-of-S-stationary MFMA kernel
+    if (P.n_smwork > 0) {   // many shared entities: dense panels + block-of-S-stationary MFMA kernel
         const size_t lds = (size_t)2 * SM_ROWS * SM_PS * sizeof(double);
         static size_t granted = 48 * 1024;
         allow_dynamic_lds(reinterpret_cast<const void *>(k_schur_mfma), lds, granted);
         HookScope _h(P, KID_SCHUR);
-        hipLaunchKernelGGL(k_schur_y, dim3((unsigned)(((int64_t)P.total_slots * 6 + 255) / 256)), dim3(256), 0, st, P.slot_frame, b.W, b.Vinv, P.total_slots, P.Yw);
-        hipLaunchKernelGGL(k_schur_mfma, dim3(P.n_smwork), dim3(512), lds, st, P.sm_ga, P.sm_gb, P.sm_fb, P.sm_fe, P.slot_of, P.fslot_start, b.W, P.Yw, b.gf,
-                           P.A, P.n_pad, sign, b.S, b.rhs);
+        hipLaunchKernelGGL(k_schur_fill, dim3((unsigned)(((int64_t)P.total_slots * 6 + (int64_t)P.F * 6 + 255) / 256)), dim3(256), 0, st, P.slot_frame, P.slot_dense,
+                           b.W, b.Vinv, b.gf, P.total_slots, P.F, P.Ad, P.Wd, P.Yd);
+        hipLaunchKernelGGL(k_schur_mfma, dim3(P.n_smwork), dim3(512), lds, st, P.sm_ga, P.sm_gb, P.sm_fb, P.sm_fe, P.sm_frames, P.dense_ent, P.Wd, P.Yd, P.Ad, P.n_pad, sign,
+                           b.S, b.rhs);
         return false;
     }
     if (P.n_swork == 0) return false;

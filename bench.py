@@ -49,6 +49,49 @@ def run_steps(problem, x0, steps, params_factory):
     return done, trials, x, rep
 
 
+def kernel_source_hash():
+    """sha1 over the HIP sources the kernels are built from: PMC traffic collected for one build is only attached to a bench line
+    of the SAME sources (profiles/pmc_traffic.json records the hash, scripts/pmc_summary.py writes it)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "automatic-ar_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
+# which roofline bounds a kernel (DESIGN.md section 5): the observation passes carry ~55-110 flop per byte of the 44-byte record
+# (ridge 10 flop/B) -> fp64 vector pipes; the trailing updates / panel solves of the dense LDL^T run on the fp64 matrix pipes;
+# single-workgroup kernels are bound by their dependent chain (latency), whatever pipe they use; the rest streams bytes
+KERNEL_BOUND = {
+    "k_passA": "fp64_valu", "k_passB": "fp64_valu", "k_residual": "fp64_valu", "k_track": "fp64_valu",
+    "k_schur": "fp64_valu",            # output-stationary kernel: VALU + LDS atomics (the opt-in AAR_SCHUR_MFMA kernel: fp64_mfma)
+    "k_ldl_update": "fp64_mfma", "k_ldl_trsm": "fp64_mfma",
+    "k_ldl_diag": "latency", "k_ldl_backsolve": "latency", "k_reduce_scalars": "latency", "k_maxdiag": "latency",
+    "k_backsub": "hbm", "k_frame_inv": "hbm", "k_unpack": "hbm",
+}
+
+
+def algorithmic_flops(kernel, N, n_pad, sum_kf2, merged_passes):
+    """fp64 flops of ONE launch, SURVEY.md 8d's F_iter split by kernel: 4800 per observation for the Jacobian / normal-equation
+    work (2600 in pass A incl. the residual, 2200 in pass B, which recomputes projection and Jacobian), 6 s_f^2 = 216 k_f^2 per frame
+    for the Schur complement, n^3/3 for the dense LDL^T (per tile: NB^3/3 in the diagonal kernel, rows x NB^2 in the panel solve,
+    rows^2 x NB in the trailing update; averaged over the tile steps)."""
+    nT, NB = max(1, n_pad // 96), 96.0
+    steps = range(nT - 1)
+    tab = {
+        "k_passA": (4800.0 if merged_passes else 2600.0) * N, "k_passB": 2200.0 * N, "k_residual": 400.0 * N,
+        "k_schur": 216.0 * sum_kf2,
+        "k_ldl_diag": NB ** 3 / 3.0,
+        "k_ldl_trsm": (sum((n_pad - NB * (s + 1)) * NB * NB for s in steps) / max(1, nT - 1)),
+        "k_ldl_update": (sum((n_pad - NB * (s + 1)) ** 2 * NB for s in steps) / max(1, nT - 1)),
+        "k_ldl_backsolve": 2.0 * n_pad * n_pad / 2.0,
+    }
+    return tab.get(kernel, 0.0)
+
+
 def algorithmic_bytes(kernel, N, A, F, n_pad):
     """Algorithmic HBM bytes of ONE launch (DESIGN.md section 5): the 44-byte observation record is SURVEY.md 8d's unit;
     the dense factorisation kernels are charged the tiles of the reduced system they must read and write once."""
@@ -265,29 +308,48 @@ def main():
         kernels = {k: {"total_ms": 1e3 * s, "launches": c, "avg_us": (1e6 * s / c if c else None)} for k, (s, c) in kt.items() if c}
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
         n_loc = problem.local_obs
-        def roof(k):
-            avg_s = kernels[k]["avg_us"] * 1e-6
-            by = algorithmic_bytes(k, n_loc, A, F, n_pad)
-            if k == "k_passA" and "k_passB" not in kernels:   # both observation passes ride in that one launch
-                by += algorithmic_bytes("k_passB", n_loc, A, F, n_pad)
-            return {"kernel": k, "bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": by / avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": by, "avg_us": kernels[k]["avg_us"]}
-        roofline = roof(dom)
-        roofline["observation_pass"] = roof("k_passA")     # the streaming scan the north star prices against HBM
-        # fp64 VALU view of the Jacobian/normal-equation pass (it is arithmetic-bound, not HBM-bound)
-        flops = n_loc * (4800.0)
-        # passes A and B normally run as ONE launch, timed under k_passA (AAR_MERGE_PASSES=0 splits them)
-        tj = (kernels["k_passA"]["avg_us"] + (kernels["k_passB"]["avg_us"] if "k_passB" in kernels else 0.0)) * 1e-6
-        roofline["fp64_valu"] = {"kernels": "k_passA+k_passB" if "k_passB" in kernels else "k_passA (passes A and B in one launch)", "achieved": flops / tj / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": flops / tj / 1e12 / FP64_PEAK_TFLOPS, "flops_per_observation": 4800}
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        merged = "k_passB" not in kernels                      # both observation passes ride in k_passA's launch
+        kf = np.array([len(set(ds.obs_cam[a:b].tolist())) + len(set(ds.obs_marker[a:b].tolist()))
+                       for a, b in zip(*(lambda st: (st[:-1], st[1:]))(np.searchsorted(ds.obs_frame, np.arange(ds.num_frames + 1))))], dtype=np.float64)
+        sum_kf2 = float((kf ** 2).sum()) / max(1, world)
+        pmc, traffic_tab, src_hash = os.path.join(ROOT, "profiles", "pmc_traffic.json"), {}, kernel_source_hash()
+        traffic_note = "no PMC collection for this build (profiles/pmc_traffic.json absent)"
         if os.path.exists(pmc):
             try:
                 tr = json.load(open(pmc)).get("workload_%d" % args.workload, {})
-                roofline["traffic"] = tr.get(dom)
-                roofline["observation_pass"]["traffic"] = tr.get("k_passA")
-            except Exception:
-                pass
+                if tr.get("_kernel_source_sha1") == src_hash:
+                    traffic_tab, traffic_note = tr, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel sources (%s)" % tr.get("_source")
+                else:
+                    traffic_note = "profiles/pmc_traffic.json was collected for other kernel sources (%s): not attached" % str(tr.get("_kernel_source_sha1"))[:12]
+            except Exception as e:
+                traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
+
+        def roof(k):
+            avg_s = kernels[k]["avg_us"] * 1e-6
+            by = algorithmic_bytes(k, n_loc, A, F, n_pad)
+            if k == "k_passA" and merged:
+                by += algorithmic_bytes("k_passB", n_loc, A, F, n_pad)
+            fl = algorithmic_flops(k, n_loc, n_pad, sum_kf2, merged)
+            kind = KERNEL_BOUND.get(k, "hbm")
+            r = {"kernel": k, "bound_detail": kind, "avg_us": kernels[k]["avg_us"], "bytes_per_launch": by, "flops_per_launch": fl,
+                 "hbm": {"achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": by / avg_s / 1e9 / HBM_PEAK_GBPS},
+                 "fp64": {"achieved": fl / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / FP64_PEAK_TFLOPS},
+                 "traffic": traffic_tab.get("k_passAB" if (k == "k_passA" and merged) else k)}
+            # the contract's four fields: the roofline that applies to this kernel.  Arithmetic-bound kernels (vector or matrix
+            # pipes: the same 78.6 TFLOP/s fp64 peak on this chip) and the single-workgroup chains (whose useful work is fp64
+            # arithmetic; their real bound is the dependent chain, bound_detail = "latency") are priced in TFLOP/s, the rest in GB/s
+            view = r["hbm"] if kind == "hbm" else r["fp64"]
+            r.update(bound="hbm" if kind == "hbm" else "mfma", achieved=view["achieved"], peak=view["peak"], unit=view["unit"], frac=view["frac"])
+            return r
+        roofline = roof(dom)
+        roofline["traffic_source"] = traffic_note
+        roofline["kernel_source_sha1"] = src_hash
+        roofline["observation_pass"] = roof("k_passA")     # the streaming scan the north star prices against HBM
+        roofline["per_kernel"] = {k: {f: v for f, v in roof(k).items() if f in ("bound", "bound_detail", "achieved", "peak", "unit", "frac", "avg_us", "traffic")}
+                                  for k in kernels if k in KERNEL_BOUND}
+        tj = (kernels["k_passA"]["avg_us"] + (kernels["k_passB"]["avg_us"] if "k_passB" in kernels else 0.0)) * 1e-6
+        roofline["fp64_valu"] = {"kernels": "k_passA+k_passB" if not merged else "k_passA (passes A and B in one launch)", "achieved": 4800.0 * n_loc / tj / 1e12,
+                                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 4800.0 * n_loc / tj / 1e12 / FP64_PEAK_TFLOPS, "flops_per_observation": 4800}
 
     # ---- next-row extra (not the headline metric): track(), every frame's own 6-DoF LM in one launch ----
     track = None

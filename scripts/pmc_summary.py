@@ -29,7 +29,9 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_path = os.path.join(root, "profiles", "pmc_traffic.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
-    entry = {"_source": tag, "_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts half of a coalesced read stream)"}
+    sys.path.insert(0, root)
+    import bench
+    entry = {"_source": tag, "_kernel_source_sha1": bench.kernel_source_hash(), "_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts half of a coalesced read stream)"}
     rows = []
     for k in sorted(f):
         if not k.startswith("k_"):
