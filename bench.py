@@ -331,10 +331,14 @@ def main():
                 by += algorithmic_bytes("k_passB", n_loc, A, F, n_pad)
             fl = algorithmic_flops(k, n_loc, n_pad, sum_kf2, merged)
             kind = KERNEL_BOUND.get(k, "hbm")
+            if k == "k_schur" and (A >= 96 or os.environ.get("AAR_SCHUR_MFMA") == "1") and os.environ.get("AAR_SCHUR_MFMA") != "0":
+                kind = "fp64_mfma"     # from 96 shared entities on: dense panels through the fp64 matrix pipes (k_schur_fill + k_schur_mfma)
             r = {"kernel": k, "bound_detail": kind, "avg_us": kernels[k]["avg_us"], "bytes_per_launch": by, "flops_per_launch": fl,
                  "hbm": {"achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": by / avg_s / 1e9 / HBM_PEAK_GBPS},
                  "fp64": {"achieved": fl / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / FP64_PEAK_TFLOPS},
                  "traffic": traffic_tab.get("k_passAB" if (k == "k_passA" and merged) else k)}
+            if k == "k_schur" and r["traffic"] is None and "k_schur_mfma" in traffic_tab:      # two kernels behind one launcher
+                r["traffic"] = traffic_tab["k_schur_mfma"] + traffic_tab.get("k_schur_fill", 0.0)
             # the contract's four fields: the roofline that applies to this kernel.  Arithmetic-bound kernels (vector or matrix
             # pipes: the same 78.6 TFLOP/s fp64 peak on this chip) and the single-workgroup chains (whose useful work is fp64
             # arithmetic; their real bound is the dependent chain, bound_detail = "latency") are priced in TFLOP/s, the rest in GB/s

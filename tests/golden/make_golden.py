@@ -123,6 +123,14 @@ if __name__ == "__main__":
     dsh.obs_uv = dsh.obs_uv.copy()
     dsh.obs_uv[bad] += rng.normal(0, 25, size=(int(bad.sum()), 8)).astype(np.float32)
     g1("g1_cfg2_huber", dsh, [2, 4, 12, 100, 1.0], with_huber=True)
+    # -with-huber AND a rejected try (far start, tiny tau): B = -J^T x64 of a step keeps the residual weights of the Huber delta
+    # in force when the point was accepted (libs/sparselevmarq.h:367), although optCallBack has lowered it since
+    dsr = aar.synth(2, init_scale=15.0)
+    rng = np.random.default_rng(11)
+    bad = rng.random(dsr.num_obs) < 0.03
+    dsr.obs_uv = dsr.obs_uv.copy()
+    dsr.obs_uv[bad] += rng.normal(0, 25, size=(int(bad.sum()), 8)).astype(np.float32)
+    g1("g1_cfg2_huber_retry", dsr, [2, 4, 12, 100, 15.0], tau=1e-6, with_huber=True)
     # optimize_cam_intrinsics (the reference's default Config): calibrations off by ~1 % / a few pixels, a skew that
     # intrinsics_vec2mats drops; z ends with 9 per camera
     dsi = aar.synth(2)

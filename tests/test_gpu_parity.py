@@ -818,3 +818,24 @@ def test_intrinsics_block_against_oracle_and_real_solver():
     # a fixed-intrinsics problem on the same data keeps the calibration's skew: other rows, other optimum
     with aar.Problem(ds) as p:
         assert not np.array_equal(p.eval_residuals(ds.x_full)[0], g["r0_f32"])
+
+
+def test_huber_schedule_with_a_rejected_try():
+    # -with-huber from a far start with a tiny tau: step 22 needs three damping tries.  After a rejected try the blocks of the
+    # current point are rebuilt; B = -J^T x64 must then carry the residual weights of the Huber delta that was in force when the
+    # point was ACCEPTED (libs/sparselevmarq.h:367: B is computed once per step() from the last accepted evaluation), not the
+    # delta optCallBack has moved to since.  Golden: the real solver, same analytic Jacobian.
+    ds, g = load_golden("g1_cfg2_huber_retry")
+    o = ol.Oracle(ds, with_huber=True)
+    prm = aar.lm_default_params(tau=float(g["tau"][0]))
+    with aar.Problem(ds, with_huber=True) as p:
+        x, rep = p.lm_solve(ds.x_full, params=prm, trace_cap=600)
+    xo, repo = o.lm_solve(ds.x_full, params=ol.mapper_params(tau=float(g["tau"][0])), jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+    tries = [t["tries"] for t in rep["trace"]]
+    assert max(tries) > 1 and tries[:60] == [t["tries"] for t in repo["trace"]][:60]      # the port records the tries, the reference does not
+    k = 60                                                                                # well past the retry, before 500 steps of rounding pile up
+    np.testing.assert_allclose([t["err"] for t in rep["trace"]][:k], g["analytic_err"][:k], rtol=1e-6)
+    np.testing.assert_allclose([t["mu"] for t in rep["trace"]][:k], g["analytic_mu"][:k], rtol=1e-5)
+    assert abs(rep["iterations"] - int(g["analytic_iterations"][0])) <= 2
+    rmse = np.sqrt(rep["final_err"] / (4 * ds.num_obs))
+    assert abs(rmse - np.sqrt(float(g["analytic_final_err"][0]) / (4 * ds.num_obs))) < 1e-4
