@@ -15,28 +15,33 @@ namespace aar {
 
 // ------------------------------------------------------------------------------------------------
 // wave-level sum of NV per-lane values through LDS, result handed to `sink(i, total)` on one lane.
-// scratch: 32*64 doubles per wave.  Values are processed 32 at a time; lane l sums half of the lanes of
-// value l>>1 with a rotated start so that a ds_read_b64 wave-instruction touches every bank once.
+// scratch: CH*64 doubles per wave.  Values are processed CH at a time; 64/CH lanes share a value, each sums CH of its 64
+// entries (start rotated so that a ds_read_b64 wave-instruction touches every bank equally often), then xor-shuffles.
+// CH = 32 is the fewest rounds; CH = 8 costs 4 KB of LDS per wave instead of 16 (pass A's four-wave variant: two
+// workgroups per CU instead of one).
 // ------------------------------------------------------------------------------------------------
-template <int NV, class Sink>
+template <int NV, int CH = 32, class Sink>
 __device__ __forceinline__ void wave_sum_lds(const double (&vals)[NV], double *__restrict__ sc, int lane, Sink sink) {
+    constexpr int L = 64 / CH;        // lanes per value
+    constexpr int SPREAD = 32 / CH > 0 ? 32 / CH : 1;   // lanes whose CH-entry segments cover the 32 double-wide banks once
 #pragma unroll
-    for (int base = 0; base < NV; base += 32) {
-        const int cnt = (NV - base) < 32 ? (NV - base) : 32;
+    for (int base = 0; base < NV; base += CH) {
+        const int cnt = (NV - base) < CH ? (NV - base) : CH;
 #pragma unroll
-        for (int i = 0; i < 32; i++)
+        for (int i = 0; i < CH; i++)
             if (i < cnt) sc[i * 64 + lane] = vals[base + i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int vi = lane >> 1, half = lane & 1;
+        const int vi = lane / L, part = lane % L;
         double s = 0;
         if (vi < cnt) {
-            const double *row = sc + vi * 64 + half * 32;
+            const double *row = sc + lane * CH;   // = vi * 64 + part * CH
 #pragma unroll 8
-            for (int k = 0; k < 32; k++) s += row[(k + lane) & 31];
+            for (int k = 0; k < CH; k++) s += row[(k + lane / SPREAD) & (CH - 1)];
         }
-        s += __shfl_xor(s, 1);
-        if (half == 0 && vi < cnt) sink(base + vi, s);
+#pragma unroll
+        for (int off = 1; off < L; off <<= 1) s += __shfl_xor(s, off);
+        if (part == 0 && vi < cnt) sink(base + vi, s);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
@@ -109,7 +114,7 @@ __device__ __forceinline__ void load_ent_lds(const double *row, Ent &e) {
 // LDS; W_cf / W_mf blocks accumulate in LDS (ds_add_f64) at the frame-local slot of the camera / marker and leave as
 // one coalesced copy.  Nothing here is shared with another workgroup: no global atomics.  The epilogue inverts
 // V_f + mu_pred I (the damping the NEXT solve is expected to use) and clears a dead block set grid-stride.
-// LDS: [max_kf*36] W blocks | [32] V,g,err | [(max_kf+1)*24] entity rows | [nwaves*2048] wave-sum scratch
+// LDS: [max_kf*36] W blocks | [32] V,g,err | [(max_kf+1)*24] entity rows | [nwaves * 64 * passA_sum_chunk] wave-sum scratch
 // ------------------------------------------------------------------------------------------------
 struct PassAArgs {
     const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat;   // ent: the {R, t, J_l} table of the point (k_backsub / k_unpack)
@@ -123,6 +128,10 @@ struct PassAArgs {
     int32_t *flags;
 };
 
+// values per round of the V/g/err wave sum: the four-wave variant trades rounds for LDS (75 KB instead of 123 KB at 122
+// slots per frame: a second workgroup per CU); the one-wave variants share their launch with pass B's 32-wide rounds
+__host__ __device__ constexpr int passA_sum_chunk(int block) { return block == 256 ? 8 : 32; }
+
 // CPL = corners per lane: 4 = one lane per observation; 2 / 1 = two / four lanes per observation for frames with few
 // observations (the wavefront's instruction stream gets that much shorter; the sums over lanes do not care)
 // INTR: camera intrinsics are optimised -- every observation also feeds W_kf, the block of its camera's intrinsics entity
@@ -132,7 +141,8 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
     double *Wl = lds;                                   // [kf][36]
     double *acc = lds + (size_t)a.max_kf * 36;            // [32]
     double *entl = acc + 32;                            // [(max_kf+1)][24]
-    double *scratch = entl + (size_t)(a.max_kf + 1) * ENT_STRIDE;  // [BLOCK/64][2048]
+    constexpr int CH = passA_sum_chunk(BLOCK);
+    double *scratch = entl + (size_t)(a.max_kf + 1) * ENT_STRIDE;  // [BLOCK/64][CH * 64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int o0 = a.frame_obs_start[f], o1 = a.frame_obs_start[f + 1];
     const int s0 = a.fslot_start[f], kf = a.fslot_start[f + 1] - s0;
@@ -261,7 +271,7 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
         }
     }
     // V, g, err: wave sums, then one LDS add per wave and value
-    wave_sum_lds<28>(vals, scratch + wave * 2048, lane, [&](int i, double s) { atomicAdd(acc + i, s); });
+    wave_sum_lds<28, CH>(vals, scratch + wave * (CH * 64), lane, [&](int i, double s) { atomicAdd(acc + i, s); });
     __syncthreads();
     // coalesced write-out
     for (int i = tid; i < kf * 36; i += BLOCK) a.W[(size_t)s0 * 36 + i] = Wl[i];
@@ -521,7 +531,7 @@ void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream
 int residual_blocks(const DeviceProblem &P) { return (int)((P.N + 255) / 256); }
 
 size_t passA_lds_bytes(int max_kf, int block) {
-    return ((size_t)max_kf * 36 + 32 + (size_t)(max_kf + 1) * ENT_STRIDE + (block / 64) * 2048) * sizeof(double);
+    return ((size_t)max_kf * 36 + 32 + (size_t)(max_kf + 1) * ENT_STRIDE + (block / 64) * passA_sum_chunk(block) * 64) * sizeof(double);
 }
 
 static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, int zero_blk) {

@@ -127,6 +127,7 @@ void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_bl
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st);              // accumulates into blk[which].S, .g0 (must be zero); with intrinsics: their shared blocks too
 // both passes in one launch (they only share the entity table ent[which], which must be complete); false = nothing launched
 bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st);
+size_t passA_lds_bytes(int max_kf, int block);   // dynamic LDS of the frame-block kernel (block = 64 or 256 threads)
 void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st);            // scal[4] = max free diagonal
 void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st);
 // S -= sign * W (V+mu I)^-1 W^T (sign -1 takes it back).  ride_seq != 0: the reduction of the step's scalars rides in the same

@@ -7,12 +7,17 @@
  * product (automatic-ar_amd/) never links, imports or calls it.
  *
  * Parity pin: the reference has no tests / golden vectors for this path (SURVEY.md
- * section 4), and libs/multicam_mapper.cpp cannot be compiled here (OpenCV absent), so
- * the residual/Jacobian half is "parity unpinned" against OpenCV's cv::Rodrigues /
- * cv::Mat arithmetic (restated from their published definitions).  The solver half IS
- * pinned: oracle/ref_harness.cpp compiles the reference's own libs/sparselevmarq.h +
- * vendored Eigen in place (oracle/_ref/) and tests/ check this restatement's LM loop,
- * J^T J and LDL^T solve against it, both live and through tests/golden/ fixtures.
+ * section 4), and libs/multicam_mapper.cpp cannot be compiled here (OpenCV absent).
+ * The solver half is pinned to the reference itself: oracle/ref_harness.cpp compiles the
+ * reference's own libs/sparselevmarq.h + vendored Eigen in place (oracle/_ref/) and
+ * tests/ check this restatement's LM loop, J^T J and LDL^T solve against it, both live
+ * and through tests/golden/ fixtures.  The residual/Jacobian half restates OpenCV
+ * arithmetic (cv::Rodrigues, cv::Mat::inv, the projection, cv::undistortPoints) from the
+ * published definitions and is pinned against an INDEPENDENT implementation of those
+ * definitions (scipy.spatial.transform.Rotation, numpy.linalg.inv, a numpy projection,
+ * the Newton-inverted distortion model: tests/golden/make_primitives.py ->
+ * tests/golden/g0_primitives.npz, tests/test_primitives_pin.py) -- not against OpenCV
+ * itself, which is absent from the image and from the reference tree.
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference).
@@ -110,7 +115,8 @@ void orc_reproj_stats(const orc_problem *p, const double *x_full, const double *
  * (libs/multicam_mapper.cpp:570).  OpenCV is not in the reference tree (third-party, tested version 3.2.0, README.md:11): this
  * restates the published algorithm of that version's cvUndistortPoints -- normalise with K, five fixed-point iterations of
  * the inverse distortion model (k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4), re-project with P = K; fp64 inside, float in / out.
- * PARITY UNPINNED against OpenCV itself.  in / out: [n][2]. */
+ * Pinned against the published model inverted by Newton (tests/test_primitives_pin.py), not against OpenCV itself.
+ * in / out: [n][2]. */
 void orc_undistort_points(const double K[9], const double *dist, int n_dist, int64_t n, const float *in, float *out);
 /* The forward model (what cv::projectPoints applies to a normalised point): ideal pixel -> distorted pixel, in fp64.  Test
  * helper for the round trip distort(undistort(p)) = p. */
