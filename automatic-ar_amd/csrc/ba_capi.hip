@@ -917,7 +917,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     }
     P.total_slots = (int)fslot_ent.size();
     const size_t ldsA = passA_lds_bytes(P.max_kf, 256) > passA_lds_bytes(P.max_kf, 64) ? passA_lds_bytes(P.max_kf, 256) : passA_lds_bytes(P.max_kf, 64);
-    if (ldsA > 160 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers; the frame-block kernel holds them in LDS (limit ~ %d)", P.max_kf, (160 * 1024 / 8 - 56 - 2048) / 60);
+    if (ldsA > 160 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers; the frame-block kernel holds them in LDS (limit ~ %d)", P.max_kf, (160 * 1024 / 8 - 58 - 2048) / 62);
     if ((size_t)A * 36 * 8 + 2048 > 160 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "%d cameras+markers exceed the Schur row panel held in LDS", A);
     {   // the limits above depend on the rank's own frames: agree on the outcome before anybody returns (see collective_status)
         if (pb->comm && (rc = dev_alloc(pb, &pb->d_status, 1))) return fail(rc);

@@ -114,7 +114,7 @@ __device__ __forceinline__ void load_ent_lds(const double *row, Ent &e) {
 // LDS; W_cf / W_mf blocks accumulate in LDS (ds_add_f64) at the frame-local slot of the camera / marker and leave as
 // one coalesced copy.  Nothing here is shared with another workgroup: no global atomics.  The epilogue inverts
 // V_f + mu_pred I (the damping the NEXT solve is expected to use) and clears a dead block set grid-stride.
-// LDS: [max_kf*36] W blocks | [32] V,g,err | [(max_kf+1)*24] entity rows | [nwaves * 64 * passA_sum_chunk] wave-sum scratch
+// LDS: [max_kf*37] W blocks | [32] V,g,err | [(max_kf+1)*25] entity rows | [nwaves * 64 * passA_sum_chunk] wave-sum scratch
 // ------------------------------------------------------------------------------------------------
 struct PassAArgs {
     const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat;   // ent: the {R, t, J_l} table of the point (k_backsub / k_unpack)
@@ -130,6 +130,9 @@ struct PassAArgs {
 
 // values per round of the V/g/err wave sum: the four-wave variant trades rounds for LDS (75 KB instead of 123 KB at 122
 // slots per frame: a second workgroup per CU); the one-wave variants share their launch with pass B's 32-wide rounds
+constexpr int ENT_LDS = 25;   // doubles between entity rows in pass A's LDS copy (24 used): odd, so that lanes reading one field of different entities hit different banks
+constexpr int WLS = 37;   // doubles between the W blocks of consecutive frame-local slots in pass A's LDS panel
+__host__ __device__ constexpr size_t passA_w_doubles(int max_kf) { return ((size_t)max_kf * WLS + 1) & ~(size_t)1; }   // what follows stays 16-byte aligned
 __host__ __device__ constexpr int passA_sum_chunk(int block) { return block == 256 ? 8 : 32; }
 
 // CPL = corners per lane: 4 = one lane per observation; 2 / 1 = two / four lanes per observation for frames with few
@@ -138,15 +141,15 @@ __host__ __device__ constexpr int passA_sum_chunk(int block) { return block == 2
 // (four live rows: fx, cx, fy, cy) against the frame, at that entity's frame-local slot
 template <int BLOCK, int CPL, bool INTR = false>
 __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, const int f, const int n_blocks_a) {
-    double *Wl = lds;                                   // [kf][36]
-    double *acc = lds + (size_t)a.max_kf * 36;            // [32]
-    double *entl = acc + 32;                            // [(max_kf+1)][24]
+    double *Wl = lds;                                   // [kf][WLS]: 36 values per slot, 37 apart (an odd stride spreads the slots over all banks)
+    double *acc = lds + passA_w_doubles(a.max_kf);         // [32]
+    double *entl = acc + 32;                            // [(max_kf+1)][ENT_LDS]
     constexpr int CH = passA_sum_chunk(BLOCK);
-    double *scratch = entl + (size_t)(a.max_kf + 1) * ENT_STRIDE;  // [BLOCK/64][CH * 64]
+    double *scratch = entl + (size_t)(a.max_kf + 1) * ENT_LDS;  // [BLOCK/64][CH * 64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int o0 = a.frame_obs_start[f], o1 = a.frame_obs_start[f + 1];
     const int s0 = a.fslot_start[f], kf = a.fslot_start[f + 1] - s0;
-    for (int i = tid; i < kf * 36; i += BLOCK) Wl[i] = 0.0;
+    for (int i = tid; i < kf * WLS; i += BLOCK) Wl[i] = 0.0;
     for (int t = tid; t < 32; t += BLOCK) acc[t] = 0.0;
     // entity rows of this frame's slot list (+ the frame itself at row kf): global table -> LDS in 16-byte pieces, all the
     // slot-list loads of a batch in flight before the first row load, all row loads before the first LDS store
@@ -168,8 +171,8 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
             }
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
-                const int idx = base + u * BLOCK + tid;
-                if (e[u] >= 0) reinterpret_cast<double2 *>(entl)[idx] = v[u];
+                const int idx = base + u * BLOCK + tid, t = idx / PCS, c = idx - t * PCS;
+                if (e[u] >= 0) { entl[t * ENT_LDS + 2 * c] = v[u].x; entl[t * ENT_LDS + 2 * c + 1] = v[u].y; }
             }
         }
     }
@@ -187,7 +190,7 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
     for (int i = 0; i < 28; i++) vals[i] = 0.0;
 
     Ent ef;
-    load_ent_lds(entl + (size_t)kf * ENT_STRIDE, ef);
+    load_ent_lds(entl + (size_t)kf * ENT_LDS, ef);
     const int nobs = o1 - o0;
     // Interleaved assignment: consecutive lanes take observations `stride` apart so that lanes of one wave
     // mostly hold different cameras (the order inside a frame is camera-major); this keeps the ds_add_f64
@@ -210,8 +213,8 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
         const int sc = id.slots & ((1 << SLOT_C_BITS) - 1), sm = (id.slots >> SLOT_C_BITS) & ((1 << SLOT_M_BITS) - 1);
         const int sk = (id.slots >> (SLOT_C_BITS + SLOT_M_BITS)) & ((1 << SLOT_M_BITS) - 1);
         Ent ec, em;
-        load_ent_lds(entl + (size_t)sc * ENT_STRIDE, ec);
-        load_ent_lds(entl + (size_t)sm * ENT_STRIDE, em);
+        load_ent_lds(entl + (size_t)sc * ENT_LDS, ec);
+        load_ent_lds(entl + (size_t)sm * ENT_LDS, em);
         double K[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) K[i] = a.Kmat[a.kstride * id.cam + i];
@@ -258,14 +261,14 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
                 }
             }
         }
-        double *wc = Wl + sc * 36;
-        double *wm = Wl + sm * 36;
+        double *wc = Wl + sc * WLS;
+        double *wm = Wl + sm * WLS;
 #pragma unroll
         for (int i = 0; i < 36; i++) atomicAdd(wc + i, Wc[i]);
 #pragma unroll
         for (int i = 0; i < 36; i++) atomicAdd(wm + i, Wm[i]);
         if (INTR) {
-            double *wk = Wl + sk * 36;
+            double *wk = Wl + sk * WLS;
 #pragma unroll
             for (int i = 0; i < 24; i++) atomicAdd(wk + i, Wk[i]);
         }
@@ -274,7 +277,7 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
     wave_sum_lds<28, CH>(vals, scratch + wave * (CH * 64), lane, [&](int i, double s) { atomicAdd(acc + i, s); });
     __syncthreads();
     // coalesced write-out
-    for (int i = tid; i < kf * 36; i += BLOCK) a.W[(size_t)s0 * 36 + i] = Wl[i];
+    for (int i = tid; i < kf * 36; i += BLOCK) a.W[(size_t)s0 * 36 + i] = Wl[i + i / 36];
     for (int t = tid; t < 36; t += BLOCK) a.V[(size_t)f * 36 + t] = acc[sym6(t / 6, t % 6)];
     for (int t = tid; t < 6; t += BLOCK) a.gf[(size_t)f * 6 + t] = acc[21 + t];
     if (tid == 0) a.err_part[f] = acc[27];
@@ -531,7 +534,7 @@ void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream
 int residual_blocks(const DeviceProblem &P) { return (int)((P.N + 255) / 256); }
 
 size_t passA_lds_bytes(int max_kf, int block) {
-    return ((size_t)max_kf * 36 + 32 + (size_t)(max_kf + 1) * ENT_STRIDE + (block / 64) * passA_sum_chunk(block) * 64) * sizeof(double);
+    return (passA_w_doubles(max_kf) + 32 + (size_t)(max_kf + 1) * ENT_LDS + (block / 64) * passA_sum_chunk(block) * 64) * sizeof(double);
 }
 
 static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, int zero_blk) {
