@@ -485,8 +485,11 @@ __device__ __forceinline__ double rcp_refined(double d) {
 // which turn every triangular solve below into small matrix products.
 // f64 MFMA lane maps (cdna_hip_programming.md section 4, checked by scripts/probe/issue_probe.hip):
 //   A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row = (l>>4) + 4 reg][col = l&15].
-// LDS (dynamic): T [NB][NB+2] | Yn [2][NB][8]
+// LDS (dynamic): T [NB][NB+2] | Yn [2][NB][DG_YS]
 constexpr int DG_THREADS = 1024, DG_ROW0 = 896;
+// doubles between panel rows: 8 are used (rank 6 padded to 8); at 10 the rows of 16 consecutive lanes tile the LDS banks (at 8 they
+// fall on four bank groups: 4-way conflicts on every panel store of the row phase and every B-operand read)
+constexpr int DG_YS = 10;
 
 // LDL^T of the 6x6 pivot block at (c0, c0) in registers plus the substitution of row g of block column c0:
 // on return y = (row g) L_kk^-T = L_g D and inv = 1 / D
@@ -527,7 +530,7 @@ __device__ __forceinline__ void dg_rows(double *__restrict__ T, double *__restri
     lt[0] = make_double2(y[0] * inv[0], y[1] * inv[1]);
     lt[1] = make_double2(y[2] * inv[2], y[3] * inv[3]);
     lt[2] = make_double2(y[4] * inv[4], y[5] * inv[5]);
-    double2 *yp = reinterpret_cast<double2 *>(Yn + g * 8);
+    double2 *yp = reinterpret_cast<double2 *>(Yn + g * DG_YS);
     yp[0] = make_double2(-y[0], -y[1]);
     yp[1] = make_double2(-y[2], -y[3]);
     yp[2] = make_double2(-y[4], -y[5]);
@@ -542,7 +545,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
                   NTILE <= 2 * NMW && DG_ROW0 % 64 == 0, "diag tile mapping");
     extern __shared__ __align__(16) double T[];
     TL_DECL
-    double *Yn = T + NB * LD;   // [2][NB][8]: minus (L D) of block column k in buffer k & 1, columns 6, 7 zero
+    double *Yn = T + NB * LD;   // [2][NB][DG_YS]: minus (L D) of block column k in buffer k & 1, columns 6, 7 zero
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = s * NB;
     const bool first = (s == 0);
@@ -555,7 +558,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
             const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
             v[u] = (j <= i) ? S[(size_t)(r0 + i) * n_pad + r0 + j] : 0.0;
         }
-        for (int i = tid; i < 2 * NB * 8; i += DG_THREADS) Yn[i] = 0.0;
+        for (int i = tid; i < 2 * NB * DG_YS; i += DG_THREADS) Yn[i] = 0.0;
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
@@ -581,7 +584,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
         const int tj = has[sl] ? NT16 - 1 - jj : 0, ti = has[sl] ? tj + nn - jj * (jj + 1) / 2 : 0;
         j16[sl] = 16 * tj;
         aoff[sl] = (16 * ti + lc) * LD + lr;          // A operand: L(row, c0 + k) in the tile
-        boff[sl] = (16 * tj + lc) * 8 + lr;           // B operand: -(L D)(col, k) in the panel
+        boff[sl] = (16 * tj + lc) * DG_YS + lr;           // B operand: -(L D)(col, k) in the panel
         toff[sl] = (16 * ti + lr) * LD + 16 * tj + lc;   // accumulator register r: row + 4 r
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[sl][r] = T[toff[sl] + 4 * r * LD];
@@ -591,7 +594,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
 
     for (int k = 0; k + 1 < NBK; k++) {
         const int c0 = 6 * k, lim = c0 + 6;
-        const double *yk = Yn + (k & 1) * NB * 8;
+        const double *yk = Yn + (k & 1) * NB * DG_YS;
         TL(k, 0);
 #pragma unroll
         for (int sl = 0; sl < 2; sl++) {   // first the sub-tiles that hold (part of) block column k+1: update, publish
@@ -617,7 +620,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
             acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[sl], 0, 0, 0);
             acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[sl], 0, 0, 0);
         }
-        dg_rows(T, Yn + ((k + 1) & 1) * NB * 8, k + 1, rt);
+        dg_rows(T, Yn + ((k + 1) & 1) * NB * DG_YS, k + 1, rt);
         TL(k, 3);
         __syncthreads();
         TL(k, 4);
@@ -1158,7 +1161,7 @@ bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
 
 void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];
-    const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * 8) * sizeof(double);
+    const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * DG_YS) * sizeof(double);
     static size_t g_diag = 48 * 1024, g_bs = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
     for (int s = 0; s < P.nT; s++) {
