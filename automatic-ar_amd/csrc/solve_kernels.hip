@@ -495,10 +495,18 @@ constexpr int DG_YS = 10;
 // on return y = (row g) L_kk^-T = L_g D and inv = 1 / D
 __device__ __forceinline__ void dg_factor_row(const double *__restrict__ T, int c0, int g, double (&a)[6][6], double (&y)[6], double (&inv)[6]) {
     constexpr int LD = NB + 2;
+    // the lower triangle of the pivot block in 16-byte pieces (c0 and LD are even): 12 LDS instructions instead of 21 -- on a lone
+    // wavefront every instruction of the row phase is ~10 cycles of the critical path, whatever it does
 #pragma unroll
-    for (int q = 0; q < 6; q++)
+    for (int q = 0; q < 6; q++) {
+        const double2 *rq = reinterpret_cast<const double2 *>(T + (c0 + q) * LD + c0);
 #pragma unroll
-        for (int p = 0; p <= q; p++) a[q][p] = T[(c0 + q) * LD + c0 + p];
+        for (int h = 0; 2 * h <= q; h++) {
+            const double2 v = rq[h];
+            a[q][2 * h] = v.x;
+            if (2 * h + 1 <= q) a[q][2 * h + 1] = v.y;
+        }
+    }
     {
         const double2 *rp = reinterpret_cast<const double2 *>(T + g * LD + c0);
         const double2 y0 = rp[0], y1 = rp[1], y2 = rp[2];
@@ -531,9 +539,9 @@ __device__ __forceinline__ void dg_rows(double *__restrict__ T, double *__restri
     lt[1] = make_double2(y[2] * inv[2], y[3] * inv[3]);
     lt[2] = make_double2(y[4] * inv[4], y[5] * inv[5]);
     double2 *yp = reinterpret_cast<double2 *>(Yn + g * DG_YS);
-    yp[0] = make_double2(-y[0], -y[1]);
-    yp[1] = make_double2(-y[2], -y[3]);
-    yp[2] = make_double2(-y[4], -y[5]);
+    yp[0] = make_double2(y[0], y[1]);   // +Y: the trailing update negates its B operand (fp64 MFMA: blgp bit 1 = neg B)
+    yp[1] = make_double2(y[2], y[3]);
+    yp[2] = make_double2(y[4], y[5]);
 }
 
 __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restrict__ S, double *__restrict__ Dfac, double *__restrict__ Linv16,
@@ -545,7 +553,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
                   NTILE <= 2 * NMW && DG_ROW0 % 64 == 0, "diag tile mapping");
     extern __shared__ __align__(16) double T[];
     TL_DECL
-    double *Yn = T + NB * LD;   // [2][NB][DG_YS]: minus (L D) of block column k in buffer k & 1, columns 6, 7 zero
+    double *Yn = T + NB * LD;   // [2][NB][DG_YS]: L D of block column k in buffer k & 1, columns 6, 7 zero
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = s * NB;
     const bool first = (s == 0);
@@ -601,8 +609,8 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
             if (!has[sl] || j16[sl] + 16 <= lim || j16[sl] >= lim + 6) continue;   // wave-uniform
             const double a1 = T[aoff[sl] + c0], a2 = T[aoff[sl] + c0 + 4];   // rank columns 6, 7: whatever follows in the row, times the zeros of the panel
             const double b1 = yk[boff[sl]], b2 = yk[boff[sl] + 4];
-            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[sl], 0, 0, 0);
-            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[sl], 0, 0, 0);
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[sl], 0, 0, 2);
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[sl], 0, 0, 2);
             const int col = j16[sl] + lc;
             if (col >= lim && col < lim + 6) {   // rows above the block land above the diagonal
 #pragma unroll
@@ -617,8 +625,8 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
             if (!has[sl] || j16[sl] < lim + 6) continue;   // wave-uniform
             const double a1 = T[aoff[sl] + c0], a2 = T[aoff[sl] + c0 + 4];
             const double b1 = yk[boff[sl]], b2 = yk[boff[sl] + 4];
-            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[sl], 0, 0, 0);
-            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[sl], 0, 0, 0);
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[sl], 0, 0, 2);
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[sl], 0, 0, 2);
         }
         dg_rows(T, Yn + ((k + 1) & 1) * NB * DG_YS, k + 1, rt);
         TL(k, 3);
