@@ -332,7 +332,9 @@ __device__ __forceinline__ void passB_body(const PassBArgs &b, double *scratch, 
     const float huber = b.huber;
     const double h = b.h;
     double *__restrict__ U0 = b.U0, *__restrict__ g0 = b.g0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the chunk index is wave-uniform and the compiler is told so: the head record, the camera's and the marker's {R, t, J_l} rows
+    // and K then arrive through the scalar cache into SGPRs instead of 102 VGPRs (512 VGPRs with 34 spilled -> 390, none spilled)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int chunk = first_chunk + wave;
     if (chunk >= n_chunks) return;
     const int o0 = chunk_start[chunk], o1 = chunk_start[chunk + 1];
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(256) k_passB(const PassBArgs b) {
 // Pass B for the intrinsics entities (optimize_cam_intrinsics): same chunks, the 62 values of U_kk (4x4, packed lower), W_kc
 // (4x6: intrinsics x the camera's own pose), W_km (4x6: intrinsics x marker) and g_k; rows of entity k_ent0 + camera.
 __device__ __forceinline__ void passB_intr_body(const PassBArgs &b, double *scratch, const int first_chunk) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, see passB_body
     const int chunk = first_chunk + wave;
     if (chunk >= b.n_chunks) return;
     const int o0 = b.chunk_start[chunk], o1 = b.chunk_start[chunk + 1];
