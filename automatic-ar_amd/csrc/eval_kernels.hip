@@ -736,7 +736,7 @@ __device__ __forceinline__ double track_eval(const TrackArgs &a, int f, const do
 }
 
 __global__ void __launch_bounds__(256) k_track(const TrackArgs a) {
-    const int lane = threadIdx.x & 63, f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, f = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     if (f >= a.F) return;
     double z[6];
 #pragma unroll

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
     double *panel = lds;
     double *pg = lds + (size_t)A * 36;
     double *ysc = pg + 8;
-    const int w = (int)blockIdx.x - rider, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = (int)blockIdx.x - rider, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: pair records in SGPRs
     const int a = sw_ent[w], pb = sw_begin[w], pe = sw_end[w];
     for (int i = tid; i < (a + 1) * 36; i += 256) panel[i] = 0.0;
     if (tid < 8) pg[tid] = 0.0;
@@ -1036,7 +1036,7 @@ __global__ void __launch_bounds__(256) k_backsub(const int32_t *__restrict__ fsl
                                                  const double *__restrict__ delta_s, const double *__restrict__ zc,
                                                  double *__restrict__ zt, int A, int F, int n_frame_blocks,
                                                  double *__restrict__ lin_part, double *__restrict__ ent_out, int k_ent0) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the frame's slot range, g_f, V_f^-1 through the scalar cache
     if ((int)blockIdx.x == n_frame_blocks) {  // shared part
         double d2 = 0.0, dg = 0.0;
         for (int i = tid; i < 6 * A; i += 256) {
