@@ -1106,6 +1106,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     }
     if (P.n_smwork) { AL(Wd, (size_t)F * P.Ad * 36); AL(Yd, (size_t)F * P.Ad * 36); }   // zeroed here, once: absent pairs are never written
     AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad); AL(bs_flags, (size_t)P.nT + 1);
+    AL(Lp, (size_t)P.nT * P.n_pad * CHOL_NB); AL(zf, P.n_pad);
     AL(err_part, std::max<size_t>((size_t)F, (size_t)((N + 255) / 256)) + 1);
     AL(lin_part, 2 * (size_t)(F + 1)); AL(scal, 8); AL(flags, 4);
 #undef AL

@@ -81,6 +81,8 @@ struct DeviceProblem {
     } blk[2];
     double *Dfac = nullptr;               // [nT][NB*NB] factored diagonal tiles (unit L below, D on the diagonal)
     double *Linv16 = nullptr;             // [nT][6][16*16] inverses of the 16x16 diagonal sub-blocks of every L_ss
+    double *Lp = nullptr;                 // [nT][n_pad][NB] block columns of L written by the fused panel kernel (stages with <= 2 tiles below the diagonal)
+    double *zf = nullptr;                 // [n_pad] forward-substituted right-hand side of those stages
     double *delta_s = nullptr;            // [n_pad]
     int32_t *bs_flags = nullptr;          // [nT] k_ldl_backsolve: flag[s] == bs_epoch <=> x_s of the current launch is in memory
     mutable int bs_epoch = 0;

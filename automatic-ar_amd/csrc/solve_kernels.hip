@@ -926,6 +926,171 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Panel solve AND trailing update of step s in ONE launch, for short block columns (m = nT - s - 1 <= 2 tiles below the
+// diagonal tile: every reduced system up to 288 unknowns).  At these sizes each of the two kernels above is ~5 us of fixed
+// cost (launch, first fetch of data another XCD has just written, completion) around <= 3 us of matrix work, and chaining them
+// with flags costs what the launch boundary does.  Here nobody waits for anybody: the workgroup of output block (I, J)
+// (16 x 16, slabs I >= J of the block column, or J = the right-hand side) solves BOTH slabs it needs itself -- one wavefront
+// each, the same blocked substitution as k_ldl_trsm, redundantly with the other workgroups that need the same slab -- and
+// then forms S(I, J) -= X_I D^-1 X_J^T from the two results in LDS (12 MFMAs per wavefront).  The diagonal workgroups (I, I)
+// also store L_I = X_I D^-1 for the back-substitution (into Lp, not in place: the block column is still being read by the
+// others); workgroup (0, rhs) stores z_s (into zf).  78 + 12 workgroups at m = 2.
+// LDS (static): St [2][16][18] | Xl [2][16][NB + 2] | dinv [NB] | red [256]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_ldl_panel(double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
+                                                   const double *__restrict__ Dfac, const double *__restrict__ Linv16, int n_pad,
+                                                   int n, int s, int nT, double mu, const int32_t *__restrict__ ent_fixed,
+                                                   double *__restrict__ Lp, double *__restrict__ zf) {
+    constexpr int PL = SBK + 2, XL = NB + 2;
+    __shared__ __align__(16) double St_all[2 * SBK * PL];
+    __shared__ __align__(16) double Xl_all[2 * SBK * XL];
+    __shared__ double dinv_l[NB];
+    __shared__ double red[256];
+    const int m = nT - s - 1, ns = NSB * m, npair = ns * (ns + 1) / 2;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int lr = lane >> 4, lc = lane & 15;
+    int I, J;   // slabs (16 rows each) counted from the first row below tile s; J == ns: the right-hand side
+    if ((int)blockIdx.x < npair) {
+        int ii = 0, rem = (int)blockIdx.x;
+        while (rem > ii) { rem -= ii + 1; ii++; }
+        I = ii; J = rem;
+    } else {
+        I = (int)blockIdx.x - npair; J = ns;
+    }
+    const int mine = wave == 0 ? I : J;           // the slab this wavefront solves
+    const bool is_rhs = (mine == ns);
+    const int r0 = s * NB;
+    const bool first = (s == 0);
+    const int row0 = (s + 1) * NB + SBK * mine;
+    const double *dd = Dfac + (size_t)s * NB * NB;
+    double *St = St_all + wave * SBK * PL;
+    double *Xl = Xl_all + wave * SBK * XL;
+    const unsigned long long gmask = gauge_ballot(first, ent_fixed, n, is_rhs ? r0 : row0, 1, r0, 6);   // bits 0-15: slab rows, 16-31: entities of tile s
+    dg_acc_t acc[NSB];
+    double4 li[NSB];
+    double4 lb[NSB * (NSB - 1) / 2];
+    double dq[NSB];
+#pragma unroll
+    for (int q = 0; q < NSB; q++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = 0.0;
+            if (!is_rhs) v = S[(size_t)(row0 + lr + 4 * r) * n_pad + r0 + 16 * q + lc];
+            else if (lr + 4 * r == 0) v = rhs[r0 + 16 * q + lc];
+            acc[q][r] = v;
+        }
+        li[q] = *reinterpret_cast<const double4 *>(Linv16 + ((size_t)s * NSB + q) * SBK * SBK + lc * SBK + 4 * lr);
+        dq[q] = dd[(16 * q + lc) * (NB + 1)];
+#pragma unroll
+        for (int q2 = q + 1; q2 < NSB; q2++)
+            lb[q * NSB - q * (q + 1) / 2 + (q2 - q - 1)] = *reinterpret_cast<const double4 *>(dd + (size_t)(16 * q2 + lc) * NB + 16 * q + 4 * lr);
+    }
+    // the output block's own values (wavefront 0 finishes the block): rows of slab I, columns of slab J (or the rhs entries of slab I)
+    const int i0 = (s + 1) * NB + SBK * I, j0 = (s + 1) * NB + SBK * (J < ns ? J : 0);
+    double tgt[4] = {0.0, 0.0, 0.0, 0.0};
+    unsigned long long omask = 0ull;
+    if (wave == 0) {
+        omask = gauge_ballot(first, ent_fixed, n, i0, 1, j0, 1);   // bits 0-15: rows of the block, 16-31: its columns
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int gi = i0 + lr + 4 * r, gj = j0 + lc;
+            if (J < ns) tgt[r] = (gj <= gi) ? S[(size_t)gi * n_pad + gj] : 0.0;
+            else if (lc == 0) tgt[r] = rhs[gi];
+        }
+    }
+    if (first) {
+#pragma unroll
+        for (int q = 0; q < NSB; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int gj = r0 + 16 * q + lc;
+                const bool fj = (gmask >> (16 + (16 * q + lc) / 6)) & 1;
+                if (!is_rhs) acc[q][r] = xform_first_flags(acc[q][r], row0 + lr + 4 * r, gj, (gmask >> (lr + 4 * r)) & 1, fj, mu);
+                else if (lr + 4 * r == 0) acc[q][r] = fj ? 0.0 : acc[q][r] + g0[gj];
+            }
+    }
+    const bool store_l = (wave == 0 && I == J) || (wave == 1 && is_rhs && I == 0);   // every slab / the rhs leaves exactly once
+#pragma unroll
+    for (int q = 0; q < NSB; q++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) St[(lr + 4 * r) * PL + lc] = acc[q][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double ar[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) ar[t] = St[lc * PL + 4 * lr + t];
+        dg_acc_t x = {0.0, 0.0, 0.0, 0.0};
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[0], li[q].x, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[1], li[q].y, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2], li[q].z, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[3], li[q].w, x, 0, 0, 0);
+        const double dinv = rcp_refined(dq[q]);
+        if (wave == 0 && lr == 0) dinv_l[16 * q + lc] = dinv;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            Xl[(lr + 4 * r) * XL + 16 * q + lc] = -x[r];   // -X_q stays in LDS: A operand of the substitution below and of the final product
+            if (store_l) {
+                // NOT in place: other workgroups are still reading the block column and the right-hand side of tile s
+                if (!is_rhs) Lp[((size_t)s * n_pad + row0 + lr + 4 * r) * NB + 16 * q + lc] = x[r] * dinv;
+                else if (lr + 4 * r == 0) zf[r0 + 16 * q + lc] = x[r] * dinv;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (q + 1 < NSB) {
+            double ax[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) ax[t] = Xl[lc * XL + 16 * q + 4 * lr + t];
+#pragma unroll
+            for (int q2 = q + 1; q2 < NSB; q2++) {
+                const double4 l4 = lb[q * NSB - q * (q + 1) / 2 + (q2 - q - 1)];
+                acc[q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[0], l4.x, acc[q2], 0, 0, 0);
+                acc[q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[1], l4.y, acc[q2], 0, 0, 0);
+                acc[q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[2], l4.z, acc[q2], 0, 0, 0);
+                acc[q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[3], l4.w, acc[q2], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // P = X_I D^-1 X_J^T: this wavefront's half of k (three 16-column blocks); both operands are read as "row lc, columns 4 lr + t",
+    // the same permutation of k on both sides; (-X_I)(-X_J) = +
+    const double *XI = Xl_all, *XJ = Xl_all + SBK * XL;
+    dg_acc_t pacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int qq = 0; qq < NSB / 2; qq++) {
+        const int q = (NSB / 2) * wave + qq;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int k = 16 * q + 4 * lr + t;
+            pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(XI[lc * XL + k], XJ[lc * XL + k] * dinv_l[k], pacc, 0, 0, 0);
+        }
+    }
+    if (wave == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[r * 64 + lane] = pacc[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const double pv = pacc[r] + red[r * 64 + lane];
+        const int gi = i0 + lr + 4 * r, gj = j0 + lc;
+        if (J < ns) {
+            if (gj <= gi) {
+                double v = tgt[r];
+                if (first) v = xform_first_flags(v, gi, gj, (omask >> (lr + 4 * r)) & 1, (omask >> (16 + lc)) & 1, mu);
+                S[(size_t)gi * n_pad + gj] = v - pv;
+            }
+        } else if (lc == 0) {   // rhs entries of slab I: b -= L_I y  (the rhs "slab" has y in its row 0 only)
+            double v = tgt[r];
+            if (first) v = ((omask >> (lr + 4 * r)) & 1) ? 0.0 : v + g0[gi];
+            rhs[gi] = v - pv;
+        }
+    }
+}
+
 // L^T x = z for the tiles above the last one (k_ldl_diag has solved that).  One workgroup per tile column s, all resident at
 // once, chained by flags in global memory: workgroup s accumulates w_s = z_s - sum_{t>s} L_ts^T x_t block by block as the
 // x_t are published (block (t, s) is already in registers when the flag arrives), then one wavefront back-substitutes
@@ -935,7 +1100,8 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
 // LDS (dynamic): Ls [NB][NB+2] | xs [NB] | w [NB] | part [10][NB]
 __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict__ S, const double *__restrict__ rhs,
                                                         const double *__restrict__ Dfac, double *__restrict__ x, int n_pad, int nT,
-                                                        int32_t *__restrict__ flag, int epoch, int32_t *__restrict__ err_flags) {
+                                                        int32_t *__restrict__ flag, int epoch, int32_t *__restrict__ err_flags,
+                                                        const double *__restrict__ Lp, const double *__restrict__ zf, int fused_m) {
     constexpr int LD = NB + 2, G = 10, RPT = (NB + G - 1) / G;
     extern __shared__ __align__(16) double lds[];
     double *Ls = lds;
@@ -947,6 +1113,11 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
     const int r0 = s * NB;
     const int j = tid % NB, gq = tid / NB;    // G*NB = 960 threads in the block products
     const double *dd = Dfac + (size_t)s * NB * NB;
+    // block column s of L and z_s: in place (k_ldl_trsm) or, for the stages the fused panel kernel handled, in Lp / zf
+    const bool from_lp = (nT - 1 - s) <= fused_m;
+    const double *lcol = from_lp ? Lp + (size_t)s * n_pad * NB : S + r0;
+    const size_t lld = from_lp ? (size_t)NB : (size_t)n_pad;
+    const double *zsrc = from_lp ? zf : rhs;
     // Fetch order = use order: block (nT-1, s) first -- its product only waits for x_{nT-1}, which the previous kernel left in
     // memory -- then L_ss, which is not needed before the final substitution and is parked in LDS after that first product.
     constexpr int NL = NB * NB / 1024;
@@ -955,7 +1126,7 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
             const int i = gq + G * k;
-            a[k] = (gq < G && i < NB) ? S[(size_t)(t * NB + i) * n_pad + r0 + j] : 0.0;
+            a[k] = (gq < G && i < NB) ? lcol[(size_t)(t * NB + i) * lld + j] : 0.0;
         }
     };
     fetch_block(nT - 1);
@@ -999,7 +1170,7 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
     if (gq < G) part[gq * NB + j] = acc;
     __syncthreads();
     if (tid < NB) {
-        double v = rhs[r0 + tid];
+        double v = zsrc[r0 + tid];
 #pragma unroll
         for (int g = 0; g < G; g++) v -= part[g * NB + tid];
         w[tid] = v;
@@ -1171,12 +1342,17 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];
     const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * DG_YS) * sizeof(double);
     static size_t g_diag = 48 * 1024, g_bs = 48 * 1024;
+    static const bool fused_panel = !(getenv("AAR_FUSED_PANEL") && atoi(getenv("AAR_FUSED_PANEL")) == 0);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
     for (int s = 0; s < P.nT; s++) {
         const int m = P.nT - s - 1;
         { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags,
                                                          P.nT, b.rhs, b.g0, P.delta_s); }
-        if (m > 0) {   // the last tile's right-hand side is solved inside k_ldl_diag
+        if (m > 0 && m <= 2 && fused_panel) {   // short block column: panel solve and trailing update in one launch
+            const int ns = NSB * m;
+            HookScope _h(P, KID_LDL_TRSM);
+            hipLaunchKernelGGL(k_ldl_panel, dim3(ns * (ns + 1) / 2 + ns), dim3(128), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed, P.Lp, P.zf);
+        } else if (m > 0) {   // the last tile's right-hand side is solved inside k_ldl_diag
             { HookScope _h(P, KID_LDL_TRSM); hipLaunchKernelGGL(k_ldl_trsm, dim3(NSB * m + 1), dim3(64), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
             { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
         }
@@ -1186,7 +1362,8 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
         allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_backsolve), lds, g_bs);
         P.bs_epoch++;
         HookScope _h(P, KID_LDL_BACKSOLVE);
-        hipLaunchKernelGGL(k_ldl_backsolve, dim3(P.nT - 1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.delta_s, P.n_pad, P.nT, P.bs_flags, P.bs_epoch, P.flags);
+        hipLaunchKernelGGL(k_ldl_backsolve, dim3(P.nT - 1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.delta_s, P.n_pad, P.nT, P.bs_flags, P.bs_epoch, P.flags, P.Lp, P.zf,
+                           fused_panel ? 2 : 0);
     }
 }
 

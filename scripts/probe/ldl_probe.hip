@@ -15,6 +15,7 @@ int main() {
     auto al = [](size_t bytes) { void *p; (void)hipMalloc(&p, bytes); (void)hipMemset(p, 0, bytes); return p; };
     P.blk[0].S = (double*)al(sizeof(double)*n*n); P.blk[0].rhs = (double*)al(8*n); P.blk[0].g0 = (double*)al(8*n);
     P.Dfac = (double*)al(8*nT*96*96); P.Linv16 = (double*)al(8*nT*6*256); P.delta_s = (double*)al(8*n);
+    P.Lp = (double*)al(8*(size_t)nT*n_pad*96); P.zf = (double*)al(8*n_pad);
     P.ent_fixed = (int32_t*)al(4*48); P.flags = (int32_t*)al(16); P.bs_flags = (int32_t*)al(64);
     std::vector<double> b(n, 1.0);
     for (int rep = 0; rep < 3; rep++) {
