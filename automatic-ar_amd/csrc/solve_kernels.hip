@@ -544,15 +544,144 @@ __device__ __forceinline__ void dg_rows(double *__restrict__ T, double *__restri
     yp[2] = make_double2(y[4], y[5]);
 }
 
+// L_ss^T x = w by one wavefront: lane l keeps rows l and l + 64; row j of L (LDS tile, zero on and above the diagonal) against
+// x_j, from the last column up; the finished entry travels through v_readlane
+__device__ __forceinline__ void bs_sweep(const double *__restrict__ Ls, const double *__restrict__ w, int lane, double &b0, double &b1) {
+    constexpr int LD = NB + 2;
+    const int i0 = lane, i1 = lane + 64;
+    const bool h1 = i1 < NB;
+    b0 = w[i0]; b1 = h1 ? w[i1] : 0.0;
+    const int i1c = h1 ? i1 : 0;
+#pragma unroll
+    for (int jj = NB - 1; jj > 0; jj--) {
+        const double v = jj < 64 ? b0 : b1;
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), jj & 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), jj & 63);
+        const double xj = __hiloint2double(hi, lo);
+        b0 = fma(-Ls[jj * LD + i0], xj, b0);
+        if (jj > 64) b1 = fma(-Ls[jj * LD + i1c], xj, b1);
+    }
+}
+
+// Back-substitution of a system of two or three tiles by ONE workgroup that rides in the launch of the LAST diagonal tile
+// (workgroup 1 of k_ldl_diag): every block of L it needs (at most three off-diagonal blocks and two diagonal tiles, 290 KB)
+// is fetched while the diagonal tile is still being factored next door, so when x_{nT-1} is published (one agent-scope flag)
+// only the arithmetic is left: matvec, sweep, [matvec, sweep].  Replaces the k_ldl_backsolve launch (its own fetch, one flag
+// hop per tile column) for nT <= 3; larger systems keep the chained kernel (one CU could not pull their L through in time).
+// LDS (the diagonal-tile kernel's allocation): Ls [NB][NB+2] | xs [2][NB] | w [NB] | part [10][NB]
+__device__ __forceinline__ void bs_small(double *__restrict__ lds, const double *__restrict__ S, const double *__restrict__ rhs,
+                                         const double *__restrict__ Dfac, double *__restrict__ x, int n_pad, int nT,
+                                         const int32_t *__restrict__ flag, int epoch, int32_t *__restrict__ err_flags,
+                                         const double *__restrict__ Lp, const double *__restrict__ zf, int fused_m) {
+    constexpr int LD = NB + 2, G = 10, RPT = (NB + G - 1) / G, NL = NB * NB / 1024;
+    double *Ls = lds, *xs = Ls + NB * LD, *w = xs + 2 * NB, *part = w + NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = tid % NB, gq = tid / NB;
+    auto block = [&](int t, int sc, double (&a)[RPT]) {   // rows gq + G k of column j of L(t, sc): in place (k_ldl_trsm) or in Lp (k_ldl_panel)
+        const bool from_lp = (nT - 1 - sc) <= fused_m;
+        const double *lcol = from_lp ? Lp + (size_t)sc * n_pad * NB : S + sc * NB;
+        const size_t lld = from_lp ? (size_t)NB : (size_t)n_pad;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            const int i = gq + G * k;
+            a[k] = (gq < G && i < NB) ? lcol[(size_t)(t * NB + i) * lld + j] : 0.0;
+        }
+    };
+    auto tile = [&](int sc, double (&v)[NL]) {   // strictly lower part of L_{sc,sc}
+        const double *dd = Dfac + (size_t)sc * NB * NB;
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
+            v[u] = (jj < i) ? dd[e] : 0.0;
+        }
+    };
+    auto park = [&](const double (&v)[NL]) {
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int e = tid + 1024 * u, i = e / NB, jj = e - i * NB;
+            Ls[i * LD + jj] = v[u];
+        }
+    };
+    const int s1 = nT - 2;                       // first tile column to solve
+    double a0[RPT], a1[RPT], a2[RPT], v0[NL], v1[NL];
+    block(nT - 1, s1, a0);
+    tile(s1, v0);
+    if (nT == 3) { block(2, 0, a1); block(1, 0, a2); }
+    park(v0);
+    if (nT == 3) tile(0, v1);
+    if (tid == 0) {
+        long spins = 0;
+        while (__hip_atomic_load(flag + (nT - 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1L << 24)) { atomicOr(err_flags, 4); break; }
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (tid < NB) xs[tid] = __hip_atomic_load(x + (nT - 1) * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        const int i = gq + G * k;
+        if (i < NB) { acc0 = fma(a0[k], xs[i], acc0); if (nT == 3) acc1 = fma(a1[k], xs[i], acc1); }
+    }
+    if (gq < G) part[gq * NB + j] = acc0;
+    __syncthreads();
+    const double *z1 = ((nT - 1 - s1) <= fused_m) ? zf : rhs;
+    if (tid < NB) {
+        double v = z1[s1 * NB + tid];
+#pragma unroll
+        for (int g = 0; g < G; g++) v -= part[g * NB + tid];
+        w[tid] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double b0, b1;
+        bs_sweep(Ls, w, lane, b0, b1);
+        x[s1 * NB + lane] = b0; xs[NB + lane] = b0;
+        if (lane + 64 < NB) { x[s1 * NB + lane + 64] = b1; xs[NB + lane + 64] = b1; }
+    }
+    if (nT != 3) return;
+    __syncthreads();
+    park(v1);
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        const int i = gq + G * k;
+        if (i < NB) acc1 = fma(a2[k], xs[NB + i], acc1);
+    }
+    if (gq < G) part[gq * NB + j] = acc1;
+    __syncthreads();
+    const double *z0 = (2 <= fused_m) ? zf : rhs;
+    if (tid < NB) {
+        double v = z0[tid];
+#pragma unroll
+        for (int g = 0; g < G; g++) v -= part[g * NB + tid];
+        w[tid] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double b0, b1;
+        bs_sweep(Ls, w, lane, b0, b1);
+        x[lane] = b0;
+        if (lane + 64 < NB) x[lane + 64] = b1;
+    }
+}
+
 __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restrict__ S, double *__restrict__ Dfac, double *__restrict__ Linv16,
                                                          int n_pad, int n, int s, double mu, const int32_t *__restrict__ ent_fixed,
                                                          int32_t *__restrict__ flags, int nT, const double *__restrict__ rhs,
-                                                         const double *__restrict__ g0, double *__restrict__ xout) {
+                                                         const double *__restrict__ g0, double *__restrict__ xout,
+                                                         const double *__restrict__ Lp, const double *__restrict__ zf, int fused_m,
+                                                         int32_t *__restrict__ bs_flag, int bs_epoch) {
     constexpr int LD = NB + 2, NBK = NB / 6, PER = NB * NB / DG_THREADS, NT16 = NB / 16, NTILE = NT16 * (NT16 + 1) / 2, NWAVE = DG_THREADS / 64, NMW = DG_ROW0 / 64;
     static_assert(NB % 16 == 0 && NB % 6 == 0 && NB * NB % DG_THREADS == 0 && NWAVE >= NSB && DG_THREADS - DG_ROW0 >= NB - 6 &&
                   NTILE <= 2 * NMW && DG_ROW0 % 64 == 0, "diag tile mapping");
     extern __shared__ __align__(16) double T[];
     TL_DECL
+    if (blockIdx.x == 1) {   // rider of the LAST tile's launch (two or three tiles): the back-substitution of the tiles above, see bs_small
+        bs_small(T, S, rhs, Dfac, xout, n_pad, nT, bs_flag, bs_epoch, flags, Lp, zf, fused_m);
+        return;
+    }
     double *Yn = T + NB * LD;   // [2][NB][DG_YS]: L D of block column k in buffer k & 1, columns 6, 7 zero
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = s * NB;
@@ -699,8 +828,12 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
             b0 = fma(-T[j * LD + i0], xj, b0);
             if (j > 64) b1 = fma(-T[j * LD + i1], xj, b1);
         }
-        xout[r0 + i0] = b0;
-        if (h1) xout[r0 + i1] = b1;
+        __hip_atomic_store(xout + r0 + i0, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h1) __hip_atomic_store(xout + r0 + i1, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gridDim.x > 1) {   // the back-substitution rides next door: x_{nT-1} is in memory
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            if (lane == 0) __hip_atomic_store(bs_flag + s, bs_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (s == nT - 1) { STAMP(9); STAMP(10); TL_DUMP; return; }   // nobody reads the last tile's factor: its solve is done
     {   // factored tile -> Dfac (not back into S: other workgroups may still be reading it); only the lower part is ever read
@@ -1343,11 +1476,14 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * DG_YS) * sizeof(double);
     static size_t g_diag = 48 * 1024, g_bs = 48 * 1024;
     static const bool fused_panel = !(getenv("AAR_FUSED_PANEL") && atoi(getenv("AAR_FUSED_PANEL")) == 0);
+    static const bool bs_rides = !(getenv("AAR_BS_RIDES") && atoi(getenv("AAR_BS_RIDES")) == 0);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
     for (int s = 0; s < P.nT; s++) {
         const int m = P.nT - s - 1;
-        { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags,
-                                                         P.nT, b.rhs, b.g0, P.delta_s); }
+        const bool ride = bs_rides && s == P.nT - 1 && (P.nT == 2 || P.nT == 3);   // the back-substitution rides in the last tile's launch
+        if (ride) P.bs_epoch++;
+        { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(ride ? 2 : 1), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags,
+                                                         P.nT, b.rhs, b.g0, P.delta_s, P.Lp, P.zf, fused_panel ? 2 : 0, P.bs_flags, P.bs_epoch); }
         if (m > 0 && m <= 2 && fused_panel) {   // short block column: panel solve and trailing update in one launch
             const int ns = NSB * m;
             HookScope _h(P, KID_LDL_TRSM);
@@ -1357,7 +1493,7 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
             { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
         }
     }
-    if (P.nT > 1) {
+    if (P.nT > 1 && !(bs_rides && P.nT <= 3)) {
         const size_t lds = ((size_t)NB * (NB + 2) + 2 * NB + 10 * NB) * sizeof(double);
         allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_backsolve), lds, g_bs);
         P.bs_epoch++;
