@@ -230,46 +230,57 @@ __device__ __forceinline__ void corner_jacobian(const Ent &ec, const Ent &em, co
     }
 }
 
-// 6x6 SPD inverse through Cholesky, one thread, registers only: out = (a)^-1 (row-major), returns false on a
-// non-positive pivot.
+// 1/d: v_rcp_f64 is good to 2^-24.4 (scripts/probe/rcp_probe.hip); one cubic step 1/d = x (1 + e + e^2 + ...), e = 1 - d x,
+// leaves 2^-73 and matches the IEEE quotient on 4 M samples -- one instruction less than two Newton steps
+__device__ __forceinline__ double rcp_refined(double d) {
+    const double x = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, x, 1.0);
+    return fma(x, fma(e, e, e), x);
+}
+
+// 6x6 SPD inverse, one thread, registers only: out = a^-1 (row-major, both triangles), returns false on a non-positive
+// pivot.  LDL^T instead of Cholesky (no square roots, the six divisions as refined reciprocals), the unit factor inverted in
+// place, and only the 21 distinct entries of L^-T D^-1 L^-1 formed: ~170 fp64 instructions instead of ~460 -- this runs on
+// ONE lane at the end of every frame's pass A workgroup, i.e. on the critical path of the kernel.
 __device__ __forceinline__ bool spd6_inverse(double a[6][6], double out[36]) {
     bool ok = true;
+    double dinv[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        double d = a[k][k];
-#pragma unroll
-        for (int p = 0; p < k; p++) d -= a[k][p] * a[k][p];
+    for (int p = 0; p < 6; p++) {
+        double d = a[p][p];
         if (!(d > 0.0)) { ok = false; d = 1.0; }
-        const double l = sqrt(d), il = 1.0 / l;
-        a[k][k] = il;   // the reciprocal is what the substitutions below need (no divisions there)
+        dinv[p] = rcp_refined(d);
+        double l[6];
 #pragma unroll
-        for (int i = k + 1; i < 6; i++) {
-            double s = a[i][k];
+        for (int q = p + 1; q < 6; q++) l[q] = a[q][p] * dinv[p];
 #pragma unroll
-            for (int p = 0; p < k; p++) s -= a[i][p] * a[k][p];
-            a[i][k] = s * il;
-        }
+        for (int q = p + 1; q < 6; q++)
+#pragma unroll
+            for (int r = p + 1; r <= q; r++) a[q][r] = fma(-l[q], a[r][p], a[q][r]);
+#pragma unroll
+        for (int q = p + 1; q < 6; q++) a[q][p] = l[q];   // unit L, strictly lower
     }
-    double li[6][6];
+    // M = L^-1 (unit lower): column c by forward substitution, M[i][c] = -(L[i][c] + sum_{c<p<i} L[i][p] M[p][c])
+    double m[6][6];
 #pragma unroll
     for (int c = 0; c < 6; c++)
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            if (i < c) { li[i][c] = 0.0; continue; }
-            double s = (i == c) ? 1.0 : 0.0;
+        for (int i = c + 1; i < 6; i++) {
+            double s = a[i][c];
 #pragma unroll
-            for (int p = c; p < i; p++) s -= a[i][p] * li[p][c];
-            li[i][c] = s * a[i][i];
+            for (int p = c + 1; p < i; p++) s = fma(a[i][p], m[p][c], s);
+            m[i][c] = -s;
         }
+    // a^-1 = M^T D^-1 M: entry (i, j), i >= j: sum_{p >= i} M[p][i] dinv_p M[p][j]   (M[p][p] = 1)
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            double s = 0.0;
+        for (int j = 0; j <= i; j++) {
+            double s = (i == j) ? dinv[i] : dinv[i] * m[i][j];
 #pragma unroll
-            for (int p = 0; p < 6; p++)
-                if (p >= i && p >= j) s += li[p][i] * li[p][j];
+            for (int p = i + 1; p < 6; p++) s = fma(m[p][i] * dinv[p], m[p][j], s);
             out[i * 6 + j] = s;
+            out[j * 6 + i] = s;
         }
     return ok;
 }

@@ -462,14 +462,6 @@ __device__ __forceinline__ unsigned long long gauge_ballot(bool first, const int
     return __ballot(f);
 }
 
-// 1/d: v_rcp_f64 is good to 2^-24.4 (scripts/probe/rcp_probe.hip); one cubic step 1/d = x (1 + e + e^2 + ...), e = 1 - d x,
-// leaves 2^-73 and matches the IEEE quotient on 4 M samples -- one instruction less than two Newton steps
-__device__ __forceinline__ double rcp_refined(double d) {
-    const double x = __builtin_amdgcn_rcp(d);
-    const double e = fma(-d, x, 1.0);
-    return fma(x, fma(e, e, e), x);
-}
-
 // The tile is walked in 6x6 block pivots (16 block steps instead of 96 column steps; a column step is latency, not work).
 // A lone wavefront issues an instruction every 5-8 cycles here whatever the instruction is, so the design rule is few
 // instructions per wavefront per step: 16 wavefronts, the trailing matrix in fp64 MFMA accumulators as the 21 lower 16x16
