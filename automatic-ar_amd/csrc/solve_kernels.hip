@@ -1053,7 +1053,8 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
 
 // ------------------------------------------------------------------------------------------------
 // Panel solve AND trailing update of step s in ONE launch, for short block columns (m = nT - s - 1 <= 2 tiles below the
-// diagonal tile: every reduced system up to 288 unknowns).  At these sizes each of the two kernels above is ~5 us of fixed
+// diagonal tile by default: every reduced system up to 288 unknowns; AAR_FUSED_PANEL moves the limit -- measured at config 5,
+// 14 tiles: the same time up to m = 4, slower beyond, 37.6 us against 10.8 + 11.8 at m = 13).  At these sizes each of the two kernels above is ~5 us of fixed
 // cost (launch, first fetch of data another XCD has just written, completion) around <= 3 us of matrix work, and chaining them
 // with flags costs what the launch boundary does.  Here nobody waits for anybody: the workgroup of output block (I, J)
 // (16 x 16, slabs I >= J of the block column, or J = the right-hand side) solves BOTH slabs it needs itself -- one wavefront
@@ -1467,7 +1468,9 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];
     const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * DG_YS) * sizeof(double);
     static size_t g_diag = 48 * 1024, g_bs = 48 * 1024;
-    static const bool fused_panel = !(getenv("AAR_FUSED_PANEL") && atoi(getenv("AAR_FUSED_PANEL")) == 0);
+    // block columns with at most this many tiles below the diagonal take the fused panel kernel (0: never); its redundancy grows
+    // with the square of the column's height, the two-kernel path's fixed cost does not
+    static const int fused_m = getenv("AAR_FUSED_PANEL") ? atoi(getenv("AAR_FUSED_PANEL")) : 2;
     static const bool bs_rides = !(getenv("AAR_BS_RIDES") && atoi(getenv("AAR_BS_RIDES")) == 0);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
     for (int s = 0; s < P.nT; s++) {
@@ -1475,8 +1478,8 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
         const bool ride = bs_rides && s == P.nT - 1 && (P.nT == 2 || P.nT == 3);   // the back-substitution rides in the last tile's launch
         if (ride) P.bs_epoch++;
         { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(ride ? 2 : 1), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags,
-                                                         P.nT, b.rhs, b.g0, P.delta_s, P.Lp, P.zf, fused_panel ? 2 : 0, P.bs_flags, P.bs_epoch); }
-        if (m > 0 && m <= 2 && fused_panel) {   // short block column: panel solve and trailing update in one launch
+                                                         P.nT, b.rhs, b.g0, P.delta_s, P.Lp, P.zf, fused_m, P.bs_flags, P.bs_epoch); }
+        if (m > 0 && m <= fused_m) {   // short block column: panel solve and trailing update in one launch
             const int ns = NSB * m;
             HookScope _h(P, KID_LDL_TRSM);
             hipLaunchKernelGGL(k_ldl_panel, dim3(ns * (ns + 1) / 2 + ns), dim3(128), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed, P.Lp, P.zf);
@@ -1491,7 +1494,7 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
         P.bs_epoch++;
         HookScope _h(P, KID_LDL_BACKSOLVE);
         hipLaunchKernelGGL(k_ldl_backsolve, dim3(P.nT - 1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.delta_s, P.n_pad, P.nT, P.bs_flags, P.bs_epoch, P.flags, P.Lp, P.zf,
-                           fused_panel ? 2 : 0);
+                           fused_m);
     }
 }
 

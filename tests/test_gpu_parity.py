@@ -392,6 +392,36 @@ def test_tile_counts_and_schur_kernels_against_oracle(mfma, cams, markers, frame
         assert rep["iterations"] < 40 and abs(rmse - 0.3 * np.sqrt(2)) < 0.05   # (few observations per unknown: the fit absorbs some noise)
 
 
+@pytest.mark.parametrize("env", [{"AAR_FUSED_PANEL": "0"}, {"AAR_BS_RIDES": "0"}, {"AAR_FUSED_PANEL": "0", "AAR_BS_RIDES": "0"}, {"AAR_FUSED_PANEL": "5"}])
+def test_dense_solve_path_switches(env):
+    # The dense LDL^T has alternative launch structures behind environment switches that libaar reads ONCE per process (the
+    # two-kernel panel solve + trailing update instead of the fused k_ldl_panel, the chained k_ldl_backsolve instead of the
+    # back-substitution riding in the last tile's launch, the fused panel kernel on taller block columns): a fresh interpreter
+    # per combination solves systems of 2, 3 and 5 tiles against the oracle's Eigen-checked LDL^T.
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import aar, oracle_lib as ol
+        worst = 0.0
+        for cams, markers, frames in ((4, 20, 60), (8, 40, 60), (4, 62, 40)):
+            ds = aar.synth(3, num_cams=cams, num_markers=markers, num_frames=frames)
+            o = ol.Oracle(ds)
+            with aar.Problem(ds) as p:
+                for mu in (1e6, 1e2):
+                    d = p.eval_damped_step(ds.x_full, mu)
+                    do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+                    worst = max(worst, float(np.abs(d - do).max() / np.abs(do).max()))
+                x, rep = p.lm_solve(ds.x_full)
+                assert rep["iterations"] < 40, rep["iterations"]
+        print("WORST", worst)
+    """) % (os.path.join(os.path.dirname(__file__), "..", "automatic-ar_amd"), os.path.dirname(__file__))
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float([l for l in out.stdout.splitlines() if l.startswith("WORST")][-1].split()[1])
+    assert worst < 1e-8, (env, worst)
+
+
 def test_randomized_shapes_against_oracle():
     # a sweep over sizes that move every structural parameter at once: camera / marker counts (shared system n from 18 to ~400,
     # i.e. one to five 96-wide tiles, n not a multiple of 16 or 96), frames from a handful to a few hundred (ragged visibility),
