@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
         reduce_scalars_body(red);
         return;
     }
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     double *panel = lds;
     double *pg = lds + (size_t)A * 36;
     double *ysc = pg + 8;
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
             __builtin_amdgcn_wave_barrier();
             double Y[36];
     #pragma unroll
-            for (int i = 0; i < 36; i++) Y[i] = ys[i];
+            for (int i = 0; i < 18; i++) { const double2 v2 = reinterpret_cast<const double2 *>(ys)[i]; Y[2 * i] = v2.x; Y[2 * i + 1] = v2.y; }   // 16-byte reads: half the LDS instructions
             __builtin_amdgcn_wave_barrier();
             const int sl = lane / 6, j = lane % 6;
             if (lane < 60) {
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
             __builtin_amdgcn_wave_barrier();
             double Y[36];
     #pragma unroll
-            for (int i = 0; i < 36; i++) Y[i] = ys[i];
+            for (int i = 0; i < 18; i++) { const double2 v2 = reinterpret_cast<const double2 *>(ys)[i]; Y[2 * i] = v2.x; Y[2 * i + 1] = v2.y; }   // 16-byte reads: half the LDS instructions
             __builtin_amdgcn_wave_barrier();
             auto accumulate = [&](int b, const double2 &w0, const double2 &w1, const double2 &w2) {
                 double *dst = panel + b * 36 + j;
