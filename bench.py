@@ -317,7 +317,9 @@ def main():
         if os.path.exists(pmc):
             try:
                 tr = json.load(open(pmc)).get("workload_%d" % args.workload, {})
-                if tr.get("_kernel_source_sha1") == src_hash:
+                if not tr:
+                    traffic_note = "no PMC pass was collected for this workload (profiles/pmc_traffic.json holds workloads 3 and 5)"
+                elif tr.get("_kernel_source_sha1") == src_hash:
                     traffic_tab, traffic_note = tr, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel sources (%s)" % tr.get("_source")
                 else:
                     traffic_note = "profiles/pmc_traffic.json was collected for other kernel sources (%s): not attached" % str(tr.get("_kernel_source_sha1"))[:12]
