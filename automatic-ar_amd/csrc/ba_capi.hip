@@ -162,7 +162,11 @@ struct aar_problem {
     double *d_diag = nullptr;        // [n_pad]
     double *d_pack = nullptr;        // multi-GPU: packed lower triangle of S | rhs | g0 | scalars, the all-reduce payload
     double *d_status = nullptr;      // multi-GPU: one double for collective status decisions
-    std::vector<double> h_z;    // staging [6A + 6F_loc]
+    std::vector<double> h_z;    // staging [6A + 6F_loc]; page-locked (hipHostRegister) once it has its size, so uploads need no sync
+    bool h_z_pinned = false;
+    hipEvent_t up_ev = nullptr;  // the last upload from h_z (it must have left before h_z is packed again)
+    bool mu_seed_valid = false;  // max diag(J^T J) of the start point, published together with its sum r^2 (aar_lm_init)
+    double mu_seed = 0;
     // host copies of the index structure (normal-equation assembly for tests)
     std::vector<int32_t> h_fslot_start, h_fslot_ent;
     // LM state (SparseLevMarq members, libs/sparselevmarq.h:129-136)
@@ -250,10 +254,16 @@ void pack_z(const aar_problem *pb, const double *x_full, std::vector<double> &z)
 }
 
 int upload_z(aar_problem *pb, const double *x_full, int which) {
+    if (pb->up_ev) HIP_TRY(hipEventSynchronize(pb->up_ev));   // the previous upload has left the staging vector (it normally has long ago)
     pack_z(pb, x_full, pb->h_z);
+    if (!pb->h_z_pinned && !pb->h_z.empty()) {   // page-lock the staging vector once (its size never changes: pack_z re-assigns in place)
+        if (hipHostRegister(pb->h_z.data(), pb->h_z.size() * sizeof(double), hipHostRegisterDefault) == hipSuccess) pb->h_z_pinned = true;
+        else (void)hipGetLastError();
+        if (pb->h_z_pinned && !pb->up_ev && hipEventCreateWithFlags(&pb->up_ev, hipEventDisableTiming) != hipSuccess) { pb->up_ev = nullptr; (void)hipGetLastError(); }
+    }
     HIP_TRY(hipMemcpyAsync(pb->P.z[which], pb->h_z.data(), pb->h_z.size() * sizeof(double), hipMemcpyHostToDevice, pb->stream));
-    // the staging vector is pageable: make the copy complete before it can be reused
-    HIP_TRY(hipStreamSynchronize(pb->stream));
+    if (pb->h_z_pinned && pb->up_ev) HIP_TRY(hipEventRecord(pb->up_ev, pb->stream));
+    else HIP_TRY(hipStreamSynchronize(pb->stream));   // pageable staging: the copy must complete before the vector can be reused
     return AAR_OK;
 }
 
@@ -406,6 +416,30 @@ int check_async(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(AAR_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     return AAR_OK;
+}
+
+// both block sets' shared system and the linear-model partials in ONE launch (aar_lm_init: seven hipMemsetAsync = seven fill
+// kernels otherwise, ~25 us of a solve's fixed cost)
+struct ZeroArgs { double *p[7]; long long n[7]; };
+__global__ void __launch_bounds__(256) k_zero_many(const ZeroArgs z) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+#pragma unroll
+    for (int b = 0; b < 7; b++)
+        for (long long i = gid; i < z.n[b]; i += stride) z.p[b][i] = 0.0;
+}
+
+int zero_for_init(aar_problem *pb) {
+    DeviceProblem &P = pb->P;
+    ZeroArgs z;
+    const long long n2 = (long long)P.n_pad * P.n_pad;
+    z.p[0] = P.blk[0].S; z.n[0] = n2; z.p[1] = P.blk[1].S; z.n[1] = n2;
+    z.p[2] = P.blk[0].rhs; z.n[2] = P.n_pad; z.p[3] = P.blk[1].rhs; z.n[3] = P.n_pad;
+    z.p[4] = P.blk[0].g0; z.n[4] = P.n_pad; z.p[5] = P.blk[1].g0; z.n[5] = P.n_pad;
+    z.p[6] = P.lin_part; z.n[6] = 2LL * (P.F + 1);
+    const long long blocks = std::min<long long>(2048, (2 * n2 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_zero_many, dim3((unsigned)blocks), dim3(256), 0, pb->stream, z);
+    pb->launches += 1;
+    return check_async("k_zero_many");
 }
 
 int zero_block_set(aar_problem *pb, int which) {
@@ -620,6 +654,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
 // Rebuild the blocks of the current point after a rejected try consumed them (rare): everything the trial wrote into
 // blk[1-cur] is garbage as well.
 int rebuild_current(aar_problem *pb) {
+    pb->mu_seed_valid = false;   // (the seed belongs to the blocks aar_lm_init built)
     int rc = zero_block_set(pb, pb->cur);
     if (rc) return rc;
     if ((rc = zero_block_set(pb, 1 - pb->cur))) return rc;
@@ -796,6 +831,8 @@ void aar_problem_destroy(aar_problem *pb) {
     if (pb->stream) (void)hipStreamSynchronize(pb->stream);
     for (void *p : pb->allocs) (void)hipFree(p);
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
+    if (pb->h_z_pinned) (void)hipHostUnregister(pb->h_z.data());
+    if (pb->up_ev) (void)hipEventDestroy(pb->up_ev);
     if (pb->ev[0]) (void)hipEventDestroy(pb->ev[0]);
     if (pb->ev[1]) (void)hipEventDestroy(pb->ev[1]);
     for (hipEvent_t e : pb->ev_pool) (void)hipEventDestroy(e);
@@ -1295,12 +1332,16 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     memset(&pb->times, 0, sizeof pb->times);
     int rc = upload_z(pb, x_full, 0);
     if (rc) return rc;
-    if ((rc = zero_block_set(pb, 0))) return rc;
-    if ((rc = zero_block_set(pb, 1))) return rc;
+    if ((rc = zero_for_init(pb))) return rc;
     if ((rc = eval_blocks(pb, 0, -1.0, -1))) return rc;
     pb->huber_of_blocks = P.huber;
-    HIP_TRY(hipMemsetAsync(P.lin_part, 0, 2 * (size_t)(P.F + 1) * sizeof(double), pb->stream));
+    pb->mu_seed_valid = false;
+    if (!pb->comm) {   // max diag(J^T J) of the start point rides to the host with its sum r^2: the first step() then needs no round trip of its own
+        launch_maxdiag(P, 0, pb->stream);
+        pb->launches += 1;
+    }
     if ((rc = read_scalars(pb, P.F))) return rc;
+    if (!pb->comm) { pb->mu_seed = pb->h_scal[4]; pb->mu_seed_valid = true; }
     pb->currErr = pb->prevErr = pb->h_scal[0];
     pb->blocks_valid = true;
     pb->vinv_mu = -1;
@@ -1320,7 +1361,9 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
     int rc;
     if (!pb->blocks_valid && (rc = rebuild_current(pb))) return rc;  // J, Jt*J, B at curr_z (:353-367)
     if (pb->mu < 0) {                                                  // first time only (:369-377)
-        if ((rc = initial_mu(pb, pb->prm.tau, &pb->mu))) return rc;
+        if (pb->mu_seed_valid && pb->cur == 0 && pb->blocks_valid) pb->mu = pb->mu_seed * pb->prm.tau;   // (the blocks of the start point are still the ones it was taken from)
+        else if ((rc = initial_mu(pb, pb->prm.tau, &pb->mu))) return rc;
+        pb->mu_seed_valid = false;
     }
     double gain = 0, dnorm = 0;
     int ntries = 0;
