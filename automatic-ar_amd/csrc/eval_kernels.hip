@@ -508,8 +508,17 @@ __global__ void __launch_bounds__(256) k_maxdiag(const double *__restrict__ U0, 
     double m = -1.7976931348623157e308;
     for (int i = threadIdx.x; i < 6 * A; i += blockDim.x)
         if (!ent_fixed[i / 6]) m = fmax(m, U0[(size_t)i * n_pad + i]);
-    if (!frames_fixed)
-        for (int i = threadIdx.x; i < 6 * F; i += blockDim.x) m = fmax(m, V[(size_t)(i / 6) * 36 + (i % 6) * 7]);
+    if (!frames_fixed)   // eight loads in flight per thread (one workgroup walks all 6 F diagonal entries)
+        for (int i0 = threadIdx.x; i0 < 6 * F; i0 += 8 * (int)blockDim.x) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + u * (int)blockDim.x;
+                v[u] = i < 6 * F ? V[(size_t)(i / 6) * 36 + (i % 6) * 7] : m;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) m = fmax(m, v[u]);
+        }
     __shared__ double wm[4];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));

@@ -82,8 +82,22 @@ __device__ __forceinline__ void reduce_scalars_body(const ReduceArgs &r) {   // 
     __shared__ double red[3][256];
     const int tid = threadIdx.x;
     double e = 0.0, d2 = 0.0, dg = 0.0;
-    for (int i = tid; i < r.n_err; i += 256) e += r.err_part[i];
-    for (int i = tid; i < r.F; i += 256) { d2 += r.lin_part[2 * (size_t)i]; dg += r.lin_part[2 * (size_t)i + 1]; }
+    // the loads of eight rounds are in flight together (a thread walks 20 rounds at 5 000 frames: one round trip each would be
+    // 20 us of a launch that rides nowhere at that size); the additions keep their order
+    for (int i0 = tid; i0 < r.n_err; i0 += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (i0 + 256 * u < r.n_err) ? r.err_part[i0 + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) e += v[u];
+    }
+    for (int i0 = tid; i0 < r.F; i0 += 8 * 256) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (i0 + 256 * u < r.F) ? reinterpret_cast<const double2 *>(r.lin_part)[i0 + 256 * u] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) { d2 += v[u].x; dg += v[u].y; }
+    }
     red[0][tid] = e; red[1][tid] = d2; red[2][tid] = dg;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
@@ -268,8 +282,12 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
 __global__ void __launch_bounds__(256) k_schur_fill(const int32_t *__restrict__ slot_frame, const int32_t *__restrict__ slot_dense,
                                                     const double *__restrict__ W, const double *__restrict__ Vinv,
                                                     const double *__restrict__ gf, int total_slots, int F, int Ad,
-                                                    double *__restrict__ Wd, double *__restrict__ Yd) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                    double *__restrict__ Wd, double *__restrict__ Yd, int rider, const ReduceArgs red) {
+    if (rider && blockIdx.x == 0) {   // rider (dispatched first): the step's scalars go to the host from here, as in k_schur
+        reduce_scalars_body(red);
+        return;
+    }
+    const int64_t gid = (int64_t)((int)blockIdx.x - rider) * 256 + threadIdx.x;
     if (gid >= (int64_t)total_slots * 6) {   // the pseudo entity: row 0 of block (f, 0) = g_f
         const int64_t q = gid - (int64_t)total_slots * 6;
         if (q < (int64_t)F * 6) Wd[(q / 6) * Ad * 36 + (q % 6)] = gf[q];
@@ -1439,12 +1457,14 @@ bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
         const size_t lds = (size_t)2 * SM_ROWS * SM_PS * sizeof(double);
         static size_t granted = 48 * 1024;
         allow_dynamic_lds(reinterpret_cast<const void *>(k_schur_mfma), lds, granted);
+        const ReduceArgs red = reduce_args(P, ride_n_err, false, ride_scal ? 0ull : ride_seq, ride_scal);
+        const int extra = (ride_seq || ride_scal) ? 1 : 0;
         HookScope _h(P, KID_SCHUR);
-        hipLaunchKernelGGL(k_schur_fill, dim3((unsigned)(((int64_t)P.total_slots * 6 + (int64_t)P.F * 6 + 255) / 256)), dim3(256), 0, st, P.slot_frame, P.slot_dense,
-                           b.W, b.Vinv, b.gf, P.total_slots, P.F, P.Ad, P.Wd, P.Yd);
+        hipLaunchKernelGGL(k_schur_fill, dim3((unsigned)(((int64_t)P.total_slots * 6 + (int64_t)P.F * 6 + 255) / 256) + extra), dim3(256), 0, st, P.slot_frame, P.slot_dense,
+                           b.W, b.Vinv, b.gf, P.total_slots, P.F, P.Ad, P.Wd, P.Yd, extra, red);
         hipLaunchKernelGGL(k_schur_mfma, dim3(P.n_smwork), dim3(512), lds, st, P.sm_ga, P.sm_gb, P.sm_fb, P.sm_fe, P.sm_frames, P.dense_ent, P.Wd, P.Yd, P.Ad, P.n_pad, sign,
                            b.S, b.rhs);
-        return false;
+        return extra != 0;
     }
     if (P.n_swork == 0) return false;
     const size_t lds = ((size_t)P.A * 36 + 8 + 4 * 48) * sizeof(double);
