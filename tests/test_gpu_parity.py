@@ -392,6 +392,23 @@ def test_tile_counts_and_schur_kernels_against_oracle(mfma, cams, markers, frame
         assert rep["iterations"] < 40 and abs(rmse - 0.3 * np.sqrt(2)) < 0.05   # (few observations per unknown: the fit absorbs some noise)
 
 
+@pytest.mark.parametrize("opt", [(True, True, True), (False, True, True), (True, False, True)])
+def test_gauge_rows_in_trailing_tiles_of_a_three_tile_system(opt):
+    # 18 cameras / 20 markers: the root marker's rows (entity 18 -> rows 108..113) and, with a group switched off, whole runs of
+    # fixed entities fall in the SECOND and THIRD tile of a three-tile system, i.e. they get their damping / identity rows on
+    # first touch inside the fused panel kernel (slabs, output blocks, right-hand side) instead of the diagonal-tile kernel
+    ds = aar.synth(3, num_cams=18, num_markers=20, num_frames=40)
+    o = ol.Oracle(ds, optimize=opt)
+    with aar.Problem(ds, optimize=opt) as p:
+        assert p.num_vars == o.num_vars
+        for mu in (1e5, 10.0):
+            d = p.eval_damped_step(ds.x_full, mu)
+            do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+            assert np.abs(d - do).max() / np.abs(do).max() < 1e-8, mu
+        x, rep = p.lm_solve(ds.x_full)
+        assert rep["iterations"] < 40 and rep["final_err"] < rep["initial_err"]
+
+
 @pytest.mark.parametrize("env", [{"AAR_FUSED_PANEL": "0"}, {"AAR_BS_RIDES": "0"}, {"AAR_FUSED_PANEL": "0", "AAR_BS_RIDES": "0"}, {"AAR_FUSED_PANEL": "5"}])
 def test_dense_solve_path_switches(env):
     # The dense LDL^T has alternative launch structures behind environment switches that libaar reads ONCE per process (the
