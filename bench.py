@@ -277,6 +277,18 @@ def main():
             dist.barrier()
 
     params = lambda **kw: aar.lm_default_params(**kw)
+    # ---- device wake-up (untimed; NOT the LM warm-up, which follows) ----
+    # The first milliseconds of GPU activity of a fresh process carry a one-off stall of ~8-13 ms (seen on every MI355X box of
+    # the pool: power state / copy-engine bring-up, 2-3 ms after the first kernel; scripts/probe/outlier2.py).  With --steps 20
+    # the timed region is 3 ms, so the stall landed inside it in ~30 % of the runs (1.2-1.8 k it/s instead of 6.9 k).  Whole
+    # solves of the same problem for 50 ms of wall time put it behind us; nothing is cached from them (every solve restarts
+    # from x0 and rebuilds all blocks).
+    t_w, n_w = time.perf_counter(), 0
+    while time.perf_counter() - t_w < 0.05:
+        problem.lm_solve(ds.x_full, params=params(), trace_cap=1)
+        n_w += 1
+    aar.lib().aar_device_synchronize()
+    wakeup = {"seconds": round(time.perf_counter() - t_w, 4), "solves": n_w}
     # ---- warmup (untimed) ----
     if args.warmup > 0:
         run_steps(problem, ds.x_full, args.warmup, params)
@@ -406,6 +418,7 @@ def main():
         "ranks_seen": comm_stats["ranks_seen"] if comm_stats else 1, "local_obs": per_rank_obs,
         "allreduce_bytes": comm_stats["system_allreduce_bytes"] if comm_stats else 0,
         "allreduce_calls": comm_stats["allreduce_calls"] if comm_stats else 0,
+        "device_wakeup": wakeup,   # untimed whole solves before the W warm-up steps (see above); not part of any reported time
     }
     if world == 1 and not args.no_cpu_baseline:
         threads = os.cpu_count() or 1
