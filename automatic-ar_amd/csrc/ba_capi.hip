@@ -1156,6 +1156,16 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     if (hipHostGetDevicePointer((void **)&P.host_result, pb->h_scal, 0) != hipSuccess)
         return fail(set_error(AAR_ERR_HIP, "hipHostGetDevicePointer failed"));
     if (hipStreamSynchronize(pb->stream) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "upload failed"));
+    {   // the runtime brings its device-to-host copy path up on first use (8-13 ms, once per process: scripts/probe/outlier2.py):
+        // better here than inside the caller's first solve
+        pb->h_z.assign((size_t)6 * (A + F), 0.0);
+        if (!pb->h_z.empty() && hipHostRegister(pb->h_z.data(), pb->h_z.size() * sizeof(double), hipHostRegisterDefault) == hipSuccess) pb->h_z_pinned = true;
+        else (void)hipGetLastError();
+        if (pb->h_z_pinned && hipEventCreateWithFlags(&pb->up_ev, hipEventDisableTiming) != hipSuccess) { pb->up_ev = nullptr; (void)hipGetLastError(); }
+        if (hipMemcpyAsync(pb->h_z.data(), P.z[0], pb->h_z.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream) != hipSuccess ||
+            hipStreamSynchronize(pb->stream) != hipSuccess)
+            return fail(set_error(AAR_ERR_HIP, "device-to-host copy failed"));
+    }
     pb->h_fslot_start = fslot_start;
     pb->h_fslot_ent = fslot_ent;
     *out = pb;
