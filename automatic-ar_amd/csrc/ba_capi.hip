@@ -124,9 +124,19 @@ __global__ void k_local_reduce(double *__restrict__ out, const double *const *__
 // The reduced system travels as the PACKED lower triangle (only that half is ever produced or read): row i of S contributes its
 // i + 1 leading entries, then the `extra` doubles that sit right behind S (rhs | g0 | the step's scalars).  grid.y = row
 // (row n_pad = the extra part), dir 0 = pack, 1 = unpack.
-__global__ void __launch_bounds__(256) k_pack_system(double *__restrict__ S, int n_pad, int extra, double *__restrict__ packed, int dir) {
+__global__ void __launch_bounds__(256) k_pack_system(double *__restrict__ S, int n_pad, int extra, double *__restrict__ packed, int dir,
+                                                     double *__restrict__ host, unsigned long long publish_seq, const int32_t *__restrict__ flags) {
     const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     const size_t tri = (size_t)n_pad * (n_pad + 1) / 2;
+    if (dir == 1 && publish_seq && i == n_pad && j == 0) {
+        // the step's scalars go to the host from HERE, beside the unpacking (the host only reads the record; the next kernel it
+        // queues is stream-ordered behind this one): tail[0..3] reduced over the ranks, tail[4..7] this rank's own
+        const double *red = packed + tri + 2 * (size_t)n_pad, *own = S + (size_t)n_pad * n_pad + 2 * (size_t)n_pad;
+        double sc[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) sc[q] = (q < extra - 2 * n_pad) ? red[q] : own[q];
+        publish_host(sc, flags, host, publish_seq, /*flags_reduced=*/1);
+    }
     if (i < n_pad) {
         if (j > i) return;
         double *a = S + (size_t)i * n_pad + j, *b = packed + (size_t)i * (i + 1) / 2 + j;
@@ -297,16 +307,16 @@ int allreduce(aar_problem *pb, double *buf, size_t count, int op) {
 // All-reduce of the reduced system of block set `which`: packed lower triangle of S | rhs | g0 (| the first n_tail doubles of
 // the tail: the step's scalars of the fused collective).  n_pad (n_pad + 1) / 2 + 2 n_pad + n_tail doubles instead of the
 // n_pad^2 + ... of the square.
-int allreduce_system(aar_problem *pb, int which, int n_tail) {
+int allreduce_system(aar_problem *pb, int which, int n_tail, unsigned long long publish_seq = 0) {
     DeviceProblem &P = pb->P;
     const int extra = 2 * P.n_pad + n_tail;
     const size_t count = (size_t)P.n_pad * (P.n_pad + 1) / 2 + (size_t)extra;
     const dim3 grid((unsigned)((std::max(P.n_pad, extra) + 255) / 256), (unsigned)P.n_pad + 1);
-    hipLaunchKernelGGL(k_pack_system, grid, dim3(256), 0, pb->stream, P.blk[which].S, P.n_pad, extra, pb->d_pack, 0);
+    hipLaunchKernelGGL(k_pack_system, grid, dim3(256), 0, pb->stream, P.blk[which].S, P.n_pad, extra, pb->d_pack, 0, nullptr, 0ull, nullptr);
     int rc = allreduce(pb, pb->d_pack, count, NCCL_SUM);
     if (rc) return rc;
     pb->comm->last_system_bytes = (int64_t)(count * sizeof(double));
-    hipLaunchKernelGGL(k_pack_system, grid, dim3(256), 0, pb->stream, P.blk[which].S, P.n_pad, extra, pb->d_pack, 1);
+    hipLaunchKernelGGL(k_pack_system, grid, dim3(256), 0, pb->stream, P.blk[which].S, P.n_pad, extra, pb->d_pack, 1, P.host_result, publish_seq, P.flags);
     pb->launches += 2;
     return AAR_OK;
 }
@@ -626,9 +636,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
             // tail[0..2] = sum r^2, sum |delta_f|^2, sum delta_f.g_f are rank sums, tail[3] carries every rank's error flags (so that
             // all ranks take the same branch); tail[5..6] (shared-parameter pieces) are computed from replicated data on every
             // rank and stay out of the reduction
-            if ((rc = allreduce_system(pb, tr, 4))) return rc;
+            if ((rc = allreduce_system(pb, tr, 4, pb->seq))) return rc;   // (the unpacking kernel publishes the reduced scalars)
         }
-        launch_publish(P, pb->seq, pb->stream, P.blk[tr].tail, /*flags_reduced=*/true);
         pb->trial_reduced = true;
     } else {
         if ((rc = launch_scalars(pb, P.F))) return rc;

@@ -147,4 +147,26 @@ int residual_blocks(const DeviceProblem &P);   // entries of err_part written by
 void launch_track(const DeviceProblem &P, int which, int max_iters, double min_error, double min_step, double min_avg, double tau,
                   int32_t *iters_out, double *err_out, hipStream_t st);
 
+// The error flags of a rank as one double that survives a SUM all-reduce over up to 4095 ranks: bit b set on k ranks adds k 4096^b.
+// Every rank decodes the same value, so every rank takes the same branch (a rank that failed alone would otherwise leave the
+// others waiting in their next collective).
+__device__ __forceinline__ double encode_flags(int f) {
+    return (double)(f & 1) + 4096.0 * (double)((f >> 1) & 1) + 16777216.0 * (double)((f >> 2) & 1);
+}
+__device__ __forceinline__ int decode_flags(double v) {
+    const long long q = (long long)v;
+    return ((q % 4096) ? 1 : 0) | (((q / 4096) % 4096) ? 2 : 0) | ((q / 16777216) ? 4 : 0);
+}
+
+// flags_reduced: the flags come from scal[3] (all ranks' flags, summed by the all-reduce) instead of this rank's flag words
+__device__ __forceinline__ void publish_host(const double *__restrict__ scal, const int32_t *__restrict__ flags,
+                                             double *__restrict__ host, unsigned long long seq, int flags_reduced = 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) host[i] = scal[i];
+    reinterpret_cast<long long *>(host)[8] = flags_reduced ? (long long)decode_flags(scal[3]) : (long long)(flags[0] | flags[1] | flags[2] | flags[3]);
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(host) + 9, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
 }  // namespace aar
