@@ -4,9 +4,11 @@
  * CPU restatement of the reference's Initializer (libs/initializer.cpp) and of the planar square pose solver it calls,
  * aruco::solvePnP_ (3rdparty/aruco/aruco/ippe.cpp:118-124 -> solvePoseOfCentredSquare :141-223).  Only tests/ may load it.
  *
- * PARITY UNPINNED: both reference files need OpenCV (cv::Mat, cv::undistortPoints, cv::Rodrigues), which is not in this
- * image, so neither can be compiled here and the reference holds no golden vectors for them.  The
- * restatement is checked by properties instead (tests/test_initializer.py): exact planar poses are recovered with ~zero
+ * PARITY UNPINNED against OpenCV / aruco themselves: both reference files need OpenCV (cv::Mat, cv::undistortPoints,
+ * cv::Rodrigues), which is not in this image, so neither can be compiled here and the reference holds no golden vectors for
+ * them.  IPPE is pinned against its two defining equations evaluated in independent numpy
+ * (tests/test_initializer.py::test_oracle_ippe_satisfies_the_defining_equations_of_ippe); the rest of the restatement is
+ * checked by properties: exact planar poses are recovered with ~zero
  * reprojection error, the two IPPE solutions are ordered by error, the vote picks the consistent candidate, the spanning
  * tree reaches every connected camera / marker, and the poses it hands to the LM converge to the ground truth.
  *

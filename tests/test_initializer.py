@@ -1,8 +1,9 @@
 """Initializer (libs/initializer.cpp) and square-marker IPPE (3rdparty/aruco/aruco/ippe.cpp): SURVEY.md section 8f, next row 1.
 
 The reference files need OpenCV and cannot be built here, and the reference holds no fixtures for them, so the oracle
-(oracle/init_oracle.cpp) is PARITY UNPINNED and is checked by properties first (CPU tests below); the GPU tests then compare
-the HIP kernels and the host pipeline with it on the same inputs.
+(oracle/init_oracle.cpp) cannot be pinned against OpenCV / aruco itself.  It is checked first by properties and, for IPPE, against
+the two equations that DEFINE the method, evaluated with independent numpy (CPU tests below); the GPU tests then compare the HIP
+kernels and the host pipeline with it on the same inputs.
 """
 import os
 import struct
@@ -96,6 +97,51 @@ def test_oracle_ippe_second_solution_is_the_reflected_ambiguity():
     c2 = T2[:, :3, 3] / T2[:, 2:3, 3]
     assert np.abs(c1 - c2).max() < 5e-3     # same marker centre direction
     assert np.mean(e2 / e1 < 2.0) > 0.2     # a fair share of ambiguous detections at 0.3 px on 25-pixel markers
+
+
+def test_oracle_ippe_satisfies_the_defining_equations_of_ippe():
+    # An INDEPENDENT pin of the IPPE restatement (OpenCV / aruco cannot be built here): IPPE (Collins & Bartoli) is defined by two
+    # equations, both checked with plain numpy that shares nothing with oracle/init_oracle.cpp.
+    #  (1) rotation: with H the homography model plane -> normalised image (numpy DLT by SVD; exact for four corners), v = H(0, 0)
+    #      and J the 2x2 Jacobian of H at the origin, BOTH returned rotations satisfy  [I2 | -v] R[:, :2] = gamma J, gamma > 0 --
+    #      the pose's first-order behaviour at the marker centre equals the homography's;
+    #  (2) translation: given R, t is the linear least-squares solution of the projection equations of the four corners.
+    ds = scene(noise=0.3, frames=12)
+    K = ds.cam_mats.reshape(-1, 3, 3)
+    h = MS / 2
+    model = np.array([[-h, h], [h, h], [h, -h], [-h, -h]])       # corner order of aruco::Marker (marker.cpp:358-367)
+    checked = 0
+    for c in (0, 2, 5):
+        sel = np.nonzero(ds.obs_cam == c)[0][:60]
+        uv = ds.obs_uv[sel].astype(np.float64).reshape(-1, 4, 2)
+        T1, e1, T2, e2 = O.ippe_square(MS, K[c], np.zeros(5), ds.obs_uv[sel])
+        Kinv = np.linalg.inv(K[c])
+        for k in range(len(sel)):
+            q = (Kinv @ np.c_[uv[k], np.ones(4)].T).T
+            q = q[:, :2] / q[:, 2:3]
+            A = []
+            for (x, y), (a, b) in zip(model, q):     # DLT rows of  q ~ H (x, y, 1)
+                A.append([x, y, 1, 0, 0, 0, -a * x, -a * y, -a])
+                A.append([0, 0, 0, x, y, 1, -b * x, -b * y, -b])
+            H = np.linalg.svd(np.array(A))[2][-1].reshape(3, 3)
+            H /= H[2, 2]
+            v = H[:2, 2]
+            J = H[:2, :2] - np.outer(v, H[2, :2])
+            for T in (T1[k], T2[k]):
+                R, t = T[:3, :3], T[:3, 3]
+                M = np.c_[np.eye(2), -v] @ R[:, :2]
+                G = M @ np.linalg.inv(J)                # = gamma I2
+                gamma = 0.5 * np.trace(G)
+                assert gamma > 0 and np.abs(G - gamma * np.eye(2)).max() / gamma < 2e-5, (c, k, G)   # float-rounded R: ~1e-7
+                rows, rhs = [], []
+                for (x, y), (a, b) in zip(model, q):   # (R X + t)_xy = q (R X + t)_z
+                    RX = R @ np.array([x, y, 0.0])
+                    rows += [[1, 0, -a], [0, 1, -b]]
+                    rhs += [a * RX[2] - RX[0], b * RX[2] - RX[1]]
+                t_ls = np.linalg.lstsq(np.array(rows), np.array(rhs), rcond=None)[0]
+                assert np.abs(t - t_ls).max() / np.abs(t_ls).max() < 2e-5, (c, k, t, t_ls)
+                checked += 1
+    assert checked >= 200
 
 
 def _random_rigid(rng, n, rot=0.3, trans=0.2):
