@@ -177,6 +177,19 @@ def test_oracle_vote_prefers_the_consistent_candidate():
     assert O.vote(MS, T[:0], A[:0], B[:0])[0] == -1
 
 
+def test_oracle_vote_costs_equal_the_formula_in_numpy():
+    # Initializer::find_best_transformation (libs/initializer.cpp:151-193) in four lines of numpy, nothing shared with the oracle:
+    # cost_i = sum_j sum_corners || p - T2inv_j T_i T1inv_j p ||, the winner is the FIRST minimum
+    rng = np.random.default_rng(11)
+    T, A, B = _vote_set(rng, 24, 17, sigma=5e-3)
+    best, weight, cost = O.vote(MS, T, A, B)
+    h = MS / 2
+    P = np.array([[-h, h, 0, 1], [h, h, 0, 1], [h, -h, 0, 1], [-h, -h, 0, 1]]).T          # 4 x corners
+    ref = np.array([sum(np.linalg.norm((P - B[j] @ T[i] @ A[j] @ P)[:3], axis=0).sum() for j in range(len(T))) for i in range(len(T))])
+    np.testing.assert_allclose(cost, ref, rtol=1e-11)
+    assert best == int(np.argmin(ref))
+
+
 def test_oracle_inverse_is_general_not_rigid():
     rng = np.random.default_rng(5)
     M = _random_rigid(rng, 1)[0].astype(np.float32).astype(np.float64)   # float-rounded: R^T is not the inverse any more
