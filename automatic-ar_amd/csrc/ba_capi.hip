@@ -619,7 +619,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         rode = launch_schur(P, tr, 1.0, pb->stream, pb->seq + 1, P.F);
         pb->launches += 1;
         if (rode) pb->seq++;
-        else if ((rc = launch_scalars(pb, P.F))) return rc;   // (queued after the Schur kernel: the MFMA variant has no rider)
+        else if ((rc = launch_scalars(pb, P.F))) return rc;   // (nothing rode: a rank without frames launches no Schur kernel)
     } else if (evaluate_trial && pb->fused_comm) {
         // Multi-GPU: this rank's scalars ride in the speculative Schur launch as on one GPU, but into the 8 doubles behind
         // g0 of the trial's block set, and ONE all-reduce then carries the step's scalars AND the next step's S | rhs | g0:
@@ -655,7 +655,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         // Only the reduced system lost positive definiteness (far from the optimum its Schur complement can, in floating point):
         // the LM loop takes that as a failed try and raises the damping; every rank sees the same replicated pivots.
         // (a zero or negative pivot fills the trial point with NaNs, which the next pass A reports as flag 1 as well: still a failed try)
-        return (pb->h_flags[0] & 2) ? TRY_NOT_POSITIVE_DEFINITE : AAR_ERR_NUMERIC;
+        // (a back-substitution chain that timed out, flag 4, is never a failed try: its delta is garbage whatever the pivots were)
+        return ((pb->h_flags[0] & 2) && !(pb->h_flags[0] & 4)) ? TRY_NOT_POSITIVE_DEFINITE : AAR_ERR_NUMERIC;
     }
     return AAR_OK;
 }
@@ -964,7 +965,22 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     P.total_slots = (int)fslot_ent.size();
     const size_t ldsA = passA_lds_bytes(P.max_kf, 256) > passA_lds_bytes(P.max_kf, 64) ? passA_lds_bytes(P.max_kf, 256) : passA_lds_bytes(P.max_kf, 64);
     if (ldsA > 160 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers; the frame-block kernel holds them in LDS (limit ~ %d)", P.max_kf, (160 * 1024 / 8 - 58 - 2048) / 62);
-    if ((size_t)A * 36 * 8 + 2048 > 160 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "%d cameras+markers exceed the Schur row panel held in LDS", A);
+    // Which Schur kernel (solve_kernels.hip): the MFMA kernel works on dense per-frame panels and is the default from 96 shared
+    // entities, where the output-stationary kernel's re-reads of W dominate (config 5); AAR_SCHUR_MFMA=0 / 1 forces it (tests
+    // force it on small problems).  Its panels cost 2 F Ad 288 bytes -- tens of GB for long sequences with many rarely seen
+    // entities -- so they must fit a budget (half of the free device memory; AAR_SCHUR_PANEL_MB overrides), else the
+    // output-stationary kernel, which needs none of this, takes over.  Only THAT kernel keeps a row panel of all entities in LDS.
+    bool schur_mfma = A >= 96 && F > 0;
+    if (const char *e = getenv("AAR_SCHUR_MFMA")) schur_mfma = atoi(e) != 0 && F > 0;
+    if (schur_mfma) {
+        const size_t panel_bytes = (size_t)2 * F * ((A + 1 + 31) / 32 * 32) * 288;
+        size_t free_b = 0, total_b = 0;
+        size_t budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? free_b / 2 : (size_t)64 << 30;
+        if (const char *e = getenv("AAR_SCHUR_PANEL_MB")) budget = (size_t)std::max(0, atoi(e)) << 20;
+        if (panel_bytes > budget) schur_mfma = false;
+    }
+    if (!schur_mfma && (size_t)A * 36 * 8 + 2048 > 160 * 1024 && !local_rc)
+        local_rc = set_error(AAR_ERR_UNSUPPORTED, "%d cameras+markers exceed the row panel the output-stationary Schur kernel holds in LDS (and the dense panels of the MFMA kernel do not fit the memory budget)", A);
     {   // the limits above depend on the rank's own frames: agree on the outcome before anybody returns (see collective_status)
         if (pb->comm && (rc = dev_alloc(pb, &pb->d_status, 1))) return fail(rc);
         int agreed = local_rc;
@@ -1053,10 +1069,6 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     // many shared entities: the MFMA kernel owns 16 x 32-entity blocks of S and streams frame ranges (solve_kernels.hip);
     // frame ranges are cut so that the grid is a few workgroups per CU
     std::vector<int32_t> sm_ga, sm_gb, sm_fb, sm_fe, slot_frame, slot_dense, dense_ent;
-    // The MFMA kernel works on dense per-frame panels (solve_kernels.hip).  Default: on from 96 shared entities, where the
-    // output-stationary kernel's re-reads of W dominate (config 5); AAR_SCHUR_MFMA=0 / 1 forces it (tests force it on small problems).
-    bool schur_mfma = A >= 96 && F > 0;
-    if (const char *e = getenv("AAR_SCHUR_MFMA")) schur_mfma = atoi(e) != 0 && F > 0;
     std::vector<int32_t> sm_frames;   // frame lists of the blocks, back to back
     if (schur_mfma) {
         // dense entity 0 = the pseudo entity g_f; then the entities that are seen at all, MOST FREQUENT FIRST (ties: ascending):
@@ -1378,6 +1390,12 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
     if (!pb->lm_ready) return set_error(AAR_ERR_INVALID, "aar_lm_step: call aar_lm_init first");
     HIP_TRY(hipSetDevice(pb->device));
     int rc;
+    // verbose: the reference's per-step stage line (:425) needs per-stage device times, i.e. the stage timers for this step
+    struct VerboseTimers {
+        aar_problem *pb; bool was; aar_stage_times t0;
+        explicit VerboseTimers(aar_problem *p) : pb(p), was(p->stage_timers), t0(p->times) { if (pb->prm.verbose) pb->stage_timers = true; }
+        ~VerboseTimers() { pb->stage_timers = was; }
+    } vt(pb);
     if (!pb->blocks_valid && (rc = rebuild_current(pb))) return rc;  // J, Jt*J, B at curr_z (:353-367)
     if (pb->mu < 0) {                                                  // first time only (:369-377)
         if (pb->mu_seed_valid && pb->cur == 0 && pb->blocks_valid) pb->mu = pb->mu_seed * pb->prm.tau;   // (the blocks of the start point are still the ones it was taken from)
@@ -1433,9 +1451,16 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
         out->accepted = accepted ? 1 : 0;
         out->tries = ntries + (accepted ? 1 : 0);
     }
-    if (pb->prm.verbose)
+    if (pb->prm.verbose) {
         fprintf(stderr, "Curr Error=%.5g AErr(prev-curr)=%.5g gain=%.5g dumping factor=%.5g\n", pb->currErr,
                 (pb->prevErr - pb->currErr) / (8.0 * (double)pb->N_global), gain, pb->mu);
+        // the reference's stage names (libs/sparselevmarq.h:425), seconds.  "J" = the fused residual + Jacobian + block accumulation
+        // passes (which ARE transpose, Jt*J and B here: nothing is transposed or multiplied afterwards), "Jt*J" = the reduction of
+        // those blocks onto the shared parameters (Schur complement), "chol" = dense LDL^T + both back-substitutions
+        const aar_stage_times &a = vt.t0, &b = pb->times;
+        fprintf(stderr, " J=%.6g transpose=%.6g Jt*J=%.6g B=%.6g chol=%.6g\n", b.jacobian_normal_eq - a.jacobian_normal_eq, 0.0, b.schur - a.schur, 0.0,
+                (b.chol - a.chol) + (b.backsub - a.backsub));
+    }
     return AAR_OK;
 }
 
@@ -1614,8 +1639,17 @@ int aar_get_kernel_times(aar_problem *pb, double seconds[AAR_NUM_KERNELS], int64
 const char *aar_kernel_name(int kid) {
     static const char *names[KID_COUNT] = {"k_unpack", "k_residual", "k_passA", "k_passB", "k_maxdiag", "k_frame_inv", "k_schur",
                                            "k_ldl_diag", "k_ldl_trsm", "k_ldl_update", "k_ldl_backsolve", "k_backsub",
-                                           "k_reduce_scalars"};
+                                           "k_reduce_scalars", "k_ldl_panel"};
     return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
+}
+
+int aar_set_stage_timers(aar_problem *pb, int on) {
+    if (!pb) return set_error(AAR_ERR_INVALID, "aar_set_stage_timers: null argument");
+    HIP_TRY(hipSetDevice(pb->device));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    pb->stage_timers = on != 0;
+    memset(&pb->times, 0, sizeof pb->times);
+    return AAR_OK;
 }
 
 int aar_get_stage_times(aar_problem *pb, aar_stage_times *t) {

@@ -11,7 +11,7 @@ constexpr int PASSB_CHUNK = 256;  // max observations of one (camera, marker) ru
 
 // Kernel ids for the optional per-launch timing hooks (aar_get_kernel_times)
 enum KernelId { KID_UNPACK = 0, KID_RESIDUAL, KID_PASSA, KID_PASSB, KID_MAXDIAG, KID_FRAME_INV, KID_SCHUR, KID_LDL_DIAG,
-                KID_LDL_TRSM, KID_LDL_UPDATE, KID_LDL_BACKSOLVE, KID_BACKSUB, KID_REDUCE, KID_COUNT };
+                KID_LDL_TRSM, KID_LDL_UPDATE, KID_LDL_BACKSOLVE, KID_BACKSUB, KID_REDUCE, KID_LDL_PANEL, KID_COUNT };
 
 struct LaunchHook {  // called around every kernel launch when profiling is on
     void (*pre)(void *ctx, int kid) = nullptr;
@@ -56,7 +56,8 @@ struct DeviceProblem {
     int n_smwork = 0;
     int32_t *sm_ga = nullptr, *sm_gb = nullptr, *sm_fb = nullptr, *sm_fe = nullptr, *sm_frames = nullptr;
     // ... which reads DENSE per-frame panels: dense entity 0 = the frame's gradient g_f (a pseudo entity whose block row 0 is g_f: its
-    // column of S is the Schur part of the right-hand side), 1.. = the shared entities that are seen at all, ascending; Ad = their
+    // column of S is the Schur part of the right-hand side), 1.. = the shared entities that are seen at all, MOST FREQUENT FIRST
+    // (ties ascending; k_schur_mfma stores a pair transposed where the real entity order is the other way round); Ad = their
     // number padded to a multiple of 32.  Blocks of absent (entity, frame) pairs are zero ONCE and for all (the visibility pattern
     // never changes), k_schur_fill only rewrites the present ones.
     int Ad = 0;

@@ -1480,7 +1480,7 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
                                                          P.nT, b.rhs, b.g0, P.delta_s, P.Lp, P.zf, fused_m, P.bs_flags, P.bs_epoch); }
         if (m > 0 && m <= fused_m) {   // short block column: panel solve and trailing update in one launch
             const int ns = NSB * m;
-            HookScope _h(P, KID_LDL_TRSM);
+            HookScope _h(P, KID_LDL_PANEL);
             hipLaunchKernelGGL(k_ldl_panel, dim3(ns * (ns + 1) / 2 + ns), dim3(128), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed, P.Lp, P.zf);
         } else if (m > 0) {   // the last tile's right-hand side is solved inside k_ldl_diag
             { HookScope _h(P, KID_LDL_TRSM); hipLaunchKernelGGL(k_ldl_trsm, dim3(NSB * m + 1), dim3(64), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }

@@ -171,8 +171,32 @@ MultiCamMapper::~MultiCamMapper() {
 }
 
 void MultiCamMapper::drop_problem() {
+    solver.detach();   // the solver keeps the raw handle between init() / step() calls: never let it outlive the problem
     if (problem_) aar_problem_destroy(problem_);
     problem_ = nullptr;
+}
+
+namespace detail {
+EvalProbe &eval_probe() {
+    static thread_local EvalProbe p;
+    return p;
+}
+aar_problem *current_problem(const MultiCamMapper *owner) { return owner ? owner->problem_ : nullptr; }
+aar_problem *bind_problem(MultiCamMapper *owner, std::vector<double> &x_full) {
+    if (!owner || !owner->data_) throw std::runtime_error("SparseLevMarq: the evaluation functions belong to a MultiCamMapper without a data set");
+    if (owner->ensure_problem()) throw std::runtime_error(aar_last_error());
+    if (owner->with_huber_ && aar_problem_set_huber_delta(owner->problem_, owner->hubberDelta)) throw std::runtime_error(aar_last_error());
+    x_full = owner->problem_vector();
+    return owner->problem_;
+}
+}  // namespace detail
+
+bool MultiCamMapper::probed(int kind) {
+    detail::EvalProbe &p = detail::eval_probe();
+    if (!p.active) return false;
+    p.id.owner = this;
+    p.id.kind = kind;
+    return true;
 }
 
 void MultiCamMapper::set_optmize_flag_cam_poses(bool f) { config_.optimize_cam_poses = f; drop_problem(); }
@@ -258,6 +282,7 @@ int MultiCamMapper::ensure_problem() {
 }
 
 void MultiCamMapper::error_function(const eVector &input, eVector &error) {
+    if (probed(detail::EVAL_ERROR_FUNCTION)) return;
     if (!data_) throw std::runtime_error("MultiCamMapper::error_function: no data set");
     if (input.size() != get_num_vars(config_)) throw std::runtime_error("MultiCamMapper::error_function: input has not the Config's number of variables");
     if (ensure_problem()) throw std::runtime_error(aar_last_error());
@@ -268,51 +293,80 @@ void MultiCamMapper::error_function(const eVector &input, eVector &error) {
     if (aar_eval_residuals(problem_, x.data(), error.data(), nullptr)) throw std::runtime_error(aar_last_error());
 }
 
+void MultiCamMapper::jacobian_function(const eVector &, SparseJacobian<double> &) {
+    if (probed(detail::EVAL_JACOBIAN_FUNCTION)) return;
+    throw std::logic_error("MultiCamMapper::jacobian_function: the Jacobian is analytic and lives on the device (k_passA / k_passB accumulate its blocks "
+                           "into J^T J); hand this function to SparseLevMarq::solve / step instead of calling it");
+}
+
+void MultiCamMapper::error_function_tracking(const eVector &, eVector &) {
+    if (probed(detail::EVAL_ERROR_FUNCTION_TRACKING)) return;
+    throw std::logic_error("MultiCamMapper::error_function_tracking: the per-frame residuals of tracking are evaluated inside k_track; hand this "
+                           "function to SparseLevMarq::solve(z, f) (or call track()) instead of calling it");
+}
+
 // optCallBack, libs/multicam_mapper.cpp:412-417: the Huber delta schedule, driven by the solver's step callback
 void MultiCamMapper::optCallBack(const eVector &) {
     if (hubberDelta > 2.5) hubberDelta -= 7.5 / 500;
     if (with_huber_ && problem_ && aar_problem_set_huber_delta(problem_, hubberDelta)) throw std::runtime_error(aar_last_error());
 }
 
-void MultiCamMapper::solve() {   // libs/multicam_mapper.cpp:419-428
+void MultiCamMapper::solve() {   // libs/multicam_mapper.cpp:419-428, statement for statement
     if (!data_) throw std::runtime_error("MultiCamMapper::solve: no data set");
-    if (ensure_problem()) throw std::runtime_error(aar_last_error());
+    using namespace std::placeholders;
     mats2eVec();
-    const std::vector<double> x_start = problem_vector();
-    solver.attach(problem_, x_start.data());
-    solver.setParams(solver_params);
-    solver.setStepCallBackFunc(std::bind(&MultiCamMapper::optCallBack, this, std::placeholders::_1), /*needs_z=*/false);
-    double e0 = 0;
-    if (aar_eval_residuals(problem_, x_start.data(), nullptr, &e0)) throw std::runtime_error(aar_last_error());
-    std::cout << "initial_error: " << e0 << "error size: " << 8 * data_->num_obs << std::endl;  // :424
+    solver.setParams(solver_params);   // (the reference installs them in init(), :326-330; a mirror's caller may edit solver_params until here)
+    solver.setStepCallBackFunc(std::bind(&MultiCamMapper::optCallBack, this, _1), /*needs_z=*/false);
+    {   // error_function(io_vec, error); cout << error.dot(error): the sum alone, without bringing 8N residuals to the host
+        std::vector<double> x_start;
+        aar_problem *pb = detail::bind_problem(this, x_start);
+        double e0 = 0;
+        if (aar_eval_residuals(pb, x_start.data(), nullptr, &e0)) throw std::runtime_error(aar_last_error());
+        std::cout << "initial_error: " << e0 << "error size: " << 8 * data_->num_obs << std::endl;  // :424
+    }
     hubberDelta = 10;
-    if (with_huber_ && aar_problem_set_huber_delta(problem_, hubberDelta)) throw std::runtime_error(aar_last_error());
-    solver.solve(io_vec);
+    solver.solve(io_vec, std::bind(&MultiCamMapper::error_function, this, _1, _2), std::bind(&MultiCamMapper::jacobian_function, this, _1, _2));
     last_report = solver.report;
     eVec2Mats(io_vec);
 }
 
-// track(): the reference refines ONE frame per call (apps/track.cpp:127-131 re-inits the mapper with the frame's detections
-// each time); here every frame held by the data set is refined in one launch, each with its own LM.
+// track(), libs/multicam_mapper.cpp:430-443.  The reference refines ONE frame per call (apps/track.cpp:127-131 re-inits the
+// mapper with the frame's detections each time); here every frame held by the data set is refined in one launch, each with
+// its own LM (detail::solve_tracking -> aar_track).
 void MultiCamMapper::track() {
     if (!data_) throw std::runtime_error("MultiCamMapper::track: no data set");
-    if (ensure_problem()) throw std::runtime_error(aar_last_error());
+    using namespace std::placeholders;
+    mats2eVec();
     hubberDelta = 10;  // :439
-    if (with_huber_ && aar_problem_set_huber_delta(problem_, hubberDelta)) throw std::runtime_error(aar_last_error());
+    solver.setParams(solver_params);
+    solver.solve(io_vec, std::bind(&MultiCamMapper::error_function_tracking, this, _1, _2));
+    eVec2Mats(io_vec);
+}
+
+namespace detail {
+double solve_tracking(MultiCamMapper *m, std::vector<double> &z) {
+    std::vector<double> x;
+    aar_problem *pb = bind_problem(m, x);
+    if (z.size() != m->get_num_vars(m->config_)) throw std::runtime_error("SparseLevMarq::solve: z has not the Config's number of variables");
+    if (aar_problem_merge_z(pb, z.data(), x.data())) throw std::runtime_error(aar_last_error());
     aar_lm_params p;
     aar_lm_default_params(&p);
-    p.max_iters = solver_params.maxIters;
-    p.min_error = solver_params.minError;
-    p.min_step_error_diff = solver_params.min_step_error_diff;
-    p.min_average_step_error_diff = solver_params.min_average_step_error_diff;
-    p.tau = solver_params.tau;
-    track_iterations.assign(data_->num_frames, 0);
-    track_errors.assign(data_->num_frames, 0.0);
-    std::vector<double> x = problem_vector();
-    if (aar_track(problem_, x.data(), &p, track_iterations.data(), track_errors.data())) throw std::runtime_error(aar_last_error());
-    memcpy(data_->x_full, x.data(), sizeof(double) * aar_dataset_full_len(data_));   // (only the frame poses have moved)
-    mats2eVec();
+    const SparseLevMarq<double>::Params &sp = m->solver._params;
+    p.max_iters = sp.maxIters;
+    p.min_error = sp.minError;
+    p.min_step_error_diff = sp.min_step_error_diff;
+    p.min_average_step_error_diff = sp.min_average_step_error_diff;
+    p.tau = sp.tau;
+    m->track_iterations.assign(m->data_->num_frames, 0);
+    m->track_errors.assign(m->data_->num_frames, 0.0);
+    if (aar_track(pb, x.data(), &p, m->track_iterations.data(), m->track_errors.data())) throw std::runtime_error(aar_last_error());
+    if (aar_problem_extract_z(pb, x.data(), z.data())) throw std::runtime_error(aar_last_error());   // (only the frame poses have moved)
+    memcpy(m->data_->x_full, x.data(), sizeof(double) * aar_dataset_full_len(m->data_));   // ... also when the Config keeps them out of z
+    double e = 0;
+    for (double v : m->track_errors) e += v;
+    return e;
 }
+}  // namespace detail
 
 bool MultiCamMapper::write_solution_file(std::string path) {
     if (!data_) return false;

@@ -18,10 +18,45 @@
 
 namespace aar {
 
+class MultiCamMapper;
+
+// Stand-in for Eigen::SparseMatrix<T> in the signature of a Jacobian function (libs/sparselevmarq.h:63): the Jacobian of the
+// accelerated path never exists as a host matrix -- its blocks are accumulated into J^T J on the device -- so the type only
+// keeps reference-shaped code compiling.
+template <typename T>
+struct SparseJacobian {
+    int64_t rows = 0, cols = 0;
+};
+
+namespace detail {
+// How the solver mirror recognises the evaluation functions it can run.  The reference's callers hand the solver
+// std::bind(&MultiCamMapper::error_function, this, _1, _2) and friends (libs/multicam_mapper.cpp:426,441), which reach the solver
+// type-erased.  The mirror calls such a callable ONCE with the probe below raised; the evaluation members of aar::MultiCamMapper
+// (error_function, jacobian_function, error_function_tracking) then answer with who they are instead of computing, and the
+// solver dispatches to the device path of that mapper (aar_lm_solve / aar_lm_step / aar_track).  A callable that does not
+// answer is a host function: the solver throws std::logic_error -- there is no CPU loop behind this class.
+enum EvalKind { EVAL_NONE = 0, EVAL_ERROR_FUNCTION = 1, EVAL_JACOBIAN_FUNCTION = 2, EVAL_ERROR_FUNCTION_TRACKING = 3 };
+struct EvalId {
+    MultiCamMapper *owner = nullptr;
+    int kind = EVAL_NONE;
+};
+struct EvalProbe {
+    bool active = false;
+    EvalId id;
+};
+EvalProbe &eval_probe();   // one per thread
+// the mapper's device problem (created on demand) and its full parameter vector for the current Config; throws on failure
+aar_problem *bind_problem(MultiCamMapper *owner, std::vector<double> &x_full);
+aar_problem *current_problem(const MultiCamMapper *owner);   // what the mapper holds right now (nullptr after a Config change)
+// MultiCamMapper::track() behind solve(z, error_function_tracking): every frame's own LM on the device; returns the summed final error
+double solve_tracking(MultiCamMapper *owner, std::vector<double> &z);
+}  // namespace detail
+
 // ucoslam::SparseLevMarq<T> (libs/sparselevmarq.h:26-141) over the C ABI: Params with the reference's field names, setParams,
-// init / step / getCurrentSolution, solve, setStepCallBackFunc, setStopFunction.  The evaluation functions f (error_function) and
-// J (jacobian_function) are the MAPPER'S OWN -- the HIP kernels of the attached aar_problem; solve(z, f, J) with arbitrary host
-// callbacks is not offered (a host-callback Jacobian cannot run on the device and a CPU loop would be a fallback path).
+// solve / init / step with the reference's signatures (:80,88,95-96,118), getCurrentSolution, setStepCallBackFunc, setStopFunction.
+// The evaluation functions must be aar::MultiCamMapper's own (see detail::EvalProbe): error_function + jacobian_function run as
+// the HIP kernels of that mapper's device problem, error_function_tracking as aar_track; any other callable -> std::logic_error.
+// solve(z, f) -- "automatic Jacobian" in the reference, central differences -- uses the same analytic device Jacobian.
 // z is the reference's parameter vector for the problem's Config (mats2eVec order).
 template <typename T>
 class SparseLevMarq {
@@ -29,6 +64,16 @@ class SparseLevMarq {
 
    public:
     struct Params {
+        Params() {}
+        // (sic) the reference's constructor stores _min_step_error_diff in BOTH step fields (libs/sparselevmarq.h:32-39)
+        Params(int _maxIters, T _minError, T _min_step_error_diff = 0, T /*_min_average_step_error_diff*/ = 0.001, T _tau = 1, T _der_epsilon = 1e-3) {
+            maxIters = _maxIters;
+            minError = _minError;
+            min_step_error_diff = _min_step_error_diff;
+            min_average_step_error_diff = _min_step_error_diff;
+            tau = _tau;
+            der_epsilon = _der_epsilon;
+        }
         int maxIters = 100;
         T minError = 1e-5;
         T min_step_error_diff = 0;
@@ -40,13 +85,47 @@ class SparseLevMarq {
         bool verbose = false;
     };
     typedef std::vector<T> eVector;
+    typedef std::function<void(const eVector &, eVector &)> F_z_x;
+    typedef std::function<void(const eVector &, SparseJacobian<T> &)> F_z_J;
 
-    // the device problem whose kernels stand for f and J; x_full supplies the groups the Config keeps fixed
+    // the device problem whose kernels stand for f and J; x_full supplies the groups the Config keeps fixed.  The overloads that
+    // take the evaluation functions attach by themselves; this is for callers that hold an aar_problem of their own.
     void attach(aar_problem *problem, const double *x_full) {
         problem_ = problem;
         x_.assign(x_full, x_full + aar_problem_full_len(problem));
     }
+    void detach() { problem_ = nullptr; }   // the problem is about to be destroyed
+    void setParams(int maxIters, T minError, T min_step_error_diff = 0, T tau = 1, T der_epsilon = 1e-3) {   // :259-266
+        _params.maxIters = maxIters;
+        _params.minError = minError;
+        _params.min_step_error_diff = min_step_error_diff;
+        _params.tau = tau;
+        _params.der_epsilon = der_epsilon;
+    }
     void setParams(const Params &p) { _params = p; }
+
+    T solve(eVector &z, F_z_x f_z_x, F_z_J f_J) {   // :80, :440-472
+        bind_eval(z, f_z_x, &f_J);
+        return solve(z);
+    }
+    T solve(eVector &z, F_z_x f_z_x) {   // :118, :474-477
+        if (bind_eval(z, f_z_x, nullptr) == detail::EVAL_ERROR_FUNCTION_TRACKING) return detail::solve_tracking(owner_, z);
+        return solve(z);
+    }
+    void init(eVector &z, F_z_x f_z_x) {   // :88, :238-249
+        if (bind_eval(z, f_z_x, nullptr) != detail::EVAL_ERROR_FUNCTION) throw std::logic_error("SparseLevMarq::init: the step-by-step mode runs MultiCamMapper::error_function only");
+        init(z);
+    }
+    bool step(F_z_x f_z_x, F_z_J f_J) {   // :95, :349-430
+        check_eval(f_z_x, &f_J);
+        return step();
+    }
+    bool step(F_z_x f_z_x) {   // :96, :250-256
+        check_eval(f_z_x, nullptr);
+        return step();
+    }
+
+    // the same entry points for a problem attached with attach(): no evaluation function to name
     T solve(eVector &z) {   // :440-472
         need();
         install();
@@ -89,6 +168,48 @@ class SparseLevMarq {
    private:
     void need() const { if (!problem_) throw std::runtime_error("SparseLevMarq: no problem attached"); }
     [[noreturn]] static void fail() { throw std::runtime_error(aar_last_error()); }
+    // call the callable once with the probe raised: who is it?
+    template <class Fn, class Out>
+    static detail::EvalId identify(const Fn &fn, const eVector &z) {
+        if (!fn) throw std::logic_error("SparseLevMarq: empty evaluation function");
+        detail::EvalProbe &p = detail::eval_probe();
+        p.active = true;
+        p.id = detail::EvalId();
+        Out out;
+        try { fn(z, out); } catch (...) { p.active = false; throw; }
+        p.active = false;
+        if (p.id.kind == detail::EVAL_NONE)
+            throw std::logic_error("SparseLevMarq: the evaluation function is not aar::MultiCamMapper's error_function / jacobian_function / "
+                                   "error_function_tracking; this solver runs those on the GPU and has no CPU loop for host callbacks");
+        return p.id;
+    }
+    static detail::EvalId identify_pair(const eVector &z, const F_z_x &f, const F_z_J *J) {
+        const detail::EvalId idf = identify<F_z_x, eVector>(f, z);
+        if (idf.kind == detail::EVAL_JACOBIAN_FUNCTION) throw std::logic_error("SparseLevMarq: a Jacobian function was passed as the error function");
+        if (J) {
+            const detail::EvalId idj = identify<F_z_J, SparseJacobian<T>>(*J, z);
+            if (idj.kind != detail::EVAL_JACOBIAN_FUNCTION || idj.owner != idf.owner || idf.kind != detail::EVAL_ERROR_FUNCTION)
+                throw std::logic_error("SparseLevMarq: error and Jacobian function must be error_function and jacobian_function of the same MultiCamMapper");
+        }
+        return idf;
+    }
+    // identify the pair and attach to their mapper's device problem; returns the kind of f
+    int bind_eval(const eVector &z, const F_z_x &f, const F_z_J *J) {
+        const detail::EvalId id = identify_pair(z, f, J);
+        owner_ = id.owner;
+        if (id.kind == detail::EVAL_ERROR_FUNCTION) problem_ = detail::bind_problem(owner_, x_);
+        return id.kind;
+    }
+    // step(f, J): the functions must be the ones init() was given
+    void check_eval(const F_z_x &f, const F_z_J *J) {
+        need();
+        const detail::EvalId id = identify_pair(eVector(), f, J);
+        if (id.owner != owner_ || id.kind != detail::EVAL_ERROR_FUNCTION) throw std::logic_error("SparseLevMarq::step: not the evaluation functions init() was called with");
+        if (detail::current_problem(owner_) != problem_) {   // a Config / data change of the mapper destroyed the problem init() ran on
+            problem_ = nullptr;
+            throw std::runtime_error("SparseLevMarq::step: the mapper's device problem has changed since init()");
+        }
+    }
     aar_lm_params c_params() const {
         aar_lm_params p;
         aar_lm_default_params(&p);
@@ -115,6 +236,7 @@ class SparseLevMarq {
         if (aar_lm_set_stop_function(problem_, stop_fn_ ? &stop_tramp : nullptr, this)) fail();
     }
     aar_problem *problem_ = nullptr;
+    MultiCamMapper *owner_ = nullptr;   // whose evaluation functions the last solve / init named
     std::vector<double> x_;
     eVector zbuf_;
     std::function<void(const eVector &)> step_cb_;
@@ -204,6 +326,14 @@ class MultiCamMapper {
     void solve();                                               // libs/multicam_mapper.cpp:419-428
     void track();                                               // :430-443, every frame of the data set at once
     void error_function(const eVector &input, eVector &error);  // :731-737
+    // :739-801 (private in the reference; public here so that reference-shaped caller code outside the class can bind it).  The
+    // Jacobian of the accelerated path is analytic and never leaves the device: called by the solver mirror's probe it names
+    // itself (detail::EvalProbe), called directly it throws std::logic_error.
+    void jacobian_function(const eVector &input, SparseJacobian<double> &J);
+    // :1021-1051, the residual of track(): recognised by SparseLevMarq::solve(z, f) (-> aar_track); a direct call throws
+    // std::logic_error (the per-frame residuals of tracking only exist inside k_track)
+    void error_function_tracking(const eVector &input, eVector &error);
+    void optCallBack(const eVector &v);                         // :412-417
     bool write_solution_file(std::string path);                 // :1053-1099
     bool read_solution_file(std::string path);                  // :1124-1205
     void write_text_solution_file(std::string text_path);       // :1233-1268
@@ -231,7 +361,10 @@ class MultiCamMapper {
     const aar_dataset *dataset() const { return data_; }
 
    private:
-    void optCallBack(const eVector &v);   // :412-417
+    friend aar_problem *detail::bind_problem(MultiCamMapper *, std::vector<double> &);
+    friend aar_problem *detail::current_problem(const MultiCamMapper *);
+    friend double detail::solve_tracking(MultiCamMapper *, std::vector<double> &);
+    bool probed(int kind);   // true: the solver mirror asked who this function is (and has been told)
     std::vector<double> problem_vector();
     void mats2eVec();
     void eVec2Mats(const eVector &v);

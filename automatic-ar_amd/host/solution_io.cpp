@@ -103,19 +103,14 @@ int aar_solution_write(const char *path, const aar_dataset *d) {
         // one record per camera of the data set, empty ones included: that is what the reference writes after its Initializer
         // (read_detections_file gives every frame an entry per camera slot, libs/initializer.cpp:333-347), and what its reader
         // needs -- it takes the c-th record of a frame for camera id c (:1117-1119)
-        std::vector<std::pair<int64_t, int64_t>> run(C, {0, 0});  // camera index -> [b,e)
-        for (int64_t o = fstart[i]; o < fstart[i + 1];) {
-            int64_t e = o;
-            while (e < fstart[i + 1] && d->obs_cam[e] == d->obs_cam[o]) e++;
-            run[d->obs_cam[o]] = {o, e};
-            o = e;
-        }
+        // (a frame's observations of one camera need not be contiguous in the caller's arrays: gather them, in order)
+        std::vector<std::vector<int64_t>> of_cam(C);
+        for (int64_t o = fstart[i]; o < fstart[i + 1]; o++) of_cam[d->obs_cam[o]].push_back(o);
         w.put<size_t>((size_t)C);
         for (int c = 0; c < C; c++) {
             w.put<int32_t>(d->cam_ids[c]);
-            w.put<size_t>((size_t)(run[c].second - run[c].first));
-            for (int64_t o = run[c].first; o < run[c].second; o++)
-                write_marker(w, d->marker_ids[d->obs_marker[o]], d->obs_uv + 8 * o);
+            w.put<size_t>(of_cam[c].size());
+            for (int64_t o : of_cam[c]) write_marker(w, d->marker_ids[d->obs_marker[o]], d->obs_uv + 8 * o);
         }
     }
     w.put<bool>(d->optimize_cam_poses != 0);

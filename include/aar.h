@@ -347,11 +347,15 @@ typedef struct aar_stage_times {
     int64_t launches;
 } aar_stage_times;
 int aar_get_stage_times(aar_problem *, aar_stage_times *);
+/* Stage timers on / off (also on with AAR_STAGE_TIMERS=1 in the environment when the problem is created): every stage of a
+ * step is then bracketed by two HIP events on the library's stream and waited for, which serialises host and device -- a
+ * diagnostic mode (bench.py's `amdahl` object, the verbose stage line), not the production path.  Resets the accumulators. */
+int aar_set_stage_timers(aar_problem *, int on);
 
 /* Per-kernel device time: when profiling is on, every kernel launch of this problem is bracketed by two HIP
  * events on the library's own stream (the stream the kernels run on) and the elapsed times are accumulated
  * per kernel.  bench.py's roofline figures come from here.  Switching profiling on resets the accumulators. */
-#define AAR_NUM_KERNELS 13
+#define AAR_NUM_KERNELS 14
 int aar_set_kernel_profiling(aar_problem *, int on);
 int aar_get_kernel_times(aar_problem *, double seconds[AAR_NUM_KERNELS], int64_t launches[AAR_NUM_KERNELS]);
 const char *aar_kernel_name(int kernel_id);

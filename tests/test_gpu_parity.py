@@ -779,7 +779,7 @@ def test_cpp_mirror_constructor_init_and_solver_seam(tmp_path):
 
 def test_unsupported_sizes_are_refused_collectively():
     # the two LDS-resident structures bound what a problem may look like: a frame that touches more than
-    # ~300 cameras+markers, more than ~560 cameras+markers in all -> AAR_ERR_UNSUPPORTED, never a wrong answer; on a sharded
+    # ~300 cameras+markers, more than ~560 cameras+markers in all ON THE OUTPUT-STATIONARY KERNEL -> AAR_ERR_UNSUPPORTED, never a wrong answer; on a sharded
     # problem EVERY rank gets the status, also the ranks whose own frames are fine (nobody is left waiting in a collective)
     def dataset(num_markers, wide_frame):
         ds = aar.Dataset()
@@ -806,9 +806,18 @@ def test_unsupported_sizes_are_refused_collectively():
     with pytest.raises(aar.AarError) as e:
         aar.Problem(dataset(400, 340))
     assert e.value.code == aar.AAR_ERR_UNSUPPORTED and "touches" in str(e.value)
-    with pytest.raises(aar.AarError) as e:
-        aar.Problem(dataset(700, 3))
-    assert e.value.code == aar.AAR_ERR_UNSUPPORTED and "exceed" in str(e.value)
+    # > ~560 cameras+markers: only the OUTPUT-STATIONARY Schur kernel keeps a row panel of all of them in LDS; the MFMA kernel
+    # (the default from 96 entities) has no such panel, so the problem is fine unless that kernel is ruled out -- switched off,
+    # or its dense panels over the memory budget
+    aar.Problem(dataset(700, 3)).close()
+    for knob, val in (("AAR_SCHUR_MFMA", "0"), ("AAR_SCHUR_PANEL_MB", "0")):
+        os.environ[knob] = val
+        try:
+            with pytest.raises(aar.AarError) as e:
+                aar.Problem(dataset(700, 3))
+            assert e.value.code == aar.AAR_ERR_UNSUPPORTED and "exceed" in str(e.value)
+        finally:
+            del os.environ[knob]
     aar.Problem(dataset(400, 280)).close()                 # inside both limits
 
     wide = dataset(400, 340)
@@ -888,3 +897,70 @@ def test_huber_schedule_with_a_rejected_try():
     assert abs(rep["iterations"] - int(g["analytic_iterations"][0])) <= 2
     rmse = np.sqrt(rep["final_err"] / (4 * ds.num_obs))
     assert abs(rmse - np.sqrt(float(g["analytic_final_err"][0]) / (4 * ds.num_obs))) < 1e-4
+
+
+def test_600_entities_take_the_mfma_schur_path_and_match_the_oracle(monkeypatch):
+    # 4 cameras + 596 markers: more shared entities than the output-stationary Schur kernel's LDS row panel holds (~560); the
+    # limit is that kernel's alone -- the dense-panel MFMA kernel (default from 96 entities) solves the problem, 38 tiles of LDL^T
+    ds = aar.synth(3, num_cams=4, num_markers=596, num_frames=24)
+    o = ol.Oracle(ds)
+    with aar.Problem(ds) as p:
+        r, ss = p.eval_residuals(ds.x_full)
+        assert np.array_equal(r, o.residuals(ds.x_full, res_mode=ol.RES_F32))
+        for mu in (1e5, 1e2):
+            d = p.eval_damped_step(ds.x_full, mu)
+            do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+            assert np.abs(d - do).max() / np.abs(do).max() < 1e-8, mu
+        x, rep = p.lm_solve(ds.x_full)
+        assert rep["iterations"] < 60 and rep["final_err"] < rep["initial_err"]
+    # ... and when the dense panels do not fit the memory budget the problem is refused (A > 560), while a problem the other
+    # kernel can hold falls back to it silently and gives the same step
+    monkeypatch.setenv("AAR_SCHUR_PANEL_MB", "0")
+    with pytest.raises(aar.AarError) as e:
+        aar.Problem(ds)
+    assert e.value.code == aar.AAR_ERR_UNSUPPORTED
+    ds2 = aar.synth(3, num_cams=4, num_markers=120, num_frames=24)
+    with aar.Problem(ds2) as p:       # budget 0 -> output-stationary kernel
+        d_os = p.eval_damped_step(ds2.x_full, 1e3)
+    monkeypatch.delenv("AAR_SCHUR_PANEL_MB")
+    with aar.Problem(ds2) as p:       # default: MFMA kernel (A = 124 >= 96)
+        d_mf = p.eval_damped_step(ds2.x_full, 1e3)
+    assert np.abs(d_os - d_mf).max() / np.abs(d_mf).max() < 1e-9
+
+
+def test_reference_shaped_solver_calls_compile_and_run_against_the_mirror(tmp_path):
+    # tests/tools/solver_seam_main.cpp: caller code in the shape of libs/multicam_mapper.cpp:419-443 -- solver.solve(io_vec,
+    # bind(&MultiCamMapper::error_function, ...), bind(&MultiCamMapper::jacobian_function, ...)), init(z, f) / step(f, J) / step(f),
+    # solve(z, bind(&MultiCamMapper::error_function_tracking, ...)) -- against aar::SparseLevMarq<double> / aar::MultiCamMapper
+    import subprocess
+    from conftest import PKG, ROOT
+    exe = str(tmp_path / "solver_seam_main")
+    cc = subprocess.run(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "tools", "solver_seam_main.cpp"), "-o", exe, "-L" + PKG, "-laar",
+                         "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe, "2"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr + run.stdout
+    kv = dict(l.split(" = ") for l in run.stdout.splitlines() if " = " in l)
+    ds = aar.synth(2)
+    # the reference-shaped call from outside the class is the mirror's own solve(): same iterations, same error, same z
+    assert int(kv["shaped_iterations"]) == int(kv["own_iterations"]) > 3
+    np.testing.assert_allclose(float(kv["shaped_final_err"]), float(kv["own_final_err"]), rtol=1e-9)
+    assert float(kv["shaped_return"]) == float(kv["shaped_final_err"]) and float(kv["shaped_vs_own_max_abs_z"]) < 1e-7
+    assert "initial_error: " in run.stdout and "error size: %d" % (8 * ds.num_obs) in run.stdout        # libs/multicam_mapper.cpp:424
+    # step-by-step: four steps from the start equal the first four iterations of a solve
+    with aar.Problem(ds, with_huber=False) as p:
+        _, rep = p.lm_solve(ds.x_full, params=aar.lm_default_params(max_iters=4), trace_cap=8)
+    assert int(kv["steps_accepted"]) == 4 and int(kv["steps_zlen"]) == ds.full_len
+    np.testing.assert_allclose(float(kv["steps_err"]), rep["trace"][3]["err"], rtol=1e-7)
+    # verbose: the reference's two lines per step, with its stage names (libs/sparselevmarq.h:421,425)
+    stage = [l for l in run.stderr.splitlines() if l.startswith(" J=")]
+    assert len(stage) == 2 and all(k in stage[0] for k in (" transpose=", " Jt*J=", " B=", " chol="))
+    assert sum(l.startswith("Curr Error=") and "dumping factor=" in l for l in run.stderr.splitlines()) == 2
+    vals = dict(t.split("=") for t in stage[0].split())
+    assert float(vals["J"]) > 0 and float(vals["chol"]) > 0 and float(vals["Jt*J"]) > 0
+    # host callbacks are refused (no CPU loop), mismatched owners too; the Jacobian function is not callable by hand; a solver
+    # whose device problem was destroyed by a Config change says so instead of using freed memory
+    assert kv["host_callback"] == "logic_error" and int(kv["host_callback_calls"]) == 1      # (called once: the probe)
+    assert kv["mixed_owners"] == "logic_error" and kv["direct_jacobian"] == "logic_error" and kv["stale_step"] == "runtime_error"
+    # track() in the reference's shape: every frame refined, z = the frame poses
+    assert int(kv["track_frames"]) == ds.num_frames and int(kv["track_zlen"]) == 6 * ds.num_frames and float(kv["track_max_err"]) < 100.0

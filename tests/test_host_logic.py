@@ -306,3 +306,47 @@ def test_cam_configs_in_readdir_order(tmp_path):
     by_readdir = [c[2][0] for c in aar.cam_configs_read(str(folder), readdir_order=True)]
     assert by_readdir == [{"cam_a": 1280, "cam_b": 1920, "cam_c": 640}[n] for n in listed]
     assert sorted(by_readdir) == sorted(by_name)
+
+
+def test_solution_writer_gathers_interleaved_cameras(tmp_path):
+    # a frame whose observations of one camera are NOT contiguous in the caller's arrays (camera 0, 1, 0 ...): every detection is
+    # written under its camera (the round trip comes back grouped by camera, nothing dropped)
+    ds = aar.synth(3, num_frames=6)
+    inter, nf0 = None, 0
+    for fr in range(ds.num_frames):           # the first frame in which ordering by marker breaks up the camera runs
+        f0 = np.nonzero(ds.obs_frame == fr)[0]
+        order = np.argsort(ds.obs_marker[f0], kind="stable")
+        cams = ds.obs_cam[f0][order]
+        if np.count_nonzero(np.diff(cams) != 0) + 1 > len(set(cams.tolist())):
+            inter = np.concatenate([np.arange(0, f0[0]), f0[order], np.arange(f0[-1] + 1, ds.num_obs)])
+            nf0, first = len(f0), f0[0]
+            break
+    assert inter is not None
+    mixed = aar.Dataset.__new__(aar.Dataset)
+    mixed.__dict__.update(ds.__dict__)
+    for k in ("obs_frame", "obs_cam", "obs_marker", "obs_uv"):
+        setattr(mixed, k, np.ascontiguousarray(getattr(ds, k)[inter]))
+    path = str(tmp_path / "mixed.solution")
+    aar.solution_write(path, mixed)
+    back = aar.solution_read(path)
+    assert back.num_obs == ds.num_obs
+    key = lambda d: sorted(zip(d.obs_frame.tolist(), d.obs_cam.tolist(), d.obs_marker.tolist(), map(tuple, d.obs_uv.tolist())))
+    assert key(back) == key(ds)
+    assert np.all(np.diff(back.obs_cam[first: first + nf0]) >= 0)        # grouped by camera again
+
+
+def test_host_code_under_address_and_ub_sanitizers(tmp_path):
+    # file formats, shard plan, detections / calibration readers (truncated and malformed inputs included) compiled with
+    # -fsanitize=address,undefined against stubs of the device entry points: the HOST code of the product, no GPU needed
+    import subprocess
+    from conftest import PKG, ROOT
+    exe = str(tmp_path / "asan_host_main")
+    host = [os.path.join(PKG, "host", f) for f in ("dataset.cpp", "synth.cpp", "solution_io.cpp", "cam_config.cpp", "initializer.cpp")]
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                         os.path.join(ROOT, "tests", "tools", "asan_host_main.cpp")] + host + ["-o", exe], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr and "LeakSanitizer" not in run.stderr
+    assert "obs " in run.stdout and "subseqs" in run.stdout

@@ -1,0 +1,131 @@
+// Test driver (not part of the product): caller code written in the shape of the reference's MultiCamMapper::solve() / track()
+// (libs/multicam_mapper.cpp:419-443) and of a step-by-step user of ucoslam::SparseLevMarq (libs/sparselevmarq.h:80-118), compiled
+// against the mirror classes of automatic-ar_amd/host/multicam_mapper.h.  Prints key = value lines for tests/test_gpu_parity.py.
+//   usage: solver_seam_main <config 1..5>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <iostream>
+
+#include "../../automatic-ar_amd/host/multicam_mapper.h"
+
+using namespace std;
+using namespace aar;
+namespace ucoslam { using aar::SparseLevMarq; }   // the reference's namespace for the solver
+
+// libs/multicam_mapper.cpp:419-428 with `this` spelled `m` (mats2eVec / eVec2Mats are private there and here: io_vec is read
+// from the mapper after a first solve() instead)
+static double reference_shaped_solve(MultiCamMapper *m, ucoslam::SparseLevMarq<double> &solver, ucoslam::SparseLevMarq<double>::eVector &io_vec) {
+    ucoslam::SparseLevMarq<double>::eVector error;
+    solver.setStepCallBackFunc(bind(&MultiCamMapper::optCallBack, m, placeholders::_1));
+    m->error_function(io_vec, error);
+    double dot = 0;
+    for (double v : error) dot += v * v;
+    cout << "initial_error: " << dot << "error size: " << error.size() << endl;
+    m->hubberDelta = 10;
+    return solver.solve(io_vec, bind(&MultiCamMapper::error_function, m, placeholders::_1, placeholders::_2),
+                        bind(&MultiCamMapper::jacobian_function, m, placeholders::_1, placeholders::_2));
+}
+
+int main(int argc, char **argv) {
+    const int cfg = argc > 1 ? atoi(argv[1]) : 2;
+    aar_synth_desc sd;
+    aar_synth_default(&sd, cfg);
+    aar_dataset *d = nullptr, *d2 = nullptr, *d3 = nullptr;
+    if (aar_synth_generate(&sd, &d) || aar_synth_generate(&sd, &d2) || aar_synth_generate(&sd, &d3)) { fprintf(stderr, "%s\n", aar_last_error()); return 1; }
+    try {
+        // ---- the mirror's own solve(): the baseline
+        MultiCamMapper a(d);
+        a.solver_params.verbose = false;
+        a.set_optmize_flag_cam_intrinsics(false);
+        // z of the Config "all poses, no intrinsics" = the data set's pose vector (mats2eVec order: cameras | markers | frames)
+        const MultiCamMapper::eVector z0(a.dataset()->x_full, a.dataset()->x_full + aar_dataset_full_len(a.dataset()));
+        a.solve();
+        printf("own_iterations = %d\nown_final_err = %.17g\n", a.last_report.iterations, a.last_report.final_err);
+
+        // ---- (1) solve(z, f, J) from OUTSIDE the class, a solver object of the caller's own
+        MultiCamMapper b(d2);
+        b.set_optmize_flag_cam_intrinsics(false);
+        ucoslam::SparseLevMarq<double> solver;
+        ucoslam::SparseLevMarq<double>::Params p = b.solver_params;
+        p.verbose = false;
+        solver.setParams(p);
+        ucoslam::SparseLevMarq<double>::eVector z = z0;
+        const double e1 = reference_shaped_solve(&b, solver, z);
+        printf("shaped_iterations = %d\nshaped_final_err = %.17g\nshaped_return = %.17g\n", solver.report.iterations, solver.report.final_err, e1);
+        double dz = 0;
+        for (size_t i = 0; i < z.size(); i++) dz = max(dz, fabs(z[i] - a.io_vec[i]));
+        printf("shaped_vs_own_max_abs_z = %.3e\n", dz);
+
+        // ---- (2) step-by-step mode: init(z, f), step(f, J), step(f), getCurrentSolution (libs/sparselevmarq.h:88,95-96,103)
+        auto f = bind(&MultiCamMapper::error_function, &b, placeholders::_1, placeholders::_2);
+        auto J = bind(&MultiCamMapper::jacobian_function, &b, placeholders::_1, placeholders::_2);
+        z = z0;
+        b.hubberDelta = 10;
+        solver.init(z, f);
+        int accepted = 0;
+        for (int i = 0; i < 3; i++) accepted += solver.step(f, J) ? 1 : 0;
+        accepted += solver.step(f) ? 1 : 0;
+        ucoslam::SparseLevMarq<double>::eVector zc;
+        const double e4 = solver.getCurrentSolution(zc);
+        printf("steps_accepted = %d\nsteps_err = %.17g\nsteps_zlen = %zu\n", accepted, e4, zc.size());
+
+        // ---- (3) verbose: the reference's two lines per step (libs/sparselevmarq.h:421,425), on stderr
+        p.verbose = true;
+        p.maxIters = 2;
+        solver.setParams(p);
+        z = z0;
+        solver.solve(z, f, J);
+        p.verbose = false;
+        p.maxIters = b.solver_params.maxIters;
+        solver.setParams(p);
+
+        // ---- (4) a host callback is refused, with std::logic_error, before anything runs
+        int host_calls = 0;
+        try {
+            z = z0;
+            solver.solve(z, [&](const ucoslam::SparseLevMarq<double>::eVector &, ucoslam::SparseLevMarq<double>::eVector &x) { host_calls++; x.assign(8, 0.0); });
+            printf("host_callback = accepted\n");
+        } catch (const std::logic_error &e) {
+            printf("host_callback = logic_error\nhost_callback_calls = %d\n", host_calls);
+        }
+        try {   // error function of one mapper with the Jacobian of another
+            solver.solve(z, bind(&MultiCamMapper::error_function, &a, placeholders::_1, placeholders::_2), J);
+            printf("mixed_owners = accepted\n");
+        } catch (const std::logic_error &) { printf("mixed_owners = logic_error\n"); }
+        try {   // the Jacobian function is not callable by hand
+            SparseJacobian<double> sj;
+            b.jacobian_function(z0, sj);
+            printf("direct_jacobian = returned\n");
+        } catch (const std::logic_error &) { printf("direct_jacobian = logic_error\n"); }
+
+        // ---- (5) a Config change destroys the device problem: the solver must notice, not use freed memory
+        b.solver.setParams(p);
+        z = z0;
+        b.solver.init(z, f);
+        b.set_optmize_flag_cam_poses(false);   // drop_problem()
+        try {
+            b.solver.step();
+            printf("stale_step = ran\n");
+        } catch (const std::runtime_error &) { printf("stale_step = runtime_error\n"); }
+        b.set_optmize_flag_cam_poses(true);
+
+        // ---- (6) track() in the reference's shape (:430-443): solve(z, error_function_tracking)
+        MultiCamMapper c(d3);
+        c.set_optmize_flag_cam_intrinsics(false);
+        c.set_optmize_flag_cam_poses(false);
+        c.set_optmize_flag_marker_poses(false);
+        const int64_t nshared = 6LL * (c.dataset()->num_cams - 1 + c.dataset()->num_markers - 1);
+        ucoslam::SparseLevMarq<double>::eVector zt(c.dataset()->x_full + nshared, c.dataset()->x_full + aar_dataset_full_len(c.dataset()));   // the frame poses
+        c.hubberDelta = 10;
+        const double et = c.solver.solve(zt, bind(&MultiCamMapper::error_function_tracking, &c, placeholders::_1, placeholders::_2));
+        double emax = 0;
+        for (double v : c.track_errors) emax = max(emax, v);
+        printf("track_frames = %zu\ntrack_sum_err = %.17g\ntrack_max_err = %.6g\ntrack_zlen = %zu\n", c.track_errors.size(), et, emax, zt.size());
+    } catch (const std::exception &e) {
+        fprintf(stderr, "exception: %s\n", e.what());
+        return 2;
+    }
+    return 0;
+}
