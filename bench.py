@@ -68,25 +68,38 @@ def kernel_source_hash():
 KERNEL_BOUND = {
     "k_passA": "fp64_valu", "k_passB": "fp64_valu", "k_residual": "fp64_valu", "k_track": "fp64_valu",
     "k_schur": "fp64_valu",            # output-stationary kernel: VALU + LDS atomics (the opt-in AAR_SCHUR_MFMA kernel: fp64_mfma)
-    "k_ldl_update": "fp64_mfma", "k_ldl_trsm": "fp64_mfma",
+    "k_ldl_update": "fp64_mfma", "k_ldl_trsm": "fp64_mfma", "k_ldl_panel": "fp64_mfma",
     "k_ldl_diag": "latency", "k_ldl_backsolve": "latency", "k_reduce_scalars": "latency", "k_maxdiag": "latency",
     "k_backsub": "hbm", "k_frame_inv": "hbm", "k_unpack": "hbm",
 }
+
+
+FUSED_PANEL_M = int(os.environ.get("AAR_FUSED_PANEL", "2"))     # block columns with at most this many tiles below the diagonal take k_ldl_panel
+
+
+def _stages(n_pad):
+    """(tiles below the diagonal) of every block column that has a panel, split by the kernel(s) that handle it."""
+    nT = max(1, n_pad // 96)
+    ms = [nT - s - 1 for s in range(nT - 1)]
+    return [m for m in ms if m > FUSED_PANEL_M], [m for m in ms if 0 < m <= FUSED_PANEL_M]
 
 
 def algorithmic_flops(kernel, N, n_pad, sum_kf2, merged_passes):
     """fp64 flops of ONE launch, SURVEY.md 8d's F_iter split by kernel: 4800 per observation for the Jacobian / normal-equation
     work (2600 in pass A incl. the residual, 2200 in pass B, which recomputes projection and Jacobian), 6 s_f^2 = 216 k_f^2 per frame
     for the Schur complement, n^3/3 for the dense LDL^T (per tile: NB^3/3 in the diagonal kernel, rows x NB^2 in the panel solve,
-    rows^2 x NB in the trailing update; averaged over the tile steps)."""
-    nT, NB = max(1, n_pad // 96), 96.0
-    steps = range(nT - 1)
+    rows^2 x NB in the trailing update -- both in ONE launch for the block columns k_ldl_panel handles; averaged over the
+    launches of each kernel)."""
+    NB = 96.0
+    split, fused = _stages(n_pad)
+    avg = lambda v: (sum(v) / len(v)) if v else 0.0
     tab = {
         "k_passA": (4800.0 if merged_passes else 2600.0) * N, "k_passB": 2200.0 * N, "k_residual": 400.0 * N,
         "k_schur": 216.0 * sum_kf2,
         "k_ldl_diag": NB ** 3 / 3.0,
-        "k_ldl_trsm": (sum((n_pad - NB * (s + 1)) * NB * NB for s in steps) / max(1, nT - 1)),
-        "k_ldl_update": (sum((n_pad - NB * (s + 1)) ** 2 * NB for s in steps) / max(1, nT - 1)),
+        "k_ldl_trsm": avg([m * NB * NB * NB for m in split]),
+        "k_ldl_update": avg([(m * NB) ** 2 * NB for m in split]),
+        "k_ldl_panel": avg([m * NB * NB * NB + (m * NB) ** 2 * NB for m in fused]),
         "k_ldl_backsolve": 2.0 * n_pad * n_pad / 2.0,
     }
     return tab.get(kernel, 0.0)
@@ -97,9 +110,9 @@ def algorithmic_bytes(kernel, N, A, F, n_pad):
     the dense factorisation kernels are charged the tiles of the reduced system they must read and write once."""
     P = 6 * (A + F)
     rec = 44 * N
-    nT = max(1, n_pad // 96)
     tile = 8 * 96 * 96
-    avg_rows = (nT + 1) / 2.0                      # row tiles in an average block column (diagonal included)
+    split, fused = _stages(n_pad)
+    avg = lambda v: (sum(v) / len(v)) if v else 0.0
     table = {
         "k_passA": rec + 8 * P,                       # every record once + the pose vector
         "k_passB": rec + 8 * P + 8 * (n_pad * n_pad // 2 + n_pad),   # + the shared system it accumulates (lower triangle)
@@ -107,12 +120,31 @@ def algorithmic_bytes(kernel, N, A, F, n_pad):
         "k_unpack": 8 * P,
         "k_schur": 8 * (n_pad * n_pad // 2 + n_pad),  # frame-owned W/V traffic is overhead, not algorithmic
         "k_ldl_diag": tile,                           # lower triangle of the diagonal tile in, lower triangle of its factor out
-        "k_ldl_trsm": 2 * tile * (avg_rows - 1) + tile,             # the block column below the diagonal in/out + L_ss
-        "k_ldl_update": 2 * 8 * (n_pad * n_pad // 2) / max(1, nT - 1) if nT > 1 else 0,   # trailing matrix, amortised over the steps
+        "k_ldl_trsm": avg([2 * tile * m + tile for m in split]),                   # the block column below the diagonal in/out + L_ss
+        "k_ldl_update": avg([tile * m + 2 * tile * m * (m + 1) / 2 for m in split]),   # the block column in, the trailing tiles in/out
+        "k_ldl_panel": avg([2 * tile * m + tile + 2 * tile * m * (m + 1) / 2 for m in fused]),   # both of the above in one launch
         "k_ldl_backsolve": 8 * (n_pad * n_pad // 2 + 2 * n_pad),
         "k_frame_inv": 8 * 48 * F * 2, "k_backsub": 8 * P * 2, "k_reduce_scalars": 8 * 3 * F, "k_maxdiag": 8 * (n_pad + 6 * F),
     }
     return table.get(kernel, 0)
+
+
+def amdahl_split(stage_times, steps, world):
+    """Where a step's device time goes, from the library's stage timers (aar_get_stage_times; a separate, instrumented pass: every
+    stage is bracketed by HIP events and waited for).  replicated = what EVERY rank does in full whatever the rank count (the dense
+    LDL^T chain of the reduced system and its back-substitution, the host's accept / reject turn-around), sharded = what divides by
+    the rank count (observation passes, per-frame Schur terms, frame back-substitution), collective = pack + all-reduce + unpack
+    (zero without a communicator).  bound_at[n] = the speed-up over one GPU that these measured components allow at n GPUs if
+    the sharded part scales perfectly and the collective costs what it costs here -- an upper bound, not a prediction of RCCL."""
+    us = lambda k: 1e6 * stage_times.get(k, 0.0) / max(1, steps)
+    rep = us("chol") + us("control")
+    shard = (us("jacobian_normal_eq") + us("schur") + us("backsub") + us("unpack") + us("residual")) * world   # (per-rank time x ranks = the one-GPU work)
+    coll = us("allreduce")
+    one_gpu = rep + shard
+    out = {"replicated_us": rep, "sharded_us_one_gpu": shard, "collective_us": coll, "n_gpus": world,
+           "source": "aar_get_stage_times over %d instrumented steps (event-bracketed stages, host waits between them: the sum exceeds ms_per_step)" % steps,
+           "bound_at": {str(n): one_gpu / (rep + shard / n + (coll if n > 1 else 0.0)) for n in (1, 2, 4, 8)}}
+    return out
 
 
 def cpu_baseline(ds, workload, max_threads):
@@ -235,6 +267,9 @@ def main():
     ap.add_argument("--workload", type=int, default=3, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--intrinsics", action="store_true", help="the reference's default Config: optimize_cam_intrinsics on (9 more parameters per camera, "
+                    "libs/multicam_mapper.h:75-81); the headline metric is quoted WITHOUT it (SURVEY.md section 8 row f4)")
+    ap.add_argument("--no-amdahl", action="store_true", help="skip the stage-timer pass behind the `amdahl` object")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher / rendezvous / JSON relay only, no GPU work (CPU test of the N-rank plumbing)")
     args = ap.parse_args()
 
@@ -269,7 +304,9 @@ def main():
         if dist is not None:
             dist.broadcast_object_list(uid, src=0)
         comm = aar.Comm(uid[0], world, rank, local_rank)
-    problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm)
+    problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics)
+    # x_full of the default Config: the pose vector, then fx cx fy cy d0..d4 per camera (fill_io_vec_cam_intrinsics, :488-498)
+    x0 = problem.x_with_intrinsics(ds.x_full) if args.intrinsics else ds.x_full
 
     def barrier():
         aar.lib().aar_device_synchronize()
@@ -286,17 +323,17 @@ def main():
     t_w, n_w = time.perf_counter(), 0
     # (with several ranks every solve is collective: a FIXED count then, the same on every rank, never a clock)
     while (n_w < 12) if comm is not None else (time.perf_counter() - t_w < 0.05):
-        problem.lm_solve(ds.x_full, params=params(), trace_cap=1)
+        problem.lm_solve(x0, params=params(), trace_cap=1)
         n_w += 1
     aar.lib().aar_device_synchronize()
     wakeup = {"seconds": round(time.perf_counter() - t_w, 4), "solves": n_w}
     # ---- warmup (untimed) ----
     if args.warmup > 0:
-        run_steps(problem, ds.x_full, args.warmup, params)
+        run_steps(problem, x0, args.warmup, params)
     # ---- timed region: exactly K steps ----
     barrier()
     t0 = time.perf_counter()
-    done, trials, _, _ = run_steps(problem, ds.x_full, args.steps, params)
+    done, trials, _, _ = run_steps(problem, x0, args.steps, params)
     aar.lib().aar_device_synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -307,15 +344,16 @@ def main():
     assert done == args.steps
 
     # ---- full solve for the accuracy half of the metric ----
-    x_fin, rep_fin = problem.lm_solve(ds.x_full, params=params())
+    x_fin, rep_fin = problem.lm_solve(x0, params=params())
     rmse, ss = problem.reproj_stats(x_fin)
 
     # ---- per-kernel device time: a second, instrumented pass over the same steps (HIP events on the library's stream) ----
     roofline, kernels = None, None
-    A, F, n_pad = ds.num_cams + ds.num_markers, ds.num_frames, ((6 * (ds.num_cams + ds.num_markers) + 95) // 96) * 96
+    A = ds.num_cams + ds.num_markers + (ds.num_cams if args.intrinsics else 0)     # an intrinsics entity per camera (fx cx fy cy + 2 idle)
+    F, n_pad = ds.num_frames, ((6 * A + 95) // 96) * 96
     if not args.no_kernel_profile:
         problem.set_kernel_profiling(True)
-        run_steps(problem, ds.x_full, args.steps, params)
+        run_steps(problem, x0, args.steps, params)
         kt = problem.kernel_times()
         problem.set_kernel_profiling(False)
         kernels = {k: {"total_ms": 1e3 * s, "launches": c, "avg_us": (1e6 * s / c if c else None)} for k, (s, c) in kt.items() if c}
@@ -325,7 +363,7 @@ def main():
         kf = np.array([len(set(ds.obs_cam[a:b].tolist())) + len(set(ds.obs_marker[a:b].tolist()))
                        for a, b in zip(*(lambda st: (st[:-1], st[1:]))(np.searchsorted(ds.obs_frame, np.arange(ds.num_frames + 1))))], dtype=np.float64)
         sum_kf2 = float((kf ** 2).sum()) / max(1, world)
-        pmc, traffic_tab, src_hash = os.path.join(ROOT, "profiles", "pmc_traffic.json"), {}, kernel_source_hash()
+        pmc, traffic_tab, src_hash, rocprof_avg = os.path.join(ROOT, "profiles", "pmc_traffic.json"), {}, kernel_source_hash(), {}
         traffic_note = "no PMC collection for this build (profiles/pmc_traffic.json absent)"
         if os.path.exists(pmc):
             try:
@@ -334,6 +372,7 @@ def main():
                     traffic_note = "no PMC pass was collected for this workload (profiles/pmc_traffic.json holds workloads 3 and 5)"
                 elif tr.get("_kernel_source_sha1") == src_hash:
                     traffic_tab, traffic_note = tr, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel sources (%s)" % tr.get("_source")
+                    rocprof_avg = {("k_passA" if kk == "k_passAB" else kk): vv for kk, vv in tr.get("_rocprofv3_avg_us", {}).items()}
                 else:
                     traffic_note = "profiles/pmc_traffic.json was collected for other kernel sources (%s): not attached" % str(tr.get("_kernel_source_sha1"))[:12]
             except Exception as e:
@@ -348,31 +387,51 @@ def main():
             kind = KERNEL_BOUND.get(k, "hbm")
             if k == "k_schur" and (A >= 96 or os.environ.get("AAR_SCHUR_MFMA") == "1") and os.environ.get("AAR_SCHUR_MFMA") != "0":
                 kind = "fp64_mfma"     # from 96 shared entities on: dense panels through the fp64 matrix pipes (k_schur_fill + k_schur_mfma)
-            r = {"kernel": k, "bound_detail": kind, "avg_us": kernels[k]["avg_us"], "bytes_per_launch": by, "flops_per_launch": fl,
+            r = {"kernel": k, "avg_us": kernels[k]["avg_us"], "bytes_per_launch": by, "flops_per_launch": fl,
                  "hbm": {"achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": by / avg_s / 1e9 / HBM_PEAK_GBPS},
                  "fp64": {"achieved": fl / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / FP64_PEAK_TFLOPS},
                  "traffic": traffic_tab.get("k_passAB" if (k == "k_passA" and merged) else k)}
             if k == "k_schur" and r["traffic"] is None and "k_schur_mfma" in traffic_tab:      # two kernels behind one launcher
                 r["traffic"] = traffic_tab["k_schur_mfma"] + traffic_tab.get("k_schur_fill", 0.0)
-            # the contract's four fields: the roofline that applies to this kernel.  Arithmetic-bound kernels (vector or matrix
-            # pipes: the same 78.6 TFLOP/s fp64 peak on this chip) and the single-workgroup chains (whose useful work is fp64
-            # arithmetic; their real bound is the dependent chain, bound_detail = "latency") are priced in TFLOP/s, the rest in GB/s
+            # the contract's fields, priced against the roofline that applies to this kernel: `bound` says which -- "hbm" (GB/s),
+            # "fp64_valu" / "fp64_mfma" (TFLOP/s against the 78.6 TFLOP/s fp64 peak of the vector / matrix pipes), or "latency": a
+            # single-workgroup dependent chain, for which a throughput fraction says nothing -- its useful flops over its duration
+            # are reported when it has any (k_ldl_diag), and `frac` is left out when it has none
             view = r["hbm"] if kind == "hbm" else r["fp64"]
-            r.update(bound="hbm" if kind == "hbm" else "mfma", achieved=view["achieved"], peak=view["peak"], unit=view["unit"], frac=view["frac"])
+            r.update(bound=kind, achieved=view["achieved"], peak=view["peak"], unit=view["unit"], frac=view["frac"])
+            if kind == "latency" and fl == 0.0:
+                for f in ("achieved", "peak", "unit", "frac"):
+                    r.pop(f)
+            if k in rocprof_avg:
+                r["avg_us_rocprofv3"] = rocprof_avg[k]     # the same kernel under rocprofv3 --kernel-trace --stats (profiles/, same sources)
             return r
         roofline = roof(dom)
         roofline["traffic_source"] = traffic_note
         roofline["kernel_source_sha1"] = src_hash
         roofline["observation_pass"] = roof("k_passA")     # the streaming scan the north star prices against HBM
-        roofline["per_kernel"] = {k: {f: v for f, v in roof(k).items() if f in ("bound", "bound_detail", "achieved", "peak", "unit", "frac", "avg_us", "traffic")}
+        roofline["per_kernel"] = {k: {f: v for f, v in roof(k).items() if f in ("bound", "achieved", "peak", "unit", "frac", "avg_us", "avg_us_rocprofv3", "traffic")}
                                   for k in kernels if k in KERNEL_BOUND}
         tj = (kernels["k_passA"]["avg_us"] + (kernels["k_passB"]["avg_us"] if "k_passB" in kernels else 0.0)) * 1e-6
         roofline["fp64_valu"] = {"kernels": "k_passA+k_passB" if not merged else "k_passA (passes A and B in one launch)", "achieved": 4800.0 * n_loc / tj / 1e12,
                                  "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 4800.0 * n_loc / tj / 1e12 / FP64_PEAK_TFLOPS, "flops_per_observation": 4800}
 
+    # ---- where the step's time goes by how it scales with the rank count: a third, stage-timed pass ----
+    amdahl = None
+    if not args.no_amdahl:
+        n_am = min(args.steps, 300)
+        problem.set_stage_timers(True)
+        acc, done_am = {}, 0
+        while done_am < n_am:
+            _, rep_am = problem.lm_solve(x0, params=params(max_iters=n_am - done_am), trace_cap=1)
+            for kk, vv in problem.stage_times().items():
+                acc[kk] = acc.get(kk, 0.0) + vv
+            done_am += rep_am["iterations"]
+        problem.set_stage_timers(False)
+        amdahl = amdahl_split(acc, done_am, world)
+
     # ---- next-row extra (not the headline metric): track(), every frame's own 6-DoF LM in one launch ----
     track = None
-    if world == 1:
+    if world == 1 and not args.intrinsics:
         ns = 6 * (ds.num_cams - 1) + 6 * (ds.num_markers - 1)
         x_tr = np.array(x_fin)
         x_tr[ns:] = ds.x_full[ns:]                 # cameras / markers at the solution, frame poses back at the initial guess
@@ -409,11 +468,12 @@ def main():
         "config": {"workload": WORKLOADS[args.workload], "survey_config": args.workload, "cams": ds.num_cams, "markers": ds.num_markers,
                    "frames": ds.num_frames, "marker_observations": int(ds.num_obs), "residual_rows": int(8 * ds.num_obs), "unknowns": int(P),
                    "reduced_unknowns": int(Ps), "parallelism": "frames sharded over %d GPU(s)" % world, "seed": 20190219 + args.workload,
-                   "residual_mode": "float32-faithful", "jacobian": "analytic"},
+                   "residual_mode": "float32-faithful", "jacobian": "analytic",
+                   "optimize_cam_intrinsics": bool(args.intrinsics)},
         "final_rmse_px": rmse, "final_sum_sq": ss, "lm_iterations_to_stop": rep_fin["iterations"], "trial_points_per_step": t_avg,
         "iteration_hbm": {"bytes_per_iteration": b_iter, "achieved": b_iter * done / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                           "frac": b_iter * done / dt / 1e9 / HBM_PEAK_GBPS},
-        "roofline": roofline, "kernels": kernels, "track": track,
+        "roofline": roofline, "kernels": kernels, "amdahl": amdahl, "track": track,
         # multi-GPU bookkeeping: ranks RCCL itself reports for the communicator, observations per rank (frame-range shards
         # balanced by observation count), payload of ONE all-reduce of the reduced system (packed lower triangle | rhs | g0 | scalars)
         "ranks_seen": comm_stats["ranks_seen"] if comm_stats else 1, "local_obs": per_rank_obs,

@@ -1,7 +1,10 @@
 """Fold two rocprofv3 --pmc runs (FETCH_SIZE, WRITE_SIZE; separate passes, as the TCC slot budget requires) into
 profiles/pmc_traffic.json: HBM bytes per launch for every kernel.
 
-    python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <tag>
+    python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <tag> [<kernel_stats.csv>]
+
+With the fifth argument (the rocprofv3 --kernel-trace --stats summary of the same command) the per-kernel average durations are
+recorded as well (`_rocprofv3_avg_us`); bench.py prints them beside its own HIP-event averages.
 
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (section HBM): the counters are in KB;
 FETCH_SIZE reports exactly half of the bytes of a wide coalesced read stream, so the read side is doubled; WRITE_SIZE is
@@ -25,6 +28,7 @@ def per_kernel(path):
 
 def main():
     fetch, write, workload, tag = sys.argv[1:5]
+    stats = sys.argv[5] if len(sys.argv) > 5 else None
     f, w = per_kernel(fetch), per_kernel(write)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_path = os.path.join(root, "profiles", "pmc_traffic.json")
@@ -41,6 +45,12 @@ def main():
         entry[k] = (2.0 * fk + wk) * 1024.0
         entry["raw_" + k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "launches": n}
         rows.append((k, n, fk, wk, entry[k]))
+    if stats:
+        entry["_rocprofv3_avg_us"] = {}
+        for row in csv.DictReader(open(stats)):
+            k = row["Name"].split("(")[0].replace("void ", "").replace("aar::", "").split("<")[0]
+            if k.startswith("k_"):
+                entry["_rocprofv3_avg_us"][k] = float(row["AverageNs"]) * 1e-3
     data["workload_%s" % workload] = entry
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
     with open(os.path.join(root, "profiles", "%s_pmc_summary.csv" % tag), "w") as fh:

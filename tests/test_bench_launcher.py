@@ -52,3 +52,24 @@ def test_single_rank_needs_no_launcher():
 def test_world_size_mismatch_is_refused():
     out = run(["--gpus", "4", "--plumbing-only"], {"WORLD_SIZE": "2", "RANK": "0"})
     assert out.returncode != 0 and "WORLD_SIZE=2" in (out.stderr + out.stdout)
+
+
+def test_amdahl_object_and_kernel_models():
+    # the `amdahl` object of the bench line: replicated / sharded / collective microseconds per step from the stage timers and the
+    # speed-up bound they allow at 1, 2, 4, 8 GPUs (pure arithmetic, checked here on made-up stage times)
+    sys.path.insert(0, ROOT)
+    import bench
+    st = {"chol": 90e-6 * 100, "control": 0.0, "jacobian_normal_eq": 14e-6 * 100, "schur": 20e-6 * 100, "backsub": 6e-6 * 100, "allreduce": 0.0}
+    a = bench.amdahl_split(st, 100, 1)
+    assert abs(a["replicated_us"] - 90.0) < 1e-9 and abs(a["sharded_us_one_gpu"] - 40.0) < 1e-9 and a["collective_us"] == 0.0 and a["n_gpus"] == 1
+    assert abs(a["bound_at"]["1"] - 1.0) < 1e-12 and abs(a["bound_at"]["8"] - 130.0 / 95.0) < 1e-9      # Amdahl: (90 + 40) / (90 + 40 / 8)
+    b = bench.amdahl_split(dict(st, allreduce=17e-6 * 100, jacobian_normal_eq=7e-6 * 100, schur=10e-6 * 100, backsub=3e-6 * 100), 100, 2)   # a 2-rank run
+    assert abs(b["sharded_us_one_gpu"] - 40.0) < 1e-9 and abs(b["collective_us"] - 17.0) < 1e-9
+    assert abs(b["bound_at"]["2"] - 130.0 / (90.0 + 20.0 + 17.0)) < 1e-9
+    # every kernel the library can time has a bound and a flop / byte model; k_ldl_panel is priced as panel solve + trailing update
+    assert bench.KERNEL_BOUND["k_ldl_panel"] == "fp64_mfma" and bench.KERNEL_BOUND["k_ldl_diag"] == "latency"
+    nb3 = 96.0 ** 3
+    assert bench.algorithmic_flops("k_ldl_panel", 0, 288, 0.0, True) == ((2 * nb3 + 4 * nb3) + (nb3 + nb3)) / 2      # m = 2 and m = 1
+    assert bench.algorithmic_flops("k_ldl_trsm", 0, 288, 0.0, True) == 0.0                                           # no split stage at three tiles
+    assert bench.algorithmic_flops("k_ldl_trsm", 0, 1344, 0.0, True) == sum(m * nb3 for m in range(3, 14)) / 11.0
+    assert bench.algorithmic_bytes("k_ldl_panel", 0, 48, 500, 288) > bench.algorithmic_bytes("k_ldl_diag", 0, 48, 500, 288)
