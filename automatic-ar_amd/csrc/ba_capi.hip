@@ -591,11 +591,13 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     }
     pb->s_reduced = false;      // the factorisation below consumes the system
     pb->trial_reduced = false;
+    bool backsub_rode = false;
     {
         StageTimer t(pb, &pb->times.chol);
-        launch_chol(P, cur, mu, pb->stream);
+        // (stage timers keep the frame back-substitution in its own launch, so that it has a time of its own)
+        backsub_rode = launch_chol(P, cur, mu, pb->stream, pb->stage_timers ? -1 : tr);
     }
-    {
+    if (!backsub_rode) {
         StageTimer t(pb, &pb->times.backsub);
         launch_backsub(P, cur, tr, pb->stream);
     }

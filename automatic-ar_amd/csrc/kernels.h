@@ -137,7 +137,8 @@ void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t 
 // launch (true is returned if it did)
 bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq = 0, int ride_n_err = 0,
                   double *ride_scal = nullptr);   // ride_scal: the rider leaves the scalars there and does not publish
-void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st);    // damping + LDL^T + both substitutions -> delta_s
+// damping + LDL^T + both substitutions -> delta_s; trial >= 0: launch_backsub(which, trial) may ride in the last launch (true: it did)
+bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial = -1);
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st,
                            double *scal_out = nullptr);  // scal[0..2], scal[5..6] (into scal_out instead of P.scal if given)

@@ -430,6 +430,25 @@ __device__ unsigned long long g_tl[3 * 16 * 5];   // per-step timeline of three 
 #define TL_DUMP do { } while (0)
 #endif
 
+// Hand-over of a small vector between workgroups of one launch WITHOUT cache-maintenance fences.  A release / acquire pair at agent
+// scope costs a write-back of the XCD's L2 plus an invalidate: 4.3-5.4 us per hop from a 1024-thread workgroup, measured
+// (scripts/probe/hop_probe.hip) -- more than a kernel boundary (2.9 us).  When the payload itself travels as relaxed agent-scope
+// atomic stores / loads (sc1: written through and read past the XCD's L2) nothing needs to be flushed: the writer drains its own
+// stores (s_waitcnt) and raises the flag, the reader polls the flag and then loads: 1.1 us per hop for up to 8 KB.
+__device__ __forceinline__ void hop_publish(int32_t *flag, int value, bool leader) {   // whole wavefront; its payload stores were atomic (agent)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (leader) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool hop_wait(const int32_t *flag, int value) {   // one thread; false = gave up (the caller raises an error flag)
+    long spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1L << 24)) return false;
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
 constexpr int NB = CHOL_NB;
 constexpr int SBK = 16;           // sub-block of the triangular solves
 constexpr int NSB = NB / SBK;     // 6
@@ -551,6 +570,140 @@ __device__ __forceinline__ void bs_sweep(const double *__restrict__ Ls, const do
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Frame back-substitution, one wavefront per frame: delta_f = (V_f+mu I)^-1 (g_f - sum_a W_af^T delta_a);
+// z_trial = z_cur + delta; per-frame pieces of L = 0.5 delta^T (mu delta - B) (libs/sparselevmarq.h:406).
+// The last workgroup updates the shared (camera / marker) parameters.
+// Runs as a kernel of its own (k_backsub) or as extra workgroups of the LAST diagonal tile's launch (systems of up to three tiles):
+// there the workgroups fetch everything that does not depend on delta_s -- the frame's W blocks, g_f, V_f^-1 -- while the tile is
+// still being factored next door, wait for ONE flag (hop_wait: delta_s travels as agent-scope atomics) and only then gather
+// delta_s: a 1.1 us hand-over instead of a kernel boundary and a cold fetch.
+// ------------------------------------------------------------------------------------------------
+struct BacksubArgs {
+    const int32_t *fslot_start, *fslot_ent;
+    const double *W, *Vinv, *gf, *g0, *delta_s, *zc;
+    double *zt;
+    int A, F, n_frame_blocks;
+    double *lin_part, *ent_out;
+    int k_ent0;
+};
+
+// blk = workgroup index among the back-substitution workgroups; wave-uniform `wave`, `nwaves` wavefronts per workgroup;
+// flag != nullptr: delta_s is not in memory before flag[0] == epoch
+__device__ __forceinline__ void backsub_body(const BacksubArgs &b, int blk, double *red, const int32_t *flag, int epoch, int32_t *err_flags) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;   // wave-uniform: the frame's slot range, g_f, V_f^-1 through the scalar cache
+    auto dl = [&](int i) -> double {   // an entry of delta_s: past the L2 when it has just been written by another workgroup of this launch
+        return flag ? __hip_atomic_load(b.delta_s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : b.delta_s[i];
+    };
+    auto wait = [&]() {
+        if (!flag) return;
+        if (tid == 0 && !hop_wait(flag, epoch)) atomicOr(err_flags, 4);
+        __syncthreads();
+    };
+    if (blk == b.n_frame_blocks) {  // shared part
+        wait();
+        double d2 = 0.0, dg = 0.0;
+        for (int i = tid; i < 6 * b.A; i += blockDim.x) {
+            const double d = dl(i);
+            b.zt[i] = b.zc[i] + d;
+            d2 += d * d;
+            dg += d * b.g0[i];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_xor(d2, off); dg += __shfl_xor(dg, off); }
+        if (lane == 0) { red[wave] = d2; red[16 + wave] = dg; }
+        __syncthreads();
+        if (tid == 0) {
+            double s2 = 0.0, sg = 0.0;
+            for (int w = 0; w < nwaves; w++) { s2 += red[w]; sg += red[16 + w]; }
+            b.lin_part[2 * (size_t)b.F] = s2;
+            b.lin_part[2 * (size_t)b.F + 1] = sg;
+        }
+        // {R, t, J_l} rows of the shared entities at the trial point: both observation passes of the trial evaluation read
+        // them from this table (so they need not run one after the other)
+        __threadfence_block();
+        __syncthreads();
+        for (int e = tid; e < b.A; e += blockDim.x) {   // entities from k_ent0 on are intrinsics entities: their row is the camera matrix
+            if (e >= b.k_ent0) make_k_row(b.zt + 6 * (size_t)e, b.ent_out + (size_t)e * ENT_STRIDE);
+            else make_ent_row(b.zt + 6 * (size_t)e, b.ent_out + (size_t)e * ENT_STRIDE);
+        }
+        return;
+    }
+    const int f = blk * nwaves + wave;
+    const bool live = f < b.F;
+    const int s0 = live ? b.fslot_start[f] : 0, s1 = live ? b.fslot_start[f + 1] : 0;
+    // first pass of the slot list (all of it for frames with up to 64 cameras+markers): W block and entity BEFORE the wait
+    const int sl = s0 + lane;
+    const bool has = sl < s1;
+    int a0 = 0;
+    double2 w0[18];
+    if (has) {
+        a0 = b.fslot_ent[sl];
+        const double2 *wb = reinterpret_cast<const double2 *>(b.W + (size_t)sl * 36);
+#pragma unroll
+        for (int q = 0; q < 18; q++) w0[q] = wb[q];
+    }
+    double g[6], vrow[6], zc6 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { g[i] = live ? b.gf[(size_t)f * 6 + i] : 0.0; vrow[i] = (live && lane < 6) ? b.Vinv[(size_t)f * 36 + lane * 6 + i] : 0.0; }
+    if (live && lane < 6) zc6 = b.zc[(size_t)6 * (b.A + f) + lane];
+    wait();
+    if (!live) return;
+    double c[6] = {0, 0, 0, 0, 0, 0};
+    if (has) {
+        double da[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) da[i] = dl(6 * a0 + i);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            c[0] += w0[3 * i].x * da[i]; c[1] += w0[3 * i].y * da[i]; c[2] += w0[3 * i + 1].x * da[i];
+            c[3] += w0[3 * i + 1].y * da[i]; c[4] += w0[3 * i + 2].x * da[i]; c[5] += w0[3 * i + 2].y * da[i];
+        }
+    }
+    for (int s = s0 + lane + 64; s < s1; s += 64) {
+        const int a = b.fslot_ent[s];
+        const double2 *wb = reinterpret_cast<const double2 *>(b.W + (size_t)s * 36);
+        double da[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) da[i] = dl(6 * a + i);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const double2 x0 = wb[3 * i], x1 = wb[3 * i + 1], x2 = wb[3 * i + 2];
+            c[0] += x0.x * da[i]; c[1] += x0.y * da[i]; c[2] += x1.x * da[i];
+            c[3] += x1.y * da[i]; c[4] += x2.x * da[i]; c[5] += x2.y * da[i];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int i = 0; i < 6; i++) c[i] += __shfl_xor(c[i], off);
+    double d = 0.0;
+    if (lane < 6) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) d += vrow[k] * (g[k] - c[k]);
+        b.zt[(size_t)6 * (b.A + f) + lane] = zc6 + d;
+    }
+    {   // the frame's own {R, t, J_l} row at the trial point (lane 0; the six new parameters come from lanes 0..5)
+        const double zn = (lane < 6) ? zc6 + d : 0.0;
+        double zv[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) zv[i] = __shfl(zn, i);
+        if (lane == 0) make_ent_row(zv, b.ent_out + (size_t)(b.A + f) * ENT_STRIDE);
+    }
+    double d2 = (lane < 6) ? d * d : 0.0;
+    double dgv = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) dgv += (lane == i) ? d * g[i] : 0.0;
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) { d2 += __shfl_xor(d2, off); dgv += __shfl_xor(dgv, off); }
+    if (lane == 0) { b.lin_part[2 * (size_t)f] = d2; b.lin_part[2 * (size_t)f + 1] = dgv; }
+}
+
+__global__ void __launch_bounds__(256) k_backsub(const BacksubArgs b) {
+    __shared__ double red[32];
+    backsub_body(b, (int)blockIdx.x, red, nullptr, 0, nullptr);
+}
+
 // Back-substitution of a system of two or three tiles by ONE workgroup that rides in the launch of the LAST diagonal tile
 // (workgroup 1 of k_ldl_diag): every block of L it needs (at most three off-diagonal blocks and two diagonal tiles, 290 KB)
 // is fetched while the diagonal tile is still being factored next door, so when x_{nT-1} is published (one agent-scope flag)
@@ -560,7 +713,7 @@ __device__ __forceinline__ void bs_sweep(const double *__restrict__ Ls, const do
 __device__ __forceinline__ void bs_small(double *__restrict__ lds, const double *__restrict__ S, const double *__restrict__ rhs,
                                          const double *__restrict__ Dfac, double *__restrict__ x, int n_pad, int nT,
                                          const int32_t *__restrict__ flag, int epoch, int32_t *__restrict__ err_flags,
-                                         const double *__restrict__ Lp, const double *__restrict__ zf, int fused_m) {
+                                         const double *__restrict__ Lp, const double *__restrict__ zf, int fused_m, int32_t *__restrict__ done_flag) {
     constexpr int LD = NB + 2, G = 10, RPT = (NB + G - 1) / G, NL = NB * NB / 1024;
     double *Ls = lds, *xs = Ls + NB * LD, *w = xs + 2 * NB, *part = w + NB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -597,15 +750,8 @@ __device__ __forceinline__ void bs_small(double *__restrict__ lds, const double 
     if (nT == 3) { block(2, 0, a1); block(1, 0, a2); }
     park(v0);
     if (nT == 3) tile(0, v1);
-    if (tid == 0) {
-        long spins = 0;
-        while (__hip_atomic_load(flag + (nT - 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1L << 24)) { atomicOr(err_flags, 4); break; }
-        }
-    }
+    if (tid == 0 && !hop_wait(flag + (nT - 1), epoch)) atomicOr(err_flags, 4);
     __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     if (tid < NB) xs[tid] = __hip_atomic_load(x + (nT - 1) * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     double acc0 = 0.0, acc1 = 0.0;
@@ -627,8 +773,9 @@ __device__ __forceinline__ void bs_small(double *__restrict__ lds, const double 
     if (wave == 0) {
         double b0, b1;
         bs_sweep(Ls, w, lane, b0, b1);
-        x[s1 * NB + lane] = b0; xs[NB + lane] = b0;
-        if (lane + 64 < NB) { x[s1 * NB + lane + 64] = b1; xs[NB + lane + 64] = b1; }
+        __hip_atomic_store(x + s1 * NB + lane, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); xs[NB + lane] = b0;
+        if (lane + 64 < NB) { __hip_atomic_store(x + s1 * NB + lane + 64, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); xs[NB + lane + 64] = b1; }
+        if (nT != 3 && done_flag) hop_publish(done_flag, epoch, lane == 0);   // all of delta_s is in memory: the frame back-substitution riding in this launch may go
     }
     if (nT != 3) return;
     __syncthreads();
@@ -651,8 +798,9 @@ __device__ __forceinline__ void bs_small(double *__restrict__ lds, const double 
     if (wave == 0) {
         double b0, b1;
         bs_sweep(Ls, w, lane, b0, b1);
-        x[lane] = b0;
-        if (lane + 64 < NB) x[lane + 64] = b1;
+        __hip_atomic_store(x + lane, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane + 64 < NB) __hip_atomic_store(x + lane + 64, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done_flag) hop_publish(done_flag, epoch, lane == 0);
     }
 }
 
@@ -661,14 +809,21 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
                                                          int32_t *__restrict__ flags, int nT, const double *__restrict__ rhs,
                                                          const double *__restrict__ g0, double *__restrict__ xout,
                                                          const double *__restrict__ Lp, const double *__restrict__ zf, int fused_m,
-                                                         int32_t *__restrict__ bs_flag, int bs_epoch) {
+                                                         int32_t *__restrict__ bs_flag, int bs_epoch, int ride_bs, int ride_backsub, const BacksubArgs bsub) {
     constexpr int LD = NB + 2, NBK = NB / 6, PER = NB * NB / DG_THREADS, NT16 = NB / 16, NTILE = NT16 * (NT16 + 1) / 2, NWAVE = DG_THREADS / 64, NMW = DG_ROW0 / 64;
     static_assert(NB % 16 == 0 && NB % 6 == 0 && NB * NB % DG_THREADS == 0 && NWAVE >= NSB && DG_THREADS - DG_ROW0 >= NB - 6 &&
                   NTILE <= 2 * NMW && DG_ROW0 % 64 == 0, "diag tile mapping");
     extern __shared__ __align__(16) double T[];
     TL_DECL
-    if (blockIdx.x == 1) {   // rider of the LAST tile's launch (two or three tiles): the back-substitution of the tiles above, see bs_small
-        bs_small(T, S, rhs, Dfac, xout, n_pad, nT, bs_flag, bs_epoch, flags, Lp, zf, fused_m);
+    // riders of the LAST tile's launch: workgroup 1 = the back-substitution of the tiles above (two or three tiles, see bs_small);
+    // the workgroups behind it = the frame back-substitution (backsub_body), which waits for the last piece of delta_s:
+    // flag[nT] from bs_small, or flag[nT - 1] from this tile's own solve when it is the only tile
+    if (ride_bs && blockIdx.x == 1) {
+        bs_small(T, S, rhs, Dfac, xout, n_pad, nT, bs_flag, bs_epoch, flags, Lp, zf, fused_m, ride_backsub ? bs_flag + nT : nullptr);
+        return;
+    }
+    if (blockIdx.x > 0) {
+        backsub_body(bsub, (int)blockIdx.x - 1 - ride_bs, T, bs_flag + (ride_bs ? nT : nT - 1), bs_epoch, flags);
         return;
     }
     double *Yn = T + NB * LD;   // [2][NB][DG_YS]: L D of block column k in buffer k & 1, columns 6, 7 zero
@@ -819,10 +974,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
         }
         __hip_atomic_store(xout + r0 + i0, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (h1) __hip_atomic_store(xout + r0 + i1, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gridDim.x > 1) {   // the back-substitution rides next door: x_{nT-1} is in memory
-            __atomic_thread_fence(__ATOMIC_RELEASE);
-            if (lane == 0) __hip_atomic_store(bs_flag + s, bs_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (gridDim.x > 1) hop_publish(bs_flag + s, bs_epoch, lane == 0);   // riders next door: x_{nT-1} is in memory
     }
     if (s == nT - 1) { STAMP(9); STAMP(10); TL_DUMP; return; }   // nobody reads the last tile's factor: its solve is done
     {   // factored tile -> Dfac (not back into S: other workgroups may still be reading it); only the lower part is ever read
@@ -1219,7 +1371,7 @@ __global__ void __launch_bounds__(128) k_ldl_panel(double *__restrict__ S, doubl
 // x_t are published (block (t, s) is already in registers when the flag arrives), then one wavefront back-substitutes
 // L_ss^T x_s = w_s column by column (v_readlane sweep, no barriers) and publishes x_s.  Every CU fetches only its own tile
 // column, so the solve no longer pulls all of L through one CU.  flag[s] == epoch means "x_s of this launch is in memory";
-// release / acquire at agent scope carry the data across the XCDs' L2s.
+// x travels as agent-scope atomics past the XCDs' L2s (hop_publish / hop_wait: no cache-maintenance fence on the chain).
 // LDS (dynamic): Ls [NB][NB+2] | xs [NB] | w [NB] | part [10][NB]
 __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict__ S, const double *__restrict__ rhs,
                                                         const double *__restrict__ Dfac, double *__restrict__ x, int n_pad, int nT,
@@ -1261,17 +1413,10 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
     double acc = 0.0;
     for (int t = nT - 1; t > s; t--) {
         if (t < nT - 1) {   // x_{nT-1} comes from the previous kernel; the others from the workgroup next door
-            if (tid == 0) {
-                // bounded: a chain that cannot complete (it always can: a workgroup only waits for ones dispatched before it)
-                // must end in an error flag on the host, never in a hung device
-                long spins = 0;
-                while (__hip_atomic_load(flag + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1L << 24)) { atomicOr(err_flags, 4); break; }
-                }
-            }
+            // bounded: a chain that cannot complete (it always can: a workgroup only waits for ones dispatched before it)
+            // must end in an error flag on the host, never in a hung device
+            if (tid == 0 && !hop_wait(flag + t, epoch)) atomicOr(err_flags, 4);
             __syncthreads();
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
         if (tid < NB) xs[tid] = __hip_atomic_load(x + t * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -1314,95 +1459,8 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
         }
         __hip_atomic_store(x + r0 + i0, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (h1) __hip_atomic_store(x + r0 + i1, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __atomic_thread_fence(__ATOMIC_RELEASE);
-        if (lane == 0) __hip_atomic_store(flag + s, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        hop_publish(flag + s, epoch, lane == 0);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Frame back-substitution, one wavefront per frame: delta_f = (V_f+mu I)^-1 (g_f - sum_a W_af^T delta_a);
-// z_trial = z_cur + delta; per-frame pieces of L = 0.5 delta^T (mu delta - B) (libs/sparselevmarq.h:406).
-// The last workgroup updates the shared (camera / marker) parameters.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_backsub(const int32_t *__restrict__ fslot_start, const int32_t *__restrict__ fslot_ent,
-                                                 const double *__restrict__ W, const double *__restrict__ Vinv,
-                                                 const double *__restrict__ gf, const double *__restrict__ g0,
-                                                 const double *__restrict__ delta_s, const double *__restrict__ zc,
-                                                 double *__restrict__ zt, int A, int F, int n_frame_blocks,
-                                                 double *__restrict__ lin_part, double *__restrict__ ent_out, int k_ent0) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the frame's slot range, g_f, V_f^-1 through the scalar cache
-    if ((int)blockIdx.x == n_frame_blocks) {  // shared part
-        double d2 = 0.0, dg = 0.0;
-        for (int i = tid; i < 6 * A; i += 256) {
-            const double d = delta_s[i];
-            zt[i] = zc[i] + d;
-            d2 += d * d;
-            dg += d * g0[i];
-        }
-        __shared__ double red[8];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_xor(d2, off); dg += __shfl_xor(dg, off); }
-        if (lane == 0) { red[wave] = d2; red[4 + wave] = dg; }
-        __syncthreads();
-        if (tid == 0) {
-            lin_part[2 * (size_t)F] = red[0] + red[1] + red[2] + red[3];
-            lin_part[2 * (size_t)F + 1] = red[4] + red[5] + red[6] + red[7];
-        }
-        // {R, t, J_l} rows of the shared entities at the trial point: both observation passes of the trial evaluation read
-        // them from this table (so they need not run one after the other)
-        __threadfence_block();
-        __syncthreads();
-        for (int e = tid; e < A; e += 256) {   // entities from k_ent0 on are intrinsics entities: their row is the camera matrix
-            if (e >= k_ent0) make_k_row(zt + 6 * (size_t)e, ent_out + (size_t)e * ENT_STRIDE);
-            else make_ent_row(zt + 6 * (size_t)e, ent_out + (size_t)e * ENT_STRIDE);
-        }
-        return;
-    }
-    const int f = blockIdx.x * 4 + wave;
-    if (f >= F) return;
-    const int s0 = fslot_start[f], s1 = fslot_start[f + 1];
-    double c[6] = {0, 0, 0, 0, 0, 0};
-    for (int s = s0 + lane; s < s1; s += 64) {
-        const int a = fslot_ent[s];
-        const double2 *wb = reinterpret_cast<const double2 *>(W + (size_t)s * 36);
-        double da[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) da[i] = delta_s[6 * a + i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const double2 w0 = wb[3 * i], w1 = wb[3 * i + 1], w2 = wb[3 * i + 2];
-            c[0] += w0.x * da[i]; c[1] += w0.y * da[i]; c[2] += w1.x * da[i];
-            c[3] += w1.y * da[i]; c[4] += w2.x * da[i]; c[5] += w2.y * da[i];
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int i = 0; i < 6; i++) c[i] += __shfl_xor(c[i], off);
-    double g[6], vv[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) { g[i] = gf[(size_t)f * 6 + i]; vv[i] = g[i] - c[i]; }
-    double d = 0.0;
-    if (lane < 6) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) d += Vinv[(size_t)f * 36 + lane * 6 + k] * vv[k];
-        const size_t zi = (size_t)6 * (A + f) + lane;
-        zt[zi] = zc[zi] + d;
-    }
-    {   // the frame's own {R, t, J_l} row at the trial point (lane 0; the six new parameters come from lanes 0..5)
-        const double zn = (lane < 6) ? zc[(size_t)6 * (A + f) + lane] + d : 0.0;
-        double zv[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) zv[i] = __shfl(zn, i);
-        if (lane == 0) make_ent_row(zv, ent_out + (size_t)(A + f) * ENT_STRIDE);
-    }
-    double d2 = (lane < 6) ? d * d : 0.0;
-    double dgv = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) dgv += (lane == i) ? d * g[i] : 0.0;
-#pragma unroll
-    for (int off = 4; off > 0; off >>= 1) { d2 += __shfl_xor(d2, off); dgv += __shfl_xor(dgv, off); }
-    if (lane == 0) { lin_part[2 * (size_t)f] = d2; lin_part[2 * (size_t)f + 1] = dgv; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1463,7 +1521,19 @@ bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
     return extra != 0;
 }
 
-void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
+static BacksubArgs backsub_args(const DeviceProblem &P, int cur, int trial, int waves_per_block) {
+    const DeviceProblem::Blocks &b = P.blk[cur];
+    BacksubArgs a;
+    a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.W = b.W; a.Vinv = b.Vinv; a.gf = b.gf; a.g0 = b.g0;
+    a.delta_s = P.delta_s; a.zc = P.z[cur]; a.zt = P.z[trial]; a.A = P.A; a.F = P.F;
+    a.n_frame_blocks = (P.F + waves_per_block - 1) / waves_per_block;
+    a.lin_part = P.lin_part; a.ent_out = P.ent[trial]; a.k_ent0 = P.intr ? P.C + P.M : P.A;
+    return a;
+}
+
+// trial >= 0: the frame back-substitution z[trial] = z[which] + delta may ride in the last tile's launch (systems of up to three
+// tiles); returns true if it did (the caller then skips launch_backsub)
+bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial) {
     const DeviceProblem::Blocks &b = P.blk[which];
     const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * DG_YS) * sizeof(double);
     static size_t g_diag = 48 * 1024, g_bs = 48 * 1024;
@@ -1471,13 +1541,25 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     // with the square of the column's height, the two-kernel path's fixed cost does not
     static const int fused_m = getenv("AAR_FUSED_PANEL") ? atoi(getenv("AAR_FUSED_PANEL")) : 2;
     static const bool bs_rides = !(getenv("AAR_BS_RIDES") && atoi(getenv("AAR_BS_RIDES")) == 0);
+    // opt-in (AAR_BACKSUB_RIDES=1): measured on one box, it buys nothing -- 7 224 vs 7 233 LM it/s at config 3, 17 480 vs 17 780 at config 2
+    // (profiles/r03_attempts.txt): the launch then ends with the riders' work instead of a 6 us kernel, and their 1024-thread workgroups
+    // cost at dispatch what the kernel boundary did
+    static const bool backsub_rides = getenv("AAR_BACKSUB_RIDES") && atoi(getenv("AAR_BACKSUB_RIDES")) != 0;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
+    bool rode_backsub = false;
     for (int s = 0; s < P.nT; s++) {
         const int m = P.nT - s - 1;
-        const bool ride = bs_rides && s == P.nT - 1 && (P.nT == 2 || P.nT == 3);   // the back-substitution rides in the last tile's launch
-        if (ride) P.bs_epoch++;
-        { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(ride ? 2 : 1), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags,
-                                                         P.nT, b.rhs, b.g0, P.delta_s, P.Lp, P.zf, fused_m, P.bs_flags, P.bs_epoch); }
+        const bool last = s == P.nT - 1;
+        const bool ride = bs_rides && last && (P.nT == 2 || P.nT == 3);   // the back-substitution rides in the last tile's launch
+        // ... and so does the frame back-substitution when the whole of delta_s comes out of that launch (one tile, or the rider above);
+        // not under per-kernel profiling (the riders would be billed to k_ldl_diag)
+        const bool ride2 = backsub_rides && last && trial >= 0 && (P.nT == 1 || ride) && !P.hook.pre;
+        BacksubArgs ba = backsub_args(P, which, trial >= 0 ? trial : which, DG_THREADS / 64);
+        if (ride || ride2) P.bs_epoch++;
+        const int grid = 1 + (ride ? 1 : 0) + (ride2 ? ba.n_frame_blocks + 1 : 0);
+        { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(grid), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags,
+                                                         P.nT, b.rhs, b.g0, P.delta_s, P.Lp, P.zf, fused_m, P.bs_flags, P.bs_epoch, ride ? 1 : 0, ride2 ? 1 : 0, ba); }
+        rode_backsub = ride2;
         if (m > 0 && m <= fused_m) {   // short block column: panel solve and trailing update in one launch
             const int ns = NSB * m;
             HookScope _h(P, KID_LDL_PANEL);
@@ -1495,13 +1577,12 @@ void launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st) {
         hipLaunchKernelGGL(k_ldl_backsolve, dim3(P.nT - 1), dim3(1024), lds, st, b.S, b.rhs, P.Dfac, P.delta_s, P.n_pad, P.nT, P.bs_flags, P.bs_epoch, P.flags, P.Lp, P.zf,
                            fused_m);
     }
+    return rode_backsub;
 }
 
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) {
-    const DeviceProblem::Blocks &b = P.blk[cur];
-    const int nfb = (P.F + 3) / 4;
-    { HookScope _h(P, KID_BACKSUB); hipLaunchKernelGGL(k_backsub, dim3(nfb + 1), dim3(256), 0, st, P.fslot_start, P.fslot_ent, b.W, b.Vinv, b.gf, b.g0,
-                       P.delta_s, P.z[cur], P.z[trial], P.A, P.F, nfb, P.lin_part, P.ent[trial], P.intr ? P.C + P.M : P.A); }
+    const BacksubArgs ba = backsub_args(P, cur, trial, 4);
+    { HookScope _h(P, KID_BACKSUB); hipLaunchKernelGGL(k_backsub, dim3(ba.n_frame_blocks + 1), dim3(256), 0, st, ba); }
 }
 
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st, double *scal_out) {

@@ -113,7 +113,9 @@ int main(int argc, char **argv) {
 
         // ---- (6) track() in the reference's shape (:430-443): solve(z, error_function_tracking)
         MultiCamMapper c(d3);
+        c.solver_params.verbose = false;
         c.set_optmize_flag_cam_intrinsics(false);
+        c.solve();   // cameras and markers at the solution first, as apps/track.cpp starts from a solved map
         c.set_optmize_flag_cam_poses(false);
         c.set_optmize_flag_marker_poses(false);
         const int64_t nshared = 6LL * (c.dataset()->num_cams - 1 + c.dataset()->num_markers - 1);
