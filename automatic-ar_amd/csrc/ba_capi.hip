@@ -972,8 +972,10 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     // force it on small problems).  Its panels cost 2 F Ad 288 bytes -- tens of GB for long sequences with many rarely seen
     // entities -- so they must fit a budget (half of the free device memory; AAR_SCHUR_PANEL_MB overrides), else the
     // output-stationary kernel, which needs none of this, takes over.  Only THAT kernel keeps a row panel of all entities in LDS.
+    { const char *e = getenv("AAR_DETERMINISTIC"); P.deterministic = (e && atoi(e) != 0) ? 1 : 0; }
     bool schur_mfma = A >= 96 && F > 0;
     if (const char *e = getenv("AAR_SCHUR_MFMA")) schur_mfma = atoi(e) != 0 && F > 0;
+    if (P.deterministic) schur_mfma = false;   // fixed-order sums exist for the output-stationary kernel only (kernels.h)
     if (schur_mfma) {
         const size_t panel_bytes = (size_t)2 * F * ((A + 1 + 31) / 32 * 32) * 288;
         size_t free_b = 0, total_b = 0;
@@ -1068,6 +1070,49 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         }
     }
     P.n_swork = (int)sw_ent.size();
+    // deterministic mode: a record per Schur work item, the items of every entity in ascending frame order; a record per
+    // pass-B chunk, the chunks of every camera / marker / (camera, marker) pair in ascending order
+    std::vector<int64_t> sp_off;
+    std::vector<int32_t> se_start, se_items, pbr_start, pbr_chunk, pbr_kind, pbr_a, pbr_b;
+    int64_t sp_total = 0;
+    if (P.deterministic) {
+        sp_off.resize(sw_ent.size());
+        std::vector<std::vector<int32_t>> items(A);
+        for (size_t w = 0; w < sw_ent.size(); w++) {
+            sp_off[w] = sp_total;
+            sp_total += ((int64_t)(sw_ent[w] + 1) * 36 + 8);
+            items[sw_ent[w]].push_back((int32_t)w);
+        }
+        se_start.assign(A + 1, 0);
+        for (int a = 0; a < A; a++) {
+            // frame-ascending: an entity's pairs are frame-ascending in pair_rec, so ordering its items by their first pair does it
+            std::sort(items[a].begin(), items[a].end(), [&](int32_t x, int32_t y) { return sw_begin[x] < sw_begin[y]; });
+            se_start[a] = (int32_t)se_items.size();
+            se_items.insert(se_items.end(), items[a].begin(), items[a].end());
+        }
+        se_start[A] = (int32_t)se_items.size();
+        std::vector<std::vector<int32_t>> by_cam(C), by_mk(A);
+        pbr_start.push_back(0);
+        auto emit = [&](int kind, int ea, int eb, const std::vector<int32_t> &chs) {
+            if (chs.empty()) return;
+            pbr_chunk.insert(pbr_chunk.end(), chs.begin(), chs.end());
+            pbr_start.push_back((int32_t)pbr_chunk.size());
+            pbr_kind.push_back(kind); pbr_a.push_back(ea); pbr_b.push_back(eb);
+        };
+        std::vector<int32_t> run;
+        for (int ch = 0; ch < P.n_chunks; ch++) {
+            const ObsIdx &h = b_idx[chunk_start[ch]];
+            by_cam[h.cam].push_back(ch);
+            by_mk[h.marker].push_back(ch);
+            run.push_back(ch);
+            const bool last = ch + 1 == P.n_chunks || b_idx[chunk_start[ch + 1]].cam != h.cam || b_idx[chunk_start[ch + 1]].marker != h.marker;
+            if (last) { emit(2, h.cam, h.marker, run); run.clear(); }
+        }
+        for (int c = 0; c < C; c++) emit(0, c, 0, by_cam[c]);
+        for (int m = 0; m < A; m++) emit(1, m, 0, by_mk[m]);
+        P.n_pbr = (int)pbr_kind.size();
+        P.pb_stride = L.oi ? 152 : 90;
+    }
     // many shared entities: the MFMA kernel owns 16 x 32-entity blocks of S and streams frame ranges (solve_kernels.hip);
     // frame ranges are cut so that the grid is a few workgroups per CU
     std::vector<int32_t> sm_ga, sm_gb, sm_fb, sm_fe, slot_frame, slot_dense, dense_ent;
@@ -1148,6 +1193,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     UP(fslot_start, fslot_start); UP(fslot_ent, fslot_ent); UP(b_idx, b_idx); UP(b_uv, b_uv);
     UP(chunk_start, chunk_start); UP(ent_fixed, ent_fixed);
     UP(sw_ent, sw_ent); UP(sw_begin, sw_begin); UP(sw_end, sw_end); UP(pair_rec, pair_rec);
+    if (P.deterministic) { UP(sp_off, sp_off); UP(se_start, se_start); UP(se_items, se_items); UP(pbr_start, pbr_start); UP(pbr_chunk, pbr_chunk); UP(pbr_kind, pbr_kind); UP(pbr_a, pbr_a); UP(pbr_b, pbr_b); }
     if (P.n_smwork) { UP(sm_ga, sm_ga); UP(sm_gb, sm_gb); UP(sm_fb, sm_fb); UP(sm_fe, sm_fe); UP(slot_dense, slot_dense); UP(slot_frame, slot_frame); UP(dense_ent, dense_ent); UP(sm_frames, sm_frames); }
 #undef UP
 #define AL(field, count) if ((rc = dev_alloc(pb, &P.field, (size_t)(count)))) return fail(rc)
@@ -1164,6 +1210,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         P.blk[w].tail = P.blk[w].g0 + P.n_pad;
         if (hipMemset(P.blk[w].tail, 0, 8 * sizeof(double)) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "hipMemset failed"));
     }
+    if (P.deterministic) { AL(sp_part, (size_t)sp_total); AL(pb_part, (size_t)P.n_chunks * P.pb_stride); }
     if (P.n_smwork) { AL(Wd, (size_t)F * P.Ad * 36); AL(Yd, (size_t)F * P.Ad * 36); }   // zeroed here, once: absent pairs are never written
     AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad); AL(bs_flags, (size_t)P.nT + 1);
     AL(Lp, (size_t)P.nT * P.n_pad * CHOL_NB); AL(zf, P.n_pad);

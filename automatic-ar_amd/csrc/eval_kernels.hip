@@ -320,9 +320,12 @@ struct PassBArgs {
     float huber;
     double h;
     double *U0, *g0;   // U0 = blk.S (zeroed), g0 = blk.g0
+    double *part; int part_stride;   // deterministic mode: the chunk's sums go to part[chunk * part_stride + value] instead of atomics
 };
 
 // one wavefront per chunk; `scratch` = 2048 doubles of LDS per wavefront of the workgroup
+// DET: the 90 sums of the chunk are stored as the chunk's record (k_passB_reduce adds the records up in a fixed order)
+template <bool DET = false>
 __device__ __forceinline__ void passB_body(const PassBArgs &b, double *scratch, const int first_chunk) {
     const ObsIdx *__restrict__ idx = b.idx;
     const float *__restrict__ uv = b.uv;
@@ -382,6 +385,7 @@ __device__ __forceinline__ void passB_body(const PassBArgs &b, double *scratch, 
     }
     const int rc = 6 * head.cam, rm = 6 * head.marker;  // first row of the camera / marker block
     wave_sum_lds<90>(vals, scratch + wave * 2048, lane, [&](int v, double s) {
+        if (DET) { b.part[(size_t)chunk * b.part_stride + v] = s; return; }
         if (v < 42) {  // U_cc / U_mm, packed lower (i >= j)
             const int base = v < 21 ? rc : rm, p = v < 21 ? v : v - 21;
             int i = 0;
@@ -412,9 +416,14 @@ __global__ void __launch_bounds__(256) k_passB(const PassBArgs b) {
     __shared__ double scratch[4 * 2048];
     passB_body(b, scratch, (int)blockIdx.x * 4);
 }
+__global__ void __launch_bounds__(256) k_passB_det(const PassBArgs b) {
+    __shared__ double scratch[4 * 2048];
+    passB_body<true>(b, scratch, (int)blockIdx.x * 4);
+}
 
 // Pass B for the intrinsics entities (optimize_cam_intrinsics): same chunks, the 62 values of U_kk (4x4, packed lower), W_kc
 // (4x6: intrinsics x the camera's own pose), W_km (4x6: intrinsics x marker) and g_k; rows of entity k_ent0 + camera.
+template <bool DET = false>
 __device__ __forceinline__ void passB_intr_body(const PassBArgs &b, double *scratch, const int first_chunk) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, see passB_body
     const int chunk = first_chunk + wave;
@@ -465,6 +474,7 @@ __device__ __forceinline__ void passB_intr_body(const PassBArgs &b, double *scra
     double *__restrict__ U0 = b.U0, *__restrict__ g0 = b.g0;
     const int n_pad = b.n_pad;
     wave_sum_lds<62>(vals, scratch + wave * 2048, lane, [&](int v, double s) {
+        if (DET) { b.part[(size_t)chunk * b.part_stride + 90 + v] = s; return; }
         if (v < 10) {
             int i = 0;
             while ((i + 1) * (i + 2) / 2 <= v) i++;
@@ -485,6 +495,63 @@ __device__ __forceinline__ void passB_intr_body(const PassBArgs &b, double *scra
 __global__ void __launch_bounds__(256) k_passB_intr(const PassBArgs b) {
     __shared__ double scratch[4 * 2048];
     passB_intr_body(b, scratch, (int)blockIdx.x * 4);
+}
+__global__ void __launch_bounds__(256) k_passB_intr_det(const PassBArgs b) {
+    __shared__ double scratch[4 * 2048];
+    passB_intr_body<true>(b, scratch, (int)blockIdx.x * 4);
+}
+
+// Deterministic mode, second half of pass B: one wavefront per reduction item (a camera, a marker, a (camera, marker) pair), one
+// lane per value; the chunk records are added in ascending chunk order = ascending (camera, marker, frame) order of the
+// observations, and the sum is STORED (the block set was cleared before).  Same destinations as the atomics of passB_body.
+struct PassBReduceArgs {
+    const int32_t *start, *chunk, *kind, *ea, *eb;
+    const double *part;
+    int stride, n_items, n_pad, intr, k_ent0;
+    double *U0, *g0;
+};
+__device__ __forceinline__ void unpack_lower(int p, int &i, int &j) {
+    i = 0;
+    while ((i + 1) * (i + 2) / 2 <= p) i++;
+    j = p - i * (i + 1) / 2;
+}
+__global__ void __launch_bounds__(256) k_passB_reduce(const PassBReduceArgs r) {
+    const int item = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (item >= r.n_items) return;
+    const int c0 = r.start[item], c1 = r.start[item + 1], kind = r.kind[item];
+    const int ea = r.ea[item], eb = r.eb[item];
+    const int nv = kind == 0 ? (r.intr ? 65 : 27) : (kind == 1 ? 27 : (r.intr ? 60 : 36));
+    for (int v = lane; v < nv; v += 64) {
+        int src, i, j;
+        double *dst;
+        if (kind == 0) {   // camera ea: U_cc, g_c (+ with intrinsics U_kk, W_kc, g_k of its intrinsics entity)
+            const int rc = 6 * ea, rk = 6 * (r.k_ent0 + ea);
+            if (v < 21) { src = v; unpack_lower(v, i, j); dst = r.U0 + (size_t)(rc + i) * r.n_pad + rc + j; }
+            else if (v < 27) { src = 78 + (v - 21); dst = r.g0 + rc + (v - 21); }
+            else if (v < 37) { src = 90 + (v - 27); unpack_lower(v - 27, i, j); dst = r.U0 + (size_t)(rk + i) * r.n_pad + rk + j; }
+            else if (v < 61) { src = 90 + 10 + (v - 37); i = (v - 37) / 6; j = (v - 37) % 6; dst = r.U0 + (size_t)(rk + i) * r.n_pad + rc + j; }
+            else { src = 90 + 58 + (v - 61); dst = r.g0 + rk + (v - 61); }
+        } else if (kind == 1) {   // marker entity ea: U_mm, g_m
+            const int rm = 6 * ea;
+            if (v < 21) { src = 21 + v; unpack_lower(v, i, j); dst = r.U0 + (size_t)(rm + i) * r.n_pad + rm + j; }
+            else { src = 84 + (v - 21); dst = r.g0 + rm + (v - 21); }
+        } else {   // pair (camera ea, marker entity eb): W_cm (+ W_km)
+            const int rc = 6 * ea, rm = 6 * eb, rk = 6 * (r.k_ent0 + ea);
+            if (v < 36) { src = 42 + v; i = v / 6; j = v % 6; dst = r.U0 + (size_t)(rm + j) * r.n_pad + rc + i; }
+            else { src = 90 + 34 + (v - 36); i = (v - 36) / 6; j = (v - 36) % 6; dst = r.U0 + (size_t)(rk + i) * r.n_pad + rm + j; }
+        }
+        double s = 0.0;
+        int k = c0;
+        for (; k + 8 <= c1; k += 8) {   // eight records in flight; the additions keep their order
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = r.part[(size_t)r.chunk[k + u] * r.stride + src];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += t[u];
+        }
+        for (; k < c1; k++) s += r.part[(size_t)r.chunk[k] * r.stride + src];
+        *dst = s;
+    }
 }
 
 template <int BLOCK, int CPL, bool INTR>
@@ -576,6 +643,7 @@ static PassBArgs passB_args(const DeviceProblem &P, int which) {
     b.k_ent0 = P.C + P.M;
     b.n_chunks = P.n_chunks; b.A = P.A; b.res_f32 = P.res_f32; b.n_pad = P.n_pad; b.huber = P.huber; b.h = P.half_size;
     b.U0 = P.blk[which].S; b.g0 = P.blk[which].g0;
+    b.part = P.pb_part; b.part_stride = P.pb_stride;
     return b;
 }
 
@@ -602,6 +670,7 @@ static void launch_passA_any(const DeviceProblem &P, const PassAArgs &a, const P
     // one wavefront per frame up to ~96 observations per frame (four / two lanes per observation while they fit in it),
     // four wavefronts above
     const double avg = (double)P.N / (double)P.F;
+    if (P.deterministic && avg > 96) return launch_passA_t<64, 4>(P, a, pbargs, st);   // ONE wavefront per frame: its LDS additions come in program order
     if (avg <= 14) launch_passA_t<64, 1>(P, a, pbargs, st);
     else if (avg <= 30) launch_passA_t<64, 2>(P, a, pbargs, st);
     else if (avg <= 96) launch_passA_t<64, 4>(P, a, pbargs, st);
@@ -615,12 +684,23 @@ void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_bl
 
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
     if (P.n_chunks == 0) return;
+    if (P.deterministic) {   // per-chunk records, then their fixed-order sums (stored: the block set is clear)
+        HookScope _h(P, KID_PASSB);
+        const PassBArgs b = passB_args(P, which);
+        hipLaunchKernelGGL(k_passB_det, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, b);
+        if (P.intr) hipLaunchKernelGGL(k_passB_intr_det, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, b);
+        PassBReduceArgs r;
+        r.start = P.pbr_start; r.chunk = P.pbr_chunk; r.kind = P.pbr_kind; r.ea = P.pbr_a; r.eb = P.pbr_b; r.part = P.pb_part;
+        r.stride = P.pb_stride; r.n_items = P.n_pbr; r.n_pad = P.n_pad; r.intr = P.intr; r.k_ent0 = P.C + P.M; r.U0 = b.U0; r.g0 = b.g0;
+        hipLaunchKernelGGL(k_passB_reduce, dim3((P.n_pbr + 3) / 4), dim3(256), 0, st, r);
+        return;
+    }
     { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which)); }
     if (P.intr) { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB_intr, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which)); }
 }
 
 bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st) {
-    if (P.F == 0 || P.n_chunks == 0 || P.intr) return false;   // nothing to merge (or the intrinsics variants): the caller launches what there is
+    if (P.F == 0 || P.n_chunks == 0 || P.intr || P.deterministic) return false;   // nothing to merge (or the intrinsics / deterministic variants): the caller launches what there is
     // Side by side pays while the two passes together are a few wavefronts per SIMD (configs 2-4: -45 % / -11 % of their
     // summed time at configs 3 / 4); once either fills the chip on its own (config 5: +7 %, pass B's workgroups then carry
     // pass A's LDS allocation) they go one after the other

@@ -65,6 +65,19 @@ struct DeviceProblem {
     int32_t *slot_frame = nullptr;        // [total_slots] frame of every W block
     int32_t *dense_ent = nullptr;         // [Ad] shared entity of a dense index (-1: the pseudo entity / padding)
     double *Wd = nullptr, *Yd = nullptr;  // [F][Ad][36] W_af and W_af (V_f + mu I)^-1
+    // AAR_DETERMINISTIC=1: every sum that the default path leaves to fp64 atomics (whose order changes from run to run) is taken
+    // in a FIXED order instead -- pass B writes per-chunk partials that a second kernel adds up chunk-ascending, the Schur kernel
+    // (always the output-stationary one, one wavefront per work item) writes per-item row panels that a second kernel adds up
+    // frame-ascending, pass A runs one wavefront per frame.  Two runs of the same problem then give the same bits.
+    int deterministic = 0;
+    double *pb_part = nullptr;            // [n_chunks][pb_stride] per-chunk sums of pass B (90 values, + 62 with intrinsics)
+    int pb_stride = 0, n_pbr = 0;
+    // reduction items of pass B: item i adds up the chunks pbr_chunk[pbr_start[i] .. pbr_start[i+1]) (ascending) for camera pbr_a
+    // (kind 0), marker entity pbr_a (kind 1) or the pair (camera pbr_a, marker entity pbr_b) (kind 2)
+    int32_t *pbr_start = nullptr, *pbr_chunk = nullptr, *pbr_kind = nullptr, *pbr_a = nullptr, *pbr_b = nullptr;
+    double *sp_part = nullptr;            // per Schur work item: its row panel [(a+1)*36] | its 6 rhs entries | 2 idle
+    int64_t *sp_off = nullptr;            // [n_swork] first double of the item's record
+    int32_t *se_start = nullptr, *se_items = nullptr;   // [A+1], [n_swork]: the work items of every entity, frame-ascending
     // state: everything that depends on a pose vector exists twice (index 0/1 = the two pose buffers), so that the
     // blocks of a trial point can be built while those of the current point are still needed for a mu retry
     double *z[2] = {nullptr, nullptr};    // [6A + 6F] pose vectors

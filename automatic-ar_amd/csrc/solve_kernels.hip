@@ -109,13 +109,17 @@ __global__ void __launch_bounds__(256) k_reduce_scalars(const ReduceArgs r) { re
 // ------------------------------------------------------------------------------------------------
 // PRE = passes of the frame's slot list (10 slots each) whose W rows are fetched up front, before Y is formed: pays at
 // config 5 (HBM-bound, -9 %), costs registers / occupancy at configs 3-4, where 0 is used
-template <int PRE>
-__global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_ent, const int32_t *__restrict__ sw_begin,
+// NW = wavefronts per workgroup.  The deterministic mode runs ONE (every LDS addition of the panel then comes in program order:
+// no two lanes of an instruction share an address, see the slot loop) and leaves the panel as the work item's record in `part`
+// (at part_off[w]: [(a+1)*36] panel | 6 rhs entries) for k_schur_reduce instead of the atomic flush.
+template <int PRE, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) k_schur(const int32_t *__restrict__ sw_ent, const int32_t *__restrict__ sw_begin,
                                                const int32_t *__restrict__ sw_end, const int4 *__restrict__ pair_rec,
                                                const int32_t *__restrict__ fslot_ent, const double *__restrict__ W,
                                                const double *__restrict__ Vinv, const double *__restrict__ hf, int A,
                                                int n_pad, double sign, double *__restrict__ S, double *__restrict__ rhs,
-                                               int rider, const ReduceArgs red) {
+                                               int rider, const ReduceArgs red, double *__restrict__ part = nullptr,
+                                               const int64_t *__restrict__ part_off = nullptr) {
     if (rider && blockIdx.x == 0) {   // rider (dispatched first): the step's scalars go to the host from here, beside the Schur workgroups
         reduce_scalars_body(red);
         return;
@@ -126,12 +130,12 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
     double *ysc = pg + 8;
     const int w = (int)blockIdx.x - rider, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: pair records in SGPRs
     const int a = sw_ent[w], pb = sw_begin[w], pe = sw_end[w];
-    for (int i = tid; i < (a + 1) * 36; i += 256) panel[i] = 0.0;
+    for (int i = tid; i < (a + 1) * 36; i += 64 * NW) panel[i] = 0.0;
     if (tid < 8) pg[tid] = 0.0;
     __syncthreads();
     double *ys = ysc + wave * 48;
     if constexpr (PRE == 0) {
-        for (int p = pb + wave; p < pe; p += 4) {
+        for (int p = pb + wave; p < pe; p += NW) {
             const int4 rec = pair_rec[p];
             const int f = rec.x, sg = rec.y, s0 = rec.z, sa = sg - s0;
             const double *Wa = W + (size_t)sg * 36;
@@ -176,9 +180,9 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
         const int sl = lane / 6, j = lane % 6;
         int4 rec = make_int4(0, 0, 0, 0);
         if (pb + wave < pe) rec = pair_rec[pb + wave];
-        for (int p = pb + wave; p < pe; p += 4) {
+        for (int p = pb + wave; p < pe; p += NW) {
             const int f = rec.x, sg = rec.y, s0 = rec.z, sa = sg - s0;
-            if (p + 4 < pe) rec = pair_rec[p + 4];
+            if (p + NW < pe) rec = pair_rec[p + NW];
             const double *Wa = W + (size_t)sg * 36;
             double wa[6], vv[6];
             if (lane < 36) {
@@ -237,7 +241,13 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < (a + 1) * 36; idx += 256) {
+    if (part) {   // deterministic mode: the record of this work item
+        double *rec = part + part_off[w];
+        for (int idx = tid; idx < (a + 1) * 36; idx += 64 * NW) rec[idx] = panel[idx];
+        if (tid < 6) rec[(a + 1) * 36 + tid] = pg[tid];
+        return;
+    }
+    for (int idx = tid; idx < (a + 1) * 36; idx += 64 * NW) {
         const double v = panel[idx];
         if (v != 0.0) {
             const int b = idx / 36, e = idx - b * 36, i = e / 6, j = e - i * 6;
@@ -245,6 +255,33 @@ __global__ void __launch_bounds__(256) k_schur(const int32_t *__restrict__ sw_en
         }
     }
     if (tid < 6) atomicAdd(rhs + 6 * a + tid, -sign * pg[tid]);
+}
+
+// Deterministic mode, second half of the Schur complement: workgroup = entity a; every value of its row panel (and of its six rhs
+// entries) is the sum of the records of a's work items, added in ascending frame order, then S(a, .) -= sign * sum -- the only
+// writer of that row, so a plain read-modify-write.
+__global__ void __launch_bounds__(256) k_schur_reduce(const int32_t *__restrict__ se_start, const int32_t *__restrict__ se_items,
+                                                      const int64_t *__restrict__ part_off, const double *__restrict__ part, int n_pad,
+                                                      double sign, double *__restrict__ S, double *__restrict__ rhs) {
+    const int a = blockIdx.x, i0 = se_start[a], i1 = se_start[a + 1], np = (a + 1) * 36;
+    for (int idx = threadIdx.x; idx < np + 6; idx += 256) {
+        double s = 0.0;
+        int k = i0;
+        for (; k + 8 <= i1; k += 8) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = part[part_off[se_items[k + u]] + idx];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += t[u];
+        }
+        for (; k < i1; k++) s += part[part_off[se_items[k]] + idx];
+        if (idx < np) {
+            const int b = idx / 36, e = idx - b * 36, i = e / 6, j = e - i * 6;
+            S[(size_t)(6 * a + i) * n_pad + 6 * b + j] -= sign * s;
+        } else {
+            rhs[6 * a + (idx - np)] -= sign * s;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1504,6 +1541,16 @@ bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
         return extra != 0;
     }
     if (P.n_swork == 0) return false;
+    if (P.deterministic) {   // one wavefront per work item, records instead of atomics, fixed-order sums; the scalars do not ride
+        const size_t lds1 = ((size_t)P.A * 36 + 8 + 48) * sizeof(double);
+        static size_t granted_d = 48 * 1024;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_schur<0, 1>), lds1, granted_d);
+        HookScope _h(P, KID_SCHUR);
+        hipLaunchKernelGGL((k_schur<0, 1>), dim3(P.n_swork), dim3(64), lds1, st, P.sw_ent, P.sw_begin, P.sw_end, P.pair_rec, P.fslot_ent, b.W, b.Vinv, b.hf, P.A, P.n_pad, sign,
+                           b.S, b.rhs, 0, ReduceArgs(), P.sp_part, P.sp_off);
+        hipLaunchKernelGGL(k_schur_reduce, dim3(P.A), dim3(256), 0, st, P.se_start, P.se_items, P.sp_off, P.sp_part, P.n_pad, sign, b.S, b.rhs);
+        return false;
+    }
     const size_t lds = ((size_t)P.A * 36 + 8 + 4 * 48) * sizeof(double);
     static size_t granted0 = 48 * 1024, granted3 = 48 * 1024;
     const ReduceArgs red = reduce_args(P, ride_n_err, false, ride_scal ? 0ull : ride_seq, ride_scal);

@@ -964,3 +964,68 @@ def test_reference_shaped_solver_calls_compile_and_run_against_the_mirror(tmp_pa
     assert kv["mixed_owners"] == "logic_error" and kv["direct_jacobian"] == "logic_error" and kv["stale_step"] == "runtime_error"
     # track() in the reference's shape: every frame refined, z = the frame poses
     assert int(kv["track_frames"]) == ds.num_frames and int(kv["track_zlen"]) == 6 * ds.num_frames and float(kv["track_max_err"]) < 100.0
+
+
+def _det_run(ds, monkeypatch, det, with_huber=False, intrinsics=False, **solve_kw):
+    monkeypatch.setenv("AAR_DETERMINISTIC", "1" if det else "0")
+    with aar.Problem(ds, with_huber=with_huber, intrinsics=intrinsics) as p:
+        x0 = p.x_with_intrinsics(ds.x_full) if intrinsics else ds.x_full
+        H, B, ss = p.eval_normal_equations(x0)
+        d = p.eval_damped_step(x0, 1e3)
+        x, rep = p.lm_solve(x0, trace_cap=600, **solve_kw)
+    return [H, B, d, x, np.array([t["err"] for t in rep["trace"]]), np.array([t["mu"] for t in rep["trace"]])]
+
+
+@pytest.mark.parametrize("name,kw", [("g1_cfg2", {}), ("g1_cfg2_huber", {"with_huber": True}), ("g1_cfg2_intr", {"intrinsics": True}), ("g1_cfg3_cut", {})])
+def test_deterministic_mode_gives_the_same_bits_twice(name, kw, monkeypatch):
+    # AAR_DETERMINISTIC=1 (csrc/kernels.h): every sum the default path leaves to fp64 atomics is taken in a fixed order, as the
+    # reference's ascending-row accumulation is (libs/sparselevmarq.h:291-303).  Normal equations, a damped step, the solution and
+    # the whole LM trace (505 steps with -with-huber) come out bit-identical in two runs -- and agree with the default path.
+    ds, g = load_golden(name)
+    a, b = _det_run(ds, monkeypatch, True, **kw), _det_run(ds, monkeypatch, True, **kw)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    c = _det_run(ds, monkeypatch, False, **kw)
+    assert np.abs(a[0] - c[0]).max() / np.abs(c[0]).max() < 1e-14 and np.abs(a[1] - c[1]).max() / np.abs(c[1]).max() < 1e-12
+    assert np.abs(a[2] - c[2]).max() / np.abs(c[2]).max() < 1e-9
+    n = len(g["analytic_err"])
+    assert len(a[4]) == n
+    np.testing.assert_allclose(a[4], g["analytic_err"], rtol=1e-6)        # (505 steps: 2.2e-7 observed; 1e-5 is the bar of the default path)
+    if n < 100:
+        np.testing.assert_allclose(a[5], g["analytic_mu"], rtol=1e-9)
+
+
+def test_deterministic_mode_tightens_the_retry_trace(monkeypatch):
+    # the same run as test_huber_schedule_with_a_rejected_try: with fixed-order sums the damping follows the real solver's to
+    # 1e-9 over the first 60 steps (2e-4 is what the default path's atomics allow: their order moves mu between runs)
+    monkeypatch.setenv("AAR_DETERMINISTIC", "1")
+    ds, g = load_golden("g1_cfg2_huber_retry")
+    prm = aar.lm_default_params(tau=float(g["tau"][0]))
+    with aar.Problem(ds, with_huber=True) as p:
+        x, rep = p.lm_solve(ds.x_full, params=prm, trace_cap=600)
+    k = 60
+    assert max(t["tries"] for t in rep["trace"]) > 1
+    np.testing.assert_allclose([t["mu"] for t in rep["trace"]][:k], g["analytic_mu"][:k], rtol=1e-9)
+    np.testing.assert_allclose([t["err"] for t in rep["trace"]][:k], g["analytic_err"][:k], rtol=1e-6)
+    n = min(len(rep["trace"]), len(g["analytic_err"]))
+    np.testing.assert_allclose([t["err"] for t in rep["trace"]][:n], g["analytic_err"][:n], rtol=2e-6)
+    assert rep["iterations"] == int(g["analytic_iterations"][0])
+
+
+def test_deterministic_mode_on_a_many_entity_problem(monkeypatch):
+    # 124 shared entities: the default path would take the MFMA Schur kernel; deterministic mode keeps the output-stationary one
+    # (fixed-order sums exist for it only) -- same step to rounding, same bits twice; beyond its LDS row panel the mode is refused
+    ds = aar.synth(3, num_cams=4, num_markers=120, num_frames=24)
+    monkeypatch.setenv("AAR_DETERMINISTIC", "1")
+    with aar.Problem(ds) as p:
+        d1 = p.eval_damped_step(ds.x_full, 1e3)
+    with aar.Problem(ds) as p:
+        d2 = p.eval_damped_step(ds.x_full, 1e3)
+    monkeypatch.setenv("AAR_DETERMINISTIC", "0")
+    with aar.Problem(ds) as p:
+        d0 = p.eval_damped_step(ds.x_full, 1e3)
+    assert np.array_equal(d1, d2) and np.abs(d1 - d0).max() / np.abs(d0).max() < 1e-9
+    monkeypatch.setenv("AAR_DETERMINISTIC", "1")
+    with pytest.raises(aar.AarError) as e:
+        aar.Problem(aar.synth(3, num_cams=4, num_markers=596, num_frames=24))
+    assert e.value.code == aar.AAR_ERR_UNSUPPORTED
