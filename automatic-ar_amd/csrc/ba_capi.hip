@@ -197,6 +197,8 @@ struct aar_problem {
     bool blocks_valid = false;         // blk[cur] holds J^T J blocks and B at z[cur], S not yet eliminated
     double vinv_mu = -1;               // damping for which blk[cur].Vinv / hf are valid (< 0: none)
     double schur_mu = -1;              // damping whose Schur terms are already subtracted from blk[cur].S / rhs (< 0: none)
+    int panels_blk = -1;               // MFMA Schur path: the block set whose dense panels Wd / Yd currently hold (-1: none) ...
+    double panels_mu = -1;             // ... and the damping of the inverses behind Yd
     bool s_reduced = false;            // multi-GPU: blk[cur].S | rhs | g0 already hold the all-reduced system for schur_mu
     bool trial_reduced = false;        // ... the same for the trial's block set, until the step is accepted or rejected
     bool fused_comm = true;            // the step's scalars and the next step's system share ONE all-reduce (AAR_FUSED_COMM=0: two)
@@ -460,6 +462,11 @@ int zero_block_set(aar_problem *pb, int which) {
     return AAR_OK;
 }
 
+// MFMA Schur path: do Wd / Yd already hold block set `which` for damping mu (pass A wrote them, or an earlier k_schur_fill)?
+bool panels_ok(const aar_problem *pb, int which, double mu) { return pb->P.n_smwork > 0 && pb->panels_blk == which && pb->panels_mu == mu; }
+// a Schur launch for (which, mu) leaves the panels behind for exactly that pair
+void panels_now(aar_problem *pb, int which, double mu) { if (pb->P.n_smwork > 0) { pb->panels_blk = which; pb->panels_mu = mu; } }
+
 // J^T J blocks and B at z[which] into blk[which] (whose S, rhs, g0 must be zero): the "J", "transpose", "Jt*J", "B"
 // stages of libs/sparselevmarq.h:353-367.  Pass A also leaves the per-frame sums of r^2 in err_part and, for
 // mu_pred >= 0, (V_f + mu_pred I)^-1; zero_blk >= 0 clears that block set on the way.
@@ -472,10 +479,14 @@ int eval_blocks(aar_problem *pb, int which, double mu_pred, int zero_blk, bool s
         int rc = zero_block_set(pb, zero_blk);
         if (rc) return rc;
     }
+    // pass A rewrites W of this block set: its old panels are stale; it writes new ones itself when it inverts V_f (mu_pred >= 0)
+    if (pb->panels_blk == which) pb->panels_blk = -1;
+    if (P.n_smwork > 0 && P.dense_from_passA && mu_pred >= 0.0 && P.F > 0) panels_now(pb, which, mu_pred);
+    const bool ready = panels_ok(pb, which, mu_pred);
     {
         StageTimer t(pb, &pb->times.jacobian_normal_eq);
         if (pb->merge_passes && launch_passAB(P, which, mu_pred, zero_blk, pb->stream)) {
-            if (spec_schur) launch_schur(P, which, 1.0, pb->stream);
+            if (spec_schur) launch_schur(P, which, 1.0, pb->stream, 0, 0, nullptr, ready);
             pb->launches += spec_schur ? 2 : 1;
             return check_async("normal-equation kernels");
         }
@@ -485,13 +496,14 @@ int eval_blocks(aar_problem *pb, int which, double mu_pred, int zero_blk, bool s
             HIP_TRY(hipStreamWaitEvent(pb->stream2, pb->ev_fork, 0));
             launch_passB(P, which, pb->stream2);
             HIP_TRY(hipEventRecord(pb->ev_join, pb->stream2));
-            launch_schur(P, which, 1.0, pb->stream);
+            launch_schur(P, which, 1.0, pb->stream, 0, 0, nullptr, ready);
             HIP_TRY(hipStreamWaitEvent(pb->stream, pb->ev_join, 0));
         } else {
             launch_passB(P, which, pb->stream);
-            if (spec_schur) launch_schur(P, which, 1.0, pb->stream);
+            if (spec_schur) launch_schur(P, which, 1.0, pb->stream, 0, 0, nullptr, ready);
         }
     }
+    if (spec_schur) panels_now(pb, which, mu_pred);
     pb->launches += spec_schur ? 3 : 2;
     return check_async("normal-equation kernels");
 }
@@ -572,7 +584,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
             // the speculative Schur complement was taken with another damping than the step now needs (gain < 0.94): take it
             // back with the inverses it used (still in Vinv), keeping the blocks -- and the residual they were built from --
             // exactly those of the accepted trial, as the reference's x64 / J are
-            launch_schur(P, cur, -1.0, pb->stream);
+            launch_schur(P, cur, -1.0, pb->stream, 0, 0, nullptr, panels_ok(pb, cur, pb->schur_mu));
+            panels_now(pb, cur, pb->schur_mu);
             pb->launches += 1;
         }
         if (pb->vinv_mu != mu) {
@@ -580,7 +593,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
             pb->vinv_mu = mu;
             pb->launches += 1;
         }
-        launch_schur(P, cur, 1.0, pb->stream);
+        launch_schur(P, cur, 1.0, pb->stream, 0, 0, nullptr, panels_ok(pb, cur, mu));
+        panels_now(pb, cur, mu);
         pb->launches += 1;
     }
     pb->schur_mu = -1;
@@ -618,7 +632,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     bool rode = false;
     if (evaluate_trial && !pb->comm) {
         StageTimer t(pb, &pb->times.schur);
-        rode = launch_schur(P, tr, 1.0, pb->stream, pb->seq + 1, P.F);
+        rode = launch_schur(P, tr, 1.0, pb->stream, pb->seq + 1, P.F, nullptr, panels_ok(pb, tr, mu * 0.33));
+        panels_now(pb, tr, mu * 0.33);
         pb->launches += 1;
         if (rode) pb->seq++;
         else if ((rc = launch_scalars(pb, P.F))) return rc;   // (nothing rode: a rank without frames launches no Schur kernel)
@@ -628,7 +643,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         // an accepted step with the predicted damping (the usual case) costs one collective, not two.
         {
             StageTimer t(pb, &pb->times.schur);
-            rode = launch_schur(P, tr, 1.0, pb->stream, 0, P.F, P.blk[tr].tail);
+            rode = launch_schur(P, tr, 1.0, pb->stream, 0, P.F, P.blk[tr].tail, panels_ok(pb, tr, mu * 0.33));
+            panels_now(pb, tr, mu * 0.33);
             pb->launches += 1;
             if (!rode) { launch_reduce_scalars(P, P.F, false, 0ull, pb->stream, P.blk[tr].tail); pb->launches += 1; }
         }
@@ -645,7 +661,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         if ((rc = launch_scalars(pb, P.F))) return rc;
         if (evaluate_trial) {
             StageTimer t(pb, &pb->times.schur);
-            launch_schur(P, tr, 1.0, pb->stream);
+            launch_schur(P, tr, 1.0, pb->stream, 0, 0, nullptr, panels_ok(pb, tr, mu * 0.33));
+            panels_now(pb, tr, mu * 0.33);
             pb->launches += 1;
         }
     }
@@ -973,6 +990,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     // entities -- so they must fit a budget (half of the free device memory; AAR_SCHUR_PANEL_MB overrides), else the
     // output-stationary kernel, which needs none of this, takes over.  Only THAT kernel keeps a row panel of all entities in LDS.
     { const char *e = getenv("AAR_DETERMINISTIC"); P.deterministic = (e && atoi(e) != 0) ? 1 : 0; }
+    { const char *e = getenv("AAR_DENSE_FROM_PASSA"); if (e) P.dense_from_passA = atoi(e) != 0 ? 1 : 0; }
     bool schur_mfma = A >= 96 && F > 0;
     if (const char *e = getenv("AAR_SCHUR_MFMA")) schur_mfma = atoi(e) != 0 && F > 0;
     if (P.deterministic) schur_mfma = false;   // fixed-order sums exist for the output-stationary kernel only (kernels.h)

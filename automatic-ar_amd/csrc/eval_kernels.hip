@@ -126,6 +126,9 @@ struct PassAArgs {
     double *V, *gf, *W, *Vinv, *hf, *err_part;
     double *zero0; int64_t zero0_n; double *zero1; int64_t zero1_n; double *zero2; int64_t zero2_n;
     int32_t *flags;
+    // MFMA Schur path: the dense per-frame panels Wd / Yd = W (V_f + mu_pred I)^-1 leave from HERE (the W blocks are still in LDS),
+    // instead of a k_schur_fill launch that reads W back; null: not wanted (or no prediction of the damping)
+    double *Wd, *Yd; const int32_t *slot_dense; int Ad;
 };
 
 // values per round of the V/g/err wave sum: the four-wave variant trades rounds for LDS (75 KB instead of 123 KB at 122
@@ -281,6 +284,7 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
     for (int t = tid; t < 36; t += BLOCK) a.V[(size_t)f * 36 + t] = acc[sym6(t / 6, t % 6)];
     for (int t = tid; t < 6; t += BLOCK) a.gf[(size_t)f * 6 + t] = acc[21 + t];
     if (tid == 0) a.err_part[f] = acc[27];
+    const bool dense = a.Yd != nullptr && a.mu_pred >= 0.0;
     if (a.mu_pred >= 0.0 && tid == BLOCK - 1) {  // (V_f + mu I)^-1 and h_f for the damping the next solve is expected to use
         double out[36];
         if (a.frames_fixed) {
@@ -301,9 +305,33 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
             for (int j = 0; j < 6; j++) {
                 a.Vinv[(size_t)f * 36 + i * 6 + j] = out[i * 6 + j];
                 hv += out[i * 6 + j] * acc[21 + j];
+                if (dense) scratch[i * 6 + j] = out[i * 6 + j];   // (the wave-sum scratch is free by now)
             }
             a.hf[(size_t)f * 6 + i] = hv;
         }
+    }
+    if (dense) {   // row (slot, i) of the frame's panels: W as it is, Y = W (V_f + mu I)^-1; the pseudo entity 0 carries g_f in its row 0
+        __syncthreads();
+        double vi[36];
+#pragma unroll
+        for (int q = 0; q < 36; q++) vi[q] = scratch[q];
+        const size_t fbase = (size_t)f * a.Ad * 36;
+        for (int r = tid; r < kf * 6; r += BLOCK) {
+            const int sl = r / 6, i = r - sl * 6;
+            const double *wr = Wl + sl * WLS + i * 6;
+            double w[6], y[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 6; k++) w[k] = wr[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) y[j] = fma(w[k], vi[k * 6 + j], y[j]);
+            const size_t o = fbase + (size_t)a.slot_dense[s0 + sl] * 36 + i * 6;
+            double2 *yp = reinterpret_cast<double2 *>(a.Yd + o), *wd = reinterpret_cast<double2 *>(a.Wd + o);
+            yp[0] = make_double2(y[0], y[1]); yp[1] = make_double2(y[2], y[3]); yp[2] = make_double2(y[4], y[5]);
+            wd[0] = make_double2(w[0], w[1]); wd[1] = make_double2(w[2], w[3]); wd[2] = make_double2(w[4], w[5]);
+        }
+        if (tid < 6) a.Wd[fbase + tid] = acc[21 + tid];
     }
 }
 
@@ -633,6 +661,8 @@ static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, i
         a.zero2 = zb.g0; a.zero2_n = P.n_pad;
     }
     a.flags = P.flags;
+    a.Wd = a.Yd = nullptr; a.slot_dense = nullptr; a.Ad = 0;
+    if (P.n_smwork > 0 && P.dense_from_passA) { a.Wd = P.Wd; a.Yd = P.Yd; a.slot_dense = P.slot_dense; a.Ad = P.Ad; }
     return a;
 }
 

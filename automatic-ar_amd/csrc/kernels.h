@@ -65,6 +65,7 @@ struct DeviceProblem {
     int32_t *slot_frame = nullptr;        // [total_slots] frame of every W block
     int32_t *dense_ent = nullptr;         // [Ad] shared entity of a dense index (-1: the pseudo entity / padding)
     double *Wd = nullptr, *Yd = nullptr;  // [F][Ad][36] W_af and W_af (V_f + mu I)^-1
+    int dense_from_passA = 1;             // pass A writes them itself whenever it inverts V_f for a predicted damping (AAR_DENSE_FROM_PASSA=0: always k_schur_fill)
     // AAR_DETERMINISTIC=1: every sum that the default path leaves to fp64 atomics (whose order changes from run to run) is taken
     // in a FIXED order instead -- pass B writes per-chunk partials that a second kernel adds up chunk-ascending, the Schur kernel
     // (always the output-stationary one, one wavefront per work item) writes per-item row panels that a second kernel adds up
@@ -148,8 +149,9 @@ void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st);         
 void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st);
 // S -= sign * W (V+mu I)^-1 W^T (sign -1 takes it back).  ride_seq != 0: the reduction of the step's scalars rides in the same
 // launch (true is returned if it did)
+// panels_ready (MFMA path): Wd / Yd already hold this block set's panels for the damping in Vinv (pass A wrote them): no k_schur_fill
 bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq = 0, int ride_n_err = 0,
-                  double *ride_scal = nullptr);   // ride_scal: the rider leaves the scalars there and does not publish
+                  double *ride_scal = nullptr, bool panels_ready = false);   // ride_scal: the rider leaves the scalars there and does not publish
 // damping + LDL^T + both substitutions -> delta_s; trial >= 0: launch_backsub(which, trial) may ride in the last launch (true: it did)
 bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial = -1);
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part

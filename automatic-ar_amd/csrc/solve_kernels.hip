@@ -57,10 +57,12 @@ struct ReduceArgs {   // the step's scalars: [sum r^2, sum |delta_f|^2, sum delt
     double *scal; const int32_t *flags; double *host; unsigned long long publish_seq;
 };
 
-__device__ __forceinline__ void reduce_scalars_body(const ReduceArgs &r) {   // 256 threads, fixed summation order
+__device__ __forceinline__ void reduce_scalars_body(const ReduceArgs &r) {   // the first 256 threads of the workgroup, fixed summation order
     __shared__ double red[3][256];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x < 256 ? threadIdx.x : 255;
+    const bool act = threadIdx.x < 256;
     double e = 0.0, d2 = 0.0, dg = 0.0;
+    if (act) {
     // the loads of eight rounds are in flight together (a thread walks 20 rounds at 5 000 frames: one round trip each would be
     // 20 us of a launch that rides nowhere at that size); the additions keep their order
     for (int i0 = tid; i0 < r.n_err; i0 += 8 * 256) {
@@ -78,16 +80,17 @@ __device__ __forceinline__ void reduce_scalars_body(const ReduceArgs &r) {   // 
         for (int u = 0; u < 8; u++) { d2 += v[u].x; dg += v[u].y; }
     }
     red[0][tid] = e; red[1][tid] = d2; red[2][tid] = dg;
+    }
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) {
+        if (act && tid < off) {
             red[0][tid] += red[0][tid + off];
             red[1][tid] += red[1][tid + off];
             red[2][tid] += red[2][tid + off];
         }
         __syncthreads();
     }
-    if (tid == 0) {
+    if (act && tid == 0) {
         r.scal[0] = red[0][0]; r.scal[1] = red[1][0];
         // multi-GPU: delta_s . g0 uses this rank's piece of the shared gradient, so it joins the rank sum
         r.scal[2] = red[2][0] + (r.fold_shared ? r.lin_part[2 * (size_t)r.F + 1] : 0.0);
@@ -334,9 +337,13 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
                                                     const int32_t *__restrict__ w_fb, const int32_t *__restrict__ w_fe,
                                                     const int32_t *__restrict__ flist, const int32_t *__restrict__ dense_ent, const double *__restrict__ Wd,
                                                     const double *__restrict__ Yd, int Ad, int n_pad, double sign,
-                                                    double *__restrict__ S, double *__restrict__ rhs) {
+                                                    double *__restrict__ S, double *__restrict__ rhs, int rider, const ReduceArgs red) {
     extern __shared__ __align__(16) double stage[];   // [2][SM_ROWS][SM_PS]
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (rider && blockIdx.x == 0) {   // the step's scalars ride here when no k_schur_fill launch precedes (pass A wrote the panels)
+        reduce_scalars_body(red);
+        return;
+    }
+    const int w = (int)blockIdx.x - rider, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ga = w_ga[w], gb = w_gb[w], fb = w_fb[w], fe = w_fe[w];
     const int lr = lane >> 4, lc = lane & 15;
     // staging role: thread t < 288 owns row t of the stage: (dense entity, parameter) of the a side (t < 96: a row of Y) or of
@@ -350,6 +357,10 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
 #pragma unroll
         for (int y = 0; y < 3; y++) acc[x][y] = dg_acc_t{0.0, 0.0, 0.0, 0.0};
     const int rt0 = 3 * (wave & 1), ct0 = 3 * (wave >> 1);
+    // Only the lower triangle (in dense order) is ever stored: a wavefront whose whole 48 x 48 piece lies above the diagonal -- in a block
+    // on the diagonal of S up to five of the eight (the a-side group is one half of the b-side group) -- issues no MFMAs at all (the
+    // matrix pipes bound this kernel); it still stages rows and keeps the barriers.  (Per-sub-tile masks cost 96 spilled registers.)
+    const bool all_dead = __builtin_amdgcn_readfirstlane((int)(SM_AR * ga + 16 * (rt0 + 3) - 1 < SM_BR * gb + 16 * ct0)) != 0;
 
     // position k of the block's frame list (frames in which both entity groups are present; two of them per step)
     auto fetch_rows = [&](int k0, double2 (&v)[6]) {   // nothing here waits: the values are stored steps later
@@ -374,6 +385,7 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
     // pipes (27 MFMAs per wavefront, ~1.4 us) is shorter than a loaded chip's memory latency, a single step of look-ahead starves
     double2 v[SM_DEPTH][6];
     auto compute = [&](int buf) {
+        if (all_dead) return;
         const double *sb = stage + (size_t)buf * SM_ROWS * SM_PS;
         double av[3][3], bv[3][3];
 #pragma unroll
@@ -1525,7 +1537,8 @@ static ReduceArgs reduce_args(const DeviceProblem &P, int n_err, bool fold_share
 // ride_seq != 0: one extra workgroup of the launch reduces the step's scalars (ride_n_err partial sums of r^2) and publishes
 // them under that sequence number -- the speculative Schur complement and that reduction only depend on the passes before
 // them, not on each other.  Returns false if the scalars did not ride (the caller launches k_reduce_scalars).
-bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq, int ride_n_err, double *ride_scal) {
+bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st, unsigned long long ride_seq, int ride_n_err, double *ride_scal,
+                  bool panels_ready) {
     const DeviceProblem::Blocks &b = P.blk[which];
     if (P.n_smwork > 0) {   // many shared entities: dense panels + block-of-S-stationary MFMA kernel
         const size_t lds = (size_t)2 * SM_ROWS * SM_PS * sizeof(double);
@@ -1534,10 +1547,12 @@ bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
         const ReduceArgs red = reduce_args(P, ride_n_err, false, ride_scal ? 0ull : ride_seq, ride_scal);
         const int extra = (ride_seq || ride_scal) ? 1 : 0;
         HookScope _h(P, KID_SCHUR);
-        hipLaunchKernelGGL(k_schur_fill, dim3((unsigned)(((int64_t)P.total_slots * 6 + (int64_t)P.F * 6 + 255) / 256) + extra), dim3(256), 0, st, P.slot_frame, P.slot_dense,
-                           b.W, b.Vinv, b.gf, P.total_slots, P.F, P.Ad, P.Wd, P.Yd, extra, red);
-        hipLaunchKernelGGL(k_schur_mfma, dim3(P.n_smwork), dim3(512), lds, st, P.sm_ga, P.sm_gb, P.sm_fb, P.sm_fe, P.sm_frames, P.dense_ent, P.Wd, P.Yd, P.Ad, P.n_pad, sign,
-                           b.S, b.rhs);
+        if (!panels_ready)   // the panels for this damping: W from memory, Y = W (V + mu I)^-1 (the scalars ride here when there is such a launch)
+            hipLaunchKernelGGL(k_schur_fill, dim3((unsigned)(((int64_t)P.total_slots * 6 + (int64_t)P.F * 6 + 255) / 256) + extra), dim3(256), 0, st, P.slot_frame, P.slot_dense,
+                               b.W, b.Vinv, b.gf, P.total_slots, P.F, P.Ad, P.Wd, P.Yd, extra, red);
+        const int extra_m = panels_ready ? extra : 0;
+        hipLaunchKernelGGL(k_schur_mfma, dim3(P.n_smwork + extra_m), dim3(512), lds, st, P.sm_ga, P.sm_gb, P.sm_fb, P.sm_fe, P.sm_frames, P.dense_ent, P.Wd, P.Yd, P.Ad, P.n_pad, sign,
+                           b.S, b.rhs, extra_m, red);
         return extra != 0;
     }
     if (P.n_swork == 0) return false;
