@@ -202,6 +202,12 @@ struct aar_problem {
     bool s_reduced = false;            // multi-GPU: blk[cur].S | rhs | g0 already hold the all-reduced system for schur_mu
     bool trial_reduced = false;        // ... the same for the trial's block set, until the step is accepted or rejected
     bool fused_comm = true;            // the step's scalars and the next step's system share ONE all-reduce (AAR_FUSED_COMM=0: two)
+    // multi-GPU: the factorisation of the NEXT step's (already reduced) system is queued right behind the fused all-reduce, before the
+    // host has seen this step's scalars -- the usual outcome (accepted, predicted damping) then finds it done, and the host's
+    // turn-around hides behind it as it hides behind the Schur kernel on one GPU; any other outcome rebuilds the system anyway
+    bool spec_chol = true;             // AAR_SPEC_CHOL=0: off
+    int spec_chol_blk = -1;            // block set whose S a speculative factorisation has consumed (-1: none pending)
+    double spec_chol_mu = -1;
     hipStream_t stream2 = nullptr;     // pass B of the trial point runs here, beside the speculative Schur complement
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = false;              // AAR_OVERLAP=1: pass B of the trial point on a second stream beside the Schur complement
@@ -311,6 +317,20 @@ int allreduce(aar_problem *pb, double *buf, size_t count, int op) {
 // n_pad^2 + ... of the square.
 int allreduce_system(aar_problem *pb, int which, int n_tail, unsigned long long publish_seq = 0) {
     DeviceProblem &P = pb->P;
+    // Small systems travel as they lie -- the square S (its upper triangle is never written: zeros) | rhs | g0 | tail are ONE allocation --
+    // without the two packing launches: below ~1 MB an all-reduce over xGMI is latency, not bytes, and each launch on this dependent
+    // chain costs 3-4 us.  From 384 unknowns on (2.4 MB square) the packed triangle's halved payload wins.  AAR_PACK_SYSTEM=0 / 1 forces.
+    static const int pack_env = getenv("AAR_PACK_SYSTEM") ? atoi(getenv("AAR_PACK_SYSTEM")) : -1;
+    const bool pack = pack_env >= 0 ? pack_env != 0 : P.n_pad > 384;
+    if (!pack) {
+        const size_t count = (size_t)P.n_pad * P.n_pad + 2 * (size_t)P.n_pad + (size_t)n_tail;
+        int rc = allreduce(pb, P.blk[which].S, count, NCCL_SUM);
+        if (rc) return rc;
+        pb->comm->last_system_bytes = (int64_t)(count * sizeof(double));
+        // tail[0..3] are now the rank sums, tail[4..7] still this rank's own: exactly the record the host reads
+        if (publish_seq) { launch_publish(P, publish_seq, pb->stream, P.blk[which].tail, /*flags_reduced=*/true); pb->launches += 1; }
+        return AAR_OK;
+    }
     const int extra = 2 * P.n_pad + n_tail;
     const size_t count = (size_t)P.n_pad * (P.n_pad + 1) / 2 + (size_t)extra;
     const dim3 grid((unsigned)((std::max(P.n_pad, extra) + 255) / 256), (unsigned)P.n_pad + 1);
@@ -569,6 +589,17 @@ constexpr int TRY_NOT_POSITIVE_DEFINITE = 1;   // damped_try: not an error code 
 int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     DeviceProblem &P = pb->P;
     const int cur = pb->cur, tr = 1 - cur;
+    bool chol_done = false;
+    if (pb->spec_chol_blk >= 0) {   // a factorisation was queued ahead of the host's decision (multi-GPU, see aar_problem::spec_chol)
+        if (pb->spec_chol_blk == cur && pb->spec_chol_mu == mu && pb->schur_mu == mu && pb->s_reduced) {
+            chol_done = true;       // the step was accepted with the predicted damping: this try's factorisation is already running
+        } else {
+            // rejected (the trial's block set is rebuilt from scratch) or accepted with another damping (s_reduced: the system is
+            // rebuilt from the blocks below): what the speculative factorisation left in S, and in the pivot flags, means nothing
+            HIP_TRY(hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream));
+        }
+        pb->spec_chol_blk = -1;
+    }
     if (pb->schur_mu != mu) {  // not already done speculatively by the try that produced this point
         StageTimer t(pb, &pb->times.schur);
         if (pb->s_reduced) {
@@ -606,7 +637,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     pb->s_reduced = false;      // the factorisation below consumes the system
     pb->trial_reduced = false;
     bool backsub_rode = false;
-    {
+    if (!chol_done) {
         StageTimer t(pb, &pb->times.chol);
         // (stage timers keep the frame back-substitution in its own launch, so that it has a time of its own)
         backsub_rode = launch_chol(P, cur, mu, pb->stream, pb->stage_timers ? -1 : tr);
@@ -657,6 +688,13 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
             if ((rc = allreduce_system(pb, tr, 4, pb->seq))) return rc;   // (the unpacking kernel publishes the reduced scalars)
         }
         pb->trial_reduced = true;
+        if (pb->spec_chol && !pb->stage_timers && !pb->profiling) {
+            StageTimer t(pb, &pb->times.chol);
+            (void)launch_chol(P, tr, mu * 0.33, pb->stream);
+            pb->spec_chol_blk = tr;
+            pb->spec_chol_mu = mu * 0.33;
+            pb->launches += 3 * P.nT;
+        }
     } else {
         if ((rc = launch_scalars(pb, P.F))) return rc;
         if (evaluate_trial) {
@@ -910,6 +948,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     { const char *e = getenv("AAR_OVERLAP"); pb->overlap = (e && e[0] == '1'); }  // measured slower than one stream at config 3: off by default
     { const char *e = getenv("AAR_MERGE_PASSES"); if (e) pb->merge_passes = (e[0] != '0'); }
     { const char *e = getenv("AAR_FUSED_COMM"); if (e) pb->fused_comm = (e[0] != '0'); }
+    { const char *e = getenv("AAR_SPEC_CHOL"); if (e) pb->spec_chol = (e[0] != '0'); }
 
     PoseLayout &L = pb->L;
     L.C = C; L.M = M; L.F = Fg; L.rc = d->root_cam; L.rm = d->root_marker;
@@ -1427,6 +1466,10 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     pb->cur = 0;
     pb->trial_points = 0;
     pb->launches = 0;
+    if (pb->spec_chol_blk >= 0) {   // a factorisation queued ahead of the last step of the previous solve: its pivot flags mean nothing
+        HIP_TRY(hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream));
+        pb->spec_chol_blk = -1;
+    }
     memset(&pb->times, 0, sizeof pb->times);
     int rc = upload_z(pb, x_full, 0);
     if (rc) return rc;

@@ -192,8 +192,10 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
 #pragma unroll
     for (int i = 0; i < 28; i++) vals[i] = 0.0;
 
+    // the frame's own row is the same for every lane of the workgroup: fetched through the scalar cache it lives in SGPRs, not in
+    // 42 VGPRs per lane (k_passA_intr<256,4>: 81 spilled registers -> see profiles/r03_vgpr_counts.txt)
     Ent ef;
-    load_ent_lds(entl + (size_t)kf * ENT_LDS, ef);
+    load_ent(a.ent, a.A + __builtin_amdgcn_readfirstlane(f), ef);
     const int nobs = o1 - o0;
     // Interleaved assignment: consecutive lanes take observations `stride` apart so that lanes of one wave
     // mostly hold different cameras (the order inside a frame is camera-major); this keeps the ds_add_f64
@@ -228,7 +230,7 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
 #pragma unroll
             for (int i = 0; i < 24; i++) Wk[i] = 0.0;
         }
-#pragma unroll
+#pragma unroll   // (NOT unrolling it for the intrinsics variant, whose 24 extra accumulators spill 80-90 registers, spills 130-180)
         for (int kk = 0; kk < CPL; kk++) {
             const int k = part * CPL + kk;
             const float2 ouv = reinterpret_cast<const float2 *>(a.uv)[4 * (int64_t)o + k];
