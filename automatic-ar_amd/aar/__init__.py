@@ -33,7 +33,7 @@ SYMBOLS = [
     "aar_cam_configs_read", "aar_detections_read", "aar_detections_free", "aar_subseqs_read", "aar_ippe_square",
     "aar_vote_transforms", "aar_init_default_params", "aar_initializer_run", "aar_initializer_object_poses",
     "aar_comm_get_stats", "aar_lm_set_step_callback", "aar_lm_set_stop_function", "aar_problem_extract_z", "aar_problem_merge_z",
-    "aar_solution_read_ex", "aar_cam_configs_read_ex", "aar_set_stage_timers",
+    "aar_solution_read_ex", "aar_cam_configs_read_ex", "aar_set_stage_timers", "aar_problem_pcg_iterations",
 ]
 NUM_KERNELS = 14
 
@@ -181,6 +181,7 @@ def lib():
     L.aar_lm_solve.argtypes = [C.c_void_p, dp, C.POINTER(CLmParams), C.POINTER(CLmReport)]
     L.aar_get_stage_times.argtypes = [C.c_void_p, C.POINTER(CStageTimes)]
     L.aar_set_stage_timers.argtypes = [C.c_void_p, C.c_int]
+    L.aar_problem_pcg_iterations.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.aar_reproj_stats.argtypes = [C.c_void_p, dp, dp, dp]
     L.aar_set_kernel_profiling.argtypes = [C.c_void_p, C.c_int]
     L.aar_get_kernel_times.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64)]
@@ -736,6 +737,12 @@ class Problem:
         cnt = np.zeros(NUM_KERNELS, dtype=np.int64)
         _check(lib().aar_get_kernel_times(self.handle, _dptr(sec), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
         return {lib().aar_kernel_name(i).decode(): (float(sec[i]), int(cnt[i])) for i in range(NUM_KERNELS)}
+
+    def pcg_iterations(self):
+        """(CG iterations of the last damped solve, running total) in AAR_SOLVER=pcg mode; zeros otherwise"""
+        out = (C.c_int32 * 2)()
+        _check(lib().aar_problem_pcg_iterations(self.handle, out))
+        return int(out[0]), int(out[1])
 
     def set_stage_timers(self, on):
         _check(lib().aar_set_stage_timers(self.handle, int(on)))

@@ -600,7 +600,18 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         }
         pb->spec_chol_blk = -1;
     }
-    if (pb->schur_mu != mu) {  // not already done speculatively by the try that produced this point
+    if (P.use_pcg) {   // opt-in: no Schur complement, no factorisation -- PCG through the frame blocks (pcg_kernels.hip)
+        if (pb->vinv_mu != mu) {
+            launch_frame_inv(P, cur, mu, pb->stream);
+            pb->vinv_mu = mu;
+            pb->launches += 1;
+        }
+        StageTimer t(pb, &pb->times.chol);
+        launch_pcg(P, cur, mu, pb->stream);
+        pb->launches += 1;
+        chol_done = true;
+    }
+    if (!P.use_pcg && pb->schur_mu != mu) {  // not already done speculatively by the try that produced this point
         StageTimer t(pb, &pb->times.schur);
         if (pb->s_reduced) {
             // multi-GPU, fused collective: S | rhs | g0 of this point already hold the ALL-REDUCED system for the predicted
@@ -661,7 +672,9 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     // On one GPU the reduction does not even get a launch of its own: it rides as one more workgroup of that kernel.
     int rc = AAR_OK;
     bool rode = false;
-    if (evaluate_trial && !pb->comm) {
+    if (P.use_pcg) {   // nothing is eliminated ahead of the next step in this mode: only the step's scalars travel
+        if ((rc = launch_scalars(pb, P.F))) return rc;
+    } else if (evaluate_trial && !pb->comm) {
         StageTimer t(pb, &pb->times.schur);
         rode = launch_schur(P, tr, 1.0, pb->stream, pb->seq + 1, P.F, nullptr, panels_ok(pb, tr, mu * 0.33));
         panels_now(pb, tr, mu * 0.33);
@@ -1030,9 +1043,18 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     // output-stationary kernel, which needs none of this, takes over.  Only THAT kernel keeps a row panel of all entities in LDS.
     { const char *e = getenv("AAR_DETERMINISTIC"); P.deterministic = (e && atoi(e) != 0) ? 1 : 0; }
     { const char *e = getenv("AAR_DENSE_FROM_PASSA"); if (e) P.dense_from_passA = atoi(e) != 0 ? 1 : 0; }
+    {   // opt-in inexact solver (pcg_kernels.hip); single GPU: a collective per CG iteration would have to be queued by the host
+        const char *e = getenv("AAR_SOLVER");
+        P.use_pcg = (e && !strcmp(e, "pcg")) ? 1 : 0;
+        if (const char *t = getenv("AAR_PCG_ETA")) P.pcg_eta = atof(t);
+        if (const char *t = getenv("AAR_PCG_MAX_IT")) P.pcg_max_it = std::max(1, atoi(t));
+        if (P.use_pcg && pb->comm && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER=pcg is a single-GPU mode");
+        if (P.use_pcg && pcg_lds_bytes(A) > 150 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER=pcg keeps the CG vectors and the preconditioner of %d unknowns in LDS: too many shared entities", 6 * A);
+    }
     bool schur_mfma = A >= 96 && F > 0;
     if (const char *e = getenv("AAR_SCHUR_MFMA")) schur_mfma = atoi(e) != 0 && F > 0;
     if (P.deterministic) schur_mfma = false;   // fixed-order sums exist for the output-stationary kernel only (kernels.h)
+    if (P.use_pcg) schur_mfma = true;          // (no Schur complement is ever formed in that mode: no LDS row panel to fit; the dense panels are not allocated either)
     if (schur_mfma) {
         const size_t panel_bytes = (size_t)2 * F * ((A + 1 + 31) / 32 * 32) * 288;
         size_t free_b = 0, total_b = 0;
@@ -1174,7 +1196,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     // frame ranges are cut so that the grid is a few workgroups per CU
     std::vector<int32_t> sm_ga, sm_gb, sm_fb, sm_fe, slot_frame, slot_dense, dense_ent;
     std::vector<int32_t> sm_frames;   // frame lists of the blocks, back to back
-    if (schur_mfma) {
+    if (schur_mfma && !P.use_pcg) {
         // dense entity 0 = the pseudo entity g_f; then the entities that are seen at all, MOST FREQUENT FIRST (ties: ascending):
         // the often-seen entities form dense groups, the rarely seen ones share groups that whole stretches of frames do not
         // touch at all -- a block of S then only streams the frames in which both of its entity groups are present
@@ -1250,6 +1272,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     UP(fslot_start, fslot_start); UP(fslot_ent, fslot_ent); UP(b_idx, b_idx); UP(b_uv, b_uv);
     UP(chunk_start, chunk_start); UP(ent_fixed, ent_fixed);
     UP(sw_ent, sw_ent); UP(sw_begin, sw_begin); UP(sw_end, sw_end); UP(pair_rec, pair_rec);
+    if (P.use_pcg) { std::vector<int32_t> eps(pair_base.begin(), pair_base.end()); UP(ent_pair_start, eps); }
     if (P.deterministic) { UP(sp_off, sp_off); UP(se_start, se_start); UP(se_items, se_items); UP(pbr_start, pbr_start); UP(pbr_chunk, pbr_chunk); UP(pbr_kind, pbr_kind); UP(pbr_a, pbr_a); UP(pbr_b, pbr_b); }
     if (P.n_smwork) { UP(sm_ga, sm_ga); UP(sm_gb, sm_gb); UP(sm_fb, sm_fb); UP(sm_fe, sm_fe); UP(slot_dense, slot_dense); UP(slot_frame, slot_frame); UP(dense_ent, dense_ent); UP(sm_frames, sm_frames); }
 #undef UP
@@ -1268,6 +1291,16 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         if (hipMemset(P.blk[w].tail, 0, 8 * sizeof(double)) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "hipMemset failed"));
     }
     if (P.deterministic) { AL(sp_part, (size_t)sp_total); AL(pb_part, (size_t)P.n_chunks * P.pb_stride); }
+    if (P.use_pcg) {
+        AL(pcg_ws, (size_t)A * 36 + 13 * (size_t)A + 6 * (size_t)F + 8); AL(pcg_counter, 4);
+        hipDeviceProp_t prop;
+        P.pcg_grid = (hipGetDeviceProperties(&prop, pb->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;   // one workgroup per CU: all resident
+        // small problems: fewer workgroups make the two grid-wide hand-overs of an iteration cheaper than the passes get slower
+        // (measured, LM it/s at config 3: 64 / 128 / 256 workgroups 4174 / 4201 / 3883; config 2: 32 best; config 5: 256 best)
+        const int64_t want = std::max<int64_t>(32, ((int64_t)F + 3) / 4);
+        P.pcg_grid = (int)std::min<int64_t>(P.pcg_grid, want);
+        if (const char *t = getenv("AAR_PCG_GRID")) P.pcg_grid = std::max(1, atoi(t));
+    }
     if (P.n_smwork) { AL(Wd, (size_t)F * P.Ad * 36); AL(Yd, (size_t)F * P.Ad * 36); }   // zeroed here, once: absent pairs are never written
     AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad); AL(bs_flags, (size_t)P.nT + 1);
     AL(Lp, (size_t)P.nT * P.n_pad * CHOL_NB); AL(zf, P.n_pad);
@@ -1751,6 +1784,16 @@ const char *aar_kernel_name(int kid) {
                                            "k_ldl_diag", "k_ldl_trsm", "k_ldl_update", "k_ldl_backsolve", "k_backsub",
                                            "k_reduce_scalars", "k_ldl_panel"};
     return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
+}
+
+int aar_problem_pcg_iterations(aar_problem *pb, int32_t out[2]) {
+    if (!pb || !out) return set_error(AAR_ERR_INVALID, "aar_problem_pcg_iterations: null argument");
+    out[0] = out[1] = 0;
+    if (!pb->P.use_pcg) return AAR_OK;
+    HIP_TRY(hipSetDevice(pb->device));
+    HIP_TRY(hipMemcpyAsync(out, pb->P.pcg_counter + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    return AAR_OK;
 }
 
 int aar_set_stage_timers(aar_problem *pb, int on) {

@@ -79,6 +79,13 @@ struct DeviceProblem {
     double *sp_part = nullptr;            // per Schur work item: its row panel [(a+1)*36] | its 6 rhs entries | 2 idle
     int64_t *sp_off = nullptr;            // [n_swork] first double of the item's record
     int32_t *se_start = nullptr, *se_items = nullptr;   // [A+1], [n_swork]: the work items of every entity, frame-ascending
+    // AAR_SOLVER=pcg (opt-in, pcg_kernels.hip): the reduced system solved by preconditioned CG through the frame blocks
+    int use_pcg = 0, pcg_grid = 0, pcg_max_it = 200;
+    double pcg_eta = 0.1;                 // |r| <= eta |b| stops an inner solve (AAR_PCG_ETA)
+    int32_t *ent_pair_start = nullptr;    // [A+1] entity -> its incidences in pair_rec
+    double *pcg_ws = nullptr;             // Minv [A][36] | b [6A] | y [6A] | pq [A] | t [6F]
+    int32_t *pcg_counter = nullptr;       // [0..1] grid-barrier counters (alternating), [2] iterations of the last solve, [3] running total
+    mutable int pcg_parity = 0;
     // state: everything that depends on a pose vector exists twice (index 0/1 = the two pose buffers), so that the
     // blocks of a trial point can be built while those of the current point are still needed for a mu retry
     double *z[2] = {nullptr, nullptr};    // [6A + 6F] pose vectors
@@ -155,6 +162,8 @@ bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
 // damping + LDL^T + both substitutions -> delta_s; trial >= 0: launch_backsub(which, trial) may ride in the last launch (true: it did)
 bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial = -1);
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
+void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st);     // AAR_SOLVER=pcg: delta_s by PCG through the frame blocks (needs Vinv, hf for mu)
+size_t pcg_lds_bytes(int A);
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st,
                            double *scal_out = nullptr);  // scal[0..2], scal[5..6] (into scal_out instead of P.scal if given)
 // scal / flags -> host record; flags_reduced: the flags are decoded from src[3] (every rank's flags, all-reduced) instead of P.flags

@@ -1,0 +1,323 @@
+// OPT-IN solver of the damped normal equations (AAR_SOLVER=pcg; the default stays the direct solve of solve_kernels.hip, whose step is
+// the reference's Eigen::SimplicialLDLT step to rounding, libs/sparselevmarq.h:394-400).
+//
+// Inexact LM: the reduced camera / marker system  S x = b,  S = U + mu I - sum_f W_f (V_f + mu I)^-1 W_f^T,  is solved by
+// block-Jacobi-preconditioned conjugate gradients THROUGH the frame blocks -- S is never formed, nothing is factored:
+//     y = S p  =  (U + mu I) p - sum_f W_f t_f,    t_f = (V_f + mu I)^-1 (W_f^T p)
+// i.e. two passes over the W blocks per iteration and n-vectors.  Stopped at |r| <= eta |b| (eta = 0.1 by default: a forcing term, as in
+// inexact Newton methods): the LM trajectory is then NOT the reference's step for step, only its fixed point is -- measured final RMSE
+// within 1e-6 px of the direct path (north star bar: 1e-4 px), same number of LM steps (profiles/r03_pcg_experiment.txt, r03_pcg_bench.txt).
+// Why it exists: it is the one formulation of this solve in which nothing O(n^3) is left -- the frame sum shards by
+// frame, an iteration exchanges 8 n bytes.
+//
+// ONE persistent launch per solve: G workgroups (one per CU), each keeps its own copy of the CG vectors x, r, p in LDS and updates them
+// redundantly (n is a few hundred to a few thousand), so an iteration needs only two grid-wide hand-overs -- t (6 F doubles) after the
+// frame pass, y and the partial p.y after the entity pass -- done with agent-scope atomic stores / loads and a counter, no
+// cache-maintenance fences (1.1 us per hop, scripts/probe/hop_probe.hip).  The convergence test is taken by every workgroup from the
+// same numbers in the same order: all leave in the same iteration.
+#include "geom.hpp"
+#include "kernels.h"
+
+namespace aar {
+
+struct PcgArgs {
+    // blocks of the current point (pass A / pass B output; S holds U: the Schur complement kernels do not run in this mode)
+    const double *U, *g0, *W, *Vinv, *hf;
+    const int32_t *fslot_start, *fslot_ent;      // frame -> its W blocks / their entities
+    const int32_t *ent_pair_start;               // [A + 1] entity -> its (entity, frame) incidences in pair_rec
+    const int4 *pair_rec;                        // {frame, W block, first W block of the frame, 0}
+    const int32_t *ent_fixed;
+    int A, F, n_pad;
+    double mu, eta2;                             // damping; eta^2
+    int max_it;
+    // work space
+    double *Minv;                                // [A][36] inverse diagonal blocks of S
+    double *b;                                   // [6 A]  right-hand side g0 - sum_f W_f h_f
+    double *t;                                   // [6 F]
+    double *y;                                   // [6 A]
+    double *pq;                                  // [A]  partial p . y per entity
+    int32_t *counter;                            // [2]  grid barrier counters: this launch uses counter[parity] (zero at entry) and clears the other
+    int parity;
+    double *x_out;                               // [6 A (.. n_pad)] delta_s
+    int32_t *iters_out;                          // [2] iterations of this solve, running total
+    int32_t *flags;
+};
+
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Every workgroup of the (co-resident) grid arrives; what it stored with st_agent before is visible to all afterwards.
+__device__ __forceinline__ void grid_hop(int32_t *counter, int &round, int G, int32_t *flags) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have been acknowledged
+    __syncthreads();
+    round++;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = round * G;
+        long spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1L << 26)) { atomicOr(flags, 4); break; }   // never a hung device
+        }
+    }
+    __syncthreads();
+}
+
+// sum of NV per-thread values over the 256 threads, fixed order; result in out[0..NV) on every thread.  lds: 4 * NV doubles
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+    }
+    __syncthreads();   // (lds may still be read from the previous call)
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) lds[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = (lds[i] + lds[NV + i]) + (lds[2 * NV + i] + lds[3 * NV + i]);
+}
+
+constexpr int PCG_THREADS = 256;
+
+// LDS (dynamic): x [n] | r [n] | p [n] | Mi [6 n] (the preconditioner: read once, used every iteration) | red [4 * 27]
+__global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
+    extern __shared__ __align__(16) double lds[];
+    const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *x = lds, *r = lds + n, *p = r + n, *Mi = p + n, *red = Mi + 6 * n;
+    int32_t *counter = a.counter + a.parity;
+    int round = 0;
+    if (wg == 0 && tid == 0) __hip_atomic_store(a.counter + (1 - a.parity), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+
+    // ---- setup: diagonal blocks of S (inverted: the preconditioner) and the right-hand side, entity by entity ----
+    for (int e = wg; e < a.A; e += G) {
+        double acc[27];   // 21: lower triangle of sum_f W (V+mu)^-1 W^T, 6: sum_f W h_f
+#pragma unroll
+        for (int i = 0; i < 27; i++) acc[i] = 0.0;
+        const bool fixed = a.ent_fixed[e] != 0;
+        if (!fixed) {
+            for (int pi = a.ent_pair_start[e] + tid; pi < a.ent_pair_start[e + 1]; pi += PCG_THREADS) {
+                const int4 rec = a.pair_rec[pi];
+                const double *Wb = a.W + (size_t)rec.y * 36, *Vi = a.Vinv + (size_t)rec.x * 36, *h = a.hf + (size_t)rec.x * 6;
+                double w[36], yv[36];
+#pragma unroll
+                for (int q = 0; q < 36; q++) w[q] = Wb[q];
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) s = fma(w[i * 6 + k], Vi[k * 6 + j], s);
+                        yv[i * 6 + j] = s;
+                    }
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+#pragma unroll
+                    for (int j = 0; j <= i; j++) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) s = fma(yv[i * 6 + k], w[j * 6 + k], s);
+                        acc[i * (i + 1) / 2 + j] += s;
+                    }
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s = fma(w[i * 6 + k], h[k], s);
+                    acc[21 + i] += s;
+                }
+            }
+        }
+        block_sum<27>(acc, red);
+        if (tid == 0) {
+            double out[36];
+            if (fixed) {
+#pragma unroll
+                for (int i = 0; i < 36; i++) out[i] = (i % 7 == 0) ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) st_agent(a.b + 6 * e + i, 0.0);
+            } else {
+                double m[6][6];
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++) {
+                        const double v = a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] + (i == j ? a.mu : 0.0) - acc[i * (i + 1) / 2 + j];
+                        m[i][j] = v; m[j][i] = v;
+                    }
+                if (!spd6_inverse(m, out)) atomicOr(a.flags, 2);
+#pragma unroll
+                for (int i = 0; i < 6; i++) st_agent(a.b + 6 * e + i, a.g0[6 * e + i] - acc[21 + i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 36; i++) st_agent(a.Minv + (size_t)e * 36 + i, out[i]);
+        }
+    }
+    grid_hop(counter, round, G, a.flags);
+
+    // ---- x = 0, r = b, z = Minv r, p = z ----
+    double rz = 0.0, bb = 0.0;
+    for (int i = tid; i < n; i += PCG_THREADS) { x[i] = 0.0; r[i] = ld_agent(a.b + i); }
+    for (int i = tid; i < 6 * n; i += PCG_THREADS) Mi[i] = ld_agent(a.Minv + i);
+    __syncthreads();
+    {
+        double s[2] = {0.0, 0.0};
+        for (int i = tid; i < n; i += PCG_THREADS) {
+            const int e = i / 6, row = i - 6 * e;
+            double z = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            p[i] = z;
+            s[0] += r[i] * z;
+            s[1] += r[i] * r[i];
+        }
+        block_sum<2>(s, red);
+        rz = s[0]; bb = s[1];
+    }
+    __syncthreads();
+
+    int it = 0;
+    double rr = bb;
+    while (it < a.max_it && rr > a.eta2 * bb && bb > 0.0) {
+        // ---- frame pass: t_f = (V_f + mu I)^-1 (W_f^T p), one wavefront per frame ----
+        for (int f = wg * (PCG_THREADS / 64) + wave; f < a.F; f += G * (PCG_THREADS / 64)) {
+            const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
+            double c[6] = {0, 0, 0, 0, 0, 0};
+            for (int s = s0 + lane; s < s1; s += 64) {
+                const int e = a.fslot_ent[s];
+                const double2 *wb = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double pe = p[6 * e + i];
+                    const double2 w0 = wb[3 * i], w1 = wb[3 * i + 1], w2 = wb[3 * i + 2];
+                    c[0] = fma(w0.x, pe, c[0]); c[1] = fma(w0.y, pe, c[1]); c[2] = fma(w1.x, pe, c[2]);
+                    c[3] = fma(w1.y, pe, c[3]); c[4] = fma(w2.x, pe, c[4]); c[5] = fma(w2.y, pe, c[5]);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int i = 0; i < 6; i++) c[i] += __shfl_xor(c[i], off);
+            if (lane < 6) {
+                double tv = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) tv = fma(a.Vinv[(size_t)f * 36 + lane * 6 + k], c[k], tv);
+                st_agent(a.t + (size_t)f * 6 + lane, tv);
+            }
+        }
+        grid_hop(counter, round, G, a.flags);
+        // ---- entity pass: y_e = ((U + mu I) p)_e - sum_f W_ef t_f, and p_e . y_e ----
+        for (int e = wg; e < a.A; e += G) {
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            const bool fixed = a.ent_fixed[e] != 0;
+            if (!fixed) {
+                for (int pi = a.ent_pair_start[e] + tid; pi < a.ent_pair_start[e + 1]; pi += PCG_THREADS) {
+                    const int4 rec = a.pair_rec[pi];
+                    const double2 *wb = reinterpret_cast<const double2 *>(a.W + (size_t)rec.y * 36);
+                    double tv[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) tv[k] = ld_agent(a.t + (size_t)rec.x * 6 + k);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        const double2 w0 = wb[3 * i], w1 = wb[3 * i + 1], w2 = wb[3 * i + 2];
+                        acc[i] -= w0.x * tv[0] + w0.y * tv[1] + w1.x * tv[2] + w1.y * tv[3] + w2.x * tv[4] + w2.y * tv[5];
+                    }
+                }
+                for (int bq = tid; bq < a.A; bq += PCG_THREADS) {   // row e of the symmetric U (lower triangle stored)
+                    if (a.ent_fixed[bq]) continue;                  // (its p is zero)
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            const double u = bq < e ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * bq + j]
+                                                    : (bq > e ? a.U[(size_t)(6 * bq + j) * a.n_pad + 6 * e + i]
+                                                              : (j <= i ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] : a.U[(size_t)(6 * e + j) * a.n_pad + 6 * e + i]));
+                            acc[i] = fma(u, p[6 * bq + j], acc[i]);
+                        }
+                }
+            }
+            block_sum<6>(acc, red);
+            if (tid == 0) {
+                double d = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double yv = fixed ? p[6 * e + i] : acc[i] + a.mu * p[6 * e + i];
+                    st_agent(a.y + 6 * e + i, yv);
+                    d = fma(p[6 * e + i], yv, d);
+                }
+                st_agent(a.pq + e, d);
+            }
+        }
+        grid_hop(counter, round, G, a.flags);
+        // ---- vector updates, redundantly in every workgroup (same numbers, same order: same decisions) ----
+        double pAp = 0.0;
+        double yl[24];   // this thread's entries of y, requested together with the partial dot products (one round trip, not two)
+        {
+            int ny = 0;
+            for (int i = tid; i < n; i += PCG_THREADS, ny++)
+                if (ny < 24) yl[ny] = ld_agent(a.y + i);
+            double s[1] = {0.0};
+            for (int e = tid; e < a.A; e += PCG_THREADS) s[0] += ld_agent(a.pq + e);
+            block_sum<1>(s, red);
+            pAp = s[0];
+        }
+        const double alpha = rz / pAp;
+        {
+            int ny = 0;
+            for (int i = tid; i < n; i += PCG_THREADS, ny++) {
+                x[i] = fma(alpha, p[i], x[i]);
+                r[i] = fma(-alpha, yl[ny < 24 ? ny : 23], r[i]);
+            }
+        }
+        __syncthreads();
+        double s2[2] = {0.0, 0.0};
+        double zloc[24];   // this thread's entries of z (n <= 24 * 256)
+        int nz = 0;
+        for (int i = tid; i < n; i += PCG_THREADS, nz++) {
+            const int e = i / 6, row = i - 6 * e;
+            double z = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            if (nz < 24) zloc[nz] = z;
+            s2[0] += r[i] * z;
+            s2[1] += r[i] * r[i];
+        }
+        block_sum<2>(s2, red);
+        const double beta = s2[0] / rz;
+        rz = s2[0];
+        rr = s2[1];
+        nz = 0;
+        for (int i = tid; i < n; i += PCG_THREADS, nz++) p[i] = fma(beta, p[i], zloc[nz < 24 ? nz : 23]);
+        __syncthreads();
+        it++;
+    }
+    if (wg == 0) {
+        for (int i = tid; i < n; i += PCG_THREADS) a.x_out[i] = x[i];
+        for (int i = n + tid; i < a.n_pad; i += PCG_THREADS) a.x_out[i] = 0.0;
+        if (tid == 0) { a.iters_out[0] = it; a.iters_out[1] += it; }   // (stopped by max_it: still an inexact step, the LM gain test judges it)
+    }
+}
+
+size_t pcg_lds_bytes(int A) { return ((size_t)9 * 6 * A + 4 * 27 + 8) * sizeof(double); }
+
+void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
+    const DeviceProblem::Blocks &b = P.blk[which];
+    PcgArgs a;
+    a.U = b.S; a.g0 = b.g0; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf;
+    a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.ent_pair_start = P.ent_pair_start; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed;
+    a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta * P.pcg_eta; a.max_it = P.pcg_max_it;
+    a.Minv = P.pcg_ws; a.b = a.Minv + (size_t)P.A * 36; a.y = a.b + 6 * (size_t)P.A; a.pq = a.y + 6 * (size_t)P.A; a.t = a.pq + P.A;
+    a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
+    a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
+    const size_t lds = pcg_lds_bytes(P.A);
+    static size_t granted = 48 * 1024;
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, granted);
+    HookScope _h(P, KID_LDL_DIAG);
+    hipLaunchKernelGGL(k_pcg, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a);
+}
+
+}  // namespace aar

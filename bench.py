@@ -270,6 +270,8 @@ def main():
     ap.add_argument("--intrinsics", action="store_true", help="the reference's default Config: optimize_cam_intrinsics on (9 more parameters per camera, "
                     "libs/multicam_mapper.h:75-81); the headline metric is quoted WITHOUT it (SURVEY.md section 8 row f4)")
     ap.add_argument("--no-amdahl", action="store_true", help="skip the stage-timer pass behind the `amdahl` object")
+    ap.add_argument("--solver", choices=("direct", "pcg"), default="direct", help="direct (default, the headline: Schur complement + dense LDL^T, the reference's "
+                    "step to rounding) or pcg (opt-in inexact LM: the reduced system by preconditioned CG through the frame blocks, csrc/pcg_kernels.hip)")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher / rendezvous / JSON relay only, no GPU work (CPU test of the N-rank plumbing)")
     args = ap.parse_args()
 
@@ -297,6 +299,8 @@ def main():
 
     if aar.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (the product has no CPU path)")
+    if args.solver == "pcg":
+        os.environ["AAR_SOLVER"] = "pcg"          # read when the problem is created
     ds = aar.synth(args.workload)
     comm = None
     if world > 1 or os.environ.get("AAR_FORCE_COMM") == "1":   # the env switch exercises the RCCL path on one GPU
@@ -331,6 +335,7 @@ def main():
     if args.warmup > 0:
         run_steps(problem, x0, args.warmup, params)
     # ---- timed region: exactly K steps ----
+    pcg0 = problem.pcg_iterations()[1]
     barrier()
     t0 = time.perf_counter()
     done, trials, _, _ = run_steps(problem, x0, args.steps, params)
@@ -342,6 +347,7 @@ def main():
         dt = float(t[0])
         dist.barrier()
     assert done == args.steps
+    pcg_total = problem.pcg_iterations()[1] - pcg0
 
     # ---- full solve for the accuracy half of the metric ----
     x_fin, rep_fin = problem.lm_solve(x0, params=params())
@@ -469,11 +475,12 @@ def main():
                    "frames": ds.num_frames, "marker_observations": int(ds.num_obs), "residual_rows": int(8 * ds.num_obs), "unknowns": int(P),
                    "reduced_unknowns": int(Ps), "parallelism": "frames sharded over %d GPU(s)" % world, "seed": 20190219 + args.workload,
                    "residual_mode": "float32-faithful", "jacobian": "analytic",
-                   "optimize_cam_intrinsics": bool(args.intrinsics)},
+                   "optimize_cam_intrinsics": bool(args.intrinsics), "solver": args.solver},
         "final_rmse_px": rmse, "final_sum_sq": ss, "lm_iterations_to_stop": rep_fin["iterations"], "trial_points_per_step": t_avg,
         "iteration_hbm": {"bytes_per_iteration": b_iter, "achieved": b_iter * done / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                           "frac": b_iter * done / dt / 1e9 / HBM_PEAK_GBPS},
         "roofline": roofline, "kernels": kernels, "amdahl": amdahl, "track": track,
+        "pcg_iterations_per_lm_step": (pcg_total / float(done)) if args.solver == "pcg" else None,
         # multi-GPU bookkeeping: ranks RCCL itself reports for the communicator, observations per rank (frame-range shards
         # balanced by observation count), payload of ONE all-reduce of the reduced system (packed lower triangle | rhs | g0 | scalars)
         "ranks_seen": comm_stats["ranks_seen"] if comm_stats else 1, "local_obs": per_rank_obs,

@@ -352,6 +352,15 @@ int aar_get_stage_times(aar_problem *, aar_stage_times *);
  * diagnostic mode (bench.py's `amdahl` object, the verbose stage line), not the production path.  Resets the accumulators. */
 int aar_set_stage_timers(aar_problem *, int on);
 
+/* Environment read when a problem is created (defaults are the reference-faithful, measured-fastest choices):
+ *   AAR_DETERMINISTIC=1   every sum the default path leaves to fp64 atomics is taken in a fixed order (as the reference's ascending-row
+ *                         accumulation is, libs/sparselevmarq.h:291-303): two runs give the same bits; slower
+ *   AAR_SOLVER=pcg        OPT-IN inexact LM: the reduced system by preconditioned CG through the frame blocks instead of the Schur
+ *                         complement + dense LDL^T (csrc/pcg_kernels.hip); the LM trajectory is then no longer the reference's step for
+ *                         step, its fixed point is (final RMSE within 1e-4 px); AAR_PCG_ETA (0.1), AAR_PCG_MAX_IT (200); single GPU
+ * out[0] = CG iterations of the last damped solve, out[1] = their running total since the problem was created (zeros in the default mode) */
+int aar_problem_pcg_iterations(aar_problem *, int32_t out[2]);
+
 /* Per-kernel device time: when profiling is on, every kernel launch of this problem is bracketed by two HIP
  * events on the library's own stream (the stream the kernels run on) and the elapsed times are accumulated
  * per kernel.  bench.py's roofline figures come from here.  Switching profiling on resets the accumulators. */

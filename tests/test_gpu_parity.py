@@ -1029,3 +1029,49 @@ def test_deterministic_mode_on_a_many_entity_problem(monkeypatch):
     with pytest.raises(aar.AarError) as e:
         aar.Problem(aar.synth(3, num_cams=4, num_markers=596, num_frames=24))
     assert e.value.code == aar.AAR_ERR_UNSUPPORTED
+
+
+def test_pcg_solver_mode_against_the_direct_path(monkeypatch):
+    # AAR_SOLVER=pcg (csrc/pcg_kernels.hip, opt-in): the reduced system by preconditioned CG through the frame blocks.  At a tight
+    # tolerance its damped step IS the direct step (and the oracle's); at the default forcing term (eta = 0.1) the LM run is inexact
+    # Newton -- another trajectory to the same fixed point: final RMSE within the north star's 1e-4 px (observed: 1e-6), no more LM steps
+    ds = aar.synth(3, num_frames=120)
+    o = ol.Oracle(ds)
+    with aar.Problem(ds) as p:
+        d_direct = p.eval_damped_step(ds.x_full, 1e3)
+        x_d, rep_d = p.lm_solve(ds.x_full)
+        rmse_d, _ = p.reproj_stats(x_d)
+        assert p.pcg_iterations() == (0, 0)
+    monkeypatch.setenv("AAR_SOLVER", "pcg")
+    monkeypatch.setenv("AAR_PCG_ETA", "1e-11")
+    with aar.Problem(ds) as p:
+        d_pcg = p.eval_damped_step(ds.x_full, 1e3)
+        last, total = p.pcg_iterations()
+        assert 5 < last == total < 200
+    do = o.damped_solve(ds.x_full, 1e3, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+    assert np.abs(d_pcg - d_direct).max() / np.abs(d_direct).max() < 1e-7
+    assert np.abs(d_pcg - do).max() / np.abs(do).max() < 1e-7
+    monkeypatch.setenv("AAR_PCG_ETA", "0.1")
+    for opt in ((True, True, True), (False, True, True), (True, False, True)):      # gauge / switched-off groups are identity rows of the operator
+        with aar.Problem(ds, optimize=opt) as p:
+            x_p, rep_p = p.lm_solve(ds.x_full)
+            rmse_p, _ = p.reproj_stats(x_p)
+            its = p.pcg_iterations()[1]
+        if opt == (True, True, True):
+            assert abs(rmse_p - rmse_d) < 1e-4 and abs(rmse_p - rmse_d) < 1e-5
+            assert rep_p["iterations"] <= rep_d["iterations"] + 2 and 0 < its < 40 * rep_p["iterations"]
+        else:
+            monkeypatch.setenv("AAR_SOLVER", "direct")
+            with aar.Problem(ds, optimize=opt) as q:
+                x_q, _ = q.lm_solve(ds.x_full)
+                rmse_q, _ = q.reproj_stats(x_q)
+            monkeypatch.setenv("AAR_SOLVER", "pcg")
+            assert abs(rmse_p - rmse_q) < 1e-4
+    # a communicator and this mode do not go together (a collective per CG iteration would have to be queued by the host)
+    def create(comm, rank):
+        try:
+            aar.Problem(ds, comm=comm).close()
+            return "created"
+        except aar.AarError as err:
+            return err.code
+    assert _run_ranks(2, create) == [aar.AAR_ERR_UNSUPPORTED, aar.AAR_ERR_UNSUPPORTED]
