@@ -1272,7 +1272,29 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     UP(fslot_start, fslot_start); UP(fslot_ent, fslot_ent); UP(b_idx, b_idx); UP(b_uv, b_uv);
     UP(chunk_start, chunk_start); UP(ent_fixed, ent_fixed);
     UP(sw_ent, sw_ent); UP(sw_begin, sw_begin); UP(sw_end, sw_end); UP(pair_rec, pair_rec);
-    if (P.use_pcg) { std::vector<int32_t> eps(pair_base.begin(), pair_base.end()); UP(ent_pair_start, eps); }
+    if (P.use_pcg) {   // balanced work items: at most `chunk` incidences of one entity each, 1 .. 8 items per entity (PCG_MAX_ITEMS)
+        hipDeviceProp_t prop;
+        const int cus = (hipGetDeviceProperties(&prop, pb->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;
+        int64_t longest = 0;
+        for (int a = 0; a < A; a++) longest = std::max<int64_t>(longest, pair_base[a + 1] - pair_base[a]);
+        int64_t chunk = std::max<int64_t>(256, (total_pairs + 2LL * cus - 1) / (2LL * cus));
+        chunk = std::max<int64_t>(chunk, (longest + 7) / 8);
+        if (const char *t = getenv("AAR_PCG_CHUNK")) chunk = std::max<int64_t>((longest + 7) / 8, atoll(t));
+        std::vector<int32_t> it_ent, it_begin, it_end, ent_item_start(A + 1, 0);
+        for (int a = 0; a < A; a++) {
+            ent_item_start[a] = (int32_t)it_ent.size();
+            const int64_t b0 = pair_base[a], e0 = ent_fixed[a] ? pair_base[a] : pair_base[a + 1];
+            int64_t b = b0;
+            do {
+                const int64_t e = std::min<int64_t>(e0, b + chunk);
+                it_ent.push_back(a); it_begin.push_back((int32_t)b); it_end.push_back((int32_t)e);
+                b = e;
+            } while (b < e0);
+        }
+        ent_item_start[A] = (int32_t)it_ent.size();
+        P.pcg_n_items = (int)it_ent.size();
+        UP(pcg_it_ent, it_ent); UP(pcg_it_begin, it_begin); UP(pcg_it_end, it_end); UP(pcg_ent_item_start, ent_item_start);
+    }
     if (P.deterministic) { UP(sp_off, sp_off); UP(se_start, se_start); UP(se_items, se_items); UP(pbr_start, pbr_start); UP(pbr_chunk, pbr_chunk); UP(pbr_kind, pbr_kind); UP(pbr_a, pbr_a); UP(pbr_b, pbr_b); }
     if (P.n_smwork) { UP(sm_ga, sm_ga); UP(sm_gb, sm_gb); UP(sm_fb, sm_fb); UP(sm_fe, sm_fe); UP(slot_dense, slot_dense); UP(slot_frame, slot_frame); UP(dense_ent, dense_ent); UP(sm_frames, sm_frames); }
 #undef UP
@@ -1292,7 +1314,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     }
     if (P.deterministic) { AL(sp_part, (size_t)sp_total); AL(pb_part, (size_t)P.n_chunks * P.pb_stride); }
     if (P.use_pcg) {
-        AL(pcg_ws, (size_t)A * 36 + 13 * (size_t)A + 6 * (size_t)F + 8); AL(pcg_counter, 4);
+        AL(pcg_ws, (size_t)P.pcg_n_items * 28 + 6 * (size_t)F + 8); AL(pcg_counter, 4);
         hipDeviceProp_t prop;
         P.pcg_grid = (hipGetDeviceProperties(&prop, pb->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;   // one workgroup per CU: all resident
         // small problems: fewer workgroups make the two grid-wide hand-overs of an iteration cheaper than the passes get slower

@@ -82,8 +82,9 @@ struct DeviceProblem {
     // AAR_SOLVER=pcg (opt-in, pcg_kernels.hip): the reduced system solved by preconditioned CG through the frame blocks
     int use_pcg = 0, pcg_grid = 0, pcg_max_it = 200;
     double pcg_eta = 0.1;                 // |r| <= eta |b| stops an inner solve (AAR_PCG_ETA)
-    int32_t *ent_pair_start = nullptr;    // [A+1] entity -> its incidences in pair_rec
-    double *pcg_ws = nullptr;             // Minv [A][36] | b [6A] | y [6A] | pq [A] | t [6F]
+    int pcg_n_items = 0;                  // work items of the entity-side passes (pcg_kernels.hip): ranges of one entity's incidences in pair_rec
+    int32_t *pcg_it_ent = nullptr, *pcg_it_begin = nullptr, *pcg_it_end = nullptr, *pcg_ent_item_start = nullptr;
+    double *pcg_ws = nullptr;             // items' shares [n_items][28] | t [6F]
     int32_t *pcg_counter = nullptr;       // [0..1] grid-barrier counters (alternating), [2] iterations of the last solve, [3] running total
     mutable int pcg_parity = 0;
     // state: everything that depends on a pose vector exists twice (index 0/1 = the two pose buffers), so that the

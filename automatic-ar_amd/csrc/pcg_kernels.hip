@@ -12,7 +12,7 @@
 //
 // ONE persistent launch per solve: G workgroups (one per CU), each keeps its own copy of the CG vectors x, r, p in LDS and updates them
 // redundantly (n is a few hundred to a few thousand), so an iteration needs only two grid-wide hand-overs -- t (6 F doubles) after the
-// frame pass, y and the partial p.y after the entity pass -- done with agent-scope atomic stores / loads and a counter, no
+// frame pass, the work items' shares of y after the entity pass -- done with agent-scope atomic stores / loads and a counter, no
 // cache-maintenance fences (1.1 us per hop, scripts/probe/hop_probe.hip).  The convergence test is taken by every workgroup from the
 // same numbers in the same order: all leave in the same iteration.
 #include "geom.hpp"
@@ -24,18 +24,17 @@ struct PcgArgs {
     // blocks of the current point (pass A / pass B output; S holds U: the Schur complement kernels do not run in this mode)
     const double *U, *g0, *W, *Vinv, *hf;
     const int32_t *fslot_start, *fslot_ent;      // frame -> its W blocks / their entities
-    const int32_t *ent_pair_start;               // [A + 1] entity -> its (entity, frame) incidences in pair_rec
+    const int32_t *it_ent, *it_begin, *it_end;   // work items of the entity-side passes: entity, range of its incidences in pair_rec
+    const int32_t *ent_item_start;               // [A + 1] entity -> its items (1 .. PCG_MAX_ITEMS each)
+    int n_items;
     const int4 *pair_rec;                        // {frame, W block, first W block of the frame, 0}
     const int32_t *ent_fixed;
     int A, F, n_pad;
     double mu, eta2;                             // damping; eta^2
     int max_it;
     // work space
-    double *Minv;                                // [A][36] inverse diagonal blocks of S
-    double *b;                                   // [6 A]  right-hand side g0 - sum_f W_f h_f
+    double *part;                                // [n_items][28] the items' shares (27 values in the set-up, 6 per iteration)
     double *t;                                   // [6 F]
-    double *y;                                   // [6 A]
-    double *pq;                                  // [A]  partial p . y per entity
     int32_t *counter;                            // [2]  grid barrier counters: this launch uses counter[parity] (zero at entry) and clears the other
     int parity;
     double *x_out;                               // [6 A (.. n_pad)] delta_s
@@ -84,7 +83,12 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *lds) {
 
 constexpr int PCG_THREADS = 256;
 
-// LDS (dynamic): x [n] | r [n] | p [n] | Mi [6 n] (the preconditioner: read once, used every iteration) | red [4 * 27]
+// Work items of the two entity-side passes: a range of at most `chunk` (entity, frame) incidences of ONE entity, at most PCG_MAX_ITEMS per
+// entity.  A workgroup per entity leaves the pass waiting for the cameras (a camera is seen in every frame: 5000 W blocks = 1.4 MB through
+// one CU at the ~13 B/cycle a CU fetches -- 67 us of a 107 us iteration at config 5, while a marker's workgroup is done in half that);
+// with balanced items every CU moves the same bytes, and the items of an entity are added up -- in item order -- by whoever needs the value.
+constexpr int PCG_MAX_ITEMS = 8;
+// LDS (dynamic): x [n] | r [n] | p [n] | Mi [6 n] (the preconditioner: built once, used every iteration) | red [4 * 27]
 __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
     extern __shared__ __align__(16) double lds[];
     const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -94,76 +98,87 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
     int round = 0;
     if (wg == 0 && tid == 0) __hip_atomic_store(a.counter + (1 - a.parity), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
 
-    // ---- setup: diagonal blocks of S (inverted: the preconditioner) and the right-hand side, entity by entity ----
-    for (int e = wg; e < a.A; e += G) {
-        double acc[27];   // 21: lower triangle of sum_f W (V+mu)^-1 W^T, 6: sum_f W h_f
+    // ---- set-up, first half: every item's share of sum_f W (V+mu)^-1 W^T (lower triangle, 21) and of sum_f W h_f (6) ----
+    for (int it = wg; it < a.n_items; it += G) {
+        double acc[27];
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] = 0.0;
-        const bool fixed = a.ent_fixed[e] != 0;
-        if (!fixed) {
-            for (int pi = a.ent_pair_start[e] + tid; pi < a.ent_pair_start[e + 1]; pi += PCG_THREADS) {
-                const int4 rec = a.pair_rec[pi];
-                const double *Wb = a.W + (size_t)rec.y * 36, *Vi = a.Vinv + (size_t)rec.x * 36, *h = a.hf + (size_t)rec.x * 6;
-                double w[36], yv[36];
+        for (int pi = a.it_begin[it] + tid; pi < a.it_end[it]; pi += PCG_THREADS) {
+            const int4 rec = a.pair_rec[pi];
+            const double *Wb = a.W + (size_t)rec.y * 36, *Vi = a.Vinv + (size_t)rec.x * 36, *h = a.hf + (size_t)rec.x * 6;
+            double w[36], yv[36];
 #pragma unroll
-                for (int q = 0; q < 36; q++) w[q] = Wb[q];
+            for (int q = 0; q < 36; q++) w[q] = Wb[q];
 #pragma unroll
-                for (int i = 0; i < 6; i++)
+            for (int i = 0; i < 6; i++)
 #pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int k = 0; k < 6; k++) s = fma(w[i * 6 + k], Vi[k * 6 + j], s);
-                        yv[i * 6 + j] = s;
-                    }
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-#pragma unroll
-                    for (int j = 0; j <= i; j++) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int k = 0; k < 6; k++) s = fma(yv[i * 6 + k], w[j * 6 + k], s);
-                        acc[i * (i + 1) / 2 + j] += s;
-                    }
+                for (int j = 0; j < 6; j++) {
                     double s = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) s = fma(w[i * 6 + k], h[k], s);
-                    acc[21 + i] += s;
+                    for (int k = 0; k < 6; k++) s = fma(w[i * 6 + k], Vi[k * 6 + j], s);
+                    yv[i * 6 + j] = s;
                 }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int j = 0; j <= i; j++) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s = fma(yv[i * 6 + k], w[j * 6 + k], s);
+                    acc[i * (i + 1) / 2 + j] += s;
+                }
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s = fma(w[i * 6 + k], h[k], s);
+                acc[21 + i] += s;
             }
         }
         block_sum<27>(acc, red);
         if (tid == 0) {
-            double out[36];
-            if (fixed) {
 #pragma unroll
-                for (int i = 0; i < 36; i++) out[i] = (i % 7 == 0) ? 1.0 : 0.0;
-#pragma unroll
-                for (int i = 0; i < 6; i++) st_agent(a.b + 6 * e + i, 0.0);
-            } else {
-                double m[6][6];
-#pragma unroll
-                for (int i = 0; i < 6; i++)
-#pragma unroll
-                    for (int j = 0; j <= i; j++) {
-                        const double v = a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] + (i == j ? a.mu : 0.0) - acc[i * (i + 1) / 2 + j];
-                        m[i][j] = v; m[j][i] = v;
-                    }
-                if (!spd6_inverse(m, out)) atomicOr(a.flags, 2);
-#pragma unroll
-                for (int i = 0; i < 6; i++) st_agent(a.b + 6 * e + i, a.g0[6 * e + i] - acc[21 + i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 36; i++) st_agent(a.Minv + (size_t)e * 36 + i, out[i]);
+            for (int i = 0; i < 27; i++) st_agent(a.part + (size_t)it * 28 + i, acc[i]);
         }
     }
     grid_hop(counter, round, G, a.flags);
-
-    // ---- x = 0, r = b, z = Minv r, p = z ----
-    double rz = 0.0, bb = 0.0;
-    for (int i = tid; i < n; i += PCG_THREADS) { x[i] = 0.0; r[i] = ld_agent(a.b + i); }
-    for (int i = tid; i < 6 * n; i += PCG_THREADS) Mi[i] = ld_agent(a.Minv + i);
+    // ---- set-up, second half, redundantly in every workgroup (one thread per entity): the items' shares in item order, the diagonal
+    //      block of S inverted straight into LDS, the right-hand side; x = 0, r = b ----
+    for (int e = tid; e < a.A; e += PCG_THREADS) {
+        double out[36], be[6];
+        if (a.ent_fixed[e]) {
+#pragma unroll
+            for (int i = 0; i < 36; i++) out[i] = (i % 7 == 0) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) be[i] = 0.0;
+        } else {
+            double acc[27];
+#pragma unroll
+            for (int i = 0; i < 27; i++) acc[i] = 0.0;
+            const int i0 = a.ent_item_start[e], i1 = a.ent_item_start[e + 1];
+            for (int it = i0; it < i1; it++)
+#pragma unroll
+                for (int i = 0; i < 27; i++) acc[i] += ld_agent(a.part + (size_t)it * 28 + i);
+            double m[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) {
+                    const double v = a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] + (i == j ? a.mu : 0.0) - acc[i * (i + 1) / 2 + j];
+                    m[i][j] = v; m[j][i] = v;
+                }
+            if (!spd6_inverse(m, out) && wg == 0) atomicOr(a.flags, 2);
+#pragma unroll
+            for (int i = 0; i < 6; i++) be[i] = a.g0[6 * e + i] - acc[21 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 36; i++) Mi[e * 36 + i] = out[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { r[6 * e + i] = be[i]; x[6 * e + i] = 0.0; }
+    }
     __syncthreads();
+    // (everybody has read the items' set-up shares before any iteration overwrites the buffer: the first entity pass is behind the next hand-over)
+
+    // ---- z = Minv r, p = z ----
+    double rz = 0.0, bb = 0.0;
     {
         double s[2] = {0.0, 0.0};
         for (int i = tid; i < n; i += PCG_THREADS) {
@@ -180,9 +195,9 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
     }
     __syncthreads();
 
-    int it = 0;
+    int it_cg = 0;
     double rr = bb;
-    while (it < a.max_it && rr > a.eta2 * bb && bb > 0.0) {
+    while (it_cg < a.max_it && rr > a.eta2 * bb && bb > 0.0) {
         // ---- frame pass: t_f = (V_f + mu I)^-1 (W_f^T p), one wavefront per frame ----
         for (int f = wg * (PCG_THREADS / 64) + wave; f < a.F; f += G * (PCG_THREADS / 64)) {
             const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
@@ -210,24 +225,24 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
             }
         }
         grid_hop(counter, round, G, a.flags);
-        // ---- entity pass: y_e = ((U + mu I) p)_e - sum_f W_ef t_f, and p_e . y_e ----
-        for (int e = wg; e < a.A; e += G) {
+        // ---- entity pass, by item: its share of -sum_f W_ef t_f; the entity's first item also carries (U p)_e ----
+        for (int it = wg; it < a.n_items; it += G) {
+            const int e = a.it_ent[it];
             double acc[6] = {0, 0, 0, 0, 0, 0};
-            const bool fixed = a.ent_fixed[e] != 0;
-            if (!fixed) {
-                for (int pi = a.ent_pair_start[e] + tid; pi < a.ent_pair_start[e + 1]; pi += PCG_THREADS) {
-                    const int4 rec = a.pair_rec[pi];
-                    const double2 *wb = reinterpret_cast<const double2 *>(a.W + (size_t)rec.y * 36);
-                    double tv[6];
+            for (int pi = a.it_begin[it] + tid; pi < a.it_end[it]; pi += PCG_THREADS) {
+                const int4 rec = a.pair_rec[pi];
+                const double2 *wb = reinterpret_cast<const double2 *>(a.W + (size_t)rec.y * 36);
+                double tv[6];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) tv[k] = ld_agent(a.t + (size_t)rec.x * 6 + k);
+                for (int k = 0; k < 6; k++) tv[k] = ld_agent(a.t + (size_t)rec.x * 6 + k);
 #pragma unroll
-                    for (int i = 0; i < 6; i++) {
-                        const double2 w0 = wb[3 * i], w1 = wb[3 * i + 1], w2 = wb[3 * i + 2];
-                        acc[i] -= w0.x * tv[0] + w0.y * tv[1] + w1.x * tv[2] + w1.y * tv[3] + w2.x * tv[4] + w2.y * tv[5];
-                    }
+                for (int i = 0; i < 6; i++) {
+                    const double2 w0 = wb[3 * i], w1 = wb[3 * i + 1], w2 = wb[3 * i + 2];
+                    acc[i] -= w0.x * tv[0] + w0.y * tv[1] + w1.x * tv[2] + w1.y * tv[3] + w2.x * tv[4] + w2.y * tv[5];
                 }
-                for (int bq = tid; bq < a.A; bq += PCG_THREADS) {   // row e of the symmetric U (lower triangle stored)
+            }
+            if (it == a.ent_item_start[e] && !a.ent_fixed[e]) {   // row e of the symmetric U (lower triangle stored)
+                for (int bq = tid; bq < a.A; bq += PCG_THREADS) {
                     if (a.ent_fixed[bq]) continue;                  // (its p is zero)
 #pragma unroll
                     for (int i = 0; i < 6; i++)
@@ -241,27 +256,30 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
                 }
             }
             block_sum<6>(acc, red);
-            if (tid == 0) {
-                double d = 0.0;
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    const double yv = fixed ? p[6 * e + i] : acc[i] + a.mu * p[6 * e + i];
-                    st_agent(a.y + 6 * e + i, yv);
-                    d = fma(p[6 * e + i], yv, d);
-                }
-                st_agent(a.pq + e, d);
-            }
+            if (tid < 6) st_agent(a.part + (size_t)it * 28 + tid, acc[tid]);
         }
         grid_hop(counter, round, G, a.flags);
         // ---- vector updates, redundantly in every workgroup (same numbers, same order: same decisions) ----
+        // y = S p: the items' shares of every entry, ALL requested before the first is used (an agent-scope load is ~1 us: one round
+        // trip, not one per item), added in item order; + mu p; identity rows for gauge entities
+        double yl[24];
         double pAp = 0.0;
-        double yl[24];   // this thread's entries of y, requested together with the partial dot products (one round trip, not two)
         {
-            int ny = 0;
-            for (int i = tid; i < n; i += PCG_THREADS, ny++)
-                if (ny < 24) yl[ny] = ld_agent(a.y + i);
             double s[1] = {0.0};
-            for (int e = tid; e < a.A; e += PCG_THREADS) s[0] += ld_agent(a.pq + e);
+            int ny = 0;
+            for (int i = tid; i < n; i += PCG_THREADS, ny++) {
+                const int e = i / 6, row = i - 6 * e;
+                const int i0 = a.ent_item_start[e], cnt = a.ent_item_start[e + 1] - i0;
+                double sh[PCG_MAX_ITEMS];
+#pragma unroll
+                for (int k = 0; k < PCG_MAX_ITEMS; k++) sh[k] = k < cnt ? ld_agent(a.part + (size_t)(i0 + k) * 28 + row) : 0.0;
+                double yv = a.mu * p[i];
+#pragma unroll
+                for (int k = 0; k < PCG_MAX_ITEMS; k++) yv += sh[k];
+                if (a.ent_fixed[e]) yv = p[i];
+                if (ny < 24) yl[ny] = yv;
+                s[0] = fma(p[i], yv, s[0]);
+            }
             block_sum<1>(s, red);
             pAp = s[0];
         }
@@ -293,12 +311,12 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
         nz = 0;
         for (int i = tid; i < n; i += PCG_THREADS, nz++) p[i] = fma(beta, p[i], zloc[nz < 24 ? nz : 23]);
         __syncthreads();
-        it++;
+        it_cg++;
     }
     if (wg == 0) {
         for (int i = tid; i < n; i += PCG_THREADS) a.x_out[i] = x[i];
         for (int i = n + tid; i < a.n_pad; i += PCG_THREADS) a.x_out[i] = 0.0;
-        if (tid == 0) { a.iters_out[0] = it; a.iters_out[1] += it; }   // (stopped by max_it: still an inexact step, the LM gain test judges it)
+        if (tid == 0) { a.iters_out[0] = it_cg; a.iters_out[1] += it_cg; }   // (stopped by max_it: still an inexact step, the LM gain test judges it)
     }
 }
 
@@ -308,9 +326,10 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];
     PcgArgs a;
     a.U = b.S; a.g0 = b.g0; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf;
-    a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.ent_pair_start = P.ent_pair_start; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed;
+    a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed;
+    a.it_ent = P.pcg_it_ent; a.it_begin = P.pcg_it_begin; a.it_end = P.pcg_it_end; a.ent_item_start = P.pcg_ent_item_start; a.n_items = P.pcg_n_items;
     a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta * P.pcg_eta; a.max_it = P.pcg_max_it;
-    a.Minv = P.pcg_ws; a.b = a.Minv + (size_t)P.A * 36; a.y = a.b + 6 * (size_t)P.A; a.pq = a.y + 6 * (size_t)P.A; a.t = a.pq + P.A;
+    a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
     a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
     const size_t lds = pcg_lds_bytes(P.A);

@@ -5,9 +5,9 @@ sys.path[:0] = [os.path.join(ROOT, "automatic-ar_amd"), os.path.join(ROOT, "test
 import numpy as np
 import aar
 os.environ["AAR_SOLVER"] = "pcg"
-for cfg, steps in ((3, 300), (4, 150), (5, 30)):
+for cfg, steps in ((4, 150), (5, 30)):
     ds = aar.synth(cfg)
-    for th in (256, 1024):
+    for th in (256, 512):
         os.environ["AAR_PCG_THREADS"] = str(th)
         with aar.Problem(ds) as p:
             x, rep = p.lm_solve(ds.x_full)
