@@ -35,7 +35,7 @@ SYMBOLS = [
     "aar_comm_get_stats", "aar_lm_set_step_callback", "aar_lm_set_stop_function", "aar_problem_extract_z", "aar_problem_merge_z",
     "aar_solution_read_ex", "aar_cam_configs_read_ex", "aar_set_stage_timers", "aar_problem_pcg_iterations",
 ]
-NUM_KERNELS = 14
+NUM_KERNELS = 15
 
 
 class AarError(RuntimeError):

@@ -335,7 +335,7 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const size_t lds = pcg_lds_bytes(P.A);
     static size_t granted = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, granted);
-    HookScope _h(P, KID_LDL_DIAG);
+    HookScope _h(P, KID_PCG);
     hipLaunchKernelGGL(k_pcg, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a);
 }
 

@@ -71,6 +71,7 @@ KERNEL_BOUND = {
     "k_ldl_update": "fp64_mfma", "k_ldl_trsm": "fp64_mfma", "k_ldl_panel": "fp64_mfma",
     "k_ldl_diag": "latency", "k_ldl_backsolve": "latency", "k_reduce_scalars": "latency", "k_maxdiag": "latency",
     "k_backsub": "hbm", "k_frame_inv": "hbm", "k_unpack": "hbm",
+    "k_pcg": "hbm",                    # --solver pcg: an iteration is two passes over the W blocks (288 B per (entity, frame) incidence)
 }
 
 
@@ -387,6 +388,8 @@ def main():
         def roof(k):
             avg_s = kernels[k]["avg_us"] * 1e-6
             by = algorithmic_bytes(k, n_loc, A, F, n_pad)
+            if k == "k_pcg":       # one pass over the W blocks for the preconditioner, two per CG iteration (SURVEY 8d has no row for this opt-in solver)
+                by = 288.0 * float(kf.sum()) / max(1, world) * (1.0 + 2.0 * pcg_total / float(done))
             if k == "k_passA" and merged:
                 by += algorithmic_bytes("k_passB", n_loc, A, F, n_pad)
             fl = algorithmic_flops(k, n_loc, n_pad, sum_kf2, merged)
@@ -423,7 +426,7 @@ def main():
 
     # ---- where the step's time goes by how it scales with the rank count: a third, stage-timed pass ----
     amdahl = None
-    if not args.no_amdahl:
+    if not args.no_amdahl and args.solver == "direct":     # (the PCG mode has no replicated part to speak of, and no multi-GPU path yet)
         n_am = min(args.steps, 300)
         problem.set_stage_timers(True)
         acc, done_am = {}, 0
