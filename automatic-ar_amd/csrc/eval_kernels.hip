@@ -596,6 +596,15 @@ __global__ void __launch_bounds__(BLOCK) k_passAB(const PassAArgs a, const PassB
     if ((int)blockIdx.x < a.F) passA_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, a.F);
     else passB_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
 }
+// the same with camera intrinsics optimised: pass A with the W_kf blocks, pass B, and pass B's intrinsics blocks (three launches before)
+template <int BLOCK, int CPL>
+__global__ void __launch_bounds__(BLOCK) k_passAB_intr(const PassAArgs a, const PassBArgs b, int nb) {
+    extern __shared__ double lds[];
+    const int blk = (int)blockIdx.x;
+    if (blk < a.F) passA_body<BLOCK, CPL, true>(a, lds, blk, a.F);
+    else if (blk < a.F + nb) passB_body(b, lds, (blk - a.F) * (BLOCK / 64));
+    else passB_intr_body(b, lds, (blk - a.F - nb) * (BLOCK / 64));
+}
 
 // ------------------------------------------------------------------------------------------------
 // max over the diagonal of J^T J restricted to free parameters (mu_0 = tau * max, libs/sparselevmarq.h:369-377)
@@ -685,7 +694,12 @@ static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, const Pas
     const size_t lds = passA_lds_bytes(P.max_kf, B);
     static size_t granted = 48 * 1024, granted_ab = 48 * 1024;
     HookScope _h(P, KID_PASSA);
-    if (P.intr) {   // (never merged with pass B: launch_passAB declines)
+    if (P.intr && pbargs) {
+        static size_t granted_abi = 48 * 1024;
+        const int nb = (P.n_chunks + B / 64 - 1) / (B / 64);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB_intr<B, CPL>), lds, granted_abi);
+        hipLaunchKernelGGL((k_passAB_intr<B, CPL>), dim3(P.F + 2 * nb), dim3(B), lds, st, a, *pbargs, nb);
+    } else if (P.intr) {
         static size_t granted_i = 48 * 1024;
         allow_dynamic_lds(reinterpret_cast<const void *>(k_passA_intr<B, CPL, true>), lds, granted_i);
         hipLaunchKernelGGL((k_passA_intr<B, CPL, true>), dim3(P.F), dim3(B), lds, st, a);
@@ -732,11 +746,11 @@ void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
 }
 
 bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st) {
-    if (P.F == 0 || P.n_chunks == 0 || P.intr || P.deterministic) return false;   // nothing to merge (or the intrinsics / deterministic variants): the caller launches what there is
+    if (P.F == 0 || P.n_chunks == 0 || P.deterministic) return false;   // nothing to merge (or the deterministic variants): the caller launches what there is
     // Side by side pays while the two passes together are a few wavefronts per SIMD (configs 2-4: -45 % / -11 % of their
     // summed time at configs 3 / 4); once either fills the chip on its own (config 5: +7 %, pass B's workgroups then carry
     // pass A's LDS allocation) they go one after the other
-    const int64_t waves = (int64_t)P.F * ((double)P.N / (double)P.F <= 96 ? 1 : 4) + P.n_chunks;
+    const int64_t waves = (int64_t)P.F * ((double)P.N / (double)P.F <= 96 ? 1 : 4) + (P.intr ? 2 : 1) * (int64_t)P.n_chunks;
     if (waves > 4096) return false;
     const PassBArgs b = passB_args(P, which);
     launch_passA_any(P, passA_args(P, which, mu_pred, zero_blk), &b, st);

@@ -1075,3 +1075,18 @@ def test_pcg_solver_mode_against_the_direct_path(monkeypatch):
         except aar.AarError as err:
             return err.code
     assert _run_ranks(2, create) == [aar.AAR_ERR_UNSUPPORTED, aar.AAR_ERR_UNSUPPORTED]
+
+
+def test_deterministic_mode_with_two_ranks(monkeypatch):
+    # fixed-order sums rank by rank, the in-process group adds the ranks' systems in rank order: two sharded runs give the same bits
+    monkeypatch.setenv("AAR_DETERMINISTIC", "1")
+    ds, g = load_golden("g1_cfg2")
+    def solve(comm, rank):
+        with aar.Problem(ds, comm=comm) as q:
+            return q.lm_solve(ds.x_full)
+    a = _run_ranks(2, solve)
+    b = _run_ranks(2, solve)
+    for (xa, ra), (xb, rb) in zip(a, b):
+        assert np.array_equal(xa, xb) and [t["err"] for t in ra["trace"]] == [t["err"] for t in rb["trace"]]
+    assert np.array_equal(a[0][0], a[1][0])                                   # every rank holds the same solution
+    np.testing.assert_allclose([t["err"] for t in a[0][1]["trace"]], g["analytic_err"], rtol=1e-7)

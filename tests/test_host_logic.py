@@ -350,3 +350,20 @@ def test_host_code_under_address_and_ub_sanitizers(tmp_path):
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr and "LeakSanitizer" not in run.stderr
     assert "obs " in run.stdout and "subseqs" in run.stdout
+
+
+def test_reference_shaped_solver_code_compiles_against_the_mirror(tmp_path):
+    # tests/tools/solver_seam_main.cpp holds caller code in the shape of libs/multicam_mapper.cpp:419-443 (solver.solve(io_vec,
+    # bind(&MultiCamMapper::error_function, ...), bind(&MultiCamMapper::jacobian_function, ...)), init(z, f), step(f, J), step(f),
+    # solve(z, bind(&MultiCamMapper::error_function_tracking, ...))): it must COMPILE and link against the mirror of
+    # automatic-ar_amd/host/multicam_mapper.h anywhere; what it computes is checked under -m gpu.  Without a device it stops at
+    # the first device call with the library's message.
+    import subprocess
+    from conftest import PKG, ROOT
+    exe = str(tmp_path / "solver_seam_main")
+    cc = subprocess.run(["g++", "-O0", "-std=c++17", "-Wall", os.path.join(ROOT, "tests", "tools", "solver_seam_main.cpp"), "-o", exe, "-L" + PKG, "-laar",
+                         "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    if aar.device_count() == 0:
+        run = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=120)
+        assert run.returncode == 2 and "no CPU path" in run.stderr        # exception: no HIP device ...; this library has no CPU path
