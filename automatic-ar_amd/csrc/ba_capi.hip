@@ -1236,7 +1236,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         // the same stretch of frames next to each other so that the workgroups in flight share panels in L2
         int target = 12 * (int)blks.size();   // pieces per block: measured optimum at config 5 (8: -1 %, 24: -9 %); AAR_SCHUR_SPLIT overrides
         if (const char *e = getenv("AAR_SCHUR_SPLIT")) target = std::max(1, atoi(e)) * (int)blks.size();
-        const int64_t plen = std::max<int64_t>(16, ((2 * total_steps + target - 1) / target + 1) / 2 * 2);
+        const int64_t plen = std::max<int64_t>(16, ((2 * total_steps + target - 1) / target + 3) / 4 * 4);   // whole steps of the kernel's K loop (2 or 4 frames)
         struct Piece { int blk; int64_t b, e; int f0; };
         std::vector<Piece> pieces;
         for (size_t k = 0; k < blks.size(); k++)

@@ -332,7 +332,13 @@ __global__ void __launch_bounds__(256) k_schur_fill(const int32_t *__restrict__ 
     wd[0] = w0; wd[1] = w1; wd[2] = w2;
 }
 
-constexpr int SM_GA = 16, SM_GB = 32, SM_AR = 6 * SM_GA, SM_BR = 6 * SM_GB, SM_ROWS = SM_AR + SM_BR, SM_PS = 14, SM_DEPTH = 4;
+// SM_FPS frames per step of the K loop (K = 6 SM_FPS per barrier), SM_DEPTH steps of row fetches in flight in registers
+#ifndef AAR_SM_FPS
+#define AAR_SM_FPS 4
+#endif
+constexpr int SM_GA = 16, SM_GB = 32, SM_AR = 6 * SM_GA, SM_BR = 6 * SM_GB, SM_ROWS = SM_AR + SM_BR, SM_FPS = AAR_SM_FPS, SM_PS = 6 * SM_FPS + 2,
+              SM_DEPTH = 8 / SM_FPS, SM_KT = 6 * SM_FPS / 4;
+static_assert((6 * SM_FPS) % 4 == 0 && SM_DEPTH >= 1, "whole MFMA k-steps per barrier");
 __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ w_ga, const int32_t *__restrict__ w_gb,
                                                     const int32_t *__restrict__ w_fb, const int32_t *__restrict__ w_fe,
                                                     const int32_t *__restrict__ flist, const int32_t *__restrict__ dense_ent, const double *__restrict__ Wd,
@@ -363,9 +369,9 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
     const bool all_dead = __builtin_amdgcn_readfirstlane((int)(SM_AR * ga + 16 * (rt0 + 3) - 1 < SM_BR * gb + 16 * ct0)) != 0;
 
     // position k of the block's frame list (frames in which both entity groups are present; two of them per step)
-    auto fetch_rows = [&](int k0, double2 (&v)[6]) {   // nothing here waits: the values are stored steps later
+    auto fetch_rows = [&](int k0, double2 (&v)[3 * SM_FPS]) {   // nothing here waits: the values are stored steps later
 #pragma unroll
-        for (int ff = 0; ff < 2; ff++) {
+        for (int ff = 0; ff < SM_FPS; ff++) {
             if (stager && k0 + ff < fe) {
                 const double2 *p = reinterpret_cast<const double2 *>(src + (size_t)flist[k0 + ff] * fstride);
                 v[3 * ff] = p[0]; v[3 * ff + 1] = p[1]; v[3 * ff + 2] = p[2];
@@ -374,39 +380,39 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
             }
         }
     };
-    auto put_rows = [&](int buf, const double2 (&v)[6]) {
+    auto put_rows = [&](int buf, const double2 (&v)[3 * SM_FPS]) {
         if (stager) {
             double2 *d = reinterpret_cast<double2 *>(stage + ((size_t)buf * SM_ROWS + tid) * SM_PS);
 #pragma unroll
-            for (int h = 0; h < 6; h++) d[h] = v[h];
+            for (int h = 0; h < 3 * SM_FPS; h++) d[h] = v[h];
         }
     };
     // Register ring SM_DEPTH steps deep: the rows of step s + SM_DEPTH are requested while step s computes -- one step of the matrix
     // pipes (27 MFMAs per wavefront, ~1.4 us) is shorter than a loaded chip's memory latency, a single step of look-ahead starves
-    double2 v[SM_DEPTH][6];
+    double2 v[SM_DEPTH][3 * SM_FPS];
     auto compute = [&](int buf) {
         if (all_dead) return;
         const double *sb = stage + (size_t)buf * SM_ROWS * SM_PS;
-        double av[3][3], bv[3][3];
+        double av[3][SM_KT], bv[3][SM_KT];
 #pragma unroll
         for (int x = 0; x < 3; x++)
 #pragma unroll
-            for (int t = 0; t < 3; t++) {
+            for (int t = 0; t < SM_KT; t++) {
                 av[x][t] = sb[(16 * (rt0 + x) + lc) * SM_PS + 4 * t + lr];            // A[i = lc][k = lr]: Y rows
                 bv[x][t] = sb[(SM_AR + 16 * (ct0 + x) + lc) * SM_PS + 4 * t + lr];    // B[k = lr][j = lc]: W rows
             }
 #pragma unroll
-        for (int t = 0; t < 3; t++)
+        for (int t = 0; t < SM_KT; t++)
 #pragma unroll
             for (int x = 0; x < 3; x++)
 #pragma unroll
                 for (int y = 0; y < 3; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x][t], bv[y][t], acc[x][y], 0, 0, 0);
     };
-    const int nsteps = (fe - fb + 1) / 2;
+    const int nsteps = (fe - fb + SM_FPS - 1) / SM_FPS;
 #pragma unroll
-    for (int d = 0; d < SM_DEPTH; d++) fetch_rows(fb + 2 * d, v[d]);     // steps 0 .. SM_DEPTH-1 (beyond the range: zeros, nothing loaded)
+    for (int d = 0; d < SM_DEPTH; d++) fetch_rows(fb + SM_FPS * d, v[d]);     // steps 0 .. SM_DEPTH-1 (beyond the range: zeros, nothing loaded)
     put_rows(0, v[0]);
-    fetch_rows(fb + 2 * SM_DEPTH, v[0]);
+    fetch_rows(fb + SM_FPS * SM_DEPTH, v[0]);
     __syncthreads();
     for (int s0 = 0; s0 < nsteps; s0 += SM_DEPTH) {
 #pragma unroll
@@ -415,7 +421,7 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
             if (s < nsteps) {
                 compute(s & 1);
                 put_rows((s + 1) & 1, v[(d + 1) % SM_DEPTH]);
-                fetch_rows(fb + 2 * (s + 1 + SM_DEPTH), v[(d + 1) % SM_DEPTH]);
+                fetch_rows(fb + SM_FPS * (s + 1 + SM_DEPTH), v[(d + 1) % SM_DEPTH]);
                 __syncthreads();
             }
         }
@@ -1250,8 +1256,8 @@ __global__ void __launch_bounds__(256) k_ldl_update(double *__restrict__ S, doub
 }
 
 // ------------------------------------------------------------------------------------------------
-// Panel solve AND trailing update of step s in ONE launch, for short block columns (m = nT - s - 1 <= 2 tiles below the
-// diagonal tile by default: every reduced system up to 288 unknowns; AAR_FUSED_PANEL moves the limit -- measured at config 5,
+// Panel solve AND trailing update of step s in ONE launch, for short block columns (m = nT - s - 1 <= 3 tiles below the
+// diagonal tile by default: every reduced system up to 384 unknowns; AAR_FUSED_PANEL moves the limit -- measured at config 5,
 // 14 tiles: the same time up to m = 4, slower beyond, 37.6 us against 10.8 + 11.8 at m = 13).  At these sizes each of the two kernels above is ~5 us of fixed
 // cost (launch, first fetch of data another XCD has just written, completion) around <= 3 us of matrix work, and chaining them
 // with flags costs what the launch boundary does.  Here nobody waits for anybody: the workgroup of output block (I, J)
@@ -1601,7 +1607,7 @@ bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, i
     static size_t g_diag = 48 * 1024, g_bs = 48 * 1024;
     // block columns with at most this many tiles below the diagonal take the fused panel kernel (0: never); its redundancy grows
     // with the square of the column's height, the two-kernel path's fixed cost does not
-    static const int fused_m = getenv("AAR_FUSED_PANEL") ? atoi(getenv("AAR_FUSED_PANEL")) : 2;
+    static const int fused_m = getenv("AAR_FUSED_PANEL") ? atoi(getenv("AAR_FUSED_PANEL")) : 3;   // (3: +2.6 % on a four-tile system, nothing at 14 tiles)
     static const bool bs_rides = !(getenv("AAR_BS_RIDES") && atoi(getenv("AAR_BS_RIDES")) == 0);
     // opt-in (AAR_BACKSUB_RIDES=1): measured on one box, it buys nothing -- 7 224 vs 7 233 LM it/s at config 3, 17 480 vs 17 780 at config 2
     // (profiles/r03_attempts.txt): the launch then ends with the riders' work instead of a 6 us kernel, and their 1024-thread workgroups

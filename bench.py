@@ -75,7 +75,7 @@ KERNEL_BOUND = {
 }
 
 
-FUSED_PANEL_M = int(os.environ.get("AAR_FUSED_PANEL", "2"))     # block columns with at most this many tiles below the diagonal take k_ldl_panel
+FUSED_PANEL_M = int(os.environ.get("AAR_FUSED_PANEL", "3"))     # block columns with at most this many tiles below the diagonal take k_ldl_panel
 
 
 def _stages(n_pad):
