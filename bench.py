@@ -301,6 +301,8 @@ def main():
     if aar.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (the product has no CPU path)")
     if args.solver == "pcg":
+        if world > 1 or os.environ.get("AAR_FORCE_COMM") == "1":
+            raise SystemExit("bench.py: --solver pcg is a single-GPU mode (a collective per CG iteration would have to be queued by the host; DESIGN.md section 11)")
         os.environ["AAR_SOLVER"] = "pcg"          # read when the problem is created
     ds = aar.synth(args.workload)
     comm = None

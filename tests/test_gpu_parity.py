@@ -1068,6 +1068,16 @@ def test_pcg_solver_mode_against_the_direct_path(monkeypatch):
                 rmse_q, _ = q.reproj_stats(x_q)
             monkeypatch.setenv("AAR_SOLVER", "pcg")
             assert abs(rmse_p - rmse_q) < 1e-4
+    # the reference's default Config (intrinsics entities are shared entities like any other) and -with-huber go through the same operator
+    with aar.Problem(ds, intrinsics=True) as p:
+        x_i, rep_i = p.lm_solve(p.x_with_intrinsics(ds.x_full))
+        rmse_i, _ = p.reproj_stats(x_i)
+    monkeypatch.setenv("AAR_SOLVER", "direct")
+    with aar.Problem(ds, intrinsics=True) as q:
+        x_j, rep_j = q.lm_solve(q.x_with_intrinsics(ds.x_full))
+        rmse_j, _ = q.reproj_stats(x_j)
+    monkeypatch.setenv("AAR_SOLVER", "pcg")
+    assert abs(rmse_i - rmse_j) < 1e-4
     # a communicator and this mode do not go together (a collective per CG iteration would have to be queued by the host)
     def create(comm, rank):
         try:
