@@ -206,6 +206,8 @@ struct aar_problem {
     // host has seen this step's scalars -- the usual outcome (accepted, predicted damping) then finds it done, and the host's
     // turn-around hides behind it as it hides behind the Schur kernel on one GPU; any other outcome rebuilds the system anyway
     bool spec_chol = true;             // AAR_SPEC_CHOL=0: off
+    double *h_pcg = nullptr;           // AAR_SOLVER=pcg with a communicator: pinned, mapped {done, iterations, -, sequence} the iteration launches publish
+    unsigned long long pcg_seq = 0;
     int spec_chol_blk = -1;            // block set whose S a speculative factorisation has consumed (-1: none pending)
     double spec_chol_mu = -1;
     hipStream_t stream2 = nullptr;     // pass B of the trial point runs here, beside the speculative Schur complement
@@ -561,7 +563,8 @@ int launch_scalars(aar_problem *pb, int n_err) {
     pb->seq++;
     {
         StageTimer t(pb, &pb->times.control);
-        launch_reduce_scalars(P, n_err, false, pb->comm ? 0ull : pb->seq, pb->stream);
+        // (PCG mode with ranks: g0 is this rank's partial sum -- it was never all-reduced --, so delta_s . g0 joins the rank sum)
+        launch_reduce_scalars(P, n_err, P.use_pcg && pb->comm, pb->comm ? 0ull : pb->seq, pb->stream);
         pb->launches += 1;
     }
     if (pb->comm) {
@@ -606,9 +609,39 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
             pb->vinv_mu = mu;
             pb->launches += 1;
         }
-        StageTimer t(pb, &pb->times.chol);
-        launch_pcg(P, cur, mu, pb->stream);
-        pb->launches += 1;
+        if (!pb->comm) {
+            StageTimer t(pb, &pb->times.chol);
+            launch_pcg(P, cur, mu, pb->stream);
+            pb->launches += 1;
+        } else {
+            // frames sharded over ranks: the set-up shares and every iteration's partial y are all-reduced between launches; every
+            // fourth launch publishes {done, iterations} so that the host stops queueing (all ranks read the same: same control flow)
+            { StageTimer t(pb, &pb->times.chol); launch_pcgd_setup(P, cur, mu, pb->stream); }
+            { StageTimer t(pb, &pb->times.allreduce); int rc = allreduce(pb, P.pcgd_setup, (size_t)P.A * 28, NCCL_SUM); if (rc) return rc; }
+            pb->launches += 1;
+            for (int k = 0;; k++) {
+                const bool last = k >= P.pcg_max_it + 1;
+                const bool poll = last || (k % 4) == 3;
+                if (poll) pb->pcg_seq++;
+                { StageTimer t(pb, &pb->times.chol); launch_pcgd_iter(P, cur, mu, k, last, poll ? pb->pcg_seq : 0ull, pb->stream); }
+                pb->launches += 1;
+                if (poll) {
+                    int rc = check_async("pcg launch");
+                    if (rc) return rc;
+                    volatile unsigned long long *sq = reinterpret_cast<volatile unsigned long long *>(pb->h_pcg) + 3;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    unsigned spins = 0;
+                    while (*sq != pb->pcg_seq) {
+                        if ((++spins & 0x3fff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
+                            return set_error(AAR_ERR_HIP, "timed out waiting for the PCG progress record");
+                        __builtin_ia32_pause();
+                    }
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    if (pb->h_pcg[0] != 0.0 || last) break;
+                }
+                { StageTimer t(pb, &pb->times.allreduce); int rc = allreduce(pb, P.pcgd_y, (size_t)6 * P.A, NCCL_SUM); if (rc) return rc; }
+            }
+        }
         chol_done = true;
     }
     if (!P.use_pcg && pb->schur_mu != mu) {  // not already done speculatively by the try that produced this point
@@ -640,7 +673,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         pb->launches += 1;
     }
     pb->schur_mu = -1;
-    if (pb->comm && !pb->s_reduced) {
+    if (pb->comm && !pb->s_reduced && !P.use_pcg) {
         StageTimer t(pb, &pb->times.allreduce);
         int rc = allreduce_system(pb, cur, 0);   // S (lower triangle) | rhs | g0
         if (rc) return rc;
@@ -911,6 +944,7 @@ void aar_problem_destroy(aar_problem *pb) {
     if (pb->stream) (void)hipStreamSynchronize(pb->stream);
     for (void *p : pb->allocs) (void)hipFree(p);
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
+    if (pb->h_pcg) (void)hipHostFree(pb->h_pcg);
     if (pb->h_z_pinned) (void)hipHostUnregister(pb->h_z.data());
     if (pb->up_ev) (void)hipEventDestroy(pb->up_ev);
     if (pb->ev[0]) (void)hipEventDestroy(pb->ev[0]);
@@ -1043,12 +1077,11 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     // output-stationary kernel, which needs none of this, takes over.  Only THAT kernel keeps a row panel of all entities in LDS.
     { const char *e = getenv("AAR_DETERMINISTIC"); P.deterministic = (e && atoi(e) != 0) ? 1 : 0; }
     { const char *e = getenv("AAR_DENSE_FROM_PASSA"); if (e) P.dense_from_passA = atoi(e) != 0 ? 1 : 0; }
-    {   // opt-in inexact solver (pcg_kernels.hip); single GPU: a collective per CG iteration would have to be queued by the host
+    {   // opt-in inexact solver (pcg_kernels.hip)
         const char *e = getenv("AAR_SOLVER");
         P.use_pcg = (e && !strcmp(e, "pcg")) ? 1 : 0;
         if (const char *t = getenv("AAR_PCG_ETA")) P.pcg_eta = atof(t);
         if (const char *t = getenv("AAR_PCG_MAX_IT")) P.pcg_max_it = std::max(1, atoi(t));
-        if (P.use_pcg && pb->comm && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER=pcg is a single-GPU mode");
         if (P.use_pcg && pcg_lds_bytes(A) > 150 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER=pcg keeps the CG vectors and the preconditioner of %d unknowns in LDS: too many shared entities", 6 * A);
     }
     bool schur_mfma = A >= 96 && F > 0;
@@ -1321,6 +1354,13 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         // (measured, LM it/s at config 3: 64 / 128 / 256 workgroups 4174 / 4201 / 3883; config 2: 32 best; config 5: 256 best)
         const int64_t want = std::max<int64_t>(32, ((int64_t)F + 3) / 4);
         P.pcg_grid = (int)std::min<int64_t>(P.pcg_grid, want);
+        if (pb->comm) {
+            AL(pcgd_setup, (size_t)A * 28); AL(pcgd_minv, (size_t)A * 36); AL(pcgd_state, 18 * (size_t)A + 8); AL(pcgd_y, 6 * (size_t)A + 8);
+            if (hipHostMalloc((void **)&pb->h_pcg, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+                return fail(set_error(AAR_ERR_HIP, "hipHostMalloc failed"));
+            memset(pb->h_pcg, 0, 8 * sizeof(double));
+            if (hipHostGetDevicePointer((void **)&P.pcgd_host, pb->h_pcg, 0) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "hipHostGetDevicePointer failed"));
+        }
         if (const char *t = getenv("AAR_PCG_GRID")) P.pcg_grid = std::max(1, atoi(t));
     }
     if (P.n_smwork) { AL(Wd, (size_t)F * P.Ad * 36); AL(Yd, (size_t)F * P.Ad * 36); }   // zeroed here, once: absent pairs are never written
@@ -1589,7 +1629,7 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
         // L = 0.5 * delta^T (mu*delta - B) (:406); frame pieces were summed over ranks; the shared-parameter pieces
         // |delta_s|^2 and delta_s . g0 are computed from replicated data (g0 was all-reduced with S) and counted once
         const double d2 = sc[1] + sc[5];
-        const double dg = sc[2] + sc[6];
+        const double dg = (pb->P.use_pcg && pb->comm) ? sc[2] : sc[2] + sc[6];   // (PCG with ranks: the shared piece is inside the rank sum)
         const double Lq = 0.5 * (mu_used * d2 - dg);
         dnorm = std::sqrt(d2);
         gain = (err - pb->prevErr) / Lq;

@@ -87,6 +87,9 @@ struct DeviceProblem {
     double *pcg_ws = nullptr;             // items' shares [n_items][28] | t [6F]
     int32_t *pcg_counter = nullptr;       // [0..1] grid-barrier counters (alternating), [2] iterations of the last solve, [3] running total
     mutable int pcg_parity = 0;
+    // ... with frames sharded over ranks: this rank's set-up share [A][28] (all-reduced), Minv [A][36], x | r | p | scalars [3 n + 8],
+    // this rank's partial y [n] (all-reduced per iteration), mapped host record {done, iterations, -, sequence}
+    double *pcgd_setup = nullptr, *pcgd_minv = nullptr, *pcgd_state = nullptr, *pcgd_y = nullptr, *pcgd_host = nullptr;
     // state: everything that depends on a pose vector exists twice (index 0/1 = the two pose buffers), so that the
     // blocks of a trial point can be built while those of the current point are still needed for a mu retry
     double *z[2] = {nullptr, nullptr};    // [6A + 6F] pose vectors
@@ -165,6 +168,9 @@ bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, i
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
 void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st);     // AAR_SOLVER=pcg: delta_s by PCG through the frame blocks (needs Vinv, hf for mu)
 size_t pcg_lds_bytes(int A);
+// the same with a communicator: set-up share -> [all-reduce] -> launches k = 0, 1, .. with an all-reduce of pcgd_y between two of them
+void launch_pcgd_setup(const DeviceProblem &P, int which, double mu, hipStream_t st);
+void launch_pcgd_iter(const DeviceProblem &P, int which, double mu, int k, bool last, unsigned long long publish_seq, hipStream_t st);
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st,
                            double *scal_out = nullptr);  // scal[0..2], scal[5..6] (into scal_out instead of P.scal if given)
 // scal / flags -> host record; flags_reduced: the flags are decoded from src[3] (every rank's flags, all-reduced) instead of P.flags

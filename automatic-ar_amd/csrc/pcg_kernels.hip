@@ -8,7 +8,7 @@
 // inexact Newton methods): the LM trajectory is then NOT the reference's step for step, only its fixed point is -- measured final RMSE
 // within 1e-6 px of the direct path (north star bar: 1e-4 px), same number of LM steps (profiles/r03_pcg_experiment.txt, r03_pcg_bench.txt).
 // Why it exists: it is the one formulation of this solve in which nothing O(n^3) is left -- the frame sum shards by
-// frame, an iteration exchanges 8 n bytes.
+// frame, an iteration exchanges 8 n bytes (k_pcgd_* below: the same solver with the frames sharded over ranks).
 //
 // ONE persistent launch per solve: G workgroups (one per CU), each keeps its own copy of the CG vectors x, r, p in LDS and updates them
 // redundantly (n is a few hundred to a few thousand), so an iteration needs only two grid-wide hand-overs -- t (6 F doubles) after the
@@ -320,6 +320,301 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same solver with the frames sharded over ranks (one process per GPU).  Nothing of it is replicated except the n-vector
+// updates: every rank holds its own frames' W blocks and its own PARTIAL U, g0 (pass B over its observations); the operator is a
+// sum over ranks,  y = mu p + sum_ranks [ U_rank p - sum_{f in rank} W_f t_f ],  so an iteration costs ONE all-reduce of 8 n bytes,
+// queued by the host between two launches (a collective cannot be issued from inside a kernel): the persistent launch of k_pcg is
+// cut at that point.  Launch k (k_pcgd_iter) = [vector updates from the reduced y of iteration k-1, redundantly in every workgroup;
+// converged -> write delta_s and leave] -> frame pass -> hand-over -> entity pass -> hand-over -> this rank's partial y.  The CG
+// vectors live in global memory between launches (workgroup 0 writes them back after the second hand-over, when everybody has
+// read the old ones).  The set-up (k_pcgd_setup) leaves the rank's partial diagonal blocks and right-hand side for one more
+// all-reduce (28 A doubles); launch 0 inverts them.  Every rank computes the same numbers from the same reduced data: all ranks
+// stop in the same launch.
+struct PcgDistArgs {
+    PcgArgs a;
+    double *setup_local;      // [A][28] this rank's share: lower triangle of (U_ee - sum_f W (V+mu)^-1 W^T) (21), g0_e - sum_f W h_f (6)
+    double *minv;             // [A][36]
+    double *state;            // x [n] | r [n] | p [n] | scal [8]: rz, bb, rr, iterations, done
+    double *y;                // [n] this rank's partial S p without the mu p term; all-reduced in place between two launches
+    int k, last;              // launch number (0: builds the preconditioner and r = b); last: budget exhausted, write delta_s and leave
+    double *host;             // mapped host record {done, iterations, -, sequence}; written when publish_seq != 0
+    unsigned long long publish_seq;
+};
+
+__device__ __forceinline__ void pcgd_items_setup(const PcgArgs &a, double *red, int wg, int G, int tid) {
+    for (int it = wg; it < a.n_items; it += G) {
+        double acc[27];
+#pragma unroll
+        for (int i = 0; i < 27; i++) acc[i] = 0.0;
+        for (int pi = a.it_begin[it] + tid; pi < a.it_end[it]; pi += PCG_THREADS) {
+            const int4 rec = a.pair_rec[pi];
+            const double *Wb = a.W + (size_t)rec.y * 36, *Vi = a.Vinv + (size_t)rec.x * 36, *h = a.hf + (size_t)rec.x * 6;
+            double w[36], yv[36];
+#pragma unroll
+            for (int q = 0; q < 36; q++) w[q] = Wb[q];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s = fma(w[i * 6 + k], Vi[k * 6 + j], s);
+                    yv[i * 6 + j] = s;
+                }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int j = 0; j <= i; j++) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s = fma(yv[i * 6 + k], w[j * 6 + k], s);
+                    acc[i * (i + 1) / 2 + j] += s;
+                }
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s = fma(w[i * 6 + k], h[k], s);
+                acc[21 + i] += s;
+            }
+        }
+        block_sum<27>(acc, red);
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 27; i++) st_agent(a.part + (size_t)it * 28 + i, acc[i]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(PCG_THREADS) k_pcgd_setup(const PcgDistArgs d) {
+    __shared__ double red[4 * 27];
+    const PcgArgs &a = d.a;
+    const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
+    int32_t *counter = a.counter + a.parity;
+    int round = 0;
+    if (wg == 0 && tid == 0) __hip_atomic_store(a.counter + (1 - a.parity), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pcgd_items_setup(a, red, wg, G, tid);
+    grid_hop(counter, round, G, a.flags);
+    for (int e = wg * PCG_THREADS + tid; e < a.A; e += G * PCG_THREADS) {
+        double acc[27];
+#pragma unroll
+        for (int i = 0; i < 27; i++) acc[i] = 0.0;
+        if (!a.ent_fixed[e]) {
+            for (int it = a.ent_item_start[e]; it < a.ent_item_start[e + 1]; it++)
+#pragma unroll
+                for (int i = 0; i < 27; i++) acc[i] += ld_agent(a.part + (size_t)it * 28 + i);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int j = 0; j <= i; j++) acc[i * (i + 1) / 2 + j] = a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] - acc[i * (i + 1) / 2 + j];
+                acc[21 + i] = a.g0[6 * e + i] - acc[21 + i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 27; i++) d.setup_local[(size_t)e * 28 + i] = acc[i];
+        d.setup_local[(size_t)e * 28 + 27] = 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter(const PcgDistArgs d) {
+    extern __shared__ __align__(16) double lds[];
+    const PcgArgs &a = d.a;
+    const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *x = lds, *r = lds + n, *p = r + n, *Mi = p + n, *red = Mi + 6 * n;
+    double *gx = d.state, *gr = gx + n, *gp = gr + n, *gs = gp + n;
+    int32_t *counter = a.counter + a.parity;
+    int round = 0;
+    if (wg == 0 && tid == 0) __hip_atomic_store(a.counter + (1 - a.parity), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto publish = [&](double done_v, double it_v) {
+        if (d.publish_seq && wg == 0 && tid == 0) {
+            d.host[0] = done_v; d.host[1] = it_v;
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(d.host) + 3, d.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    double rz, bb, rr, itc;
+    if (d.k == 0) {   // the preconditioner and r = b from the all-reduced set-up, x = 0, p = z = Minv r
+        for (int e = tid; e < a.A; e += PCG_THREADS) {
+            double out[36], be[6];
+            if (a.ent_fixed[e]) {
+#pragma unroll
+                for (int i = 0; i < 36; i++) out[i] = (i % 7 == 0) ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) be[i] = 0.0;
+            } else {
+                double m[6][6];
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++) {
+                        const double v = d.setup_local[(size_t)e * 28 + i * (i + 1) / 2 + j] + (i == j ? a.mu : 0.0);
+                        m[i][j] = v; m[j][i] = v;
+                    }
+                if (!spd6_inverse(m, out) && wg == 0) atomicOr(a.flags, 2);
+#pragma unroll
+                for (int i = 0; i < 6; i++) be[i] = d.setup_local[(size_t)e * 28 + 21 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 36; i++) Mi[e * 36 + i] = out[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { r[6 * e + i] = be[i]; x[6 * e + i] = 0.0; }
+        }
+        __syncthreads();
+        double s[2] = {0.0, 0.0};
+        for (int i = tid; i < n; i += PCG_THREADS) {
+            const int e = i / 6, row = i - 6 * e;
+            double z = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            p[i] = z;
+            s[0] += r[i] * z;
+            s[1] += r[i] * r[i];
+        }
+        block_sum<2>(s, red);
+        rz = s[0]; bb = s[1]; rr = bb; itc = 0.0;
+        __syncthreads();
+    } else {
+        if (gs[4] != 0.0) {   // converged in an earlier launch (the host had queued this one already)
+            publish(1.0, gs[3]);
+            return;
+        }
+        for (int i = tid; i < 6 * n; i += PCG_THREADS) Mi[i] = d.minv[i];
+        for (int i = tid; i < n; i += PCG_THREADS) { x[i] = gx[i]; r[i] = gr[i]; p[i] = gp[i]; }
+        rz = gs[0]; bb = gs[1]; itc = gs[3];
+        __syncthreads();
+        // y = S p of the iteration before: the rank sum + mu p (identity rows for gauge entities)
+        double yl[24];
+        double s1[1] = {0.0};
+        {
+            int ny = 0;
+            for (int i = tid; i < n; i += PCG_THREADS, ny++) {
+                const double yv = a.ent_fixed[i / 6] ? p[i] : d.y[i] + a.mu * p[i];
+                if (ny < 24) yl[ny] = yv;
+                s1[0] = fma(p[i], yv, s1[0]);
+            }
+        }
+        block_sum<1>(s1, red);
+        const double alpha = rz / s1[0];
+        {
+            int ny = 0;
+            for (int i = tid; i < n; i += PCG_THREADS, ny++) {
+                x[i] = fma(alpha, p[i], x[i]);
+                r[i] = fma(-alpha, yl[ny < 24 ? ny : 23], r[i]);
+            }
+        }
+        __syncthreads();
+        double s2[2] = {0.0, 0.0};
+        double zloc[24];
+        int nz = 0;
+        for (int i = tid; i < n; i += PCG_THREADS, nz++) {
+            const int e = i / 6, row = i - 6 * e;
+            double z = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            if (nz < 24) zloc[nz] = z;
+            s2[0] += r[i] * z;
+            s2[1] += r[i] * r[i];
+        }
+        block_sum<2>(s2, red);
+        const double beta = s2[0] / rz;
+        rz = s2[0];
+        rr = s2[1];
+        nz = 0;
+        for (int i = tid; i < n; i += PCG_THREADS, nz++) p[i] = fma(beta, p[i], zloc[nz < 24 ? nz : 23]);
+        itc += 1.0;
+        __syncthreads();
+    }
+    const bool done = !(itc < (double)a.max_it && rr > a.eta2 * bb && bb > 0.0);
+    if (done || d.last) {
+        if (wg == 0) {
+            for (int i = tid; i < n; i += PCG_THREADS) a.x_out[i] = x[i];
+            for (int i = n + tid; i < a.n_pad; i += PCG_THREADS) a.x_out[i] = 0.0;
+            if (tid == 0) { gs[3] = itc; gs[4] = 1.0; a.iters_out[0] = (int)itc; a.iters_out[1] += (int)itc; }
+        }
+        publish(1.0, itc);
+        return;
+    }
+    // ---- frame pass over this rank's frames ----
+    for (int f = wg * (PCG_THREADS / 64) + wave; f < a.F; f += G * (PCG_THREADS / 64)) {
+        const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
+        double c[6] = {0, 0, 0, 0, 0, 0};
+        for (int s = s0 + lane; s < s1; s += 64) {
+            const int e = a.fslot_ent[s];
+            const double2 *wb = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double pe = p[6 * e + i];
+                const double2 w0 = wb[3 * i], w1 = wb[3 * i + 1], w2 = wb[3 * i + 2];
+                c[0] = fma(w0.x, pe, c[0]); c[1] = fma(w0.y, pe, c[1]); c[2] = fma(w1.x, pe, c[2]);
+                c[3] = fma(w1.y, pe, c[3]); c[4] = fma(w2.x, pe, c[4]); c[5] = fma(w2.y, pe, c[5]);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int i = 0; i < 6; i++) c[i] += __shfl_xor(c[i], off);
+        if (lane < 6) {
+            double tv = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) tv = fma(a.Vinv[(size_t)f * 36 + lane * 6 + k], c[k], tv);
+            st_agent(a.t + (size_t)f * 6 + lane, tv);
+        }
+    }
+    grid_hop(counter, round, G, a.flags);
+    // ---- entity pass over this rank's incidences, by item; the entity's first item also carries (U_rank p)_e ----
+    for (int it = wg; it < a.n_items; it += G) {
+        const int e = a.it_ent[it];
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int pi = a.it_begin[it] + tid; pi < a.it_end[it]; pi += PCG_THREADS) {
+            const int4 rec = a.pair_rec[pi];
+            const double2 *wb = reinterpret_cast<const double2 *>(a.W + (size_t)rec.y * 36);
+            double tv[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) tv[k] = ld_agent(a.t + (size_t)rec.x * 6 + k);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double2 w0 = wb[3 * i], w1 = wb[3 * i + 1], w2 = wb[3 * i + 2];
+                acc[i] -= w0.x * tv[0] + w0.y * tv[1] + w1.x * tv[2] + w1.y * tv[3] + w2.x * tv[4] + w2.y * tv[5];
+            }
+        }
+        if (it == a.ent_item_start[e] && !a.ent_fixed[e]) {
+            for (int bq = tid; bq < a.A; bq += PCG_THREADS) {
+                if (a.ent_fixed[bq]) continue;
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        const double u = bq < e ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * bq + j]
+                                                : (bq > e ? a.U[(size_t)(6 * bq + j) * a.n_pad + 6 * e + i]
+                                                          : (j <= i ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] : a.U[(size_t)(6 * e + j) * a.n_pad + 6 * e + i]));
+                        acc[i] = fma(u, p[6 * bq + j], acc[i]);
+                    }
+            }
+        }
+        block_sum<6>(acc, red);
+        if (tid < 6) st_agent(a.part + (size_t)it * 28 + tid, acc[tid]);
+    }
+    grid_hop(counter, round, G, a.flags);
+    // ---- this rank's partial y (the items' shares in item order), the CG state back to memory ----
+    for (int i = wg * PCG_THREADS + tid; i < n; i += G * PCG_THREADS) {
+        const int e = i / 6, row = i - 6 * e;
+        const int i0 = a.ent_item_start[e], cnt = a.ent_item_start[e + 1] - i0;
+        double sh[PCG_MAX_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PCG_MAX_ITEMS; k++) sh[k] = k < cnt ? ld_agent(a.part + (size_t)(i0 + k) * 28 + row) : 0.0;
+        double yv = 0.0;
+#pragma unroll
+        for (int k = 0; k < PCG_MAX_ITEMS; k++) yv += sh[k];
+        d.y[i] = a.ent_fixed[e] ? 0.0 : yv;
+    }
+    if (wg == 0) {
+        for (int i = tid; i < n; i += PCG_THREADS) { gx[i] = x[i]; gr[i] = r[i]; gp[i] = p[i]; }
+        if (d.k == 0) for (int i = tid; i < 6 * n; i += PCG_THREADS) d.minv[i] = Mi[i];
+        if (tid == 0) { gs[0] = rz; gs[1] = bb; gs[2] = rr; gs[3] = itc; gs[4] = 0.0; }
+    }
+    publish(0.0, itc);
+}
+
 size_t pcg_lds_bytes(int A) { return ((size_t)9 * 6 * A + 4 * 27 + 8) * sizeof(double); }
 
 void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
@@ -337,6 +632,38 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, granted);
     HookScope _h(P, KID_PCG);
     hipLaunchKernelGGL(k_pcg, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a);
+}
+
+static PcgDistArgs pcgd_args(const DeviceProblem &P, int which, double mu) {
+    const DeviceProblem::Blocks &b = P.blk[which];
+    PcgDistArgs d;
+    PcgArgs &a = d.a;
+    a.U = b.S; a.g0 = b.g0; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf;
+    a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed;
+    a.it_ent = P.pcg_it_ent; a.it_begin = P.pcg_it_begin; a.it_end = P.pcg_it_end; a.ent_item_start = P.pcg_ent_item_start; a.n_items = P.pcg_n_items;
+    a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta * P.pcg_eta; a.max_it = P.pcg_max_it;
+    a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
+    a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
+    a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
+    d.setup_local = P.pcgd_setup; d.minv = P.pcgd_minv; d.state = P.pcgd_state; d.y = P.pcgd_y;
+    d.k = 0; d.last = 0; d.host = P.pcgd_host; d.publish_seq = 0;
+    return d;
+}
+
+void launch_pcgd_setup(const DeviceProblem &P, int which, double mu, hipStream_t st) {
+    const PcgDistArgs d = pcgd_args(P, which, mu);
+    HookScope _h(P, KID_PCG);
+    hipLaunchKernelGGL(k_pcgd_setup, dim3(P.pcg_grid), dim3(PCG_THREADS), 0, st, d);
+}
+
+void launch_pcgd_iter(const DeviceProblem &P, int which, double mu, int k, bool last, unsigned long long publish_seq, hipStream_t st) {
+    PcgDistArgs d = pcgd_args(P, which, mu);
+    d.k = k; d.last = last ? 1 : 0; d.publish_seq = publish_seq;
+    const size_t lds = pcg_lds_bytes(P.A);
+    static size_t granted = 48 * 1024;
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter), lds, granted);
+    HookScope _h(P, KID_PCG);
+    hipLaunchKernelGGL(k_pcgd_iter, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, d);
 }
 
 }  // namespace aar

@@ -301,8 +301,6 @@ def main():
     if aar.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (the product has no CPU path)")
     if args.solver == "pcg":
-        if world > 1 or os.environ.get("AAR_FORCE_COMM") == "1":
-            raise SystemExit("bench.py: --solver pcg is a single-GPU mode (a collective per CG iteration would have to be queued by the host; DESIGN.md section 11)")
         os.environ["AAR_SOLVER"] = "pcg"          # read when the problem is created
     ds = aar.synth(args.workload)
     comm = None
@@ -428,7 +426,7 @@ def main():
 
     # ---- where the step's time goes by how it scales with the rank count: a third, stage-timed pass ----
     amdahl = None
-    if not args.no_amdahl and args.solver == "direct":     # (the PCG mode has no replicated part to speak of, and no multi-GPU path yet)
+    if not args.no_amdahl and args.solver == "direct":     # (the PCG mode has no replicated part to speak of: nothing for this split to say)
         n_am = min(args.steps, 300)
         problem.set_stage_timers(True)
         acc, done_am = {}, 0

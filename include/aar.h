@@ -357,7 +357,8 @@ int aar_set_stage_timers(aar_problem *, int on);
  *                         accumulation is, libs/sparselevmarq.h:291-303): two runs give the same bits; slower
  *   AAR_SOLVER=pcg        OPT-IN inexact LM: the reduced system by preconditioned CG through the frame blocks instead of the Schur
  *                         complement + dense LDL^T (csrc/pcg_kernels.hip); the LM trajectory is then no longer the reference's step for
- *                         step, its fixed point is (final RMSE within 1e-4 px); AAR_PCG_ETA (0.1), AAR_PCG_MAX_IT (200); single GPU
+ *                         step, its fixed point is (final RMSE within 1e-4 px); AAR_PCG_ETA (0.1), AAR_PCG_MAX_IT (200).  With a communicator the frames'
+ *                         blocks stay on their ranks and every CG iteration all-reduces 8 n bytes (nothing O(n^3) is replicated)
  * out[0] = CG iterations of the last damped solve, out[1] = their running total since the problem was created (zeros in the default mode) */
 int aar_problem_pcg_iterations(aar_problem *, int32_t out[2]);
 
