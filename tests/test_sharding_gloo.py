@@ -114,3 +114,82 @@ def test_shard_plan_is_identical_on_every_rank_and_covers_all_frames():
         b = aar.plan_shards(counts, world)
         per = [counts[b[r]:b[r + 1]].sum() for r in range(world)]
         assert sum(per) == ds.num_obs and max(per) / (ds.num_obs / world) < 1.05
+
+
+def _pcg_worker(rank, world, port, out):
+    """The sharded PCG of csrc/pcg_kernels.hip (k_pcgd_*) in numpy, one process per rank: a rank's own frames' W blocks and its PARTIAL U, g0;
+    set-up shares all-reduced once, then one all-reduce of the n-vector y per CG iteration; the vector updates replicated."""
+    import torch
+    import torch.distributed as dist
+
+    import aar
+    import oracle_lib as ol
+    from conftest import load_golden
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    ds, _ = load_golden("g2_small")
+    begin = aar.plan_shards(np.bincount(ds.obs_frame, minlength=ds.num_frames), world)
+    sub = shard_dataset(ds, begin[rank], begin[rank + 1])
+    H, B = ol.Oracle(sub).normal_equations(sub.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F64)
+    mu, eta = 123.0, 1e-10
+    ns = 6 * (ds.num_cams - 1) + 6 * (ds.num_markers - 1)
+    U, g0 = H[:ns, :ns], B[:ns]                                     # this rank's partial sums (pass B over its observations)
+    mine = range(begin[rank], begin[rank + 1])
+    Wf = {f: H[:ns, ns + 6 * f: ns + 6 * f + 6] for f in mine}
+    Vi = {f: np.linalg.inv(H[ns + 6 * f: ns + 6 * f + 6, ns + 6 * f: ns + 6 * f + 6] + mu * np.eye(6)) for f in mine}
+    hf = {f: Vi[f] @ B[ns + 6 * f: ns + 6 * f + 6] for f in mine}
+
+    def allreduce(v):
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64).copy())
+        dist.all_reduce(t)
+        return t.numpy()
+
+    # set-up: the rank's share of the diagonal blocks of S (without mu) and of the right-hand side -> one all-reduce
+    ne = ns // 6
+    share = np.zeros((ne, 6, 7))
+    for e in range(ne):
+        sl = slice(6 * e, 6 * e + 6)
+        share[e, :, :6] = U[sl, sl] - sum(Wf[f][sl] @ Vi[f] @ Wf[f][sl].T for f in mine)
+        share[e, :, 6] = g0[sl] - sum(Wf[f][sl] @ hf[f] for f in mine)
+    share = allreduce(share.reshape(-1)).reshape(ne, 6, 7)
+    Minv = np.stack([np.linalg.inv(share[e, :, :6] + mu * np.eye(6)) for e in range(ne)])
+    b = share[:, :, 6].reshape(-1)
+    prec = lambda r: np.einsum("eij,ej->ei", Minv, r.reshape(ne, 6)).reshape(-1)
+    x, r = np.zeros(ns), b.copy()
+    z = prec(r); p = z.copy(); rz = r @ z; bb = r @ r
+    its, collectives = 0, 1
+    while r @ r > eta * eta * bb and its < 500:
+        y_local = U @ p - sum(Wf[f] @ (Vi[f] @ (Wf[f].T @ p)) for f in mine)        # frame pass + entity pass over THIS rank's frames
+        y = allreduce(y_local) + mu * p                                               # the iteration's one collective: 8 n bytes
+        collectives += 1
+        alpha = rz / (p @ y)
+        x += alpha * p; r -= alpha * y
+        z = prec(r); rz_new = r @ z
+        p = z + (rz_new / rz) * p; rz = rz_new
+        its += 1
+    if rank == 0:
+        np.save(out, np.concatenate([x, [its, collectives]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pcg_through_the_frame_blocks_equals_the_direct_step(tmp_path):
+    # AAR_SOLVER=pcg with a communicator (DESIGN.md section 11): nothing but n-vectors is ever exchanged, and the converged CG solution
+    # of the rank-summed operator is the shared part of the full damped step
+    import torch.multiprocessing as mp
+
+    import oracle_lib as ol
+    from conftest import load_golden
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "pcg.npy")
+    mp.spawn(_pcg_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    ds, _ = load_golden("g2_small")
+    d = ol.Oracle(ds).damped_solve(ds.x_full, 123.0, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F64)
+    ns = len(got) - 2
+    np.testing.assert_allclose(got[:ns], d[:ns], rtol=1e-6, atol=1e-8 * np.abs(d).max())
+    assert 3 < got[ns] < 500 and got[ns + 1] == got[ns] + 1            # one all-reduce per iteration + the set-up's
