@@ -413,6 +413,8 @@ def main():
                     r.pop(f)
             if k in rocprof_avg:
                 r["avg_us_rocprofv3"] = rocprof_avg[k]     # the same kernel under rocprofv3 --kernel-trace --stats (profiles/, same sources)
+            elif k == "k_schur" and "k_schur_mfma" in rocprof_avg:
+                r["avg_us_rocprofv3"] = rocprof_avg["k_schur_mfma"]     # (k_schur_fill only runs when the damping was not the predicted one)
             return r
         roofline = roof(dom)
         roofline["traffic_source"] = traffic_note
