@@ -50,9 +50,10 @@ for cfg in ():
         res = {m: schur_pcg2(*parts, mu, 0.1, nc, m) for m in ("bj","cam","schur2")}
         print("config", cfg, "mu/mu0 %.0e" % (mu/mu0), res, flush=True)
 
+CFGS = [int(a) for a in sys.argv[1:]] or [3]
 print("---- along the exact LM trajectory ----")
-for cfg in (3,):
-    ds = aar.synth(cfg)
+for cfg in CFGS:
+    ds = aar.synth(cfg) if cfg <= 3 else aar.synth(5, num_frames=400)
     o = ol.Oracle(ds); ns = 6*(ds.num_cams-1+ds.num_markers-1); nc = 6*(ds.num_cams-1)
     x=ds.x_full; z=o.extract_z(x)
     H,B = o.normal_equations(x, z=z, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)

@@ -1109,3 +1109,47 @@ def test_deterministic_mode_with_two_ranks(monkeypatch):
         assert np.array_equal(xa, xb) and [t["err"] for t in ra["trace"]] == [t["err"] for t in rb["trace"]]
     assert np.array_equal(a[0][0], a[1][0])                                   # every rank holds the same solution
     np.testing.assert_allclose([t["err"] for t in a[0][1]["trace"]], g["analytic_err"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("mode", ["deterministic", "pcg"])
+def test_randomized_shapes_in_the_optional_modes(mode, monkeypatch):
+    # the same sweep of shapes as test_randomized_shapes_against_oracle (1-5 tiles, ragged visibility, switched-off groups, 2-3 in-process ranks
+    # now and then) through AAR_DETERMINISTIC=1 and through AAR_SOLVER=pcg at a tight tolerance: the damped step is the oracle's in both
+    if mode == "deterministic":
+        monkeypatch.setenv("AAR_DETERMINISTIC", "1")
+    else:
+        monkeypatch.setenv("AAR_SOLVER", "pcg")
+        monkeypatch.setenv("AAR_PCG_ETA", "1e-12")
+        monkeypatch.setenv("AAR_PCG_MAX_IT", "2000")
+    rng = np.random.default_rng(20190221)
+    done = 0
+    for k in range(40):
+        C, M, F = int(rng.integers(3, 11)), int(rng.integers(4, 60)), int(rng.integers(2, 160))
+        try:
+            ds = aar.synth(3, num_cams=C, num_markers=M, num_frames=F, seed=int(rng.integers(1, 2 ** 31)))
+        except aar.AarError:
+            continue
+        if ds.num_obs < 20:
+            continue
+        opt = [(True, True, True), (True, True, True), (False, True, True), (True, False, True)][k % 4]
+        o = ol.Oracle(ds, optimize=opt)
+        mu = float(10.0 ** rng.integers(2, 7))
+        do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+        with aar.Problem(ds, optimize=opt) as p:
+            d = p.eval_damped_step(ds.x_full, mu)
+            assert np.abs(d - do).max() / np.abs(do).max() < 1e-6, (mode, C, M, F, mu)
+            x, rep = p.lm_solve(ds.x_full)
+        xo, repo = o.lm_solve(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+        assert abs(rep["iterations"] - repo["iterations"]) <= 1, (mode, C, M, F)
+        np.testing.assert_allclose(rep["final_err"], repo["final_err"], rtol=1e-5, err_msg=str((mode, C, M, F)))
+        if k % 3 == 0 and opt == (True, True, True):
+            def solve(comm, rank, ds=ds):
+                with aar.Problem(ds, comm=comm) as q:
+                    return q.lm_solve(ds.x_full)
+            for xs, reps in _run_ranks(2 + k % 2, solve):
+                assert abs(reps["iterations"] - rep["iterations"]) <= 1, (mode, C, M, F)
+                np.testing.assert_allclose(reps["final_err"], rep["final_err"], rtol=1e-6)
+        done += 1
+        if done >= 8:
+            break
+    assert done >= 6
