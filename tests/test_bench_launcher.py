@@ -73,3 +73,25 @@ def test_amdahl_object_and_kernel_models():
     assert bench.algorithmic_flops("k_ldl_trsm", 0, 288, 0.0, True) == 0.0                                           # no split stage at three tiles
     assert bench.algorithmic_flops("k_ldl_trsm", 0, 1344, 0.0, True) == sum(m * nb3 for m in range(4, 14)) / 10.0   # the last three block columns take k_ldl_panel
     assert bench.algorithmic_bytes("k_ldl_panel", 0, 48, 500, 288) > bench.algorithmic_bytes("k_ldl_diag", 0, 48, 500, 288)
+
+
+def test_committed_bench_lines_keep_the_contract():
+    # profiles/r03_bench_cfg{3,5}.json are bench.py's own lines from the GPU box (scripts/collect_profiles.sh): the fields the driver and the
+    # judge read must be there, with the metric of BASELINE.json, the roofline of the dominant kernel and the CPU baseline beside it
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for name, workload in (("r03_bench_cfg3.json", "8-cam/40-marker/500-frame"), ("r03_bench_cfg5.json", "16-cam/200-marker/5000-frame")):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                  "roofline", "cpu_baseline", "amdahl", "final_rmse_px"):
+            assert k in d, (name, k)
+        assert d["metric"].startswith("LM iterations/sec") and base["metric"].startswith("LM iterations/sec")
+        assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+        assert workload in d["config"]["workload"] and "model" not in d["config"]
+        assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+        r = d["roofline"]
+        assert r["bound"] in ("hbm", "fp64_valu", "fp64_mfma", "latency") and r["kernel"] in r["per_kernel"]
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] is not None and r["traffic"] > 0
+        assert set(d["amdahl"]["bound_at"]) == {"1", "2", "4", "8"} and d["amdahl"]["bound_at"]["1"] == 1.0
+    d3 = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_cfg3.json")))
+    cb = d3["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
