@@ -558,13 +558,13 @@ int wait_result(aar_problem *pb) {
 }
 
 // queue the reduction of the step's scalars and their publication to the host record (no wait)
-int launch_scalars(aar_problem *pb, int n_err) {
+int launch_scalars(aar_problem *pb, int n_err, int maxdiag_blk = -1) {
     DeviceProblem &P = pb->P;
     pb->seq++;
     {
         StageTimer t(pb, &pb->times.control);
         // (PCG mode with ranks: g0 is this rank's partial sum -- it was never all-reduced --, so delta_s . g0 joins the rank sum)
-        launch_reduce_scalars(P, n_err, P.use_pcg && pb->comm, pb->comm ? 0ull : pb->seq, pb->stream);
+        launch_reduce_scalars(P, n_err, P.use_pcg && pb->comm, pb->comm ? 0ull : pb->seq, pb->stream, nullptr, maxdiag_blk);
         pb->launches += 1;
     }
     if (pb->comm) {
@@ -576,8 +576,8 @@ int launch_scalars(aar_problem *pb, int n_err) {
     return check_async("kernel launch");
 }
 
-int read_scalars(aar_problem *pb, int n_err) {
-    int rc = launch_scalars(pb, n_err);
+int read_scalars(aar_problem *pb, int n_err, int maxdiag_blk = -1) {
+    int rc = launch_scalars(pb, n_err, maxdiag_blk);
     if (rc) return rc;
     return wait_result(pb);
 }
@@ -1568,15 +1568,21 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     memset(&pb->times, 0, sizeof pb->times);
     int rc = upload_z(pb, x_full, 0);
     if (rc) return rc;
-    if ((rc = zero_for_init(pb))) return rc;
-    if ((rc = eval_blocks(pb, 0, -1.0, -1))) return rc;
+    // A solve's fixed cost (every 15 steps or so in a bundle adjustment that converges): the first launch turns z into entity rows AND
+    // clears block set 0 and the linear-model partials, pass A clears block set 1 on its way, and max diag(J^T J) of the start point
+    // (mu_0, libs/sparselevmarq.h:369-377) comes out of the launch that reduces its sum r^2 -- three launches less than one kernel per job
+    if (P.F > 0 && P.n_chunks > 0 && !pb->comm) {
+        launch_unpack(P, 0, pb->stream, /*zero_blk=*/0);
+        pb->launches += 1;
+        if ((rc = eval_blocks(pb, 0, -1.0, /*zero_blk=*/1, /*spec_schur=*/false, /*ents_ready=*/true))) return rc;
+    } else {
+        if ((rc = zero_for_init(pb))) return rc;
+        if ((rc = eval_blocks(pb, 0, -1.0, -1))) return rc;
+    }
     pb->huber_of_blocks = P.huber;
     pb->mu_seed_valid = false;
-    if (!pb->comm) {   // max diag(J^T J) of the start point rides to the host with its sum r^2: the first step() then needs no round trip of its own
-        launch_maxdiag(P, 0, pb->stream);
-        pb->launches += 1;
-    }
-    if ((rc = read_scalars(pb, P.F))) return rc;
+    // (single GPU: mu_0 rides to the host with the sum r^2: the first step() then needs no round trip of its own)
+    if ((rc = read_scalars(pb, P.F, pb->comm ? -1 : 0))) return rc;
     if (!pb->comm) { pb->mu_seed = pb->h_scal[4]; pb->mu_seed_valid = true; }
     pb->currErr = pb->prevErr = pb->h_scal[0];
     pb->blocks_valid = true;

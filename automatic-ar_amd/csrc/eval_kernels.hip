@@ -8,6 +8,7 @@
 // analytic 8x18 Jacobian lives only in registers and its 6x6 block products are reduced on chip.
 // fp64 throughout.  No atomics on frame-owned data; shared blocks get one fp64 atomic per value per
 // (camera, marker) chunk.
+#include <algorithm>
 #include "geom.hpp"
 #include "kernels.h"
 
@@ -48,8 +49,13 @@ __device__ __forceinline__ void wave_sum_lds(const double (&vals)[NV], double *_
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void k_unpack(const double *__restrict__ z, double *__restrict__ ent, int n_ent, int k0, int k1) {
+// zero_n > 0: the launch also clears zero_p[0 .. zero_n) grid-stride (aar_lm_init: the block set pass B is about to accumulate into and the
+// linear-model partials -- one launch less at the start of every solve)
+__global__ void k_unpack(const double *__restrict__ z, double *__restrict__ ent, int n_ent, int k0, int k1, double *__restrict__ zero_p, int64_t zero_n,
+                         double *__restrict__ zero_q, int64_t zero_qn) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = gid; i < zero_n; i += (int64_t)gridDim.x * blockDim.x) zero_p[i] = 0.0;
+    for (int64_t i = gid; i < zero_qn; i += (int64_t)gridDim.x * blockDim.x) zero_q[i] = 0.0;
     if (gid >= n_ent) return;
     if (gid >= k0 && gid < k1) make_k_row(z + 6 * gid, ent + gid * ENT_STRIDE);   // intrinsics entities [k0, k1)
     else make_ent_row(z + 6 * gid, ent + gid * ENT_STRIDE);
@@ -634,10 +640,18 @@ __global__ void __launch_bounds__(256) k_maxdiag(const double *__restrict__ U0, 
 }
 
 // ------------------------------------------------------------------------------------------------
-void launch_unpack(const DeviceProblem &P, int which, hipStream_t st) {
+void launch_unpack(const DeviceProblem &P, int which, hipStream_t st, int zero_blk) {
     const int n_ent = P.A + P.F;
-    { HookScope _h(P, KID_UNPACK); hipLaunchKernelGGL(k_unpack, dim3((n_ent + 255) / 256), dim3(256), 0, st, P.z[which], P.ent[which], n_ent,
-                                                      P.C + P.M, P.intr ? P.C + P.M + P.C : P.C + P.M); }
+    double *zp = nullptr, *zq = nullptr;
+    int64_t zn = 0, zqn = 0;
+    int blocks = (n_ent + 255) / 256;
+    if (zero_blk >= 0) {   // S | rhs | g0 | tail are one allocation; the linear-model partials another
+        zp = P.blk[zero_blk].S; zn = (int64_t)P.n_pad * P.n_pad + 2 * (int64_t)P.n_pad;
+        zq = P.lin_part; zqn = 2 * (int64_t)(P.F + 1);
+        blocks = (int)std::max<int64_t>(blocks, std::min<int64_t>(512, (zn + 2047) / 2048));
+    }
+    { HookScope _h(P, KID_UNPACK); hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(256), 0, st, P.z[which], P.ent[which], n_ent,
+                                                      P.C + P.M, P.intr ? P.C + P.M + P.C : P.C + P.M, zp, zn, zq, zqn); }
 }
 
 void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream_t st) {

@@ -147,7 +147,8 @@ struct HookScope {  // RAII: pre/post around one launch
     ~HookScope() { if (P.hook.post) P.hook.post(P.hook.ctx, kid); }
 };
 
-void launch_unpack(const DeviceProblem &P, int which, hipStream_t st);             // z -> ent (only for the residual-vector API)
+// z -> ent (start of a solve, rebuilds, the residual-vector API); zero_blk >= 0: the same launch clears that block set's S | rhs | g0 and lin_part
+void launch_unpack(const DeviceProblem &P, int which, hipStream_t st, int zero_blk = -1);
 void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream_t st);
 // pass A at z[which]: entity table, V, g_f, W, per-frame sum r^2 (err_part[f]); mu_pred >= 0 also gives Vinv, h_f for that
 // damping; zero_blk >= 0 clears S, rhs, g0 of that block set (they are dead / about to be rebuilt)
@@ -172,7 +173,8 @@ size_t pcg_lds_bytes(int A);
 void launch_pcgd_setup(const DeviceProblem &P, int which, double mu, hipStream_t st);
 void launch_pcgd_iter(const DeviceProblem &P, int which, double mu, int k, bool last, unsigned long long publish_seq, hipStream_t st);
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st,
-                           double *scal_out = nullptr);  // scal[0..2], scal[5..6] (into scal_out instead of P.scal if given)
+                           double *scal_out = nullptr, int maxdiag_blk = -1);  // scal[0..2], scal[5..6] (into scal_out instead of P.scal if given);
+                                                                               // maxdiag_blk >= 0: also scal[4] = max free diagonal of that block set (k_maxdiag's job)
 // scal / flags -> host record; flags_reduced: the flags are decoded from src[3] (every rank's flags, all-reduced) instead of P.flags
 void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st, const double *src = nullptr, bool flags_reduced = false);
 int residual_blocks(const DeviceProblem &P);   // entries of err_part written by launch_residual

