@@ -364,13 +364,17 @@ int collective_status(aar_problem *pb, int local_rc, int *agreed) {
 }
 
 // device pose vector -> x_full; fixed groups keep the caller's values
-int download_z(aar_problem *pb, int which, double *x_full) {
+// side_stream: the copy goes through the problem's second stream and only THAT is waited for.  z[which] must be complete already (the host has
+// seen the scalars of the step that wrote it); what is still running on the main stream -- the speculative Schur complement of a step that
+// turned out to be the last, ~20 us -- then overlaps with the caller's own work instead of being waited for.  Single GPU only.
+int download_z(aar_problem *pb, int which, double *x_full, bool side_stream = false) {
     const PoseLayout &L = pb->L;
     const int A = pb->P.A, F = pb->P.F;
     std::vector<double> &z = pb->h_z;
     z.resize((size_t)6 * (A + F));
-    HIP_TRY(hipMemcpyAsync(z.data(), pb->P.z[which], z.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-    HIP_TRY(hipStreamSynchronize(pb->stream));
+    hipStream_t st = (side_stream && !pb->comm && pb->stream2) ? pb->stream2 : pb->stream;
+    HIP_TRY(hipMemcpyAsync(z.data(), pb->P.z[which], z.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (L.oc)
         for (int c = 0; c < L.C; c++)
             if (c != L.rc) memcpy(x_full + L.full_cam0() + 6LL * L.cam_slot(c), &z[6 * (size_t)c], 6 * sizeof(double));
@@ -1736,11 +1740,13 @@ int aar_lm_solve(aar_problem *pb, double *x_full, const aar_lm_params *prm, aar_
             pb->prevErr = pb->currErr;
         }
     }
-    HIP_TRY(hipStreamSynchronize(pb->stream));
+    // (the last step's speculative work may still be running: only waited for when somebody reads timers)
+    const bool lazy = !pb->comm && !pb->profiling && !pb->stage_timers && iters > 0;
+    if (!lazy) HIP_TRY(hipStreamSynchronize(pb->stream));
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     pb->times.total = secs;
     pb->times.launches = pb->launches;
-    if ((rc = download_z(pb, pb->cur, x_full))) return rc;
+    if ((rc = download_z(pb, pb->cur, x_full, lazy))) return rc;
     if (rep) {
         rep->iterations = iters;
         rep->stop_code = mustExit;
