@@ -1,0 +1,30 @@
+"""Scratch (GPU): soak of the fence-free hand-overs -- thousands of solves at 1-, 2-, 3-, 4- and 14-tile systems (bs rider, chained back-substitution) and
+of the PCG grid hand-overs; every solve must land on the same final error (to the atomics' noise) in the same number of iterations."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "automatic-ar_amd"), os.path.join(ROOT, "tests")]
+import numpy as np
+import aar
+bad = 0
+for label, kw, reps, env in (("1 tile (cfg2)", dict(cfg=2), 1500, {}), ("3 tiles (cfg3)", dict(cfg=3), 1500, {}), ("2 tiles", dict(cfg=3, num_cams=4, num_markers=20, num_frames=60), 800, {}),
+                             ("4 tiles (intr)", dict(cfg=3, intr=True), 500, {}), ("5 tiles", dict(cfg=3, num_cams=4, num_markers=62, num_frames=40), 500, {}),
+                             ("14 tiles (cfg5)", dict(cfg=5), 12, {}), ("pcg cfg3", dict(cfg=3), 600, {"AAR_SOLVER": "pcg"}), ("pcg cfg5", dict(cfg=5), 12, {"AAR_SOLVER": "pcg"})):
+    for k, v in env.items(): os.environ[k] = v
+    cfg = kw.pop("cfg"); intr = kw.pop("intr", False)
+    ds = aar.synth(cfg, **kw)
+    t0 = time.time()
+    with aar.Problem(ds, intrinsics=intr) as p:
+        x0 = p.x_with_intrinsics(ds.x_full) if intr else ds.x_full
+        x, rep = p.lm_solve(x0)
+        ref_err, ref_it = rep["final_err"], rep["iterations"]
+        worst = 0.0
+        for i in range(reps):
+            x, rep = p.lm_solve(x0)
+            dev = abs(rep["final_err"] - ref_err) / ref_err
+            worst = max(worst, dev)
+            if rep["iterations"] != ref_it or not (dev < 1e-6):
+                bad += 1
+                print("  DEVIATION", label, i, rep["iterations"], ref_it, dev, flush=True)
+    for k in env: os.environ.pop(k)
+    print("%-16s %5d solves x %d iterations: worst relative deviation of the final error %.2e  (%.1f s)" % (label, reps, ref_it, worst, time.time() - t0), flush=True)
+print("BAD", bad)
