@@ -142,7 +142,7 @@ struct PassAArgs {
 constexpr int ENT_LDS = 25;   // doubles between entity rows in pass A's LDS copy (24 used): odd, so that lanes reading one field of different entities hit different banks
 constexpr int WLS = 37;   // doubles between the W blocks of consecutive frame-local slots in pass A's LDS panel
 __host__ __device__ constexpr size_t passA_w_doubles(int max_kf) { return ((size_t)max_kf * WLS + 1) & ~(size_t)1; }   // what follows stays 16-byte aligned
-__host__ __device__ constexpr int passA_sum_chunk(int block) { return block == 256 ? 8 : 32; }
+__host__ __device__ constexpr int passA_sum_chunk(int block) { return block >= 128 ? 8 : 32; }
 
 // CPL = corners per lane: 4 = one lane per observation; 2 / 1 = two / four lanes per observation for frames with few
 // observations (the wavefront's instruction stream gets that much shorter; the sums over lanes do not care)
@@ -705,7 +705,8 @@ static PassBArgs passB_args(const DeviceProblem &P, int which) {
 // with_b: pass B's chunks ride in the same launch (the caller must not launch pass B again)
 template <int B, int CPL>
 static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, const PassBArgs *pbargs, hipStream_t st) {
-    const size_t lds = passA_lds_bytes(P.max_kf, B);
+    size_t lds = passA_lds_bytes(P.max_kf, B);
+    if (pbargs) lds = std::max(lds, (size_t)(B / 64) * 2048 * sizeof(double));   // pass B's wave-sum scratch, when its chunks ride along
     static size_t granted = 48 * 1024, granted_ab = 48 * 1024;
     HookScope _h(P, KID_PASSA);
     if (P.intr && pbargs) {
@@ -728,13 +729,18 @@ static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, const Pas
 
 static void launch_passA_any(const DeviceProblem &P, const PassAArgs &a, const PassBArgs *pbargs, hipStream_t st) {
     // one wavefront per frame up to ~96 observations per frame (four / two lanes per observation while they fit in it),
-    // four wavefronts above
+    // two wavefronts above
     const double avg = (double)P.N / (double)P.F;
     if (P.deterministic && avg > 96) return launch_passA_t<64, 4>(P, a, pbargs, st);   // ONE wavefront per frame: its LDS additions come in program order
+    static const int var = getenv("AAR_PASSA_VARIANT") ? atoi(getenv("AAR_PASSA_VARIANT")) : 0;   // experiments: 1281 / 1282 / 1284 / 2564
+    if (var == 1281) return launch_passA_t<128, 1>(P, a, pbargs, st);
+    if (var == 1282) return launch_passA_t<128, 2>(P, a, pbargs, st);
+    if (var == 1284) return launch_passA_t<128, 4>(P, a, pbargs, st);
+    if (var == 2564) return launch_passA_t<256, 4>(P, a, pbargs, st);
     if (avg <= 14) launch_passA_t<64, 1>(P, a, pbargs, st);
     else if (avg <= 30) launch_passA_t<64, 2>(P, a, pbargs, st);
     else if (avg <= 96) launch_passA_t<64, 4>(P, a, pbargs, st);
-    else launch_passA_t<256, 4>(P, a, pbargs, st);
+    else launch_passA_t<128, 4>(P, a, pbargs, st);
 }
 
 void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st) {
