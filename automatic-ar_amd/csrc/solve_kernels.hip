@@ -379,10 +379,20 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
     const int w = (int)blockIdx.x - rider, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ga = w_ga[w], gb = w_gb[w], fb = w_fb[w], fe = w_fe[w];
     const int lr = lane >> 4, lc = lane & 15;
-    // staging role: thread t < 288 owns row t of the stage: (dense entity, parameter) of the a side (t < 96: a row of Y) or of
-    // the b side (a row of W); consecutive threads read consecutive 48-byte rows of one frame's panel
-    const bool isA = tid < SM_AR, stager = tid < SM_ROWS;
-    const double *src = (isA ? Yd + (size_t)SM_GA * ga * 36 + (size_t)tid * 6 : Wd + (size_t)SM_GB * gb * 36 + (size_t)(tid - SM_AR) * 6);
+    // staging: the SM_ROWS rows x SM_FPS frames of a step travel as 16-byte pieces, SM_PPT per thread over ALL wavefronts (piece q = tid + 512 u:
+    // frame q / 864 of the step, then piece (row, part) of that frame's 288 rows; rows 0-95 are the a side (Y), the rest the b side (W): within
+    // a side consecutive pieces are consecutive in memory) -- every wavefront then carries the same staging work to the barrier
+    constexpr int SM_PIECES = SM_ROWS * 3 * SM_FPS, SM_PPT = (SM_PIECES + 511) / 512;
+    int p_lds[SM_PPT], p_off[SM_PPT];
+    unsigned sideA = 0;   // bit u: piece u is a row of Y
+    auto piece_ff = [&](int u) -> int { const int q = tid + 512 * u; return q >= SM_PIECES ? -1 : q / (SM_ROWS * 3); };
+#pragma unroll
+    for (int u = 0; u < SM_PPT; u++) {
+        const int q = tid + 512 * u, ff = q / (SM_ROWS * 3), r3 = q - ff * (SM_ROWS * 3), row = r3 / 3, part = r3 - 3 * row;
+        p_lds[u] = row * SM_PS + 6 * ff + 2 * part;
+        p_off[u] = row < SM_AR ? SM_GA * ga * 36 + 2 * r3 : SM_GB * gb * 36 + 2 * (r3 - 3 * SM_AR);
+        sideA |= (row < SM_AR ? 1u : 0u) << u;
+    }
     const size_t fstride = (size_t)Ad * 36;
     dg_acc_t acc[3][3];
 #pragma unroll
@@ -395,28 +405,30 @@ __global__ void __launch_bounds__(512) k_schur_mfma(const int32_t *__restrict__ 
     // matrix pipes bound this kernel); it still stages rows and keeps the barriers.  (Per-sub-tile masks cost 96 spilled registers.)
     const bool all_dead = __builtin_amdgcn_readfirstlane((int)(SM_AR * ga + 16 * (rt0 + 3) - 1 < SM_BR * gb + 16 * ct0)) != 0;
 
-    // position k of the block's frame list (frames in which both entity groups are present; two of them per step)
-    auto fetch_rows = [&](int k0, double2 (&v)[3 * SM_FPS]) {   // nothing here waits: the values are stored steps later
+    // position k of the block's frame list (frames in which both entity groups are present)
+    auto fetch_rows = [&](int k0, double2 (&v)[SM_PPT]) {   // nothing here waits: the values are stored steps later
+        int fr[SM_FPS];   // the step's frames: wave-uniform, through the scalar cache (a per-lane flist[k0 + ff] would put a dependent vector load in front of every piece)
 #pragma unroll
-        for (int ff = 0; ff < SM_FPS; ff++) {
-            if (stager && k0 + ff < fe) {
-                const double2 *p = reinterpret_cast<const double2 *>(src + (size_t)flist[k0 + ff] * fstride);
-                v[3 * ff] = p[0]; v[3 * ff + 1] = p[1]; v[3 * ff + 2] = p[2];
-            } else {
-                v[3 * ff] = v[3 * ff + 1] = v[3 * ff + 2] = make_double2(0.0, 0.0);
-            }
+        for (int i = 0; i < SM_FPS; i++) fr[i] = k0 + i < fe ? flist[k0 + i] : -1;
+#pragma unroll
+        for (int u = 0; u < SM_PPT; u++) {
+            const int ff = piece_ff(u);
+            int frame = -1;
+#pragma unroll
+            for (int i = 0; i < SM_FPS; i++) frame = ff == i ? fr[i] : frame;
+            if (frame >= 0) v[u] = *reinterpret_cast<const double2 *>(((sideA >> u) & 1 ? Yd : Wd) + (size_t)frame * fstride + p_off[u]);
+            else v[u] = make_double2(0.0, 0.0);   // (loading unconditionally and zeroing at the store: 1 050 us against 996)
         }
     };
-    auto put_rows = [&](int buf, const double2 (&v)[3 * SM_FPS]) {
-        if (stager) {
-            double2 *d = reinterpret_cast<double2 *>(stage + ((size_t)buf * SM_ROWS + tid) * SM_PS);
+    auto put_rows = [&](int buf, const double2 (&v)[SM_PPT]) {
 #pragma unroll
-            for (int h = 0; h < 3 * SM_FPS; h++) d[h] = v[h];
-        }
+        for (int u = 0; u < SM_PPT; u++)
+            if (piece_ff(u) >= 0) *reinterpret_cast<double2 *>(stage + (size_t)buf * SM_ROWS * SM_PS + p_lds[u]) = v[u];
     };
-    // Register ring SM_DEPTH steps deep: the rows of step s + SM_DEPTH are requested while step s computes -- one step of the matrix
-    // pipes (27 MFMAs per wavefront, ~1.4 us) is shorter than a loaded chip's memory latency, a single step of look-ahead starves
-    double2 v[SM_DEPTH][3 * SM_FPS];
+    // Register ring SM_DEPTH steps deep: the rows of step s + SM_DEPTH are requested while step s computes -- one two-frame step of the
+    // matrix pipes (27 MFMAs per wavefront, ~1.4 us) is shorter than a loaded chip's memory latency.  (Three steps deep at four frames per
+    // step: 1 025 us against 1 000.)
+    double2 v[SM_DEPTH][SM_PPT];
     auto compute = [&](int buf) {
         if (all_dead) return;
         const double *sb = stage + (size_t)buf * SM_ROWS * SM_PS;
