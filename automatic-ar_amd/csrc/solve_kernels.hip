@@ -587,7 +587,7 @@ __device__ __forceinline__ unsigned long long gauge_ballot(bool first, const int
 // which turn every triangular solve below into small matrix products.
 // f64 MFMA lane maps (cdna_hip_programming.md section 4, checked by scripts/probe/issue_probe.hip):
 //   A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row = (l>>4) + 4 reg][col = l&15].
-// LDS (dynamic): T [NB][NB+2] | Yn [2][NB][DG_YS]
+// LDS (dynamic): T [NB][NB+2] | Yn [2][NB][DG_YS] | Lh [NB][NB/2+2] (look-ahead)
 constexpr int DG_THREADS = 1024, DG_ROW0 = 896;
 // doubles between panel rows: 8 are used (rank 6 padded to 8); at 10 the rows of 16 consecutive lanes tile the LDS banks (at 8 they
 // fall on four bank groups: 4-way conflicts on every panel store of the row phase and every B-operand read)
@@ -898,12 +898,95 @@ __device__ __forceinline__ void bs_small(double *__restrict__ lds, const double 
     }
 }
 
+// Look-ahead (launch_chol): the trailing update of block column s does not get a launch of its own -- the NEXT diagonal tile's workgroup
+// brings its own tile up to date in its prologue (see k_ldl_diag) and starts factoring, while these riders, workgroups of the same launch, do
+// every other trailing tile and the right-hand side.  The body of k_ldl_update (below) for one wavefront = one 16 x 16 block, in two halves
+// of k so that it fits the 128 registers of a 1024-thread workgroup.  zs = D_s in LDS.
+__device__ __forceinline__ void ldl_update_block_lean(double *__restrict__ S, const double *__restrict__ zs, int n_pad, int n, int s, double mu,
+                                                      const int32_t *__restrict__ ent_fixed, int ti, int tj, int q) {
+    constexpr int RUN = NB / 4, HALF = RUN / 2;
+    const int lane = threadIdx.x & 63, lr = lane >> 4, lc = lane & 15;
+    const int bi = q / (NB / 16), bj = q % (NB / 16);
+    if (ti == tj && bj > bi) return;   // blocks above the diagonal of a diagonal tile are never read
+    const bool first = (s == 0);
+    const int r0 = s * NB, i0 = (s + 1 + ti) * NB + 16 * bi, j0 = (s + 1 + tj) * NB + 16 * bj;
+    const unsigned long long gmask = gauge_ballot(first, ent_fixed, n, i0, 1, j0, 1);
+    double tgt[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int gi = i0 + lr + 4 * r, gj = j0 + lc;
+        tgt[r] = (gj <= gi) ? S[(size_t)gi * n_pad + gj] : 0.0;
+    }
+    dg_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const double2 *pa = reinterpret_cast<const double2 *>(S + (size_t)(i0 + lc) * n_pad + r0 + RUN * lr + HALF * h);
+        const double2 *pb = reinterpret_cast<const double2 *>(S + (size_t)(j0 + lc) * n_pad + r0 + RUN * lr + HALF * h);
+        double2 va[HALF / 2], vb[HALF / 2];
+#pragma unroll
+        for (int u = 0; u < HALF / 2; u++) { va[u] = pa[u]; vb[u] = pb[u]; }
+#pragma unroll
+        for (int u = 0; u < HALF / 2; u++) {
+            const double d0 = zs[RUN * lr + HALF * h + 2 * u], d1 = zs[RUN * lr + HALF * h + 2 * u + 1];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u].x, vb[u].x * d0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u].y, vb[u].y * d1, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int gi = i0 + lr + 4 * r, gj = j0 + lc;
+        if (gj <= gi) {
+            double v = tgt[r];
+            if (first) v = xform_first_flags(v, gi, gj, (gmask >> (lr + 4 * r)) & 1, (gmask >> (16 + lc)) & 1, mu);
+            S[(size_t)gi * n_pad + gj] = v - acc[r];
+        }
+    }
+}
+// rider workgroup rb of the update of block column s: sixteen blocks of the trailing tiles other than the first (= the next diagonal tile), or
+// -- the last workgroups -- the right-hand side rows of ten row tiles each
+constexpr int UPD_RHS_TILES = DG_THREADS / NB;
+__host__ __device__ constexpr int ldl_update_riders_blk(int m) { return ((m * (m + 1) / 2 - 1) * 36 + 15) / 16; }
+__host__ __device__ constexpr int ldl_update_riders(int m) { return ldl_update_riders_blk(m) + (m + UPD_RHS_TILES - 1) / UPD_RHS_TILES; }
+__device__ __forceinline__ void ldl_update_rider(double *__restrict__ zs, double *__restrict__ S, double *__restrict__ rhs, const double *__restrict__ g0,
+                                                 const double *__restrict__ Dfac, int n_pad, int n, int s, int nT, double mu,
+                                                 const int32_t *__restrict__ ent_fixed, int rb) {
+    const int m = nT - s - 1, nblk = (m * (m + 1) / 2 - 1) * 36, nbw = ldl_update_riders_blk(m);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = s * NB;
+    const double *dd = Dfac + (size_t)s * NB * NB;
+    if (rb < nbw) {
+        if (tid < NB) zs[tid] = dd[tid * NB + tid];
+        __syncthreads();
+        const int b = rb * 16 + wave;
+        if (b >= nblk) return;
+        const int tile = 1 + b / 36;
+        int ti = 0, rem = tile;
+        while (rem > ti) { rem -= ti + 1; ti++; }
+        ldl_update_block_lean(S, zs, n_pad, n, s, mu, ent_fixed, ti, rem, b % 36);
+        return;
+    }
+    if (tid < NB) zs[tid] = rhs[r0 + tid] * dd[tid * NB + tid];   // D_s z_s
+    __syncthreads();
+    const int k = tid / NB, i = tid - k * NB, t = s + 1 + (rb - nbw) * UPD_RHS_TILES + k;
+    if (k < UPD_RHS_TILES && t < nT) {
+        const int gi = t * NB + i;
+        const double *row = S + (size_t)gi * n_pad + r0;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < NB; c++) acc += row[c] * zs[c];
+        double v = rhs[gi];
+        if (s == 0) v = (gi >= n || ent_fixed[gi / 6]) ? 0.0 : v + g0[gi];
+        rhs[gi] = v - acc;
+    }
+}
+
 __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restrict__ S, double *__restrict__ Dfac, double *__restrict__ Linv16,
                                                          int n_pad, int n, int s, double mu, const int32_t *__restrict__ ent_fixed,
                                                          int32_t *__restrict__ flags, int nT, const double *__restrict__ rhs,
                                                          const double *__restrict__ g0, double *__restrict__ xout,
                                                          const double *__restrict__ Lp, const double *__restrict__ zf, int fused_m,
-                                                         int32_t *__restrict__ bs_flag, int bs_epoch, int ride_bs, int ride_backsub, const BacksubArgs bsub) {
+                                                         int32_t *__restrict__ bs_flag, int bs_epoch, int ride_bs, int ride_backsub, const BacksubArgs bsub,
+                                                         int upd_s, double *__restrict__ Sw, double *__restrict__ rhsw) {
     constexpr int LD = NB + 2, NBK = NB / 6, PER = NB * NB / DG_THREADS, NT16 = NB / 16, NTILE = NT16 * (NT16 + 1) / 2, NWAVE = DG_THREADS / 64, NMW = DG_ROW0 / 64;
     static_assert(NB % 16 == 0 && NB % 6 == 0 && NB * NB % DG_THREADS == 0 && NWAVE >= NSB && DG_THREADS - DG_ROW0 >= NB - 6 &&
                   NTILE <= 2 * NMW && DG_ROW0 % 64 == 0, "diag tile mapping");
@@ -912,6 +995,10 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
     // riders of the LAST tile's launch: workgroup 1 = the back-substitution of the tiles above (two or three tiles, see bs_small);
     // the workgroups behind it = the frame back-substitution (backsub_body), which waits for the last piece of delta_s:
     // flag[nT] from bs_small, or flag[nT - 1] from this tile's own solve when it is the only tile
+    if (upd_s >= 0 && blockIdx.x > 0) {   // look-ahead: the rest of block column upd_s's trailing update rides beside this tile's factorisation
+        ldl_update_rider(T, Sw, rhsw, g0, Dfac, n_pad, n, upd_s, nT, mu, ent_fixed, (int)blockIdx.x - 1);
+        return;
+    }
     if (ride_bs && blockIdx.x == 1) {
         bs_small(T, S, rhs, Dfac, xout, n_pad, nT, bs_flag, bs_epoch, flags, Lp, zf, fused_m, ride_backsub ? bs_flag + nT : nullptr);
         return;
@@ -924,8 +1011,22 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = s * NB;
     const bool first = (s == 0);
+    const bool touch = first || upd_s == 0;   // nobody has touched this tile yet: damping / gauge go in as it is loaded (look-ahead: block column 0's update happens HERE)
     STAMP(0);
-    const unsigned long long gmask = gauge_ballot(first, ent_fixed, n, r0, 6, r0, 6);   // bit e: entity e of this tile is a gauge / padding entity
+    const unsigned long long gmask = gauge_ballot(touch, ent_fixed, n, r0, 6, r0, 6);   // bit e: entity e of this tile is a gauge / padding entity
+    // look-ahead: the panel tile of block column upd_s (both halves of k) is requested first, so that it travels while the tile is staged
+    constexpr int KH = NB / 2, LHS = KH + 2, PVN = (NB * KH / 2 + DG_THREADS - 1) / DG_THREADS;   // LDS rows 50 doubles apart: the 16 rows of an operand fetch tile the banks
+    double2 pv[2][PVN];
+    if (upd_s >= 0) {
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+            for (int u = 0; u < PVN; u++) {
+                const int idx = tid + DG_THREADS * u, row = idx / (KH / 2), c2 = idx - row * (KH / 2);
+                pv[hh][u] = make_double2(0.0, 0.0);
+                if (idx < NB * KH / 2) pv[hh][u] = reinterpret_cast<const double2 *>(S + (size_t)(r0 + row) * n_pad + upd_s * NB + KH * hh)[c2];
+            }
+    }
     {   // tile -> LDS, coalesced; damping / gauge on first touch; zeros above the diagonal
         double v[PER];
 #pragma unroll
@@ -938,7 +1039,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
         for (int u = 0; u < PER; u++) {
             const int idx = tid + DG_THREADS * u, i = idx / NB, j = idx - i * NB;
             double x = v[u];
-            if (first && j <= i) x = xform_first_flags(x, i, j, (gmask >> (i / 6)) & 1, (gmask >> (j / 6)) & 1, mu);
+            if (touch && j <= i) x = xform_first_flags(x, r0 + i, r0 + j, (gmask >> (i / 6)) & 1, (gmask >> (j / 6)) & 1, mu);
             T[i * LD + j] = x;
         }
     }
@@ -946,7 +1047,7 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
     STAMP(1);
     const int rt = tid - DG_ROW0 + 6;     // row thread: row number counted from the pivot block (< 6: not one)
     // sub-tiles of a matrix wavefront (wave-uniform): tile number 14 slot + wave in the order (column descending, row ascending)
-    int j16[2], aoff[2], boff[2], toff[2];
+    int j16[2], i16[2], aoff[2], boff[2], toff[2];
     bool has[2];
     dg_acc_t acc[2];
     const int lr = lane >> 4, lc = lane & 15;
@@ -958,11 +1059,48 @@ __global__ void __launch_bounds__(DG_THREADS) k_ldl_diag(const double *__restric
         has[sl] = wave < NMW && nn < NTILE;
         const int tj = has[sl] ? NT16 - 1 - jj : 0, ti = has[sl] ? tj + nn - jj * (jj + 1) / 2 : 0;
         j16[sl] = 16 * tj;
+        i16[sl] = 16 * ti;
         aoff[sl] = (16 * ti + lc) * LD + lr;          // A operand: L(row, c0 + k) in the tile
         boff[sl] = (16 * tj + lc) * DG_YS + lr;           // B operand: -(L D)(col, k) in the panel
         toff[sl] = (16 * ti + lr) * LD + 16 * tj + lc;   // accumulator register r: row + 4 r
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[sl][r] = T[toff[sl] + 4 * r * LD];
+    }
+    if (upd_s >= 0) {
+        // Look-ahead: block column upd_s's update of THIS tile, A -= L D L^T with L = this tile row of the column's panel (k_ldl_trsm left it in
+        // S), straight into the accumulators.  The 96 x 96 panel tile comes through LDS in two halves of k (one CU pulls ~13 bytes per cycle:
+        // every sub-tile fetching its own operand slabs from memory, as k_ldl_update's wavefronts do on 9 CUs, costs 7x the bytes here);
+        // D_upd sits in the padding column of the tile rows.  The sub-tiles then go back to the LDS tile for the row threads.
+        double *Lh = Yn + 2 * NB * DG_YS;          // [NB][LHS]
+        const double *du = Dfac + (size_t)upd_s * NB * NB;
+        if (tid < NB) T[tid * LD + NB] = du[tid * NB + tid];
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            if (hh) __syncthreads();   // the first half has been read
+#pragma unroll
+            for (int u = 0; u < PVN; u++) {
+                const int idx = tid + DG_THREADS * u, row = idx / (KH / 2), c2 = idx - row * (KH / 2);
+                if (idx < NB * KH / 2) *reinterpret_cast<double2 *>(Lh + row * LHS + 2 * c2) = pv[hh][u];
+            }
+            __syncthreads();
+            auto sub = [&](dg_acc_t &a, bool live, int ia, int ja) {
+                if (!live) return;   // wave-uniform
+                const double *la = Lh + (ia + lc) * LHS + lr, *lb = Lh + (ja + lc) * LHS + lr;
+#pragma unroll
+                for (int t = 0; t < KH / 4; t++) {
+                    const double d = T[(KH * hh + 4 * t + lr) * LD + NB];
+                    a = __builtin_amdgcn_mfma_f64_16x16x4f64(la[4 * t], lb[4 * t] * d, a, 0, 0, 2);   // (blgp bit 1: B negated)
+                }
+            };
+            sub(acc[0], has[0], i16[0], j16[0]);
+            sub(acc[1], has[1], i16[1], j16[1]);
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++)
+            if (has[sl])
+#pragma unroll
+                for (int r = 0; r < 4; r++) T[toff[sl] + 4 * r * LD] = acc[sl][r];
+        __syncthreads();
     }
     dg_rows(T, Yn, 0, rt);
     __syncthreads();
@@ -1643,7 +1781,7 @@ static BacksubArgs backsub_args(const DeviceProblem &P, int cur, int trial, int 
 // tiles); returns true if it did (the caller then skips launch_backsub)
 bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial) {
     const DeviceProblem::Blocks &b = P.blk[which];
-    const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * DG_YS) * sizeof(double);
+    const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * DG_YS + (size_t)NB * (NB / 2 + 2)) * sizeof(double);   // tile | panel | look-ahead half panel
     static size_t g_diag = 48 * 1024, g_bs = 48 * 1024;
     // block columns with at most this many tiles below the diagonal take the fused panel kernel (0: never); its redundancy grows
     // with the square of the column's height, the two-kernel path's fixed cost does not
@@ -1653,8 +1791,12 @@ bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, i
     // (profiles/r03_attempts.txt): the launch then ends with the riders' work instead of a 6 us kernel, and their 1024-thread workgroups
     // cost at dispatch what the kernel boundary did
     static const bool backsub_rides = getenv("AAR_BACKSUB_RIDES") && atoi(getenv("AAR_BACKSUB_RIDES")) != 0;
+    // Look-ahead: where trsm and update are launches of their own (tall block columns), the update is not launched: the next diagonal tile's
+    // workgroup applies it to its own tile and starts factoring, riders of that launch do the other tiles (AAR_LDL_LOOKAHEAD=0: off)
+    static const bool lookahead = !(getenv("AAR_LDL_LOOKAHEAD") && atoi(getenv("AAR_LDL_LOOKAHEAD")) == 0);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
     bool rode_backsub = false;
+    int upd_s = -1;   // the block column whose update the next k_ldl_diag launch carries
     for (int s = 0; s < P.nT; s++) {
         const int m = P.nT - s - 1;
         const bool last = s == P.nT - 1;
@@ -1664,9 +1806,11 @@ bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, i
         const bool ride2 = backsub_rides && last && trial >= 0 && (P.nT == 1 || ride) && !P.hook.pre;
         BacksubArgs ba = backsub_args(P, which, trial >= 0 ? trial : which, DG_THREADS / 64);
         if (ride || ride2) P.bs_epoch++;
-        const int grid = 1 + (ride ? 1 : 0) + (ride2 ? ba.n_frame_blocks + 1 : 0);
+        const int grid = 1 + (ride ? 1 : 0) + (ride2 ? ba.n_frame_blocks + 1 : 0) + (upd_s >= 0 ? ldl_update_riders(P.nT - upd_s - 1) : 0);
         { HookScope _h(P, KID_LDL_DIAG); hipLaunchKernelGGL(k_ldl_diag, dim3(grid), dim3(DG_THREADS), lds_diag, st, b.S, P.Dfac, P.Linv16, P.n_pad, P.n, s, mu, P.ent_fixed, P.flags,
-                                                         P.nT, b.rhs, b.g0, P.delta_s, P.Lp, P.zf, fused_m, P.bs_flags, P.bs_epoch, ride ? 1 : 0, ride2 ? 1 : 0, ba); }
+                                                         P.nT, b.rhs, b.g0, P.delta_s, P.Lp, P.zf, fused_m, P.bs_flags, P.bs_epoch, ride ? 1 : 0, ride2 ? 1 : 0, ba,
+                                                         upd_s, b.S, b.rhs); }
+        upd_s = -1;
         rode_backsub = ride2;
         if (m > 0 && m <= fused_m) {   // short block column: panel solve and trailing update in one launch
             const int ns = NSB * m;
@@ -1674,7 +1818,8 @@ bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, i
             hipLaunchKernelGGL(k_ldl_panel, dim3(ns * (ns + 1) / 2 + ns), dim3(128), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed, P.Lp, P.zf);
         } else if (m > 0) {   // the last tile's right-hand side is solved inside k_ldl_diag
             { HookScope _h(P, KID_LDL_TRSM); hipLaunchKernelGGL(k_ldl_trsm, dim3(NSB * m + 1), dim3(64), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.Linv16, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
-            { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
+            if (lookahead && m >= 2) upd_s = s;   // (m >= 2: the next tile is not the last one, whose launch has riders of its own)
+            else { HookScope _h(P, KID_LDL_UPDATE); hipLaunchKernelGGL(k_ldl_update, dim3(m * (m + 1) / 2 * 9 + m), dim3(256), 0, st, b.S, b.rhs, b.g0, P.Dfac, P.n_pad, P.n, s, P.nT, mu, P.ent_fixed); }
         }
     }
     if (P.nT > 1 && !(bs_rides && P.nT <= 3)) {

@@ -410,7 +410,8 @@ def test_gauge_rows_in_trailing_tiles_of_a_three_tile_system(opt):
 
 
 @pytest.mark.parametrize("env", [{"AAR_FUSED_PANEL": "0"}, {"AAR_BS_RIDES": "0"}, {"AAR_FUSED_PANEL": "0", "AAR_BS_RIDES": "0"}, {"AAR_FUSED_PANEL": "5"}, {"AAR_FUSED_PANEL": "2"},
-                                 {"AAR_BACKSUB_RIDES": "1"}, {"AAR_DENSE_FROM_PASSA": "0", "AAR_SCHUR_MFMA": "1"}])
+                                 {"AAR_BACKSUB_RIDES": "1"}, {"AAR_DENSE_FROM_PASSA": "0", "AAR_SCHUR_MFMA": "1"}, {"AAR_LDL_LOOKAHEAD": "0"},
+                                 {"AAR_LDL_LOOKAHEAD": "0", "AAR_FUSED_PANEL": "0"}])
 def test_dense_solve_path_switches(env):
     # The dense LDL^T has alternative launch structures behind environment switches that libaar reads ONCE per process (the
     # two-kernel panel solve + trailing update instead of the fused k_ldl_panel, the chained k_ldl_backsolve instead of the
@@ -438,6 +439,34 @@ def test_dense_solve_path_switches(env):
     assert out.returncode == 0, out.stderr[-2000:]
     worst = float([l for l in out.stdout.splitlines() if l.startswith("WORST")][-1].split()[1])
     assert worst < 1e-8, (env, worst)
+
+
+@pytest.mark.parametrize("lookahead", ["1", "0"])
+def test_dense_lookahead_seven_tiles(lookahead):
+    # Tall block columns (more than three tiles below the diagonal) take k_ldl_trsm and then NO update launch: the next diagonal tile's
+    # workgroup applies the column's update to its own tile (first touch included, for column 0) while riders of that launch do the other
+    # tiles and the right-hand side.  A seven-tile system (four such columns, then the fused panels) against the oracle's LDL^T, both ways.
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import aar, oracle_lib as ol
+        ds = aar.synth(3, num_cams=8, num_markers=100, num_frames=120)
+        o = ol.Oracle(ds)
+        worst = 0.0
+        with aar.Problem(ds) as p:
+            for mu in (1e4, 1e-2):
+                d = p.eval_damped_step(ds.x_full, mu)
+                do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+                worst = max(worst, float(np.abs(d - do).max() / np.abs(do).max()))
+            x, rep = p.lm_solve(ds.x_full)
+            assert rep["iterations"] < 40 and rep["final_err"] < rep["initial_err"]
+        print("WORST", worst, "N", ds.num_vars)
+    """) % (os.path.join(os.path.dirname(__file__), "..", "automatic-ar_amd"), os.path.dirname(__file__))
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "AAR_LDL_LOOKAHEAD": lookahead}, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float([l for l in out.stdout.splitlines() if l.startswith("WORST")][-1].split()[1])
+    assert worst < 1e-8, (lookahead, worst)
 
 
 def test_randomized_shapes_against_oracle():
