@@ -18,7 +18,7 @@ for label, kw, reps, env in (("1 tile (cfg2)", dict(cfg=2), 1500, {}), ("3 tiles
         x, rep = p.lm_solve(x0)
         ref_err, ref_it = rep["final_err"], rep["iterations"]
         worst = 0.0
-        for i in range(reps):
+        for i in range(reps * int(os.environ.get("SOAK_X", "1"))):
             x, rep = p.lm_solve(x0)
             dev = abs(rep["final_err"] - ref_err) / ref_err
             worst = max(worst, dev)
@@ -26,5 +26,5 @@ for label, kw, reps, env in (("1 tile (cfg2)", dict(cfg=2), 1500, {}), ("3 tiles
                 bad += 1
                 print("  DEVIATION", label, i, rep["iterations"], ref_it, dev, flush=True)
     for k in env: os.environ.pop(k)
-    print("%-16s %5d solves x %d iterations: worst relative deviation of the final error %.2e  (%.1f s)" % (label, reps, ref_it, worst, time.time() - t0), flush=True)
+    print("%-16s %5d solves x %d iterations: worst relative deviation of the final error %.2e  (%.1f s)" % (label, reps * int(os.environ.get("SOAK_X", "1")), ref_it, worst, time.time() - t0), flush=True)
 print("BAD", bad)
