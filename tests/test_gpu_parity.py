@@ -446,12 +446,14 @@ def test_dense_lookahead_seven_tiles(lookahead):
     # Tall block columns (more than three tiles below the diagonal) take k_ldl_trsm and then NO update launch: the next diagonal tile's
     # workgroup applies the column's update to its own tile (first touch included, for column 0) while riders of that launch do the other
     # tiles and the right-hand side.  A seven-tile system (four such columns, then the fused panels) against the oracle's LDL^T, both ways.
+    # Sixteen cameras put the root marker -- a gauge entity: identity rows, zero right-hand side -- at the FIRST row of tile 1, whose first touch
+    # (damping, gauge) then happens in that tile's look-ahead prologue.
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import sys, numpy as np
         sys.path.insert(0, %r); sys.path.insert(0, %r)
         import aar, oracle_lib as ol
-        ds = aar.synth(3, num_cams=8, num_markers=100, num_frames=120)
+        ds = aar.synth(3, num_cams=16, num_markers=92, num_frames=120)
         o = ol.Oracle(ds)
         worst = 0.0
         with aar.Problem(ds) as p:
