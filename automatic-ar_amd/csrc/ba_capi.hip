@@ -1586,12 +1586,30 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     pb->huber_of_blocks = P.huber;
     pb->mu_seed_valid = false;
     // (single GPU: mu_0 rides to the host with the sum r^2: the first step() then needs no round trip of its own)
-    if ((rc = read_scalars(pb, P.F, pb->comm ? -1 : 0))) return rc;
+    if ((rc = launch_scalars(pb, P.F, pb->comm ? -1 : 0))) return rc;
+    // Head start of the first step (single GPU, direct solver): its damping mu_0 = tau * max diag(J^T J) is on the device one kernel before the host
+    // can read it, and the frame inverses and the Schur complement need nothing else -- they are queued HERE, with mu_0 read on the device, and
+    // run while the record travels to the host and the host queues the factorisation.  (tau changed between init and step: the damped try finds
+    // another damping than schur_mu and takes the complement back, as after a mispredicted step.)  AAR_INIT_HEADSTART=0: off.
+    static const bool headstart_on = !(getenv("AAR_INIT_HEADSTART") && atoi(getenv("AAR_INIT_HEADSTART")) == 0);
+    const bool headstart = headstart_on && !pb->comm && !P.use_pcg && !pb->stage_timers && !pb->profiling && P.F > 0;
+    if (headstart) {
+        launch_frame_inv(P, 0, 0.0, pb->stream, P.scal + 4, pb->prm.tau);
+        launch_schur(P, 0, 1.0, pb->stream, 0, 0, nullptr, false);
+        pb->launches += 2;
+    }
+    if ((rc = wait_result(pb))) return rc;
     if (!pb->comm) { pb->mu_seed = pb->h_scal[4]; pb->mu_seed_valid = true; }
     pb->currErr = pb->prevErr = pb->h_scal[0];
     pb->blocks_valid = true;
     pb->vinv_mu = -1;
     pb->schur_mu = -1;
+    if (headstart) {
+        const double mu0 = pb->mu_seed * pb->prm.tau;   // (the expression aar_lm_step uses: the same double as the device's tau * scal[4])
+        pb->vinv_mu = mu0;
+        pb->schur_mu = mu0;
+        panels_now(pb, 0, mu0);
+    }
     pb->s_reduced = pb->trial_reduced = false;
     pb->mu = -1;
     pb->v = 2;  // indeterminate in the reference (libs/sparselevmarq.h:133); every accepted step sets 2 (:411)

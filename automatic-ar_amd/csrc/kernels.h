@@ -158,7 +158,7 @@ void launch_passB(const DeviceProblem &P, int which, hipStream_t st);           
 bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st);
 size_t passA_lds_bytes(int max_kf, int block);   // dynamic LDS of the frame-block kernel (block = 64 or 256 threads)
 void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st);            // scal[4] = max free diagonal
-void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st);
+void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st, const double *mu_dev = nullptr, double mu_scale = 0.0);   // mu_dev: mu = mu_scale * mu_dev[0], read on the device
 // S -= sign * W (V+mu I)^-1 W^T (sign -1 takes it back).  ride_seq != 0: the reduction of the step's scalars rides in the same
 // launch (true is returned if it did)
 // panels_ready (MFMA path): Wd / Yd already hold this block set's panels for the damping in Vinv (pass A wrote them): no k_schur_fill

@@ -19,9 +19,11 @@ typedef double dg_acc_t __attribute__((ext_vector_type(4)));   // one lane's sha
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_frame_inv(const double *__restrict__ V, const double *__restrict__ gf, int F,
                                                    double mu, int frames_fixed, double *__restrict__ Vinv,
-                                                   double *__restrict__ hf, int32_t *__restrict__ flags) {
+                                                   double *__restrict__ hf, int32_t *__restrict__ flags,
+                                                   const double *__restrict__ mu_dev = nullptr, double mu_scale = 0.0) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
+    if (mu_dev) mu = mu_scale * mu_dev[0];   // the first step's damping tau * max diag(J^T J), still on its way to the host (aar_lm_init)
     double out[36];
     if (frames_fixed) {
 #pragma unroll
@@ -1704,10 +1706,11 @@ __global__ void __launch_bounds__(1024) k_ldl_backsolve(const double *__restrict
 // publish the scalars and the error flags to the mapped host record; the sequence number goes last, system scope
 
 // ------------------------------------------------------------------------------------------------
-void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st) {
+void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st, const double *mu_dev, double mu_scale) {
     if (P.F == 0) return;
     const DeviceProblem::Blocks &b = P.blk[which];
-    { HookScope _h(P, KID_FRAME_INV); hipLaunchKernelGGL(k_frame_inv, dim3((P.F + 255) / 256), dim3(256), 0, st, b.V, b.gf, P.F, mu, P.frames_fixed, b.Vinv, b.hf, P.flags); }
+    { HookScope _h(P, KID_FRAME_INV); hipLaunchKernelGGL(k_frame_inv, dim3((P.F + 255) / 256), dim3(256), 0, st, b.V, b.gf, P.F, mu, P.frames_fixed, b.Vinv, b.hf, P.flags,
+                                                         mu_dev, mu_scale); }
 }
 
 static ReduceArgs reduce_args(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, double *scal_out = nullptr) {

@@ -411,7 +411,7 @@ def test_gauge_rows_in_trailing_tiles_of_a_three_tile_system(opt):
 
 @pytest.mark.parametrize("env", [{"AAR_FUSED_PANEL": "0"}, {"AAR_BS_RIDES": "0"}, {"AAR_FUSED_PANEL": "0", "AAR_BS_RIDES": "0"}, {"AAR_FUSED_PANEL": "5"}, {"AAR_FUSED_PANEL": "2"},
                                  {"AAR_BACKSUB_RIDES": "1"}, {"AAR_DENSE_FROM_PASSA": "0", "AAR_SCHUR_MFMA": "1"}, {"AAR_LDL_LOOKAHEAD": "0"},
-                                 {"AAR_LDL_LOOKAHEAD": "0", "AAR_FUSED_PANEL": "0"}])
+                                 {"AAR_LDL_LOOKAHEAD": "0", "AAR_FUSED_PANEL": "0"}, {"AAR_INIT_HEADSTART": "0"}])
 def test_dense_solve_path_switches(env):
     # The dense LDL^T has alternative launch structures behind environment switches that libaar reads ONCE per process (the
     # two-kernel panel solve + trailing update instead of the fused k_ldl_panel, the chained k_ldl_backsolve instead of the
