@@ -34,8 +34,12 @@ SYMBOLS = [
     "aar_vote_transforms", "aar_init_default_params", "aar_initializer_run", "aar_initializer_object_poses",
     "aar_comm_get_stats", "aar_lm_set_step_callback", "aar_lm_set_stop_function", "aar_problem_extract_z", "aar_problem_merge_z",
     "aar_solution_read_ex", "aar_cam_configs_read_ex", "aar_set_stage_timers", "aar_problem_pcg_iterations",
+    "aar_solver_default_options", "aar_problem_create_ex", "aar_problem_get_solver_stats",
 ]
-NUM_KERNELS = 15
+NUM_KERNELS = 16
+SOLVER_DIRECT, SOLVER_PCG, SOLVER_SPCG, SOLVER_AUTO = 0, 1, 2, 3
+SOLVERS = {"direct": SOLVER_DIRECT, "pcg": SOLVER_PCG, "spcg": SOLVER_SPCG, "auto": SOLVER_AUTO}
+SOLVER_NAMES = {v: k for k, v in SOLVERS.items()}
 
 
 class AarError(RuntimeError):
@@ -78,6 +82,17 @@ class CProblemDesc(C.Structure):
         ("optimize_cam_intrinsics", C.c_int32),
         ("residual_mode", C.c_int32), ("with_huber", C.c_int32), ("device_id", C.c_int32), ("comm", C.c_void_p),
     ]
+
+
+class CSolverOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("solver", C.c_int32), ("deterministic", C.c_int32), ("pcg_max_it", C.c_int32),
+                ("pcg_eta", C.c_double)]
+
+
+class CSolverStats(C.Structure):
+    _fields_ = [("solver", C.c_int32), ("deterministic", C.c_int32), ("last_iterations", C.c_int32), ("reserved", C.c_int32),
+                ("total_iterations", C.c_int64), ("solves", C.c_int64), ("fallbacks", C.c_int64), ("pcg_eta", C.c_double),
+                ("pcg_max_it", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class CLmParams(C.Structure):
@@ -164,6 +179,10 @@ def lib():
     L.aar_problem_desc_from_dataset.argtypes = [C.POINTER(CDataset), C.POINTER(CProblemDesc)]
     L.aar_problem_desc_from_dataset.restype = None
     L.aar_problem_create.argtypes = [C.POINTER(CProblemDesc), C.POINTER(C.c_void_p)]
+    L.aar_problem_create_ex.argtypes = [C.POINTER(CProblemDesc), C.POINTER(CSolverOptions), C.POINTER(C.c_void_p)]
+    L.aar_solver_default_options.argtypes = [C.POINTER(CSolverOptions)]
+    L.aar_solver_default_options.restype = None
+    L.aar_problem_get_solver_stats.argtypes = [C.c_void_p, C.POINTER(CSolverStats)]
     L.aar_problem_destroy.argtypes = [C.c_void_p]
     L.aar_problem_destroy.restype = None
     for n in ("aar_problem_full_len", "aar_problem_num_vars", "aar_problem_local_obs"):
@@ -585,8 +604,10 @@ class LocalGroup:
 class Problem:
     """aar_problem: the bundle-adjustment problem resident on one GPU."""
 
-    def __init__(self, ds, residual_mode=RES_F32, device=0, comm=None, optimize=None, with_huber=False, intrinsics=False):
-        """intrinsics=True: Config::optimize_cam_intrinsics -- every vector ends with 9 per camera (x_with_intrinsics builds one)"""
+    def __init__(self, ds, residual_mode=RES_F32, device=0, comm=None, optimize=None, with_huber=False, intrinsics=False,
+                 solver=None, deterministic=None, pcg_eta=None, pcg_max_it=None):
+        """intrinsics=True: Config::optimize_cam_intrinsics -- every vector ends with 9 per camera (x_with_intrinsics builds one)
+        solver ("direct" | "spcg" | "pcg" | "auto"), deterministic, pcg_eta, pcg_max_it: aar_solver_options (None = the library's default)"""
         self.ds = ds
         self._cds = ds.as_c()
         d = CProblemDesc()
@@ -599,7 +620,20 @@ class Problem:
         d.device_id = device
         d.comm = comm.handle if comm is not None else None
         self.handle = C.c_void_p()
-        _check(lib().aar_problem_create(C.byref(d), C.byref(self.handle)))
+        if solver is None and deterministic is None and pcg_eta is None and pcg_max_it is None:
+            _check(lib().aar_problem_create(C.byref(d), C.byref(self.handle)))
+        else:
+            so = CSolverOptions()
+            lib().aar_solver_default_options(C.byref(so))
+            if solver is not None:
+                so.solver = SOLVERS[solver] if isinstance(solver, str) else int(solver)
+            if deterministic is not None:
+                so.deterministic = int(bool(deterministic))
+            if pcg_eta is not None:
+                so.pcg_eta = float(pcg_eta)
+            if pcg_max_it is not None:
+                so.pcg_max_it = int(pcg_max_it)
+            _check(lib().aar_problem_create_ex(C.byref(d), C.byref(so), C.byref(self.handle)))
         self.full_len = lib().aar_problem_full_len(self.handle)
         self.num_vars = lib().aar_problem_num_vars(self.handle)
         self.local_obs = lib().aar_problem_local_obs(self.handle)
@@ -739,10 +773,17 @@ class Problem:
         return {lib().aar_kernel_name(i).decode(): (float(sec[i]), int(cnt[i])) for i in range(NUM_KERNELS)}
 
     def pcg_iterations(self):
-        """(CG iterations of the last damped solve, running total) in AAR_SOLVER=pcg mode; zeros otherwise"""
+        """(CG iterations of the last damped solve, running total) of the pcg / spcg solvers; zeros for direct"""
         out = (C.c_int32 * 2)()
         _check(lib().aar_problem_pcg_iterations(self.handle, out))
         return int(out[0]), int(out[1])
+
+    def solver_stats(self):
+        """aar_problem_get_solver_stats: the solver the problem runs with (AUTO resolved) and what its inner CG has done so far"""
+        st = CSolverStats()
+        _check(lib().aar_problem_get_solver_stats(self.handle, C.byref(st)))
+        return dict(solver=SOLVER_NAMES[st.solver], deterministic=bool(st.deterministic), last_iterations=st.last_iterations,
+                    total_iterations=st.total_iterations, solves=st.solves, fallbacks=st.fallbacks, pcg_eta=st.pcg_eta, pcg_max_it=st.pcg_max_it)
 
     def set_stage_timers(self, on):
         _check(lib().aar_set_stage_timers(self.handle, int(on)))

@@ -206,7 +206,10 @@ struct aar_problem {
     // host has seen this step's scalars -- the usual outcome (accepted, predicted damping) then finds it done, and the host's
     // turn-around hides behind it as it hides behind the Schur kernel on one GPU; any other outcome rebuilds the system anyway
     bool spec_chol = true;             // AAR_SPEC_CHOL=0: off
-    double *h_pcg = nullptr;           // AAR_SOLVER=pcg with a communicator: pinned, mapped {done, iterations, -, sequence} the iteration launches publish
+    int solver = AAR_SOLVER_DIRECT;    // what the problem runs with (aar_solver_options.solver, AUTO resolved)
+    bool force_direct = false;         // solver spcg: THIS try takes the direct chain (the CG solve of the same system hit its cap / timed out)
+    int64_t spcg_fallbacks = 0;
+    double *h_pcg = nullptr;           // solver pcg with a communicator: pinned, mapped {done, iterations, -, sequence} the iteration launches publish
     unsigned long long pcg_seq = 0;
     int spec_chol_blk = -1;            // block set whose S a speculative factorisation has consumed (-1: none pending)
     double spec_chol_mu = -1;
@@ -592,6 +595,7 @@ int read_scalars(aar_problem *pb, int n_err, int maxdiag_blk = -1) {
 //      trial is accepted, and the trial's sum r^2 comes out of pass A) -> scalars to the host.
 // blk[cur].S/rhs are consumed; pass A clears them together with blk[cur].g0 on the way.
 constexpr int TRY_NOT_POSITIVE_DEFINITE = 1;   // damped_try: not an error code of the C ABI (those are negative)
+constexpr int TRY_CG_FAILED = 2;               // solver spcg: the CG solve hit its iteration cap or its hand-over timed out; S is intact, the caller redoes the try with the direct chain
 
 int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     DeviceProblem &P = pb->P;
@@ -685,10 +689,12 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     pb->s_reduced = false;      // the factorisation below consumes the system
     pb->trial_reduced = false;
     bool backsub_rode = false;
+    const bool by_cg = P.use_spcg && !pb->force_direct;   // CG on the explicit reduced system instead of the LDL^T chain (S stays as it is)
     if (!chol_done) {
         StageTimer t(pb, &pb->times.chol);
         // (stage timers keep the frame back-substitution in its own launch, so that it has a time of its own)
-        backsub_rode = launch_chol(P, cur, mu, pb->stream, pb->stage_timers ? -1 : tr);
+        if (by_cg) launch_spcg(P, cur, mu, pb->stream);
+        else backsub_rode = launch_chol(P, cur, mu, pb->stream, pb->stage_timers ? -1 : tr);
     }
     if (!backsub_rode) {
         StageTimer t(pb, &pb->times.backsub);
@@ -740,7 +746,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         pb->trial_reduced = true;
         if (pb->spec_chol && !pb->stage_timers && !pb->profiling) {
             StageTimer t(pb, &pb->times.chol);
-            (void)launch_chol(P, tr, mu * 0.33, pb->stream);
+            if (P.use_spcg) launch_spcg(P, tr, mu * 0.33, pb->stream);
+            else (void)launch_chol(P, tr, mu * 0.33, pb->stream);
             pb->spec_chol_blk = tr;
             pb->spec_chol_mu = mu * 0.33;
             pb->launches += 3 * P.nT;
@@ -758,6 +765,13 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     if ((rc = wait_result(pb))) return rc;
     if (pb->h_flags[0]) {
         (void)hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream);
+        if (by_cg && (pb->h_flags[0] & (8 | 4))) {
+            // the CG solve gave up (8: iteration cap; 4: a wavefront of its grid never showed up within ~1 s -- the device is shared): whatever
+            // followed it in this try is meaningless, but S was not touched.  Not an error: the caller redoes the try with the direct chain.
+            if (pb->h_flags[0] & 4) spcg_ws_reset(P, pb->stream);   // (a timed-out launch leaves slots of both buffer sets in an unknown state)
+            pb->spcg_fallbacks++;
+            return TRY_CG_FAILED;
+        }
         set_error(AAR_ERR_NUMERIC, "device flags %d at mu=%g (1: a frame block is not positive definite, 2: non-positive pivot of the reduced system, 4: back-substitution chain timed out)", pb->h_flags[0], mu);
         // Only the reduced system lost positive definiteness (far from the optimum its Schur complement can, in floating point):
         // the LM loop takes that as a failed try and raises the damping; every rank sees the same replicated pivots.
@@ -787,6 +801,19 @@ int rebuild_current(aar_problem *pb) {
     pb->schur_mu = -1;
     pb->s_reduced = pb->trial_reduced = false;
     return AAR_OK;
+}
+
+// damped_try, and -- solver spcg -- the same try once more with the direct chain when the CG solve gave up (iteration cap, hand-over
+// time-out): the blocks of the current point are rebuilt (the abandoned try's trial evaluation cleared them), the damping stays
+int damped_try_fb(aar_problem *pb, double mu, bool evaluate_trial) {
+    int rc = damped_try(pb, mu, evaluate_trial);
+    if (rc != TRY_CG_FAILED) return rc;
+    pb->trial_reduced = false;
+    if ((rc = rebuild_current(pb))) return rc;
+    pb->force_direct = true;
+    rc = damped_try(pb, mu, evaluate_trial);
+    pb->force_direct = false;
+    return rc;
 }
 
 // x_full -> z of the reference for the problem's Config (mats2eVec order: cameras | markers | frames), and back
@@ -961,8 +988,36 @@ void aar_problem_destroy(aar_problem *pb) {
     delete pb;
 }
 
-int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
+void aar_solver_default_options(aar_solver_options *o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->struct_size = (uint32_t)sizeof *o;
+    o->solver = AAR_SOLVER_DIRECT;
+}
+
+int aar_problem_create(const aar_problem_desc *d, aar_problem **out) { return aar_problem_create_ex(d, nullptr, out); }
+
+int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *opts, aar_problem **out) {
     if (!d || !out) return set_error(AAR_ERR_INVALID, "aar_problem_create: null argument");
+    aar_solver_options so;
+    aar_solver_default_options(&so);
+    if (opts) {   // a caller built against an older header passes a shorter struct: the fields it does not know keep their defaults
+        if (opts->struct_size < 2 * sizeof(uint32_t)) return set_error(AAR_ERR_INVALID, "aar_solver_options.struct_size is not set (use aar_solver_default_options)");
+        memcpy(&so, opts, std::min<size_t>(opts->struct_size, sizeof so));
+        so.struct_size = (uint32_t)sizeof so;
+    }
+    // environment overrides (tuning / bisecting only: the options struct is the interface)
+    if (const char *e = getenv("AAR_SOLVER")) {
+        if (!strcmp(e, "direct")) so.solver = AAR_SOLVER_DIRECT;
+        else if (!strcmp(e, "pcg")) so.solver = AAR_SOLVER_PCG;
+        else if (!strcmp(e, "spcg")) so.solver = AAR_SOLVER_SPCG;
+        else if (!strcmp(e, "auto")) so.solver = AAR_SOLVER_AUTO;
+    }
+    if (const char *e = getenv("AAR_DETERMINISTIC")) so.deterministic = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("AAR_PCG_ETA")) so.pcg_eta = atof(e);
+    if (const char *e = getenv("AAR_PCG_MAX_IT")) so.pcg_max_it = atoi(e);
+    if (so.solver < AAR_SOLVER_DIRECT || so.solver > AAR_SOLVER_AUTO) return set_error(AAR_ERR_INVALID, "aar_solver_options.solver %d is not one of AAR_SOLVER_*", so.solver);
+    if (so.pcg_eta < 0 || so.pcg_max_it < 0) return set_error(AAR_ERR_INVALID, "aar_solver_options: negative pcg_eta / pcg_max_it");
     const int C = d->num_cams, M = d->num_markers, Fg = d->num_frames;
     const int64_t Ng = d->num_obs;
     if (C < 1 || M < 1 || Fg < 0 || Ng < 0) return set_error(AAR_ERR_INVALID, "aar_problem_create: bad sizes");
@@ -1079,14 +1134,30 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
     // force it on small problems).  Its panels cost 2 F Ad 288 bytes -- tens of GB for long sequences with many rarely seen
     // entities -- so they must fit a budget (half of the free device memory; AAR_SCHUR_PANEL_MB overrides), else the
     // output-stationary kernel, which needs none of this, takes over.  Only THAT kernel keeps a row panel of all entities in LDS.
-    { const char *e = getenv("AAR_DETERMINISTIC"); P.deterministic = (e && atoi(e) != 0) ? 1 : 0; }
+    P.deterministic = so.deterministic ? 1 : 0;
     { const char *e = getenv("AAR_DENSE_FROM_PASSA"); if (e) P.dense_from_passA = atoi(e) != 0 ? 1 : 0; }
-    {   // opt-in inexact solver (pcg_kernels.hip)
-        const char *e = getenv("AAR_SOLVER");
-        P.use_pcg = (e && !strcmp(e, "pcg")) ? 1 : 0;
-        if (const char *t = getenv("AAR_PCG_ETA")) P.pcg_eta = atof(t);
-        if (const char *t = getenv("AAR_PCG_MAX_IT")) P.pcg_max_it = std::max(1, atoi(t));
-        if (P.use_pcg && pcg_lds_bytes(A) > 150 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER=pcg keeps the CG vectors and the preconditioner of %d unknowns in LDS: too many shared entities", 6 * A);
+    {   // which solver (aar_solver_options; AUTO: DESIGN.md section 12)
+        hipDeviceProp_t prop;
+        const int cus = (hipGetDeviceProperties(&prop, pb->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;
+        const bool pcg_ok = pcg_lds_bytes(A) <= 150 * 1024;
+        const bool spcg_ok = spcg_fits(P.nT) && P.n_pad / 6 <= cus;   // one wavefront per entity, every one of them resident
+        int solver = so.solver;
+        if (solver == AAR_SOLVER_AUTO) {
+            // measured on MI355X (profiles/r04_auto_crossover.txt): from ~96 shared entities on the Schur complement itself is the
+            // largest kernel of a step and CG through the frame blocks, which never forms it, wins; below, CG on the explicit
+            // complement replaces the LDL^T chain; a system neither fits takes the direct chain
+            if (A >= 96 && pcg_ok) solver = AAR_SOLVER_PCG;
+            else if (spcg_ok) solver = AAR_SOLVER_SPCG;
+            else if (pcg_ok) solver = AAR_SOLVER_PCG;
+            else solver = AAR_SOLVER_DIRECT;
+        }
+        pb->solver = solver;
+        P.use_pcg = solver == AAR_SOLVER_PCG ? 1 : 0;
+        P.use_spcg = solver == AAR_SOLVER_SPCG ? 1 : 0;
+        if (so.pcg_eta > 0) P.pcg_eta = so.pcg_eta;
+        if (so.pcg_max_it > 0) { P.pcg_max_it = so.pcg_max_it; P.spcg_max_it = std::min(so.pcg_max_it, SPCG_MAX_IT); }
+        if (P.use_pcg && !pcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_PCG keeps the CG vectors and the preconditioner of %d unknowns in LDS: too many shared entities", 6 * A);
+        if (P.use_spcg && !spcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_SPCG keeps the reduced system in the registers of one wavefront per shared entity: %d unknowns are too many (limit %d, and at most %d entities)", 6 * A, 96 * SPCG_MAX_NT, cus);
     }
     bool schur_mfma = A >= 96 && F > 0;
     if (const char *e = getenv("AAR_SCHUR_MFMA")) schur_mfma = atoi(e) != 0 && F > 0;
@@ -1367,6 +1438,10 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) {
         }
         if (const char *t = getenv("AAR_PCG_GRID")) P.pcg_grid = std::max(1, atoi(t));
     }
+    if (P.use_spcg) {
+        AL(spcg_ws, spcg_ws_doubles(P.n_pad)); AL(spcg_iters, 4);
+        spcg_ws_reset(P, pb->stream);
+    }
     if (P.n_smwork) { AL(Wd, (size_t)F * P.Ad * 36); AL(Yd, (size_t)F * P.Ad * 36); }   // zeroed here, once: absent pairs are never written
     AL(Dfac, (size_t)P.nT * CHOL_NB * CHOL_NB); AL(Linv16, (size_t)P.nT * (CHOL_NB / 16) * 256); AL(delta_s, P.n_pad); AL(bs_flags, (size_t)P.nT + 1);
     AL(Lp, (size_t)P.nT * P.n_pad * CHOL_NB); AL(zf, P.n_pad);
@@ -1543,7 +1618,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     pb->vinv_mu = -1;
     pb->schur_mu = -1;
     pb->s_reduced = pb->trial_reduced = false;
-    if ((rc = damped_try(pb, mu, false))) return rc == TRY_NOT_POSITIVE_DEFINITE ? AAR_ERR_NUMERIC : rc;
+    if ((rc = damped_try_fb(pb, mu, false))) return rc == TRY_NOT_POSITIVE_DEFINITE ? AAR_ERR_NUMERIC : rc;
     pb->lm_ready = false;
     std::vector<double> x0(x_full, x_full + L.full_len()), x1(x0);
     if ((rc = download_z(pb, 1 - pb->cur, x1.data()))) return rc;
@@ -1641,7 +1716,7 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
     do {
         if (!pb->blocks_valid && (rc = rebuild_current(pb))) return rc;  // a rejected try consumed them
         const double mu_used = pb->mu;
-        if ((rc = damped_try(pb, mu_used, true))) {
+        if ((rc = damped_try_fb(pb, mu_used, true))) {
             if (rc != TRY_NOT_POSITIVE_DEFINITE) return rc;
             // J^T J + mu I came out indefinite in floating point: the reference's LDL^T would hand back the stationary point
             // of an indefinite model and its gain test would reject the trial (libs/sparselevmarq.h:408-419); same outcome here
@@ -1874,17 +1949,38 @@ int aar_get_kernel_times(aar_problem *pb, double seconds[AAR_NUM_KERNELS], int64
 const char *aar_kernel_name(int kid) {
     static const char *names[KID_COUNT] = {"k_unpack", "k_residual", "k_passA", "k_passB", "k_maxdiag", "k_frame_inv", "k_schur",
                                            "k_ldl_diag", "k_ldl_trsm", "k_ldl_update", "k_ldl_backsolve", "k_backsub",
-                                           "k_reduce_scalars", "k_ldl_panel", "k_pcg"};
+                                           "k_reduce_scalars", "k_ldl_panel", "k_pcg", "k_spcg"};
     return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
 }
 
 int aar_problem_pcg_iterations(aar_problem *pb, int32_t out[2]) {
     if (!pb || !out) return set_error(AAR_ERR_INVALID, "aar_problem_pcg_iterations: null argument");
     out[0] = out[1] = 0;
-    if (!pb->P.use_pcg) return AAR_OK;
+    if (!pb->P.use_pcg && !pb->P.use_spcg) return AAR_OK;
     HIP_TRY(hipSetDevice(pb->device));
-    HIP_TRY(hipMemcpyAsync(out, pb->P.pcg_counter + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipMemcpyAsync(out, pb->P.use_pcg ? pb->P.pcg_counter + 2 : pb->P.spcg_iters, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
     HIP_TRY(hipStreamSynchronize(pb->stream));
+    if (out[0] > SPCG_MAX_IT && pb->P.use_spcg) out[0] = SPCG_MAX_IT;   // (a timed-out launch records SPCG_BUFS)
+    return AAR_OK;
+}
+
+int aar_problem_get_solver_stats(aar_problem *pb, aar_solver_stats *out) {
+    if (!pb || !out) return set_error(AAR_ERR_INVALID, "aar_problem_get_solver_stats: null argument");
+    memset(out, 0, sizeof *out);
+    out->solver = pb->solver;
+    out->deterministic = pb->P.deterministic;
+    out->pcg_eta = pb->P.pcg_eta;
+    out->pcg_max_it = pb->P.use_spcg ? pb->P.spcg_max_it : pb->P.pcg_max_it;
+    out->fallbacks = pb->spcg_fallbacks;
+    if (!pb->P.use_pcg && !pb->P.use_spcg) return AAR_OK;
+    int32_t c[4] = {0, 0, 0, 0};
+    HIP_TRY(hipSetDevice(pb->device));
+    if (pb->P.use_spcg) HIP_TRY(hipMemcpyAsync(c, pb->P.spcg_iters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
+    else HIP_TRY(hipMemcpyAsync(c, pb->P.pcg_counter + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
+    HIP_TRY(hipStreamSynchronize(pb->stream));
+    out->last_iterations = std::min(c[0], pb->P.use_spcg ? SPCG_MAX_IT : c[0]);
+    out->total_iterations = c[1];
+    out->solves = c[2];
     return AAR_OK;
 }
 

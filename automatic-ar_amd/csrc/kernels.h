@@ -8,10 +8,14 @@ namespace aar {
 
 constexpr int CHOL_NB = 96;       // dense LDL^T tile (16 entity blocks of 6)
 constexpr int PASSB_CHUNK = 256;  // max observations of one (camera, marker) run handled by one wavefront
+// CG on the explicit reduced system (spcg_kernels.hip): iteration cap (sizes the hand-over buffers: one per iteration plus the
+// start-up and the final one), largest system (tiles of 96 unknowns: the six rows of an entity live in one wavefront's registers)
+constexpr int SPCG_MAX_IT = 64, SPCG_BUFS = SPCG_MAX_IT + 2, SPCG_MAX_NT = 16;
+inline int spcg_stride(int n_pad) { return (n_pad + 3 * (n_pad / 6) + 63) / 64 * 64; }   // doubles per hand-over buffer: m [n_pad] | shares [3][n_pad / 6]
 
 // Kernel ids for the optional per-launch timing hooks (aar_get_kernel_times)
 enum KernelId { KID_UNPACK = 0, KID_RESIDUAL, KID_PASSA, KID_PASSB, KID_MAXDIAG, KID_FRAME_INV, KID_SCHUR, KID_LDL_DIAG,
-                KID_LDL_TRSM, KID_LDL_UPDATE, KID_LDL_BACKSOLVE, KID_BACKSUB, KID_REDUCE, KID_LDL_PANEL, KID_PCG, KID_COUNT };
+                KID_LDL_TRSM, KID_LDL_UPDATE, KID_LDL_BACKSOLVE, KID_BACKSUB, KID_REDUCE, KID_LDL_PANEL, KID_PCG, KID_SPCG, KID_COUNT };
 
 struct LaunchHook {  // called around every kernel launch when profiling is on
     void (*pre)(void *ctx, int kid) = nullptr;
@@ -87,6 +91,11 @@ struct DeviceProblem {
     double *pcg_ws = nullptr;             // items' shares [n_items][28] | t [6F]
     int32_t *pcg_counter = nullptr;       // [0..1] grid-barrier counters (alternating), [2] iterations of the last solve, [3] running total
     mutable int pcg_parity = 0;
+    // solver spcg (spcg_kernels.hip): CG on the explicit Schur complement, one wavefront per shared entity
+    int use_spcg = 0, spcg_max_it = SPCG_MAX_IT;
+    double *spcg_ws = nullptr;            // [2][SPCG_BUFS][spcg_stride(n_pad)] hand-over slots (sentinel-filled when idle)
+    int32_t *spcg_iters = nullptr;        // [0] iterations of the last solve, [1] running total, [2] solves, [3] solves that hit the cap (flag 8)
+    mutable int spcg_parity = 0;
     // ... with frames sharded over ranks: this rank's set-up share [A][28] (all-reduced), Minv [A][36], x | r | p | scalars [3 n + 8],
     // this rank's partial y [n] (all-reduced per iteration), mapped host record {done, iterations, -, sequence}
     double *pcgd_setup = nullptr, *pcgd_minv = nullptr, *pcgd_state = nullptr, *pcgd_y = nullptr, *pcgd_host = nullptr;
@@ -169,6 +178,11 @@ bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, i
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
 void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st);     // AAR_SOLVER=pcg: delta_s by PCG through the frame blocks (needs Vinv, hf for mu)
 size_t pcg_lds_bytes(int A);
+// solver spcg: delta_s by CG on the explicit reduced system S of block set `which` (the Schur complement for mu must have been taken; S is not modified)
+void launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st);
+bool spcg_fits(int nT);                                    // the system's rows fit the wavefronts' registers
+size_t spcg_ws_doubles(int n_pad);
+void spcg_ws_reset(const DeviceProblem &P, hipStream_t st);   // every hand-over slot back to the sentinel (at creation, after a timed-out launch)
 // the same with a communicator: set-up share -> [all-reduce] -> launches k = 0, 1, .. with an all-reduce of pcgd_y between two of them
 void launch_pcgd_setup(const DeviceProblem &P, int which, double mu, hipStream_t st);
 void launch_pcgd_iter(const DeviceProblem &P, int which, double mu, int k, bool last, unsigned long long publish_seq, hipStream_t st);
@@ -182,15 +196,15 @@ int residual_blocks(const DeviceProblem &P);   // entries of err_part written by
 void launch_track(const DeviceProblem &P, int which, int max_iters, double min_error, double min_step, double min_avg, double tau,
                   int32_t *iters_out, double *err_out, hipStream_t st);
 
-// The error flags of a rank as one double that survives a SUM all-reduce over up to 4095 ranks: bit b set on k ranks adds k 4096^b.
+// The error flags of a rank (bits 0..3) as one double that survives a SUM all-reduce over up to 4095 ranks: bit b set on k ranks adds k 4096^b.
 // Every rank decodes the same value, so every rank takes the same branch (a rank that failed alone would otherwise leave the
 // others waiting in their next collective).
 __device__ __forceinline__ double encode_flags(int f) {
-    return (double)(f & 1) + 4096.0 * (double)((f >> 1) & 1) + 16777216.0 * (double)((f >> 2) & 1);
+    return (double)(f & 1) + 4096.0 * (double)((f >> 1) & 1) + 16777216.0 * (double)((f >> 2) & 1) + 68719476736.0 * (double)((f >> 3) & 1);
 }
 __device__ __forceinline__ int decode_flags(double v) {
     const long long q = (long long)v;
-    return ((q % 4096) ? 1 : 0) | (((q / 4096) % 4096) ? 2 : 0) | ((q / 16777216) ? 4 : 0);
+    return ((q % 4096) ? 1 : 0) | (((q / 4096) % 4096) ? 2 : 0) | (((q / 16777216) % 4096) ? 4 : 0) | ((q / 68719476736LL) ? 8 : 0);
 }
 
 // flags_reduced: the flags come from scal[3] (all ranks' flags, summed by the all-reduce) instead of this rank's flag words

@@ -271,8 +271,9 @@ def main():
     ap.add_argument("--intrinsics", action="store_true", help="the reference's default Config: optimize_cam_intrinsics on (9 more parameters per camera, "
                     "libs/multicam_mapper.h:75-81); the headline metric is quoted WITHOUT it (SURVEY.md section 8 row f4)")
     ap.add_argument("--no-amdahl", action="store_true", help="skip the stage-timer pass behind the `amdahl` object")
-    ap.add_argument("--solver", choices=("direct", "pcg"), default="direct", help="direct (default, the headline: Schur complement + dense LDL^T, the reference's "
-                    "step to rounding) or pcg (opt-in inexact LM: the reduced system by preconditioned CG through the frame blocks, csrc/pcg_kernels.hip)")
+    ap.add_argument("--solver", choices=("direct", "spcg", "pcg", "auto"), default="direct", help="aar_solver_options.solver: direct (Schur complement + dense LDL^T, the "
+                    "reference's step to rounding), spcg (the same Schur complement, then CG on the explicit reduced system, csrc/spcg_kernels.hip), pcg (CG through "
+                    "the frame blocks, no Schur complement, csrc/pcg_kernels.hip), auto (the library picks by size and rank count)")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher / rendezvous / JSON relay only, no GPU work (CPU test of the N-rank plumbing)")
     args = ap.parse_args()
 
@@ -300,8 +301,6 @@ def main():
 
     if aar.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (the product has no CPU path)")
-    if args.solver == "pcg":
-        os.environ["AAR_SOLVER"] = "pcg"          # read when the problem is created
     ds = aar.synth(args.workload)
     comm = None
     if world > 1 or os.environ.get("AAR_FORCE_COMM") == "1":   # the env switch exercises the RCCL path on one GPU
@@ -309,7 +308,7 @@ def main():
         if dist is not None:
             dist.broadcast_object_list(uid, src=0)
         comm = aar.Comm(uid[0], world, rank, local_rank)
-    problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics)
+    problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics, solver=args.solver)
     # x_full of the default Config: the pose vector, then fx cx fy cy d0..d4 per camera (fill_io_vec_cam_intrinsics, :488-498)
     x0 = problem.x_with_intrinsics(ds.x_full) if args.intrinsics else ds.x_full
 

@@ -257,7 +257,47 @@ typedef struct aar_problem_desc {
 } aar_problem_desc;
 
 void aar_problem_desc_from_dataset(const aar_dataset *, aar_problem_desc *);
-int aar_problem_create(const aar_problem_desc *, aar_problem **out);
+int aar_problem_create(const aar_problem_desc *, aar_problem **out);   /* = aar_problem_create_ex(desc, NULL, out) */
+
+/* How the damped normal equations of a try are solved -- the counterpart of configuring the reference's solver object through
+ * SparseLevMarq::Params / setParams (libs/sparselevmarq.h:30-50,60-66): PER PROBLEM, fixed when the problem is created; two problems
+ * of one process may differ.  The reference itself knows one way only (Eigen::SimplicialLDLT, :394-400): AAR_SOLVER_DIRECT is that
+ * step to rounding and is what a NULL options pointer means.
+ *   AAR_SOLVER_DIRECT  per-frame elimination (Schur complement) + dense blocked LDL^T of the reduced system: the reference's step
+ *   AAR_SOLVER_SPCG    the same Schur complement, then block-Jacobi-preconditioned CG on the EXPLICIT reduced system, one wavefront
+ *                      per camera / marker (csrc/spcg_kernels.hip), stopped at |r| <= pcg_eta |b|: an inexact LM step -- the trajectory is
+ *                      no longer the reference's step for step, its fixed point is (final reprojection error within 1e-5 px in every
+ *                      measured case; bar 1e-4).  A solve that needs more than pcg_max_it iterations (cap 64) or whose hand-over times out
+ *                      (device shared with another process) is redone with the direct chain automatically.  Needs 6 (C + M [+ C]) <= 1344.
+ *   AAR_SOLVER_PCG     no Schur complement at all: CG THROUGH the frame blocks (csrc/pcg_kernels.hip); with a communicator the frames'
+ *                      blocks stay on their ranks and every CG iteration all-reduces 8 n bytes (nothing O(n^3) is replicated)
+ *   AAR_SOLVER_AUTO    the fastest of the three for the problem's size and rank count as measured on MI355X
+ * deterministic: every sum the default path leaves to fp64 atomics is taken in a fixed order (as the reference's ascending-row
+ * accumulation is, libs/sparselevmarq.h:291-303): two runs give the same bits; slower.
+ * Environment variables AAR_SOLVER (direct|spcg|pcg|auto), AAR_DETERMINISTIC, AAR_PCG_ETA, AAR_PCG_MAX_IT override the options of every
+ * problem created afterwards: tuning and bisecting only. */
+enum { AAR_SOLVER_DIRECT = 0, AAR_SOLVER_PCG = 1, AAR_SOLVER_SPCG = 2, AAR_SOLVER_AUTO = 3 };
+typedef struct aar_solver_options {
+    uint32_t struct_size;                     /* sizeof(aar_solver_options) of the caller: fields beyond it keep their defaults      */
+    int32_t solver;                           /* AAR_SOLVER_*                                                                        */
+    int32_t deterministic;                    /* 0 | 1                                                                               */
+    int32_t pcg_max_it;                       /* iteration cap of an inner CG solve; 0 = default (PCG 200; SPCG 64, also its maximum)  */
+    double pcg_eta;                           /* forcing term |r| <= eta |b| of the inexact solvers; 0 = default (0.1)                 */
+} aar_solver_options;
+void aar_solver_default_options(aar_solver_options *);   /* struct_size set, DIRECT, not deterministic, default eta / cap */
+int aar_problem_create_ex(const aar_problem_desc *, const aar_solver_options *, aar_problem **out);
+/* what the problem runs with (AUTO resolved), and what its inner solver has done so far */
+typedef struct aar_solver_stats {
+    int32_t solver;                           /* AAR_SOLVER_DIRECT | _PCG | _SPCG: never AUTO                                         */
+    int32_t deterministic;
+    int32_t last_iterations;                  /* CG iterations of the last damped solve (0 for DIRECT)                                */
+    int32_t reserved;
+    int64_t total_iterations, solves;         /* since the problem was created                                                        */
+    int64_t fallbacks;                        /* SPCG: tries redone with the direct chain (iteration cap, hand-over time-out)          */
+    double pcg_eta;
+    int32_t pcg_max_it, reserved2;
+} aar_solver_stats;
+int aar_problem_get_solver_stats(aar_problem *, aar_solver_stats *out);
 void aar_problem_destroy(aar_problem *);
 int64_t aar_problem_full_len(const aar_problem *);    /* length of x_full (+ 9 per camera with optimize_cam_intrinsics) */
 int64_t aar_problem_num_vars(const aar_problem *);    /* length of the reference's z for the Config  */
@@ -352,20 +392,14 @@ int aar_get_stage_times(aar_problem *, aar_stage_times *);
  * diagnostic mode (bench.py's `amdahl` object, the verbose stage line), not the production path.  Resets the accumulators. */
 int aar_set_stage_timers(aar_problem *, int on);
 
-/* Environment read when a problem is created (defaults are the reference-faithful, measured-fastest choices):
- *   AAR_DETERMINISTIC=1   every sum the default path leaves to fp64 atomics is taken in a fixed order (as the reference's ascending-row
- *                         accumulation is, libs/sparselevmarq.h:291-303): two runs give the same bits; slower
- *   AAR_SOLVER=pcg        OPT-IN inexact LM: the reduced system by preconditioned CG through the frame blocks instead of the Schur
- *                         complement + dense LDL^T (csrc/pcg_kernels.hip); the LM trajectory is then no longer the reference's step for
- *                         step, its fixed point is (final RMSE within 1e-4 px); AAR_PCG_ETA (0.1), AAR_PCG_MAX_IT (200).  With a communicator the frames'
- *                         blocks stay on their ranks and every CG iteration all-reduces 8 n bytes (nothing O(n^3) is replicated)
- * out[0] = CG iterations of the last damped solve, out[1] = their running total since the problem was created (zeros in the default mode) */
+/* out[0] = CG iterations of the last damped solve, out[1] = their running total since the problem was created (zeros for AAR_SOLVER_DIRECT);
+ * aar_problem_get_solver_stats says more */
 int aar_problem_pcg_iterations(aar_problem *, int32_t out[2]);
 
 /* Per-kernel device time: when profiling is on, every kernel launch of this problem is bracketed by two HIP
  * events on the library's own stream (the stream the kernels run on) and the elapsed times are accumulated
  * per kernel.  bench.py's roofline figures come from here.  Switching profiling on resets the accumulators. */
-#define AAR_NUM_KERNELS 15
+#define AAR_NUM_KERNELS 16
 int aar_set_kernel_profiling(aar_problem *, int on);
 int aar_get_kernel_times(aar_problem *, double seconds[AAR_NUM_KERNELS], int64_t launches[AAR_NUM_KERNELS]);
 const char *aar_kernel_name(int kernel_id);

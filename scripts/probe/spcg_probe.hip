@@ -1,0 +1,52 @@
+// Diagnostic (not part of the product): cycle stamps inside k_spcg on a random SPD system of the size of config 3's reduced system.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics scripts/probe/spcg_probe.hip -o scripts/probe/spcg_probe
+#define AAR_STAMPS 1
+#include "../../automatic-ar_amd/csrc/spcg_kernels.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <random>
+using namespace aar;
+int main(int argc, char **argv) {
+    const int nT = argc > 1 ? atoi(argv[1]) : 3;
+    const double eta = argc > 2 ? atof(argv[2]) : 1e-6;
+    const int n = 96 * nT, n_pad = n, A = n / 6;
+    std::vector<double> S((size_t)n * n), M((size_t)n * n);
+    std::mt19937_64 g(1); std::normal_distribution<double> nd;
+    for (auto &v : M) v = nd(g);
+    for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) { double s = 0; for (int k = 0; k < n / 4; k++) s += M[(size_t)i*n+k]*M[(size_t)j*n+k]; S[(size_t)i*n+j] = s + (i==j ? 1.0 : 0); }
+    DeviceProblem P; P.n = n; P.n_pad = n_pad; P.nT = nT; P.A = A; P.pcg_eta = eta;
+    auto al = [](size_t bytes) { void *p; (void)hipMalloc(&p, bytes); (void)hipMemset(p, 0, bytes); return p; };
+    P.blk[0].S = (double*)al(sizeof(double)*n*n); P.blk[0].rhs = (double*)al(8*n); P.blk[0].g0 = (double*)al(8*n);
+    P.delta_s = (double*)al(8*n); P.ent_fixed = (int32_t*)al(4*A); P.flags = (int32_t*)al(16);
+    P.spcg_ws = (double*)al(8 * spcg_ws_doubles(n_pad)); P.spcg_iters = (int32_t*)al(16);
+    spcg_ws_reset(P, 0);
+    std::vector<int32_t> fx(A, 0); fx[0] = 1; fx[8 < A ? 8 : A - 1] = 1;   // two gauge entities, as in a bundle problem
+    (void)hipMemcpy(P.ent_fixed, fx.data(), 4 * A, hipMemcpyHostToDevice);
+    std::vector<double> b(n, 1.0);
+    (void)hipMemcpy(P.blk[0].S, S.data(), 8*(size_t)n*n, hipMemcpyHostToDevice);
+    (void)hipMemcpy(P.blk[0].g0, b.data(), 8*n, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 4; rep++) {
+        int zero[64] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sp_polls), zero, sizeof zero);
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0);
+        launch_spcg(P, 0, 0.5, 0);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long st[512]; int polls[64], it[4];
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_sp_stamps), sizeof st);
+        (void)hipMemcpyFromSymbol(polls, HIP_SYMBOL(g_sp_polls), sizeof polls);
+        (void)hipMemcpy(it, P.spcg_iters, 16, hipMemcpyDeviceToHost);
+        printf("rep %d: k_spcg %.1f us (events), %d iterations; memtime ticks (100 MHz): slab %llu | inverse %llu | publish0 %llu | gather0 %llu | total %llu\n", rep, ms*1e3, it[0],
+               st[1]-st[0], st[2]-st[1], st[3]-st[2], st[4]-st[3], st[5]-st[0]);
+        if (rep == 3) for (int k = 0; k < it[0] && k < 24; k++)
+            printf("   it %2d: prec+shares+publish %llu | gather %llu (re-polls %d) | matvec %llu | scalars+updates %llu\n", k, st[9+4*k]-st[8+4*k], st[10+4*k]-st[9+4*k], polls[k+1],
+                   st[11+4*k]-st[10+4*k], (k + 1 < it[0] ? st[8+4*(k+1)] : st[11+4*k]) - st[11+4*k]);
+    }
+    std::vector<double> x(n); (void)hipMemcpy(x.data(), P.delta_s, 8*n, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int i = 0; i < n; i++) { if (fx[i / 6]) continue; double s = 0; for (int j = 0; j < n; j++) { if (fx[j / 6]) continue; double a = (j <= i) ? S[(size_t)i*n+j] : S[(size_t)j*n+i]; s += (a + (i==j?0.5:0))*x[j]; } worst = fmax(worst, fabs(s - 1.0)); }
+    printf("residual of the solve (max norm, b = 1): %.3e\n", worst);
+    return 0;
+}
