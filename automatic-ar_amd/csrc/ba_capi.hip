@@ -1147,13 +1147,16 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
             // largest kernel of a step and CG through the frame blocks, which never forms it, wins; below, CG on the explicit
             // complement replaces the LDL^T chain; a system neither fits takes the direct chain
             if (A >= 96 && pcg_ok) solver = AAR_SOLVER_PCG;
-            else if (spcg_ok) solver = AAR_SOLVER_SPCG;
-            else if (pcg_ok) solver = AAR_SOLVER_PCG;
+            else if (spcg_ok && P.nT >= 2) solver = AAR_SOLVER_SPCG;   // (one tile: the direct chain is a single 25 us launch, about what 10 CG iterations cost)
+            else if (P.nT >= 2 && pcg_ok) solver = AAR_SOLVER_PCG;
             else solver = AAR_SOLVER_DIRECT;
         }
         pb->solver = solver;
         P.use_pcg = solver == AAR_SOLVER_PCG ? 1 : 0;
         P.use_spcg = solver == AAR_SOLVER_SPCG ? 1 : 0;
+        // forcing term: |r| <= 0.1 |b| for the CG through the frame blocks; the CG on the explicit system measures in the preconditioner's norm
+        // (r^T M^-1 r, which its recurrences carry anyway), where 0.02 gives the same distance to the exact LM run
+        P.pcg_eta = P.use_spcg ? 0.02 : 0.1;
         if (so.pcg_eta > 0) P.pcg_eta = so.pcg_eta;
         if (so.pcg_max_it > 0) { P.pcg_max_it = so.pcg_max_it; P.spcg_max_it = std::min(so.pcg_max_it, SPCG_MAX_IT); }
         if (P.use_pcg && !pcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_PCG keeps the CG vectors and the preconditioner of %d unknowns in LDS: too many shared entities", 6 * A);

@@ -10,8 +10,8 @@ constexpr int CHOL_NB = 96;       // dense LDL^T tile (16 entity blocks of 6)
 constexpr int PASSB_CHUNK = 256;  // max observations of one (camera, marker) run handled by one wavefront
 // CG on the explicit reduced system (spcg_kernels.hip): iteration cap (sizes the hand-over buffers: one per iteration plus the
 // start-up and the final one), largest system (tiles of 96 unknowns: the six rows of an entity live in one wavefront's registers)
-constexpr int SPCG_MAX_IT = 64, SPCG_BUFS = SPCG_MAX_IT + 2, SPCG_MAX_NT = 16;
-inline int spcg_stride(int n_pad) { return (n_pad + 3 * (n_pad / 6) + 63) / 64 * 64; }   // doubles per hand-over buffer: m [n_pad] | shares [3][n_pad / 6]
+constexpr int SPCG_MAX_IT = 64, SPCG_BUFS = SPCG_MAX_IT + 2, SPCG_MAX_NT = 14;
+inline int spcg_stride(int n_pad) { return 8 * (n_pad / 6); }   // doubles per hand-over buffer: one 64-byte record per entity
 
 // Kernel ids for the optional per-launch timing hooks (aar_get_kernel_times)
 enum KernelId { KID_UNPACK = 0, KID_RESIDUAL, KID_PASSA, KID_PASSB, KID_MAXDIAG, KID_FRAME_INV, KID_SCHUR, KID_LDL_DIAG,

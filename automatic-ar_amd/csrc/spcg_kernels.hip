@@ -12,7 +12,7 @@
 // There is no workgroup barrier and no shared state inside a CU: a wavefront talks to the others only through the hand-over below.
 //
 // Pipelined CG (Ghysels & Vanroose 2014, Alg. 3), so that an iteration has ONE hand-over: every wavefront publishes
-// m = M^-1 w (its six entries) together with its shares of (r,u), (w,u), (r,r) -- all of which exist BEFORE the matrix-vector
+// m = M^-1 w (its six entries) together with its shares of (r,u), (w,u) -- both of which exist BEFORE the matrix-vector
 // product --, gathers everybody's, and then computes its six rows of n = A m, the scalars alpha / beta (every wavefront adds the same
 // shares in the same order: same bits, same decisions) and the eight vector recurrences, all in registers.
 //
@@ -41,7 +41,7 @@ __device__ __forceinline__ double dpp(double v) {   // lane permutation inside a
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROR4 = 0x124, DPP_ROR8 = 0x128;
 
 __device__ __forceinline__ double rl(double v, int l) {   // lane l's value, wave-uniform
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
@@ -53,26 +53,33 @@ __device__ __forceinline__ double sum8(double v) {
     v += dpp<DPP_HALF_MIRROR>(v);
     return v;
 }
-// sum over all 64 lanes, the same bits in every lane
-__device__ __forceinline__ double sum64(double v) {
-    v = sum8(v);
-    v += dpp<DPP_MIRROR>(v);
-    return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
-}
-// sum over the six matrix rows of a wavefront of a value that is the same in the 8 lanes of a row (rows 6, 7 hold zeros)
-__device__ __forceinline__ double sum_rows(double v) {
-    v += dpp<DPP_ROR8>(v);
-    return (rl(v, 0) + rl(v, 16)) + rl(v, 32);
+// v(row r of 16 lanes) <- v(r) + v(r ^ 1), then + the other pair of rows: gfx950's v_permlane16_swap / v_permlane32_swap exchange whole
+// rows between two registers, so a cross-row all-reduce of a 64-bit value is 4 + 4 exchanges and two additions, in the same order
+// in every row (same bits everywhere)
+__device__ __forceinline__ double sum_across_rows(double v) {
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    return v;
 }
 
 }  // namespace
 
 #ifdef AAR_STAMPS   // diagnostic build (scripts/probe/spcg_probe.hip): cycle stamps of the reporting wavefront
 __device__ unsigned long long g_sp_stamps[512];
-__device__ int g_sp_polls[64];
+__device__ int g_sp_polls[80];
 #define SP_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (e == e0 && lane == 0 && (k) < 512) g_sp_stamps[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SP_VAL(k, v) do { if (e == e0 && lane == 0 && (k) < 512) g_sp_stamps[k] = (unsigned long long)__double_as_longlong(v); } while (0)
 #else
 #define SP_STAMP(k) do { } while (0)
+#define SP_VAL(k, v) do { } while (0)
 #endif
 
 struct SpcgArgs {
@@ -81,80 +88,83 @@ struct SpcgArgs {
     int n, n_pad;
     double mu, eta2;
     int max_it;
-    double *ws;                       // [2][SPCG_BUFS][stride] hand-over slots: m [n_pad] | shares [3][n_pad / 6]
+    double *ws;                       // [2][SPCG_BUFS][stride] hand-over records, one of 8 doubles (64 bytes) per entity: m [6] | share of (r,u) | share of (w,u)
     long long set_len;                // doubles per set
     int stride, parity;
     double *x_out;                    // [n_pad] delta_s
-    int32_t *iters;                   // [0] iterations of this solve, [1] running total, [2] solves, [3] fallbacks requested (flag 8)
+    int32_t *iters;                   // [0] iterations of this solve, [1] running total, [2] solves, [3] solves that hit the cap (flag 8)
     int32_t *flags;
 };
 
+typedef unsigned int sp_u32x4 __attribute__((ext_vector_type(4)));
+
 template <int NT>
 __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
-    constexpr int NPAD = 96 * NT, NK = 6 * NT, NENT = 16 * NT, NM = (NPAD + 63) / 64, NE = (NENT + 63) / 64;
+    // NL: 16-byte pieces of a buffer per lane (a buffer = 16 NT records of 64 bytes = 64 NT pieces); piece c = lane + 64 k belongs to record
+    // c / 4 and holds its words 2 (lane % 4), 2 (lane % 4) + 1: lanes with lane % 4 < 3 gather entries of m, lanes with lane % 4 == 3 the two shares
+    constexpr int NPAD = 96 * NT, NK = 6 * NT, NENT = 16 * NT, NL = NT, NEB = (NENT + 63) / 64;
     __shared__ __align__(16) double mv[NPAD];
-    __shared__ int32_t fx[NENT];
     const int lane = threadIdx.x, e = blockIdx.x, i = lane >> 3, g = lane & 7;
-    for (int q = lane; q < NENT; q += 64) fx[q] = (6 * q >= a.n) ? 1 : a.ent_fixed[q];
-    __syncthreads();
-    if (fx[e]) {   // gauge / switched-off / padding entity: identity rows, zero right-hand side; nobody waits for this wavefront
+    const int n_free_ent = a.n / 6;   // entities beyond are padding: identity rows
+    auto fixed = [&](int ent) -> bool { return ent >= n_free_ent || a.ent_fixed[ent < n_free_ent ? ent : 0] != 0; };
+    if (fixed(e)) {   // gauge / switched-off / padding entity: identity rows, zero right-hand side; nobody waits for this wavefront
         if (lane < 6) a.x_out[6 * e + lane] = 0.0;
         return;
     }
-    int e0 = 0;    // the first free entity: its wavefront reports
-    while (fx[e0]) e0++;
     double *set = a.ws + (size_t)a.parity * a.set_len, *other = a.ws + (size_t)(1 - a.parity) * a.set_len;
-    SP_STAMP(0);
-    {   // the slots this wavefront owns in the other set, for the launch after this one (the previous launch dirtied iters[0] + 2 buffers of it)
-        const int nprev = min(a.iters[0] + 2, SPCG_BUFS);
-        for (int bq = lane; bq < nprev; bq += 64) {
-            double *b = other + (size_t)bq * a.stride;
+    // ---- every load of the set-up is issued before the first is used: one memory latency, not one per stage ----
+    const int nprev_raw = a.iters[0];
+    int e0 = -1;    // the first free entity: its wavefront reports
 #pragma unroll
-            for (int k = 0; k < 6; k++) sp_st(b + 6 * e + k, __longlong_as_double((long long)SPCG_EMPTY));
-#pragma unroll
-            for (int k = 0; k < 3; k++) sp_st(b + NPAD + k * NENT + e, __longlong_as_double((long long)SPCG_EMPTY));
-        }
+    for (int k = 0; k < NEB; k++) {
+        const unsigned long long fr = __ballot(lane + 64 * k < NENT && !fixed(lane + 64 * k));
+        if (e0 < 0 && fr) e0 = 64 * k + __builtin_ctzll(fr);
     }
-    // which of the slots this lane gathers belong to free entities (the others read as zero without being polled)
-    unsigned mact = 0, eact = 0;
+    unsigned pact = 0;   // bit k: piece lane + 64 k belongs to a free entity (the others read as zero without being polled)
 #pragma unroll
-    for (int k = 0; k < NM; k++) { const int idx = lane + 64 * k; if (idx < NPAD && !fx[idx / 6]) mact |= 1u << k; }
-#pragma unroll
-    for (int k = 0; k < NE; k++) { const int en = lane + 64 * k; if (en < NENT && !fx[en]) eact |= 1u << k; }
-
-    // ---- rows 6e .. 6e+5 of S + mu I into registers (S holds its lower triangle: the part right of the diagonal is read transposed) ----
+    for (int k = 0; k < NL; k++) if (!fixed((lane + 64 * k) >> 2)) pact |= 1u << k;
+    // rows 6e .. 6e+5 of S + mu I into registers (S holds its lower triangle: the part right of the diagonal is read transposed)
     const bool ra = i < 6;
     const int row = 6 * e + (ra ? i : 0);
     double A2[2 * NK];
+    unsigned cfx = 0;   // bit k: column pair k belongs to a gauge / padding entity
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int c0 = 16 * k + 2 * g, c1 = c0 + 1;
+        A2[2 * k] = a.S[(c0 <= row) ? (size_t)row * a.n_pad + c0 : (size_t)c0 * a.n_pad + row];
+        A2[2 * k + 1] = a.S[(c1 <= row) ? (size_t)row * a.n_pad + c1 : (size_t)c1 * a.n_pad + row];
+        if (fixed(c0 / 6)) cfx |= 1u << k;
+    }
+    double blk[6][6];
+#pragma unroll
+    for (int p = 0; p < 6; p++)
+#pragma unroll
+        for (int q = 0; q <= p; q++) blk[p][q] = a.S[(size_t)(6 * e + p) * a.n_pad + 6 * e + q];
+    double r = a.rhs[row] + a.g0[row];
+    SP_STAMP(0);
+    {   // the record this wavefront owns in the other set's buffers, for the launch after this one (the previous launch dirtied iters[0] + 2 of them): 8 buffers per store
+        const int nprev = min(nprev_raw + 2, SPCG_BUFS);
+        for (int bq = lane >> 3; bq < nprev; bq += 8) sp_st(other + (size_t)bq * a.stride + 8 * e + (lane & 7), __longlong_as_double((long long)SPCG_EMPTY));
+    }
 #pragma unroll
     for (int k = 0; k < NK; k++) {
         const int c0 = 16 * k + 2 * g;
-        double v0 = 0.0, v1 = 0.0;
-        if (ra && !fx[c0 / 6]) {
-            if (c0 + 1 <= row) {
-                const double2 t = *reinterpret_cast<const double2 *>(a.S + (size_t)row * a.n_pad + c0);
-                v0 = t.x; v1 = t.y;
-            } else {
-                v0 = (c0 <= row) ? a.S[(size_t)row * a.n_pad + c0] : a.S[(size_t)c0 * a.n_pad + row];
-                v1 = a.S[(size_t)(c0 + 1) * a.n_pad + row];
-            }
-            if (c0 == row) v0 += a.mu;
-            if (c0 + 1 == row) v1 += a.mu;
-        }
-        A2[2 * k] = v0; A2[2 * k + 1] = v1;
+        const bool off = !ra || ((cfx >> k) & 1);
+        A2[2 * k] = off ? 0.0 : A2[2 * k] + (c0 == row ? a.mu : 0.0);
+        A2[2 * k + 1] = off ? 0.0 : A2[2 * k + 1] + (c0 + 1 == row ? a.mu : 0.0);
     }
+    if (!ra) r = 0.0;
     SP_STAMP(1);
     // ---- the preconditioner: inverse of the damped diagonal block, every lane the whole block (same instruction stream), keeps its row ----
     double mi[6];
     {
-        double blk[6][6], inv[36];
+        double inv[36];
 #pragma unroll
-        for (int p = 0; p < 6; p++)
+        for (int p = 0; p < 6; p++) {
+            blk[p][p] += a.mu;
 #pragma unroll
-            for (int q = 0; q <= p; q++) {
-                const double v = a.S[(size_t)(6 * e + p) * a.n_pad + 6 * e + q] + (p == q ? a.mu : 0.0);
-                blk[p][q] = v; blk[q][p] = v;
-            }
+            for (int q = 0; q < p; q++) blk[q][p] = blk[p][q];
+        }
         if (!spd6_inverse(blk, inv) && lane == 0) atomicOr(a.flags, 2);
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -171,56 +181,64 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
         return s;
     };
     bool dead = false;   // a hand-over timed out: flag 4, leave (wave-uniform)
-    // publish: buffer b <- this wavefront's six entries of `val` and its three shares
-    auto publish = [&](int b, double val, double s0, double s1, double s2) {
-        double *buf = set + (size_t)b * a.stride;
-        double *dst = nullptr;
-        double v = 0.0;
-        if (ra && g == 0) { dst = buf + 6 * e + i; v = val; }
-        else if (lane == 1) { dst = buf + NPAD + e; v = s0; }
-        else if (lane == 2) { dst = buf + NPAD + NENT + e; v = s1; }
-        else if (lane == 3) { dst = buf + NPAD + 2 * NENT + e; v = s2; }
-        if (dst) sp_st(dst, v);
+    // publish: buffer b <- this wavefront's record: its six entries of `val` (lanes 8 i -> words 0..5) and its shares of the two dot products
+    // (lanes 1, 2 -> words 6, 7): ONE store instruction, 64 contiguous bytes.  s1, s2 are per-row products (the same in the 8 lanes of a row, zero in
+    // rows 6 and 7): lane g picks its quantity, the rows are added by a rotation and two row exchanges -- the sum arrives in the lanes that store it
+    auto publish = [&](int b, double val, double s1, double s2) {
+        double *rec = set + (size_t)b * a.stride + 8 * e;
+        double sh = (g & 1) ? s1 : s2;
+        sh += dpp<DPP_ROR8>(sh);
+        sh = sum_across_rows(sh);
+        const bool is_m = ra && g == 0, is_s = lane == 1 || lane == 2;
+        if (is_m || is_s) sp_st(rec + (is_m ? i : 5 + lane), is_m ? val : sh);
     };
-    // gather: buffer b -> the whole vector in mv (LDS), the three sums over all wavefronts
-    auto gather = [&](int b, double &t0, double &t1, double &t2) {
-        const double *buf = set + (size_t)b * a.stride;
-        double v[NM], sh[3][NE];
+    // gather: buffer b -> the whole vector in mv (LDS), the two sums over all wavefronts.  The poll IS the load of the payload (16-byte sc1
+    // loads: a CU's memory queue is what a hand-over costs, so as few requests as possible; every 8-byte half is validated by itself)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(set, 0, (int)(a.set_len * 8), 0x00020000);
+    auto gather = [&](int b, double &t1, double &t2) {
+        const int soff = b * a.stride * 8;
+        double2 cur[NL];
 #pragma unroll
-        for (int k = 0; k < NM; k++) v[k] = ((mact >> k) & 1) ? sp_ld(buf + lane + 64 * k) : 0.0;
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-#pragma unroll
-            for (int k = 0; k < NE; k++) sh[q][k] = ((eact >> k) & 1) ? sp_ld(buf + NPAD + q * NENT + lane + 64 * k) : 0.0;
+        for (int k = 0; k < NL; k++) cur[k] = ((pact >> k) & 1) ? make_double2(__longlong_as_double((long long)SPCG_EMPTY), __longlong_as_double((long long)SPCG_EMPTY)) : make_double2(0.0, 0.0);
         long spins = 0;
         for (;;) {
+            sp_u32x4 t[NL];
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                if (sp_empty(cur[k].x) || sp_empty(cur[k].y)) t[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 16 * (lane + 64 * k), soff, 16 /* sc1 */);
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < NM; k++) ok = ok && !sp_empty(v[k]);
-#pragma unroll
-            for (int q = 0; q < 3; q++)
-#pragma unroll
-                for (int k = 0; k < NE; k++) ok = ok && !sp_empty(sh[q][k]);
+            for (int k = 0; k < NL; k++) {
+                if (sp_empty(cur[k].x) || sp_empty(cur[k].y)) {
+                    const double lo = __hiloint2double((int)t[k][1], (int)t[k][0]), hi = __hiloint2double((int)t[k][3], (int)t[k][2]);
+                    if (sp_empty(cur[k].x)) cur[k].x = lo;
+                    if (sp_empty(cur[k].y)) cur[k].y = hi;
+                    ok = ok && !sp_empty(cur[k].x) && !sp_empty(cur[k].y);
+                }
+            }
             if (__ballot(!ok) == 0ull) break;
 #ifdef AAR_STAMPS
-            if (e == e0 && lane == 0 && b < 64) g_sp_polls[b]++;
+            if (e == e0 && lane == 0 && b < 80) g_sp_polls[b]++;
 #endif
-            if (++spins > (1L << 20)) { dead = true; break; }   // ~1 s: a wavefront of the grid is not running (device shared / oversubscribed)
+            if (++spins > (1L << 19)) { dead = true; break; }   // ~1 s: a wavefront of the grid is not running (device shared / oversubscribed)
             __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-            for (int k = 0; k < NM; k++) if (sp_empty(v[k])) v[k] = sp_ld(buf + lane + 64 * k);
-#pragma unroll
-            for (int q = 0; q < 3; q++)
-#pragma unroll
-                for (int k = 0; k < NE; k++) if (sp_empty(sh[q][k])) sh[q][k] = sp_ld(buf + NPAD + q * NENT + lane + 64 * k);
         }
+        const int w2 = lane & 3;
+        double sg = 0.0, sd = 0.0;
 #pragma unroll
-        for (int k = 0; k < NM; k++) if (lane + 64 * k < NPAD) mv[lane + 64 * k] = v[k];
-        double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < NE; k++) { p0 += sh[0][k]; p1 += sh[1][k]; p2 += sh[2][k]; }
-        t0 = sum64(p0); t1 = sum64(p1); t2 = sum64(p2);
-        __syncthreads();   // (one wavefront: the LDS stores above are visible to its own reads below)
+        for (int k = 0; k < NL; k++) {
+            if (w2 < 3) *reinterpret_cast<double2 *>(mv + 6 * ((lane + 64 * k) >> 2) + 2 * w2) = cur[k];
+            else { sg += cur[k].x; sd += cur[k].y; }
+        }
+        // lanes = 3 mod 4 hold (sum of shares of (r,u), of (w,u)) of their records: the second moves one lane down, then both are added over the quads
+        // (rotations by 4 and 8 keep the position in the quad) and over the rows
+        const double sd_dn = dpp<0xF4>(sd);   // quad_perm [0,1,3,3]: lane 2 of a quad reads lane 3 (outside the selection below: a DPP source lane must be active)
+        double sh = w2 == 3 ? sg : (w2 == 2 ? sd_dn : 0.0);
+        sh += dpp<DPP_ROR4>(sh);
+        sh += dpp<DPP_ROR8>(sh);
+        sh = sum_across_rows(sh);
+        t1 = rl(sh, 3); t2 = rl(sh, 2);
+        __builtin_amdgcn_wave_barrier();   // (one wavefront, LDS operations complete in order: the reads below see the stores above)
     };
     auto matvec = [&]() -> double {   // this lane's row of A against the vector in mv, summed over the row's 8 lanes
         double s0 = 0.0, s1 = 0.0;
@@ -231,42 +249,47 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             s1 = fma(A2[2 * k + 1], t.y, s1);
         }
         const double s = sum8(s0 + s1);
-        __syncthreads();   // mv may be overwritten by the next gather
+        __builtin_amdgcn_wave_barrier();   // (mv is overwritten by the next gather: program order is enough)
         return s;
     };
 
-    // ---- x = 0, r = b, u = M^-1 r, w = A u ----
-    double x = 0.0, r = ra ? a.rhs[row] + a.g0[row] : 0.0;
-    double u = prec(r), w, z = 0.0, q = 0.0, s = 0.0, p = 0.0;
-    double bb, d0, d1;
+    // ---- x = 0, r = b, u = M^-1 r, w = A u.  Stopping rule in the preconditioner's norm: r^T M^-1 r <= eta^2 b^T M^-1 b -- it is the (r,u) the
+    //      recurrences need anyway (a third reduction for r^T r would be a ninth word in every record), and along real LM runs it stops
+    //      earlier AND ends closer to the exact run than the Euclidean rule (profiles/r04_spcg_experiment.txt) ----
+    double x = 0.0;
+    double u = prec(r), w = 0.0, z = 0.0, q = 0.0, s = 0.0, p = 0.0;
+    double bb, d1;
     SP_STAMP(2);
-    publish(0, u, sum_rows(r * r), 0.0, 0.0);
+    publish(0, u, r * u, 0.0);
     SP_STAMP(3);
-    gather(0, bb, d0, d1);
+    gather(0, bb, d1);
     SP_STAMP(4);
+    SP_VAL(400, bb); SP_VAL(401, d1); SP_VAL(402, u); SP_VAL(403, r); SP_VAL(404, mv[0]); SP_VAL(405, mv[6]); SP_VAL(406, mv[7]);
     int it = 0, status = 0;   // status: 1 converged, 2 cap, 3 not positive definite
     if (!dead) {
         w = matvec();
-        double g_old = 0.0, a_old = 0.0;
+        double inv_g = 0.0, inv_a = 0.0;   // 1 / gamma and 1 / alpha of the previous iteration
         if (!(bb > 0.0)) status = 1;   // b = 0: x = 0
         while (!status) {
             const double m = prec(w);
-            const double ru = r * u, wu = w * u, rr = r * r;
             SP_STAMP(8 + 4 * it);
-            publish(it + 1, m, sum_rows(ru), sum_rows(wu), sum_rows(rr));
+            publish(it + 1, m, r * u, w * u);
             SP_STAMP(9 + 4 * it);
-            double gam, dlt, rho;
-            gather(it + 1, gam, dlt, rho);
+            double gam, dlt;
+            gather(it + 1, gam, dlt);
             SP_STAMP(10 + 4 * it);
+            if (it == 0) { SP_VAL(410, gam); SP_VAL(411, dlt); SP_VAL(412, m); SP_VAL(413, w); }
             if (dead) break;
-            if (rho <= a.eta2 * bb) { status = 1; break; }
+            if (gam <= a.eta2 * bb) { status = 1; break; }
             if (it >= a.max_it) { status = 2; break; }
             const double nn = matvec();
             SP_STAMP(11 + 4 * it);
-            const double beta = it ? gam / g_old : 0.0;
-            const double den = it ? dlt - beta * gam / a_old : dlt;
-            if (!(den > 0.0) || !(gam > 0.0)) { status = 3; break; }   // p^T A p <= 0: the damped system is not positive definite in floating point
-            const double alpha = gam / den;
+            const double beta = gam * inv_g;                   // (0 in the first iteration)
+            const double den = dlt - beta * gam * inv_a;       // p^T A p
+            if (!(den > 0.0) || !(gam > 0.0)) { status = 3; break; }   // not positive definite in floating point
+            const double inv_den = rcp_refined(den);
+            const double alpha = gam * inv_den;
+            inv_a = den * (inv_g = rcp_refined(gam));
             z = fma(beta, z, nn);
             q = fma(beta, q, m);
             s = fma(beta, s, w);
@@ -275,7 +298,6 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             r = fma(-alpha, s, r);
             u = fma(-alpha, q, u);
             w = fma(-alpha, z, w);
-            g_old = gam; a_old = alpha;
             it++;
         }
     }
@@ -319,7 +341,7 @@ void launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     switch (P.nT) {
 #define SPCG_CASE(t) case t: launch_spcg_nt<t>(a, n_ent, st); break;
         SPCG_CASE(1) SPCG_CASE(2) SPCG_CASE(3) SPCG_CASE(4) SPCG_CASE(5) SPCG_CASE(6) SPCG_CASE(7) SPCG_CASE(8)
-        SPCG_CASE(9) SPCG_CASE(10) SPCG_CASE(11) SPCG_CASE(12) SPCG_CASE(13) SPCG_CASE(14) SPCG_CASE(15) SPCG_CASE(16)
+        SPCG_CASE(9) SPCG_CASE(10) SPCG_CASE(11) SPCG_CASE(12) SPCG_CASE(13) SPCG_CASE(14)
 #undef SPCG_CASE
         default: break;   // (spcg_fits() is checked when the solver is chosen)
     }

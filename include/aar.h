@@ -265,7 +265,7 @@ int aar_problem_create(const aar_problem_desc *, aar_problem **out);   /* = aar_
  * step to rounding and is what a NULL options pointer means.
  *   AAR_SOLVER_DIRECT  per-frame elimination (Schur complement) + dense blocked LDL^T of the reduced system: the reference's step
  *   AAR_SOLVER_SPCG    the same Schur complement, then block-Jacobi-preconditioned CG on the EXPLICIT reduced system, one wavefront
- *                      per camera / marker (csrc/spcg_kernels.hip), stopped at |r| <= pcg_eta |b|: an inexact LM step -- the trajectory is
+ *                      per camera / marker (csrc/spcg_kernels.hip), stopped at a relative residual pcg_eta: an inexact LM step -- the trajectory is
  *                      no longer the reference's step for step, its fixed point is (final reprojection error within 1e-5 px in every
  *                      measured case; bar 1e-4).  A solve that needs more than pcg_max_it iterations (cap 64) or whose hand-over times out
  *                      (device shared with another process) is redone with the direct chain automatically.  Needs 6 (C + M [+ C]) <= 1344.
@@ -282,7 +282,8 @@ typedef struct aar_solver_options {
     int32_t solver;                           /* AAR_SOLVER_*                                                                        */
     int32_t deterministic;                    /* 0 | 1                                                                               */
     int32_t pcg_max_it;                       /* iteration cap of an inner CG solve; 0 = default (PCG 200; SPCG 64, also its maximum)  */
-    double pcg_eta;                           /* forcing term |r| <= eta |b| of the inexact solvers; 0 = default (0.1)                 */
+    double pcg_eta;                           /* forcing term of the inexact solvers; 0 = default: PCG |r| <= 0.1 |b|, SPCG
+                                                 sqrt(r^T M^-1 r) <= 0.02 sqrt(b^T M^-1 b) (M = the block-Jacobi preconditioner)        */
 } aar_solver_options;
 void aar_solver_default_options(aar_solver_options *);   /* struct_size set, DIRECT, not deterministic, default eta / cap */
 int aar_problem_create_ex(const aar_problem_desc *, const aar_solver_options *, aar_problem **out);

@@ -3,6 +3,7 @@
 #define AAR_STAMPS 1
 #include "../../automatic-ar_amd/csrc/spcg_kernels.hip"
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 #include <random>
@@ -44,6 +45,9 @@ int main(int argc, char **argv) {
             printf("   it %2d: prec+shares+publish %llu | gather %llu (re-polls %d) | matvec %llu | scalars+updates %llu\n", k, st[9+4*k]-st[8+4*k], st[10+4*k]-st[9+4*k], polls[k+1],
                    st[11+4*k]-st[10+4*k], (k + 1 < it[0] ? st[8+4*(k+1)] : st[11+4*k]) - st[11+4*k]);
     }
+    { unsigned long long st[512]; (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_sp_stamps), sizeof st); int fl[4]; (void)hipMemcpy(fl, P.flags, 16, hipMemcpyDeviceToHost);
+      auto dv = [&](int k) { double d; memcpy(&d, &st[k], 8); return d; };
+      printf("flags %d %d %d %d | bb %g d1 %g u %g r %g mv0 %g mv6 %g mv7 %g | gam %g dlt %g m %g w %g\n", fl[0], fl[1], fl[2], fl[3], dv(400), dv(401), dv(402), dv(403), dv(404), dv(405), dv(406), dv(410), dv(411), dv(412), dv(413)); }
     std::vector<double> x(n); (void)hipMemcpy(x.data(), P.delta_s, 8*n, hipMemcpyDeviceToHost);
     double worst = 0;
     for (int i = 0; i < n; i++) { if (fx[i / 6]) continue; double s = 0; for (int j = 0; j < n; j++) { if (fx[j / 6]) continue; double a = (j <= i) ? S[(size_t)i*n+j] : S[(size_t)j*n+i]; s += (a + (i==j?0.5:0))*x[j]; } worst = fmax(worst, fabs(s - 1.0)); }
