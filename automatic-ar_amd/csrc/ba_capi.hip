@@ -808,6 +808,7 @@ int rebuild_current(aar_problem *pb) {
 int damped_try_fb(aar_problem *pb, double mu, bool evaluate_trial) {
     int rc = damped_try(pb, mu, evaluate_trial);
     if (rc != TRY_CG_FAILED) return rc;
+    if (evaluate_trial) pb->trial_points--;   // (the abandoned try's trial evaluation is not a residual evaluation of the LM loop)
     pb->trial_reduced = false;
     if ((rc = rebuild_current(pb))) return rc;
     pb->force_direct = true;
@@ -1154,6 +1155,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         pb->solver = solver;
         P.use_pcg = solver == AAR_SOLVER_PCG ? 1 : 0;
         P.use_spcg = solver == AAR_SOLVER_SPCG ? 1 : 0;
+        if (const char *t = getenv("AAR_SPCG_TEST_DROP")) P.spcg_test_drop = atoi(t);   // test hook: see kernels.h
         // forcing term: |r| <= 0.1 |b| for the CG through the frame blocks; the CG on the explicit system measures in the preconditioner's norm
         // (r^T M^-1 r, which its recurrences carry anyway), where 0.02 gives the same distance to the exact LM run
         P.pcg_eta = P.use_spcg ? 0.02 : 0.1;

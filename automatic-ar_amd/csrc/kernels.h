@@ -93,6 +93,7 @@ struct DeviceProblem {
     mutable int pcg_parity = 0;
     // solver spcg (spcg_kernels.hip): CG on the explicit Schur complement, one wavefront per shared entity
     int use_spcg = 0, spcg_max_it = SPCG_MAX_IT;
+    int spcg_test_drop = -1;              // test hook (AAR_SPCG_TEST_DROP=entity): that entity's wavefront never shows up -> every hand-over times out -> flag 4 -> direct chain
     double *spcg_ws = nullptr;            // [2][SPCG_BUFS][spcg_stride(n_pad)] hand-over slots (sentinel-filled when idle)
     int32_t *spcg_iters = nullptr;        // [0] iterations of the last solve, [1] running total, [2] solves, [3] solves that hit the cap (flag 8)
     mutable int spcg_parity = 0;

@@ -94,6 +94,7 @@ struct SpcgArgs {
     double *x_out;                    // [n_pad] delta_s
     int32_t *iters;                   // [0] iterations of this solve, [1] running total, [2] solves, [3] solves that hit the cap (flag 8)
     int32_t *flags;
+    int test_drop;                    // test hook (AAR_SPCG_TEST_DROP): the wavefront of this entity leaves without a word, as if it had never been scheduled
 };
 
 typedef unsigned int sp_u32x4 __attribute__((ext_vector_type(4)));
@@ -111,6 +112,7 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
         if (lane < 6) a.x_out[6 * e + lane] = 0.0;
         return;
     }
+    if (e == a.test_drop) return;
     double *set = a.ws + (size_t)a.parity * a.set_len, *other = a.ws + (size_t)(1 - a.parity) * a.set_len;
     // ---- every load of the set-up is issued before the first is used: one memory latency, not one per stage ----
     const int nprev_raw = a.iters[0];
@@ -127,13 +129,13 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     const bool ra = i < 6;
     const int row = 6 * e + (ra ? i : 0);
     double A2[2 * NK];
-    unsigned cfx = 0;   // bit k: column pair k belongs to a gauge / padding entity
+    unsigned long long cfx[(NK + 63) / 64] = {};   // bit k: column pair k belongs to a gauge / padding entity
 #pragma unroll
     for (int k = 0; k < NK; k++) {
         const int c0 = 16 * k + 2 * g, c1 = c0 + 1;
         A2[2 * k] = a.S[(c0 <= row) ? (size_t)row * a.n_pad + c0 : (size_t)c0 * a.n_pad + row];
         A2[2 * k + 1] = a.S[(c1 <= row) ? (size_t)row * a.n_pad + c1 : (size_t)c1 * a.n_pad + row];
-        if (fixed(c0 / 6)) cfx |= 1u << k;
+        if (fixed(c0 / 6)) cfx[k >> 6] |= 1ull << (k & 63);
     }
     double blk[6][6];
 #pragma unroll
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
 #pragma unroll
     for (int k = 0; k < NK; k++) {
         const int c0 = 16 * k + 2 * g;
-        const bool off = !ra || ((cfx >> k) & 1);
+        const bool off = !ra || ((cfx[k >> 6] >> (k & 63)) & 1);
         A2[2 * k] = off ? 0.0 : A2[2 * k] + (c0 == row ? a.mu : 0.0);
         A2[2 * k + 1] = off ? 0.0 : A2[2 * k + 1] + (c0 + 1 == row ? a.mu : 0.0);
     }
@@ -286,7 +288,12 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             SP_STAMP(11 + 4 * it);
             const double beta = gam * inv_g;                   // (0 in the first iteration)
             const double den = dlt - beta * gam * inv_a;       // p^T A p
-            if (!(den > 0.0) || !(gam > 0.0)) { status = 3; break; }   // not positive definite in floating point
+            if (!(den > 0.0) || !(gam > 0.0)) {
+                // p^T A p <= 0: the damped system is not positive definite in floating point -- unless the recurrences have simply reached their floor
+                // (a forcing term below what pipelined CG can attain: |r| / |b| ~ 1e-8 .. 1e-12): then x is as good as it gets
+                status = (gam <= 1e-16 * bb) ? 1 : 3;
+                break;
+            }
             const double inv_den = rcp_refined(den);
             const double alpha = gam * inv_den;
             inv_a = den * (inv_g = rcp_refined(gam));
@@ -334,7 +341,7 @@ void launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.S = b.S; a.rhs = b.rhs; a.g0 = b.g0; a.ent_fixed = P.ent_fixed; a.n = P.n; a.n_pad = P.n_pad;
     a.mu = mu; a.eta2 = P.pcg_eta * P.pcg_eta; a.max_it = std::min(P.spcg_max_it, SPCG_MAX_IT);
     a.ws = P.spcg_ws; a.stride = spcg_stride(P.n_pad); a.set_len = (long long)SPCG_BUFS * a.stride; a.parity = P.spcg_parity;
-    a.x_out = P.delta_s; a.iters = P.spcg_iters; a.flags = P.flags;
+    a.x_out = P.delta_s; a.iters = P.spcg_iters; a.flags = P.flags; a.test_drop = P.spcg_test_drop;
     P.spcg_parity ^= 1;
     const int n_ent = P.n_pad / 6;
     HookScope _h(P, KID_SPCG);

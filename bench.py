@@ -72,6 +72,7 @@ KERNEL_BOUND = {
     "k_ldl_diag": "latency", "k_ldl_backsolve": "latency", "k_reduce_scalars": "latency", "k_maxdiag": "latency",
     "k_backsub": "hbm", "k_frame_inv": "hbm", "k_unpack": "hbm",
     "k_pcg": "hbm",                    # --solver pcg: an iteration is two passes over the W blocks (288 B per (entity, frame) incidence)
+    "k_spcg": "latency",               # --solver spcg: one wavefront per entity, an iteration is one hand-over between them (~1.3 us) + a 6 x n matrix-vector product
 }
 
 
@@ -271,7 +272,7 @@ def main():
     ap.add_argument("--intrinsics", action="store_true", help="the reference's default Config: optimize_cam_intrinsics on (9 more parameters per camera, "
                     "libs/multicam_mapper.h:75-81); the headline metric is quoted WITHOUT it (SURVEY.md section 8 row f4)")
     ap.add_argument("--no-amdahl", action="store_true", help="skip the stage-timer pass behind the `amdahl` object")
-    ap.add_argument("--solver", choices=("direct", "spcg", "pcg", "auto"), default="direct", help="aar_solver_options.solver: direct (Schur complement + dense LDL^T, the "
+    ap.add_argument("--solver", choices=("direct", "spcg", "pcg", "auto"), default="auto", help="aar_solver_options.solver: direct (Schur complement + dense LDL^T, the "
                     "reference's step to rounding), spcg (the same Schur complement, then CG on the explicit reduced system, csrc/spcg_kernels.hip), pcg (CG through "
                     "the frame blocks, no Schur complement, csrc/pcg_kernels.hip), auto (the library picks by size and rank count)")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher / rendezvous / JSON relay only, no GPU work (CPU test of the N-rank plumbing)")
@@ -335,6 +336,7 @@ def main():
     if args.warmup > 0:
         run_steps(problem, x0, args.warmup, params)
     # ---- timed region: exactly K steps ----
+    solver = problem.solver_stats()["solver"]          # what AUTO resolved to
     pcg0 = problem.pcg_iterations()[1]
     barrier()
     t0 = time.perf_counter()
@@ -352,6 +354,26 @@ def main():
     # ---- full solve for the accuracy half of the metric ----
     x_fin, rep_fin = problem.lm_solve(x0, params=params())
     rmse, ss = problem.reproj_stats(x_fin)
+    # ---- the same through the direct solver (the reference's step to rounding): rate, LM steps to stop, final error -- what an inexact solver is judged against ----
+    direct = None
+    if solver != "direct":
+        with aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics, solver="direct") as pdir:
+            for _ in range(3):
+                pdir.lm_solve(x0, params=params(), trace_cap=1)
+            n_d = min(args.steps, 200)
+            run_steps(pdir, x0, min(args.warmup, 50), params)
+            barrier()
+            t0 = time.perf_counter()
+            run_steps(pdir, x0, n_d, params)
+            aar.lib().aar_device_synchronize()
+            dt_d = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt_d], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_d = float(t[0])
+            x_d, rep_d = pdir.lm_solve(x0, params=params())
+            rmse_d, _ = pdir.reproj_stats(x_d)
+            direct = {"it_per_s": n_d / dt_d, "steps": n_d, "lm_iterations_to_stop": rep_d["iterations"], "final_rmse_px": rmse_d}
 
     # ---- per-kernel device time: a second, instrumented pass over the same steps (HIP events on the library's stream) ----
     roofline, kernels = None, None
@@ -387,11 +409,15 @@ def main():
         def roof(k):
             avg_s = kernels[k]["avg_us"] * 1e-6
             by = algorithmic_bytes(k, n_loc, A, F, n_pad)
-            if k == "k_pcg":       # one pass over the W blocks for the preconditioner, two per CG iteration (SURVEY 8d has no row for this opt-in solver)
+            if k == "k_pcg":       # one pass over the W blocks for the preconditioner, two per CG iteration (SURVEY 8d has no row for this solver)
                 by = 288.0 * float(kf.sum()) / max(1, world) * (1.0 + 2.0 * pcg_total / float(done))
+            if k == "k_spcg":      # both triangles of the reduced system once into registers; a 6 x n product per wavefront per iteration (+ the one of the set-up)
+                by = 8.0 * n_pad * n_pad
             if k == "k_passA" and merged:
                 by += algorithmic_bytes("k_passB", n_loc, A, F, n_pad)
             fl = algorithmic_flops(k, n_loc, n_pad, sum_kf2, merged)
+            if k == "k_spcg":
+                fl = 2.0 * n_pad * n_pad * (1.0 + pcg_total / float(done))
             kind = KERNEL_BOUND.get(k, "hbm")
             if k == "k_schur" and (A >= 96 or os.environ.get("AAR_SCHUR_MFMA") == "1") and os.environ.get("AAR_SCHUR_MFMA") != "0":
                 kind = "fp64_mfma"     # from 96 shared entities on: dense panels through the fp64 matrix pipes (k_schur_fill + k_schur_mfma)
@@ -427,7 +453,7 @@ def main():
 
     # ---- where the step's time goes by how it scales with the rank count: a third, stage-timed pass ----
     amdahl = None
-    if not args.no_amdahl and args.solver == "direct":     # (the PCG mode has no replicated part to speak of: nothing for this split to say)
+    if not args.no_amdahl and solver != "pcg":     # (the PCG solver has no replicated part to speak of: nothing for this split to say)
         n_am = min(args.steps, 300)
         problem.set_stage_timers(True)
         acc, done_am = {}, 0
@@ -479,12 +505,16 @@ def main():
                    "frames": ds.num_frames, "marker_observations": int(ds.num_obs), "residual_rows": int(8 * ds.num_obs), "unknowns": int(P),
                    "reduced_unknowns": int(Ps), "parallelism": "frames sharded over %d GPU(s)" % world, "seed": 20190219 + args.workload,
                    "residual_mode": "float32-faithful", "jacobian": "analytic",
-                   "optimize_cam_intrinsics": bool(args.intrinsics), "solver": args.solver},
+                   "optimize_cam_intrinsics": bool(args.intrinsics), "solver": args.solver, "solver_resolved": solver},
         "final_rmse_px": rmse, "final_sum_sq": ss, "lm_iterations_to_stop": rep_fin["iterations"], "trial_points_per_step": t_avg,
         "iteration_hbm": {"bytes_per_iteration": b_iter, "achieved": b_iter * done / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                           "frac": b_iter * done / dt / 1e9 / HBM_PEAK_GBPS},
         "roofline": roofline, "kernels": kernels, "amdahl": amdahl, "track": track,
-        "pcg_iterations_per_lm_step": (pcg_total / float(done)) if args.solver == "pcg" else None,
+        "pcg_iterations_per_lm_step": (pcg_total / float(done)) if solver != "direct" else None,
+        "solver_stats": problem.solver_stats(),
+        # the direct solver on the same problem (the reference's step to rounding): what the inexact default is judged against
+        "direct_it_per_s": direct["it_per_s"] if direct else None, "direct": direct,
+        "rmse_delta_vs_direct_px": abs(rmse - direct["final_rmse_px"]) if direct else None,
         # multi-GPU bookkeeping: ranks RCCL itself reports for the communicator, observations per rank (frame-range shards
         # balanced by observation count), payload of ONE all-reduce of the reduced system (packed lower triangle | rhs | g0 | scalars)
         "ranks_seen": comm_stats["ranks_seen"] if comm_stats else 1, "local_obs": per_rank_obs,

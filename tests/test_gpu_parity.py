@@ -998,9 +998,8 @@ def test_reference_shaped_solver_calls_compile_and_run_against_the_mirror(tmp_pa
     assert int(kv["track_frames"]) == ds.num_frames and int(kv["track_zlen"]) == 6 * ds.num_frames and float(kv["track_max_err"]) < 100.0
 
 
-def _det_run(ds, monkeypatch, det, with_huber=False, intrinsics=False, **solve_kw):
-    monkeypatch.setenv("AAR_DETERMINISTIC", "1" if det else "0")
-    with aar.Problem(ds, with_huber=with_huber, intrinsics=intrinsics) as p:
+def _det_run(ds, det, with_huber=False, intrinsics=False, **solve_kw):
+    with aar.Problem(ds, with_huber=with_huber, intrinsics=intrinsics, deterministic=det) as p:
         x0 = p.x_with_intrinsics(ds.x_full) if intrinsics else ds.x_full
         H, B, ss = p.eval_normal_equations(x0)
         d = p.eval_damped_step(x0, 1e3)
@@ -1009,15 +1008,15 @@ def _det_run(ds, monkeypatch, det, with_huber=False, intrinsics=False, **solve_k
 
 
 @pytest.mark.parametrize("name,kw", [("g1_cfg2", {}), ("g1_cfg2_huber", {"with_huber": True}), ("g1_cfg2_intr", {"intrinsics": True}), ("g1_cfg3_cut", {})])
-def test_deterministic_mode_gives_the_same_bits_twice(name, kw, monkeypatch):
-    # AAR_DETERMINISTIC=1 (csrc/kernels.h): every sum the default path leaves to fp64 atomics is taken in a fixed order, as the
+def test_deterministic_mode_gives_the_same_bits_twice(name, kw):
+    # aar_solver_options.deterministic (csrc/kernels.h): every sum the default path leaves to fp64 atomics is taken in a fixed order, as the
     # reference's ascending-row accumulation is (libs/sparselevmarq.h:291-303).  Normal equations, a damped step, the solution and
     # the whole LM trace (505 steps with -with-huber) come out bit-identical in two runs -- and agree with the default path.
     ds, g = load_golden(name)
-    a, b = _det_run(ds, monkeypatch, True, **kw), _det_run(ds, monkeypatch, True, **kw)
+    a, b = _det_run(ds, True, **kw), _det_run(ds, True, **kw)
     for u, v in zip(a, b):
         assert np.array_equal(u, v)
-    c = _det_run(ds, monkeypatch, False, **kw)
+    c = _det_run(ds, False, **kw)
     assert np.abs(a[0] - c[0]).max() / np.abs(c[0]).max() < 1e-14 and np.abs(a[1] - c[1]).max() / np.abs(c[1]).max() < 1e-12
     assert np.abs(a[2] - c[2]).max() / np.abs(c[2]).max() < 1e-9
     n = len(g["analytic_err"])
@@ -1027,13 +1026,12 @@ def test_deterministic_mode_gives_the_same_bits_twice(name, kw, monkeypatch):
         np.testing.assert_allclose(a[5], g["analytic_mu"], rtol=1e-9)
 
 
-def test_deterministic_mode_tightens_the_retry_trace(monkeypatch):
+def test_deterministic_mode_tightens_the_retry_trace():
     # the same run as test_huber_schedule_with_a_rejected_try: with fixed-order sums the damping follows the real solver's to
     # 1e-9 over the first 60 steps (2e-4 is what the default path's atomics allow: their order moves mu between runs)
-    monkeypatch.setenv("AAR_DETERMINISTIC", "1")
     ds, g = load_golden("g1_cfg2_huber_retry")
     prm = aar.lm_default_params(tau=float(g["tau"][0]))
-    with aar.Problem(ds, with_huber=True) as p:
+    with aar.Problem(ds, with_huber=True, deterministic=True) as p:
         x, rep = p.lm_solve(ds.x_full, params=prm, trace_cap=600)
     k = 60
     assert max(t["tries"] for t in rep["trace"]) > 1
@@ -1044,27 +1042,26 @@ def test_deterministic_mode_tightens_the_retry_trace(monkeypatch):
     assert rep["iterations"] == int(g["analytic_iterations"][0])
 
 
-def test_deterministic_mode_on_a_many_entity_problem(monkeypatch):
+def test_deterministic_mode_on_a_many_entity_problem():
     # 124 shared entities: the default path would take the MFMA Schur kernel; deterministic mode keeps the output-stationary one
     # (fixed-order sums exist for it only) -- same step to rounding, same bits twice; beyond its LDS row panel the mode is refused
     ds = aar.synth(3, num_cams=4, num_markers=120, num_frames=24)
-    monkeypatch.setenv("AAR_DETERMINISTIC", "1")
-    with aar.Problem(ds) as p:
+    with aar.Problem(ds, deterministic=True) as p:
         d1 = p.eval_damped_step(ds.x_full, 1e3)
-    with aar.Problem(ds) as p:
+        assert p.solver_stats()["deterministic"]
+    with aar.Problem(ds, deterministic=True) as p:
         d2 = p.eval_damped_step(ds.x_full, 1e3)
-    monkeypatch.setenv("AAR_DETERMINISTIC", "0")
     with aar.Problem(ds) as p:
         d0 = p.eval_damped_step(ds.x_full, 1e3)
+        assert not p.solver_stats()["deterministic"]
     assert np.array_equal(d1, d2) and np.abs(d1 - d0).max() / np.abs(d0).max() < 1e-9
-    monkeypatch.setenv("AAR_DETERMINISTIC", "1")
     with pytest.raises(aar.AarError) as e:
-        aar.Problem(aar.synth(3, num_cams=4, num_markers=596, num_frames=24))
+        aar.Problem(aar.synth(3, num_cams=4, num_markers=596, num_frames=24), deterministic=True)
     assert e.value.code == aar.AAR_ERR_UNSUPPORTED
 
 
-def test_pcg_solver_mode_against_the_direct_path(monkeypatch):
-    # AAR_SOLVER=pcg (csrc/pcg_kernels.hip, opt-in): the reduced system by preconditioned CG through the frame blocks.  At a tight
+def test_pcg_solver_mode_against_the_direct_path():
+    # aar_solver_options.solver = AAR_SOLVER_PCG (csrc/pcg_kernels.hip): the reduced system by preconditioned CG through the frame blocks.  At a tight
     # tolerance its damped step IS the direct step (and the oracle's); at the default forcing term (eta = 0.1) the LM run is inexact
     # Newton -- another trajectory to the same fixed point: final RMSE within the north star's 1e-4 px (observed: 1e-6), no more LM steps
     ds = aar.synth(3, num_frames=120)
@@ -1074,18 +1071,16 @@ def test_pcg_solver_mode_against_the_direct_path(monkeypatch):
         x_d, rep_d = p.lm_solve(ds.x_full)
         rmse_d, _ = p.reproj_stats(x_d)
         assert p.pcg_iterations() == (0, 0)
-    monkeypatch.setenv("AAR_SOLVER", "pcg")
-    monkeypatch.setenv("AAR_PCG_ETA", "1e-11")
-    with aar.Problem(ds) as p:
+    with aar.Problem(ds, solver="pcg", pcg_eta=1e-11) as p:
         d_pcg = p.eval_damped_step(ds.x_full, 1e3)
         last, total = p.pcg_iterations()
         assert 5 < last == total < 200
     do = o.damped_solve(ds.x_full, 1e3, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
     assert np.abs(d_pcg - d_direct).max() / np.abs(d_direct).max() < 1e-7
     assert np.abs(d_pcg - do).max() / np.abs(do).max() < 1e-7
-    monkeypatch.setenv("AAR_PCG_ETA", "0.1")
     for opt in ((True, True, True), (False, True, True), (True, False, True)):      # gauge / switched-off groups are identity rows of the operator
-        with aar.Problem(ds, optimize=opt) as p:
+        with aar.Problem(ds, optimize=opt, solver="pcg") as p:
+            assert p.solver_stats()["pcg_eta"] == 0.1
             x_p, rep_p = p.lm_solve(ds.x_full)
             rmse_p, _ = p.reproj_stats(x_p)
             its = p.pcg_iterations()[1]
@@ -1093,29 +1088,25 @@ def test_pcg_solver_mode_against_the_direct_path(monkeypatch):
             assert abs(rmse_p - rmse_d) < 1e-4 and abs(rmse_p - rmse_d) < 1e-5
             assert rep_p["iterations"] <= rep_d["iterations"] + 2 and 0 < its < 40 * rep_p["iterations"]
         else:
-            monkeypatch.setenv("AAR_SOLVER", "direct")
             with aar.Problem(ds, optimize=opt) as q:
                 x_q, _ = q.lm_solve(ds.x_full)
                 rmse_q, _ = q.reproj_stats(x_q)
-            monkeypatch.setenv("AAR_SOLVER", "pcg")
             assert abs(rmse_p - rmse_q) < 1e-4
     # the reference's default Config (intrinsics entities are shared entities like any other) and -with-huber go through the same operator
-    with aar.Problem(ds, intrinsics=True) as p:
+    with aar.Problem(ds, intrinsics=True, solver="pcg") as p:
         x_i, rep_i = p.lm_solve(p.x_with_intrinsics(ds.x_full))
         rmse_i, _ = p.reproj_stats(x_i)
-    monkeypatch.setenv("AAR_SOLVER", "direct")
     with aar.Problem(ds, intrinsics=True) as q:
         x_j, rep_j = q.lm_solve(q.x_with_intrinsics(ds.x_full))
         rmse_j, _ = q.reproj_stats(x_j)
-    monkeypatch.setenv("AAR_SOLVER", "pcg")
     assert abs(rmse_i - rmse_j) < 1e-4
     # frames sharded over ranks: the operator is a sum over ranks (one all-reduce of 8 n bytes per CG iteration, queued by the host between two
     # launches); same LM steps, the same solution and (almost) the same CG iteration counts as on one GPU
-    with aar.Problem(ds) as p:
+    with aar.Problem(ds, solver="pcg") as p:
         x_1, rep_1 = p.lm_solve(ds.x_full)
         its_1 = p.pcg_iterations()[1]
     def solve(comm, rank):
-        with aar.Problem(ds, comm=comm) as q:
+        with aar.Problem(ds, comm=comm, solver="pcg") as q:
             xs, reps = q.lm_solve(ds.x_full)
             return xs, reps, q.pcg_iterations()[1]
     for world in (2, 3):
@@ -1127,12 +1118,11 @@ def test_pcg_solver_mode_against_the_direct_path(monkeypatch):
             np.testing.assert_allclose(xs, x_1, atol=1e-5)
 
 
-def test_deterministic_mode_with_two_ranks(monkeypatch):
+def test_deterministic_mode_with_two_ranks():
     # fixed-order sums rank by rank, the in-process group adds the ranks' systems in rank order: two sharded runs give the same bits
-    monkeypatch.setenv("AAR_DETERMINISTIC", "1")
     ds, g = load_golden("g1_cfg2")
     def solve(comm, rank):
-        with aar.Problem(ds, comm=comm) as q:
+        with aar.Problem(ds, comm=comm, deterministic=True) as q:
             return q.lm_solve(ds.x_full)
     a = _run_ranks(2, solve)
     b = _run_ranks(2, solve)
@@ -1142,16 +1132,12 @@ def test_deterministic_mode_with_two_ranks(monkeypatch):
     np.testing.assert_allclose([t["err"] for t in a[0][1]["trace"]], g["analytic_err"], rtol=1e-7)
 
 
-@pytest.mark.parametrize("mode", ["deterministic", "pcg"])
-def test_randomized_shapes_in_the_optional_modes(mode, monkeypatch):
+@pytest.mark.parametrize("mode", ["deterministic", "pcg", "spcg"])
+def test_randomized_shapes_in_the_optional_modes(mode):
     # the same sweep of shapes as test_randomized_shapes_against_oracle (1-5 tiles, ragged visibility, switched-off groups, 2-3 in-process ranks
-    # now and then) through AAR_DETERMINISTIC=1 and through AAR_SOLVER=pcg at a tight tolerance: the damped step is the oracle's in both
-    if mode == "deterministic":
-        monkeypatch.setenv("AAR_DETERMINISTIC", "1")
-    else:
-        monkeypatch.setenv("AAR_SOLVER", "pcg")
-        monkeypatch.setenv("AAR_PCG_ETA", "1e-12")
-        monkeypatch.setenv("AAR_PCG_MAX_IT", "2000")
+    # now and then) with deterministic sums, through the PCG solver and through the CG on the explicit reduced system at a tight tolerance
+    # (whatever needs more than its 64 iterations falls back to the direct chain by itself): the damped step is the oracle's in all three
+    kw = {"deterministic": dict(deterministic=True), "pcg": dict(solver="pcg", pcg_eta=1e-12, pcg_max_it=2000), "spcg": dict(solver="spcg", pcg_eta=1e-12)}[mode]
     rng = np.random.default_rng(20190221)
     done = 0
     for k in range(40):
@@ -1166,7 +1152,7 @@ def test_randomized_shapes_in_the_optional_modes(mode, monkeypatch):
         o = ol.Oracle(ds, optimize=opt)
         mu = float(10.0 ** rng.integers(2, 7))
         do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
-        with aar.Problem(ds, optimize=opt) as p:
+        with aar.Problem(ds, optimize=opt, **kw) as p:
             d = p.eval_damped_step(ds.x_full, mu)
             assert np.abs(d - do).max() / np.abs(do).max() < 1e-6, (mode, C, M, F, mu)
             x, rep = p.lm_solve(ds.x_full)
@@ -1175,7 +1161,7 @@ def test_randomized_shapes_in_the_optional_modes(mode, monkeypatch):
         np.testing.assert_allclose(rep["final_err"], repo["final_err"], rtol=1e-5, err_msg=str((mode, C, M, F)))
         if k % 3 == 0 and opt == (True, True, True):
             def solve(comm, rank, ds=ds):
-                with aar.Problem(ds, comm=comm) as q:
+                with aar.Problem(ds, comm=comm, **kw) as q:
                     return q.lm_solve(ds.x_full)
             for xs, reps in _run_ranks(2 + k % 2, solve):
                 assert abs(reps["iterations"] - rep["iterations"]) <= 1, (mode, C, M, F)
