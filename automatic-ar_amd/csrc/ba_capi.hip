@@ -639,12 +639,28 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
                     volatile unsigned long long *sq = reinterpret_cast<volatile unsigned long long *>(pb->h_pcg) + 3;
                     const auto t0 = std::chrono::steady_clock::now();
                     unsigned spins = 0;
+                    int poll_rc = AAR_OK;
                     while (*sq != pb->pcg_seq) {
-                        if ((++spins & 0x3fff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
-                            return set_error(AAR_ERR_HIP, "timed out waiting for the PCG progress record");
+                        if ((++spins & 0x3fff) == 0) {
+                            if (hipStreamQuery(pb->stream) == hipSuccess && *sq != pb->pcg_seq) {   // the stream drained but the record is stale: an asynchronous failure
+                                poll_rc = set_error(AAR_ERR_HIP, "device did not publish the PCG progress record: %s", hipGetErrorString(hipGetLastError()));
+                                break;
+                            }
+                            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+                                poll_rc = set_error(AAR_ERR_HIP, "timed out waiting for the PCG progress record");
+                                break;
+                            }
+                        }
                         __builtin_ia32_pause();
                     }
                     std::atomic_thread_fence(std::memory_order_acquire);
+                    {   // a rank that failed alone would leave the others waiting in the next all-reduce: agree on the outcome first
+                        int agreed = poll_rc;
+                        int rc2 = collective_status(pb, poll_rc, &agreed);
+                        if (rc2) return rc2;
+                        if (poll_rc) return poll_rc;
+                        if (agreed) return set_error(agreed, "another rank lost its PCG progress record (status %d)", agreed);
+                    }
                     if (pb->h_pcg[0] != 0.0 || last) break;
                 }
                 { StageTimer t(pb, &pb->times.allreduce); int rc = allreduce(pb, P.pcgd_y, (size_t)6 * P.A, NCCL_SUM); if (rc) return rc; }
@@ -1442,6 +1458,12 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
             if (hipHostGetDevicePointer((void **)&P.pcgd_host, pb->h_pcg, 0) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "hipHostGetDevicePointer failed"));
         }
         if (const char *t = getenv("AAR_PCG_GRID")) P.pcg_grid = std::max(1, atoi(t));
+        // the kernels' grid-wide hand-overs need every workgroup resident: never more than the occupancy query admits (the override included)
+        {
+            hipDeviceProp_t prop2;
+            const int cus2 = (hipGetDeviceProperties(&prop2, pb->device) == hipSuccess && prop2.multiProcessorCount > 0) ? prop2.multiProcessorCount : 64;
+            P.pcg_grid = std::min(P.pcg_grid, pcg_max_grid(A, cus2));
+        }
     }
     if (P.use_spcg) {
         AL(spcg_ws, spcg_ws_doubles(P.n_pad)); AL(spcg_iters, 4);

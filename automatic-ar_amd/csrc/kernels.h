@@ -179,6 +179,7 @@ bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, i
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
 void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st);     // AAR_SOLVER=pcg: delta_s by PCG through the frame blocks (needs Vinv, hf for mu)
 size_t pcg_lds_bytes(int A);
+int pcg_max_grid(int A, int cus);   // largest co-resident grid of the persistent PCG kernels
 // solver spcg: delta_s by CG on the explicit reduced system S of block set `which` (the Schur complement for mu must have been taken; S is not modified)
 void launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st);
 bool spcg_fits(int nT);                                    // the system's rows fit the wavefronts' registers

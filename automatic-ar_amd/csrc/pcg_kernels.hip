@@ -46,7 +46,12 @@ __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_sto
 __device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Every workgroup of the (co-resident) grid arrives; what it stored with st_agent before is visible to all afterwards.
-__device__ __forceinline__ void grid_hop(int32_t *counter, int &round, int G, int32_t *flags) {
+// false: the grid is not whole -- this workgroup waited 2^26 polls for the others, or somebody else already has (device flag 4) -- and every
+// workgroup LEAVES the kernel at its next hop instead of spinning through the remaining ones (up to two per CG iteration): the launch ends within
+// one time-out, the host reports AAR_ERR_NUMERIC ("chain timed out").  Co-residency itself is not assumed blindly: the grid is clamped to what the
+// occupancy query admits (pcg_max_grid).
+__device__ __forceinline__ bool grid_hop(int32_t *counter, int &round, int G, int32_t *flags) {
+    __shared__ int hop_dead;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have been acknowledged
     __syncthreads();
     round++;
@@ -54,12 +59,16 @@ __device__ __forceinline__ void grid_hop(int32_t *counter, int &round, int G, in
         __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int target = round * G;
         long spins = 0;
+        int dead = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1L << 26)) { atomicOr(flags, 4); break; }   // never a hung device
+            if ((++spins & 0x3ff) == 0 && (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) { dead = 1; break; }   // another workgroup gave up: its arrivals will never come
+            if (spins > (1L << 26)) { atomicOr(flags, 4); dead = 1; break; }   // never a hung device
         }
+        hop_dead = dead;
     }
     __syncthreads();
+    return hop_dead == 0;
 }
 
 // sum of NV per-thread values over the 256 threads, fixed order; result in out[0..NV) on every thread.  lds: 4 * NV doubles
@@ -139,7 +148,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
             for (int i = 0; i < 27; i++) st_agent(a.part + (size_t)it * 28 + i, acc[i]);
         }
     }
-    grid_hop(counter, round, G, a.flags);
+    if (!grid_hop(counter, round, G, a.flags)) return;
     // ---- set-up, second half, redundantly in every workgroup (one thread per entity): the items' shares in item order, the diagonal
     //      block of S inverted straight into LDS, the right-hand side; x = 0, r = b ----
     for (int e = tid; e < a.A; e += PCG_THREADS) {
@@ -224,7 +233,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
                 st_agent(a.t + (size_t)f * 6 + lane, tv);
             }
         }
-        grid_hop(counter, round, G, a.flags);
+        if (!grid_hop(counter, round, G, a.flags)) return;
         // ---- entity pass, by item: its share of -sum_f W_ef t_f; the entity's first item also carries (U p)_e ----
         for (int it = wg; it < a.n_items; it += G) {
             const int e = a.it_ent[it];
@@ -258,7 +267,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
             block_sum<6>(acc, red);
             if (tid < 6) st_agent(a.part + (size_t)it * 28 + tid, acc[tid]);
         }
-        grid_hop(counter, round, G, a.flags);
+        if (!grid_hop(counter, round, G, a.flags)) return;
         // ---- vector updates, redundantly in every workgroup (same numbers, same order: same decisions) ----
         // y = S p: the items' shares of every entry, ALL requested before the first is used (an agent-scope load is ~1 us: one round
         // trip, not one per item), added in item order; + mu p; identity rows for gauge entities
@@ -393,7 +402,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_setup(const PcgDistArgs d)
     int round = 0;
     if (wg == 0 && tid == 0) __hip_atomic_store(a.counter + (1 - a.parity), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pcgd_items_setup(a, red, wg, G, tid);
-    grid_hop(counter, round, G, a.flags);
+    if (!grid_hop(counter, round, G, a.flags)) return;
     for (int e = wg * PCG_THREADS + tid; e < a.A; e += G * PCG_THREADS) {
         double acc[27];
 #pragma unroll
@@ -560,7 +569,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter(const PcgDistArgs d) 
             st_agent(a.t + (size_t)f * 6 + lane, tv);
         }
     }
-    grid_hop(counter, round, G, a.flags);
+    if (!grid_hop(counter, round, G, a.flags)) { publish(1.0, itc); return; }   // (the host stops queueing; device flag 4 says why)
     // ---- entity pass over this rank's incidences, by item; the entity's first item also carries (U_rank p)_e ----
     for (int it = wg; it < a.n_items; it += G) {
         const int e = a.it_ent[it];
@@ -594,7 +603,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter(const PcgDistArgs d) 
         block_sum<6>(acc, red);
         if (tid < 6) st_agent(a.part + (size_t)it * 28 + tid, acc[tid]);
     }
-    grid_hop(counter, round, G, a.flags);
+    if (!grid_hop(counter, round, G, a.flags)) { publish(1.0, itc); return; }
     // ---- this rank's partial y (the items' shares in item order), the CG state back to memory ----
     for (int i = wg * PCG_THREADS + tid; i < n; i += G * PCG_THREADS) {
         const int e = i / 6, row = i - 6 * e;
@@ -616,6 +625,19 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter(const PcgDistArgs d) 
 }
 
 size_t pcg_lds_bytes(int A) { return ((size_t)9 * 6 * A + 4 * 27 + 8) * sizeof(double); }
+
+// the largest grid of the persistent PCG kernels that is resident as a whole (their hand-overs wait for every workgroup): what the occupancy query
+// admits per CU for the kernel with the larger footprint, times the CUs
+int pcg_max_grid(int A, int cus) {
+    const size_t lds = pcg_lds_bytes(A);
+    static size_t g1 = 48 * 1024, g2 = 48 * 1024;
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, g1);
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter), lds, g2);
+    int n1 = 0, n2 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_pcg, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n1 = 1; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_pcgd_iter, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n2 = 1; }
+    return std::max(1, std::min(n1, n2)) * cus;
+}
 
 void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];

@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--solver", choices=("direct", "spcg", "pcg", "auto"), default="auto", help="aar_solver_options.solver: direct (Schur complement + dense LDL^T, the "
                     "reference's step to rounding), spcg (the same Schur complement, then CG on the explicit reduced system, csrc/spcg_kernels.hip), pcg (CG through "
                     "the frame blocks, no Schur complement, csrc/pcg_kernels.hip), auto (the library picks by size and rank count)")
+    ap.add_argument("--no-direct", action="store_true", help="skip the comparison leg through the direct solver (profiling runs: only the chosen solver's kernels in the trace)")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher / rendezvous / JSON relay only, no GPU work (CPU test of the N-rank plumbing)")
     args = ap.parse_args()
 
@@ -356,7 +357,7 @@ def main():
     rmse, ss = problem.reproj_stats(x_fin)
     # ---- the same through the direct solver (the reference's step to rounding): rate, LM steps to stop, final error -- what an inexact solver is judged against ----
     direct = None
-    if solver != "direct":
+    if solver != "direct" and not args.no_direct:
         with aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics, solver="direct") as pdir:
             for _ in range(3):
                 pdir.lm_solve(x0, params=params(), trace_cap=1)
