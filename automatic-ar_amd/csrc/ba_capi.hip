@@ -654,13 +654,10 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
                         __builtin_ia32_pause();
                     }
                     std::atomic_thread_fence(std::memory_order_acquire);
-                    {   // a rank that failed alone would leave the others waiting in the next all-reduce: agree on the outcome first
-                        int agreed = poll_rc;
-                        int rc2 = collective_status(pb, poll_rc, &agreed);
-                        if (rc2) return rc2;
-                        if (poll_rc) return poll_rc;
-                        if (agreed) return set_error(agreed, "another rank lost its PCG progress record (status %d)", agreed);
-                    }
+                    // (a rank whose device has faulted or hangs cannot tell the others: its stream carries nothing any more, and an agreement per poll --
+                    //  one more collective -- would cost every healthy step ~50 us; the peers then sit in their next all-reduce until the launcher's
+                    //  watchdog ends the job, as with any rank that dies mid-collective)
+                    if (poll_rc) return poll_rc;
                     if (pb->h_pcg[0] != 0.0 || last) break;
                 }
                 { StageTimer t(pb, &pb->times.allreduce); int rc = allreduce(pb, P.pcgd_y, (size_t)6 * P.A, NCCL_SUM); if (rc) return rc; }
