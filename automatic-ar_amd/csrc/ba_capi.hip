@@ -325,8 +325,7 @@ int allreduce_system(aar_problem *pb, int which, int n_tail, unsigned long long 
     // Small systems travel as they lie -- the square S (its upper triangle is never written: zeros) | rhs | g0 | tail are ONE allocation --
     // without the two packing launches: below ~1 MB an all-reduce over xGMI is latency, not bytes, and each launch on this dependent
     // chain costs 3-4 us.  From 384 unknowns on (2.4 MB square) the packed triangle's halved payload wins.  AAR_PACK_SYSTEM=0 / 1 forces.
-    static const int pack_env = getenv("AAR_PACK_SYSTEM") ? atoi(getenv("AAR_PACK_SYSTEM")) : -1;
-    const bool pack = pack_env >= 0 ? pack_env != 0 : P.n_pad > 384;
+    const bool pack = P.tune.pack_system >= 0 ? P.tune.pack_system != 0 : P.n_pad > 384;
     if (!pack) {
         const size_t count = (size_t)P.n_pad * P.n_pad + 2 * (size_t)P.n_pad + (size_t)n_tail;
         int rc = allreduce(pb, P.blk[which].S, count, NCCL_SUM);
@@ -875,6 +874,12 @@ int initial_mu(aar_problem *pb, double tau, double *mu) {
         rc = allreduce(pb, P.scal + 4, 1, NCCL_MAX);
         if (rc) return rc;
     } else {
+        if (pb->schur_mu >= 0) {   // (the init head start has already reduced S for its damping: the diagonal of J^T J is read from the blocks, so give the terms back first)
+            launch_schur(P, cur, -1.0, pb->stream, 0, 0, nullptr, panels_ok(pb, cur, pb->schur_mu));
+            panels_now(pb, cur, pb->schur_mu);
+            pb->schur_mu = -1;
+            pb->launches += 1;
+        }
         launch_maxdiag(P, cur, pb->stream);
     }
     pb->launches += 1;
@@ -1149,6 +1154,12 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
     // entities -- so they must fit a budget (half of the free device memory; AAR_SCHUR_PANEL_MB overrides), else the
     // output-stationary kernel, which needs none of this, takes over.  Only THAT kernel keeps a row panel of all entities in LDS.
     P.deterministic = so.deterministic ? 1 : 0;
+    {   // tuning switches of this problem (kernels.h, DeviceProblem::Tuning)
+        auto env_int = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
+        env_int("AAR_FUSED_PANEL", P.tune.fused_panel); env_int("AAR_BS_RIDES", P.tune.bs_rides); env_int("AAR_BACKSUB_RIDES", P.tune.backsub_rides);
+        env_int("AAR_LDL_LOOKAHEAD", P.tune.lookahead); env_int("AAR_PASSA_VARIANT", P.tune.passA_variant); env_int("AAR_PACK_SYSTEM", P.tune.pack_system);
+        env_int("AAR_INIT_HEADSTART", P.tune.init_headstart);
+    }
     { const char *e = getenv("AAR_DENSE_FROM_PASSA"); if (e) P.dense_from_passA = atoi(e) != 0 ? 1 : 0; }
     {   // which solver (aar_solver_options; AUTO: DESIGN.md section 12)
         hipDeviceProp_t prop;
@@ -1690,8 +1701,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     // can read it, and the frame inverses and the Schur complement need nothing else -- they are queued HERE, with mu_0 read on the device, and
     // run while the record travels to the host and the host queues the factorisation.  (tau changed between init and step: the damped try finds
     // another damping than schur_mu and takes the complement back, as after a mispredicted step.)  AAR_INIT_HEADSTART=0: off.
-    static const bool headstart_on = !(getenv("AAR_INIT_HEADSTART") && atoi(getenv("AAR_INIT_HEADSTART")) == 0);
-    const bool headstart = headstart_on && !pb->comm && !P.use_pcg && !pb->stage_timers && !pb->profiling && P.F > 0;
+    const bool headstart = P.tune.init_headstart && !pb->comm && !P.use_pcg && !pb->stage_timers && !pb->profiling && P.F > 0;
     if (headstart) {
         launch_frame_inv(P, 0, 0.0, pb->stream, P.scal + 4, pb->prm.tau);
         launch_schur(P, 0, 1.0, pb->stream, 0, 0, nullptr, false);

@@ -732,7 +732,7 @@ static void launch_passA_any(const DeviceProblem &P, const PassAArgs &a, const P
     // two wavefronts above
     const double avg = (double)P.N / (double)P.F;
     if (P.deterministic && avg > 96) return launch_passA_t<64, 4>(P, a, pbargs, st);   // ONE wavefront per frame: its LDS additions come in program order
-    static const int var = getenv("AAR_PASSA_VARIANT") ? atoi(getenv("AAR_PASSA_VARIANT")) : 0;   // experiments: 1281 / 1282 / 1284 / 2564
+    const int var = P.tune.passA_variant;   // experiments (AAR_PASSA_VARIANT): 1281 / 1282 / 1284 / 2564
     if (var == 1281) return launch_passA_t<128, 1>(P, a, pbargs, st);
     if (var == 1282) return launch_passA_t<128, 2>(P, a, pbargs, st);
     if (var == 1284) return launch_passA_t<128, 4>(P, a, pbargs, st);

@@ -100,6 +100,17 @@ struct DeviceProblem {
     // ... with frames sharded over ranks: this rank's set-up share [A][28] (all-reduced), Minv [A][36], x | r | p | scalars [3 n + 8],
     // this rank's partial y [n] (all-reduced per iteration), mapped host record {done, iterations, -, sequence}
     double *pcgd_setup = nullptr, *pcgd_minv = nullptr, *pcgd_state = nullptr, *pcgd_y = nullptr, *pcgd_host = nullptr;
+    // tuning switches (environment, read when THE PROBLEM is created -- aar_problem_create_ex -- so that two problems of one process may differ;
+    // defaults are the measured optima)
+    struct Tuning {
+        int fused_panel = 3;       // AAR_FUSED_PANEL: block columns with at most this many tiles below the diagonal take k_ldl_panel
+        int bs_rides = 1;          // AAR_BS_RIDES=0: the back-substitution of 2-3 tile systems as its own chained launch
+        int backsub_rides = 0;     // AAR_BACKSUB_RIDES=1: the frame back-substitution rides in the last tile's launch
+        int lookahead = 1;         // AAR_LDL_LOOKAHEAD=0: tall block columns launch k_ldl_update
+        int passA_variant = 0;     // AAR_PASSA_VARIANT: 1281 / 1282 / 1284 / 2564 force a pass A workgroup shape
+        int pack_system = -1;      // AAR_PACK_SYSTEM=0/1: the reduced system travels as it lies / as the packed triangle (default: by size)
+        int init_headstart = 1;    // AAR_INIT_HEADSTART=0: the first step's frame inverses and Schur complement wait for the host to have read mu_0
+    } tune;
     // state: everything that depends on a pose vector exists twice (index 0/1 = the two pose buffers), so that the
     // blocks of a trial point can be built while those of the current point are still needed for a mu retry
     double *z[2] = {nullptr, nullptr};    // [6A + 6F] pose vectors

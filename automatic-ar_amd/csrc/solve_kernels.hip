@@ -1787,16 +1787,16 @@ bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, i
     const size_t lds_diag = ((size_t)NB * (NB + 2) + 2 * NB * DG_YS + (size_t)NB * (NB / 2 + 2)) * sizeof(double);   // tile | panel | look-ahead half panel
     static size_t g_diag = 48 * 1024, g_bs = 48 * 1024;
     // block columns with at most this many tiles below the diagonal take the fused panel kernel (0: never); its redundancy grows
-    // with the square of the column's height, the two-kernel path's fixed cost does not
-    static const int fused_m = getenv("AAR_FUSED_PANEL") ? atoi(getenv("AAR_FUSED_PANEL")) : 3;   // (3: +2.6 % on a four-tile system, nothing at 14 tiles)
-    static const bool bs_rides = !(getenv("AAR_BS_RIDES") && atoi(getenv("AAR_BS_RIDES")) == 0);
+    // with the square of the column's height, the two-kernel path's fixed cost does not  (3: +2.6 % on a four-tile system, nothing at 14 tiles)
+    const int fused_m = P.tune.fused_panel;
+    const bool bs_rides = P.tune.bs_rides != 0;
     // opt-in (AAR_BACKSUB_RIDES=1): measured on one box, it buys nothing -- 7 224 vs 7 233 LM it/s at config 3, 17 480 vs 17 780 at config 2
     // (profiles/r03_attempts.txt): the launch then ends with the riders' work instead of a 6 us kernel, and their 1024-thread workgroups
     // cost at dispatch what the kernel boundary did
-    static const bool backsub_rides = getenv("AAR_BACKSUB_RIDES") && atoi(getenv("AAR_BACKSUB_RIDES")) != 0;
+    const bool backsub_rides = P.tune.backsub_rides != 0;
     // Look-ahead: where trsm and update are launches of their own (tall block columns), the update is not launched: the next diagonal tile's
     // workgroup applies it to its own tile and starts factoring, riders of that launch do the other tiles (AAR_LDL_LOOKAHEAD=0: off)
-    static const bool lookahead = !(getenv("AAR_LDL_LOOKAHEAD") && atoi(getenv("AAR_LDL_LOOKAHEAD")) == 0);
+    const bool lookahead = P.tune.lookahead != 0;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_ldl_diag), lds_diag, g_diag);
     bool rode_backsub = false;
     int upd_s = -1;   // the block column whose update the next k_ldl_diag launch carries
