@@ -239,3 +239,23 @@ def test_config5_shaped_problem_against_the_oracle():
         for rmse_r, reps in _run_ranks(4, solve):
             assert abs(rmse_r - rmse_o) < (1e-7 if s == "direct" else 1e-5), (s, rmse_r, rmse_o)
             assert abs(reps["iterations"] - repo["iterations"]) <= 1, s
+
+
+def test_init_head_start_leaves_the_trajectory_alone(monkeypatch):
+    # aar_lm_init queues the first step's frame inverses and Schur complement before the host has read mu_0 (AAR_INIT_HEADSTART, a per-problem
+    # tuning switch): with fixed-order sums the whole LM run is the same bit for bit with and without it -- also when the step then wants another
+    # damping than the one the head start assumed (tau changed between init and step: the complement is taken back and redone)
+    ds, g = load_golden("g1_cfg3_cut")
+    runs = {}
+    for hs in ("1", "0"):
+        monkeypatch.setenv("AAR_INIT_HEADSTART", hs)
+        with aar.Problem(ds, deterministic=True) as p:
+            x, rep = p.lm_solve(ds.x_full)
+            p.lm_init(ds.x_full, params=aar.lm_default_params(tau=1.0))
+            p.lm_init(ds.x_full, params=aar.lm_default_params(tau=1e-3))     # a second init: the first one's head start is discarded
+            steps = [p.lm_step() for _ in range(4)]
+            runs[hs] = (x, [t["err"] for t in rep["trace"]], [t["mu"] for t in rep["trace"]], [s["err"] for s in steps], [s["mu"] for s in steps])
+    monkeypatch.delenv("AAR_INIT_HEADSTART")
+    for a, b in zip(runs["1"], runs["0"]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    np.testing.assert_allclose(runs["1"][1], g["analytic_err"], rtol=1e-7)
