@@ -659,7 +659,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
                     if (poll_rc) return poll_rc;
                     if (pb->h_pcg[0] != 0.0 || last) break;
                 }
-                { StageTimer t(pb, &pb->times.allreduce); int rc = allreduce(pb, P.pcgd_y, (size_t)6 * P.A, NCCL_SUM); if (rc) return rc; }
+                { StageTimer t(pb, &pb->times.allreduce); int rc = allreduce(pb, pcgd_y_of_launch(P, k), (size_t)6 * P.A, NCCL_SUM); if (rc) return rc; }
             }
         }
         chol_done = true;
@@ -1451,7 +1451,9 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
     }
     if (P.deterministic) { AL(sp_part, (size_t)sp_total); AL(pb_part, (size_t)P.n_chunks * P.pb_stride); }
     if (P.use_pcg) {
-        AL(pcg_ws, (size_t)P.pcg_n_items * 28 + 6 * (size_t)F + 8); AL(pcg_counter, 4);
+        AL(pcg_ws, (size_t)P.pcg_n_items * 28 + 6 * (size_t)F + 8); AL(pcg_counter, 8);
+        AL(pcg_yg, (size_t)3 * P.n_pad + (size_t)28 * A + 8);
+        if (const char *t = getenv("AAR_PCG_FUSED")) P.pcg_fused = atoi(t) != 0 ? 1 : 0;
         hipDeviceProp_t prop;
         P.pcg_grid = (hipGetDeviceProperties(&prop, pb->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;   // one workgroup per CU: all resident
         // small problems: fewer workgroups make the two grid-wide hand-overs of an iteration cheaper than the passes get slower
@@ -1459,7 +1461,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         const int64_t want = std::max<int64_t>(32, ((int64_t)F + 3) / 4);
         P.pcg_grid = (int)std::min<int64_t>(P.pcg_grid, want);
         if (pb->comm) {
-            AL(pcgd_setup, (size_t)A * 28); AL(pcgd_minv, (size_t)A * 36); AL(pcgd_state, 18 * (size_t)A + 8); AL(pcgd_y, 6 * (size_t)A + 8);
+            AL(pcgd_setup, (size_t)A * 28); AL(pcgd_minv, (size_t)A * 36); AL(pcgd_state, 2 * (18 * (size_t)A + 8)); AL(pcgd_y, 3 * (6 * (size_t)A + 8));
             if (hipHostMalloc((void **)&pb->h_pcg, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
                 return fail(set_error(AAR_ERR_HIP, "hipHostMalloc failed"));
             memset(pb->h_pcg, 0, 8 * sizeof(double));
@@ -2010,7 +2012,7 @@ int aar_problem_get_solver_stats(aar_problem *pb, aar_solver_stats *out) {
     int32_t c[4] = {0, 0, 0, 0};
     HIP_TRY(hipSetDevice(pb->device));
     if (pb->P.use_spcg) HIP_TRY(hipMemcpyAsync(c, pb->P.spcg_iters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
-    else HIP_TRY(hipMemcpyAsync(c, pb->P.pcg_counter + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
+    else HIP_TRY(hipMemcpyAsync(c, pb->P.pcg_counter + 2, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
     HIP_TRY(hipStreamSynchronize(pb->stream));
     out->last_iterations = std::min(c[0], pb->P.use_spcg ? SPCG_MAX_IT : c[0]);
     out->total_iterations = c[1];

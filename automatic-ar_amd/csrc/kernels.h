@@ -91,6 +91,8 @@ struct DeviceProblem {
     double *pcg_ws = nullptr;             // items' shares [n_items][28] | t [6F]
     int32_t *pcg_counter = nullptr;       // [0..1] grid-barrier counters (alternating), [2] iterations of the last solve, [3] running total
     mutable int pcg_parity = 0;
+    int pcg_fused = 1;                    // AAR_PCG_FUSED=0: k_pcg (two passes over W and two hand-overs per iteration) instead of k_pcgf
+    double *pcg_yg = nullptr;             // k_pcgf: y [3][n_pad] (rotating) | the set-up's sums [A][28]
     // solver spcg (spcg_kernels.hip): CG on the explicit Schur complement, one wavefront per shared entity
     int use_spcg = 0, spcg_max_it = SPCG_MAX_IT;
     int spcg_test_drop = -1;              // test hook (AAR_SPCG_TEST_DROP=entity): that entity's wavefront never shows up -> every hand-over times out -> flag 4 -> direct chain
@@ -199,6 +201,7 @@ void spcg_ws_reset(const DeviceProblem &P, hipStream_t st);   // every hand-over
 // the same with a communicator: set-up share -> [all-reduce] -> launches k = 0, 1, .. with an all-reduce of pcgd_y between two of them
 void launch_pcgd_setup(const DeviceProblem &P, int which, double mu, hipStream_t st);
 void launch_pcgd_iter(const DeviceProblem &P, int which, double mu, int k, bool last, unsigned long long publish_seq, hipStream_t st);
+double *pcgd_y_of_launch(const DeviceProblem &P, int k);   // this rank's partial y of launch k: what the host all-reduces before launch k + 1
 void launch_reduce_scalars(const DeviceProblem &P, int n_err, bool fold_shared, unsigned long long publish_seq, hipStream_t st,
                            double *scal_out = nullptr, int maxdiag_blk = -1);  // scal[0..2], scal[5..6] (into scal_out instead of P.scal if given);
                                                                                // maxdiag_blk >= 0: also scal[4] = max free diagonal of that block set (k_maxdiag's job)

@@ -325,7 +325,294 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
     if (wg == 0) {
         for (int i = tid; i < n; i += PCG_THREADS) a.x_out[i] = x[i];
         for (int i = n + tid; i < a.n_pad; i += PCG_THREADS) a.x_out[i] = 0.0;
-        if (tid == 0) { a.iters_out[0] = it_cg; a.iters_out[1] += it_cg; }   // (stopped by max_it: still an inexact step, the LM gain test judges it)
+        if (tid == 0) { a.iters_out[0] = it_cg; a.iters_out[1] += it_cg; a.iters_out[2] += 1; }   // (stopped by max_it: still an inexact step, the LM gain test judges it)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pcgf: the same solver with the operator applied in ONE pass over the W blocks and ONE grid-wide hand-over per iteration
+// (k_pcg above: two of each).  The wavefront that owns frame f keeps the frame's W blocks in registers across both uses:
+//     c = sum_s W_s^T p_e(s),   t = (V_f + mu I)^-1 c,   y_e(s) -= W_s t
+// and the contributions to y are SCATTERED instead of gathered by entity: first into the workgroup's own copy of y in LDS (ds_add_f64: a workgroup
+// walks ~F / G frames, the cameras are in every one of them), then -- once per iteration -- into one global vector with fp64 atomics (n per workgroup).
+// (U p)_e rides in the same LDS vector (entities dealt over the workgroups).  After the hand-over every workgroup reads the n sums past the L2 and
+// updates its own copy of x, r, p redundantly, as before.  Three y buffers rotate: iteration i adds into buffer i % 3, reads it after the hand-over and
+// clears buffer (i + 1) % 3, whose last readers (iteration i - 2) passed a hand-over ago.  The set-up (diagonal blocks of S, right-hand side) takes the
+// same route: per slot in LDS, one atomic flush, one hand-over.
+// The sums come in whatever order the atomics arrive: the deterministic mode keeps k_pcg (item shares added in item order).
+// LDS (dynamic): x [n] | r [n] | p [n] | Mi [6 n] (the set-up's accumulators [A][27] live there first) | yacc [n] | red [4 * 27]
+// yg: [3][n_pad] zero at entry; sg: [A][28] zero at entry (the launcher clears both)
+// ------------------------------------------------------------------------------------------------
+// every slot's share of W (V+mu)^-1 W^T (lower triangle, 21) and of W h_f (6) for the frames dealt to this workgroup, into sacc [A][27] (LDS, zeroed here)
+__device__ __forceinline__ void pcgf_setup_slots(const PcgArgs &a, double *__restrict__ sacc, int wg, int G) {
+    constexpr int NW = PCG_THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 27 * a.A; i += PCG_THREADS) sacc[i] = 0.0;
+    __syncthreads();
+    for (int f = wg * NW + wave; f < a.F; f += G * NW) {
+        const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
+        const double *Vi = a.Vinv + (size_t)f * 36, *h = a.hf + (size_t)f * 6;
+        for (int s = s0 + lane; s < s1; s += 64) {
+            const int e = a.fslot_ent[s];
+            if (a.ent_fixed[e]) continue;
+            const double *Wb = a.W + (size_t)s * 36;
+            double w[36], yv[36];
+#pragma unroll
+            for (int q = 0; q < 36; q++) w[q] = Wb[q];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) t = fma(w[i * 6 + k], Vi[k * 6 + j], t);
+                    yv[i * 6 + j] = t;
+                }
+            double *dst = sacc + 27 * e;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int j = 0; j <= i; j++) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) t = fma(yv[i * 6 + k], w[j * 6 + k], t);
+                    atomicAdd(dst + i * (i + 1) / 2 + j, t);
+                }
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) t = fma(w[i * 6 + k], h[k], t);
+                atomicAdd(dst + 21 + i, t);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// this workgroup's share of  y = U p - sum_f W_f (V_f + mu I)^-1 W_f^T p  (no mu p term) into yacc [n] (LDS, zeroed here): ONE pass over the W blocks of
+// its frames -- c = W^T p, t = Vinv c, y -= W t, the first two rounds of a frame's slot list staying in registers across both uses -- and (U p)_e for the
+// entities dealt to it.  p: this workgroup's copy of the search direction (LDS)
+__device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__restrict__ p, double *__restrict__ yacc, double *__restrict__ red, int wg, int G) {
+    constexpr int NW = PCG_THREADS / 64;
+    const int n = 6 * a.A, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < n; i += PCG_THREADS) yacc[i] = 0.0;
+    __syncthreads();
+    for (int f = wg * NW + wave; f < a.F; f += G * NW) {
+        const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
+        const double *Vi = a.Vinv + (size_t)f * 36;
+        double2 w0[18], w1[18];
+        int e0 = -1, e1 = -1;
+        double c[6] = {0, 0, 0, 0, 0, 0};
+        auto gather_c = [&](const double2 (&wb)[18], int e) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double pe = p[6 * e + i];
+                c[0] = fma(wb[3 * i].x, pe, c[0]); c[1] = fma(wb[3 * i].y, pe, c[1]); c[2] = fma(wb[3 * i + 1].x, pe, c[2]);
+                c[3] = fma(wb[3 * i + 1].y, pe, c[3]); c[4] = fma(wb[3 * i + 2].x, pe, c[4]); c[5] = fma(wb[3 * i + 2].y, pe, c[5]);
+            }
+        };
+        if (s0 + lane < s1) {
+            e0 = a.fslot_ent[s0 + lane];
+            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)(s0 + lane) * 36);
+#pragma unroll
+            for (int u = 0; u < 18; u++) w0[u] = q[u];
+        }
+        if (s0 + lane + 64 < s1) {
+            e1 = a.fslot_ent[s0 + lane + 64];
+            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)(s0 + lane + 64) * 36);
+#pragma unroll
+            for (int u = 0; u < 18; u++) w1[u] = q[u];
+        }
+        if (e0 >= 0) gather_c(w0, e0);
+        if (e1 >= 0) gather_c(w1, e1);
+        for (int s = s0 + lane + 128; s < s1; s += 64) {
+            const int e = a.fslot_ent[s];
+            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
+            double2 wt[18];
+#pragma unroll
+            for (int u = 0; u < 18; u++) wt[u] = q[u];
+            gather_c(wt, e);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int i = 0; i < 6; i++) c[i] += __shfl_xor(c[i], off);
+        double t[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            double tv = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) tv = fma(Vi[k * 6 + j], c[j], tv);
+            t[k] = tv;
+        }
+        auto scatter = [&](const double2 (&wb)[18], int e) {
+            if (a.ent_fixed[e]) return;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double v = wb[3 * i].x * t[0] + wb[3 * i].y * t[1] + wb[3 * i + 1].x * t[2] + wb[3 * i + 1].y * t[3] + wb[3 * i + 2].x * t[4] + wb[3 * i + 2].y * t[5];
+                atomicAdd(yacc + 6 * e + i, -v);
+            }
+        };
+        if (e0 >= 0) scatter(w0, e0);
+        if (e1 >= 0) scatter(w1, e1);
+        for (int s = s0 + lane + 128; s < s1; s += 64) {
+            const int e = a.fslot_ent[s];
+            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
+            double2 wt[18];
+#pragma unroll
+            for (int u = 0; u < 18; u++) wt[u] = q[u];
+            scatter(wt, e);
+        }
+    }
+    // (U p)_e for the entities dealt to this workgroup (row e of the symmetric U, lower triangle stored)
+    for (int e = wg; e < a.A; e += G) {
+        if (a.ent_fixed[e]) continue;   // (uniform per workgroup)
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int bq = tid; bq < a.A; bq += PCG_THREADS) {
+            if (a.ent_fixed[bq]) continue;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const double u = bq < e ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * bq + j]
+                                            : (bq > e ? a.U[(size_t)(6 * bq + j) * a.n_pad + 6 * e + i]
+                                                      : (j <= i ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] : a.U[(size_t)(6 * e + j) * a.n_pad + 6 * e + i]));
+                    acc[i] = fma(u, p[6 * bq + j], acc[i]);
+                }
+        }
+        block_sum<6>(acc, red);
+        if (tid < 6) atomicAdd(yacc + 6 * e + tid, acc[tid]);
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *__restrict__ yg, double *__restrict__ sg) {
+    extern __shared__ __align__(16) double lds[];
+    const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *x = lds, *r = lds + n, *p = r + n, *Mi = p + n, *yacc = Mi + 6 * n, *red = yacc + n;
+    int32_t *counter = a.counter + a.parity;
+    int round = 0;
+    if (wg == 0 && tid == 0) __hip_atomic_store(a.counter + (1 - a.parity), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+
+    // ---- set-up, first half: every slot's share of the diagonal blocks and of the right-hand side, by entity in LDS, then ONE atomic flush ----
+    double *sacc = Mi;
+    pcgf_setup_slots(a, sacc, wg, G);
+    for (int i = tid; i < 27 * a.A; i += PCG_THREADS) {
+        const double v = sacc[i];
+        if (v != 0.0) atomicAdd(sg + (size_t)(i / 27) * 28 + (i % 27), v);
+    }
+    if (!grid_hop(counter, round, G, a.flags)) return;
+    // ---- set-up, second half, redundantly in every workgroup (one thread per entity): the diagonal block of S inverted straight into LDS,
+    //      the right-hand side; x = 0, r = b.  (Every thread reads its sums into registers before the barrier below lets Mi overwrite sacc.) ----
+    // (every thread reads the sums it needs past the L2, not from sacc: Mi may take sacc's place at once -- but only when all threads have flushed it)
+    for (int e = tid; e < a.A; e += PCG_THREADS) {
+        double out[36], be[6];
+        if (a.ent_fixed[e]) {
+#pragma unroll
+            for (int i = 0; i < 36; i++) out[i] = (i % 7 == 0) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) be[i] = 0.0;
+        } else {
+            double acc[27];
+#pragma unroll
+            for (int i = 0; i < 27; i++) acc[i] = ld_agent(sg + (size_t)e * 28 + i);
+            double m[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) {
+                    const double v = a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] + (i == j ? a.mu : 0.0) - acc[i * (i + 1) / 2 + j];
+                    m[i][j] = v; m[j][i] = v;
+                }
+            if (!spd6_inverse(m, out) && wg == 0) atomicOr(a.flags, 2);
+#pragma unroll
+            for (int i = 0; i < 6; i++) be[i] = a.g0[6 * e + i] - acc[21 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 36; i++) Mi[e * 36 + i] = out[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { r[6 * e + i] = be[i]; x[6 * e + i] = 0.0; }
+    }
+    __syncthreads();
+
+    // ---- z = Minv r, p = z ----
+    double rz = 0.0, bb = 0.0;
+    {
+        double sv[2] = {0.0, 0.0};
+        for (int i = tid; i < n; i += PCG_THREADS) {
+            const int e = i / 6, row = i - 6 * e;
+            double z = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            p[i] = z;
+            sv[0] += r[i] * z;
+            sv[1] += r[i] * r[i];
+        }
+        block_sum<2>(sv, red);
+        rz = sv[0]; bb = sv[1];
+    }
+    __syncthreads();
+
+    int it_cg = 0;
+    double rr = bb;
+    while (it_cg < a.max_it && rr > a.eta2 * bb && bb > 0.0) {
+        double *ygc = yg + (size_t)(it_cg % 3) * a.n_pad, *ygn = yg + (size_t)((it_cg + 1) % 3) * a.n_pad;
+        for (int i = wg * PCG_THREADS + tid; i < n; i += G * PCG_THREADS) st_agent(ygn + i, 0.0);
+        pcgf_operator(a, p, yacc, red, wg, G);
+        for (int i = tid; i < n; i += PCG_THREADS) {
+            const double v = yacc[i];
+            if (v != 0.0) atomicAdd(ygc + i, v);
+        }
+        if (!grid_hop(counter, round, G, a.flags)) return;
+        // ---- vector updates, redundantly in every workgroup (same numbers, same order: same decisions) ----
+        double yl[24];
+        double pAp = 0.0;
+        {
+            double sv[1] = {0.0};
+            int ny = 0;
+            for (int i = tid; i < n; i += PCG_THREADS, ny++) {
+                double yv = fma(a.mu, p[i], ld_agent(ygc + i));
+                if (a.ent_fixed[i / 6]) yv = p[i];
+                if (ny < 24) yl[ny] = yv;
+                sv[0] = fma(p[i], yv, sv[0]);
+            }
+            block_sum<1>(sv, red);
+            pAp = sv[0];
+        }
+        const double alpha = rz / pAp;
+        {
+            int ny = 0;
+            for (int i = tid; i < n; i += PCG_THREADS, ny++) {
+                x[i] = fma(alpha, p[i], x[i]);
+                r[i] = fma(-alpha, yl[ny < 24 ? ny : 23], r[i]);
+            }
+        }
+        __syncthreads();
+        double s2[2] = {0.0, 0.0};
+        double zloc[24];
+        int nz = 0;
+        for (int i = tid; i < n; i += PCG_THREADS, nz++) {
+            const int e = i / 6, row = i - 6 * e;
+            double z = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            if (nz < 24) zloc[nz] = z;
+            s2[0] += r[i] * z;
+            s2[1] += r[i] * r[i];
+        }
+        block_sum<2>(s2, red);
+        const double beta = s2[0] / rz;
+        rz = s2[0];
+        rr = s2[1];
+        nz = 0;
+        for (int i = tid; i < n; i += PCG_THREADS, nz++) p[i] = fma(beta, p[i], zloc[nz < 24 ? nz : 23]);
+        __syncthreads();
+        it_cg++;
+    }
+    if (wg == 0) {
+        for (int i = tid; i < n; i += PCG_THREADS) a.x_out[i] = x[i];
+        for (int i = n + tid; i < a.n_pad; i += PCG_THREADS) a.x_out[i] = 0.0;
+        if (tid == 0) { a.iters_out[0] = it_cg; a.iters_out[1] += it_cg; a.iters_out[2] += 1; }
     }
 }
 
@@ -538,7 +825,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter(const PcgDistArgs d) 
         if (wg == 0) {
             for (int i = tid; i < n; i += PCG_THREADS) a.x_out[i] = x[i];
             for (int i = n + tid; i < a.n_pad; i += PCG_THREADS) a.x_out[i] = 0.0;
-            if (tid == 0) { gs[3] = itc; gs[4] = 1.0; a.iters_out[0] = (int)itc; a.iters_out[1] += (int)itc; }
+            if (tid == 0) { gs[3] = itc; gs[4] = 1.0; a.iters_out[0] = (int)itc; a.iters_out[1] += (int)itc; a.iters_out[2] += 1; }
         }
         publish(1.0, itc);
         return;
@@ -624,17 +911,179 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter(const PcgDistArgs d) 
     publish(0.0, itc);
 }
 
-size_t pcg_lds_bytes(int A) { return ((size_t)9 * 6 * A + 4 * 27 + 8) * sizeof(double); }
+// ------------------------------------------------------------------------------------------------
+// The sharded solver with the one-pass operator of k_pcgf.  Between two launches there is a kernel boundary AND an all-reduce, so NOTHING
+// inside a launch has to wait for another workgroup: the set-up scatters this rank's sums straight into its share (atomics, cleared by the
+// launcher), launch k scatters this rank's partial y into buffer k % 3, reads the reduced one of launch k - 1 and clears the one of launch k + 1;
+// the CG state alternates between two buffers (a late workgroup still reads the old one while workgroup 0 writes the new one).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PCG_THREADS) k_pcgd_setup_f(const PcgDistArgs d) {
+    extern __shared__ __align__(16) double lds[];
+    const PcgArgs &a = d.a;
+    const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
+    pcgf_setup_slots(a, lds, wg, G);
+    for (int i = tid; i < 27 * a.A; i += PCG_THREADS) {
+        const double v = lds[i];
+        if (v != 0.0) atomicAdd(d.setup_local + (size_t)(i / 27) * 28 + (i % 27), -v);
+    }
+    for (int e = wg * PCG_THREADS + tid; e < a.A; e += G * PCG_THREADS) {   // this rank's U_ee and g0_e (partial sums over its observations)
+        if (a.ent_fixed[e]) continue;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int j = 0; j <= i; j++) atomicAdd(d.setup_local + (size_t)e * 28 + i * (i + 1) / 2 + j, a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j]);
+            atomicAdd(d.setup_local + (size_t)e * 28 + 21 + i, a.g0[6 * e + i]);
+        }
+    }
+}
+
+struct PcgDistBufs { const double *state_rd; double *state_wr; const double *y_rd; double *y_wr, *y_zero; };
+
+__global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d, const PcgDistBufs bf) {
+    extern __shared__ __align__(16) double lds[];
+    const PcgArgs &a = d.a;
+    const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
+    double *x = lds, *r = lds + n, *p = r + n, *Mi = p + n, *yacc = Mi + 6 * n, *red = yacc + n;
+    const double *gx = bf.state_rd, *gr = gx + n, *gp = gr + n, *gs = gp + n;
+    double *hx = bf.state_wr, *hr = hx + n, *hp = hr + n, *hs = hp + n;
+    auto publish = [&](double done_v, double it_v) {
+        if (d.publish_seq && wg == 0 && tid == 0) {
+            d.host[0] = done_v; d.host[1] = it_v;
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(d.host) + 3, d.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    double rz, bb, rr, itc;
+    if (d.k == 0) {   // the preconditioner and r = b from the all-reduced set-up, x = 0, p = z = Minv r
+        for (int e = tid; e < a.A; e += PCG_THREADS) {
+            double out[36], be[6];
+            if (a.ent_fixed[e]) {
+#pragma unroll
+                for (int i = 0; i < 36; i++) out[i] = (i % 7 == 0) ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) be[i] = 0.0;
+            } else {
+                double m[6][6];
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++) {
+                        const double v = d.setup_local[(size_t)e * 28 + i * (i + 1) / 2 + j] + (i == j ? a.mu : 0.0);
+                        m[i][j] = v; m[j][i] = v;
+                    }
+                if (!spd6_inverse(m, out) && wg == 0) atomicOr(a.flags, 2);
+#pragma unroll
+                for (int i = 0; i < 6; i++) be[i] = d.setup_local[(size_t)e * 28 + 21 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 36; i++) Mi[e * 36 + i] = out[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { r[6 * e + i] = be[i]; x[6 * e + i] = 0.0; }
+        }
+        __syncthreads();
+        double sv[2] = {0.0, 0.0};
+        for (int i = tid; i < n; i += PCG_THREADS) {
+            const int e = i / 6, row = i - 6 * e;
+            double z = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            p[i] = z;
+            sv[0] += r[i] * z;
+            sv[1] += r[i] * r[i];
+        }
+        block_sum<2>(sv, red);
+        rz = sv[0]; bb = sv[1]; rr = bb; itc = 0.0;
+        __syncthreads();
+    } else {
+        if (gs[4] != 0.0) {   // converged in an earlier launch (the host had queued this one already): hand the verdict on to the next one
+            if (wg == 0 && tid == 0) { hs[3] = gs[3]; hs[4] = 1.0; }
+            publish(1.0, gs[3]);
+            return;
+        }
+        for (int i = tid; i < 6 * n; i += PCG_THREADS) Mi[i] = d.minv[i];
+        for (int i = tid; i < n; i += PCG_THREADS) { x[i] = gx[i]; r[i] = gr[i]; p[i] = gp[i]; }
+        rz = gs[0]; bb = gs[1]; itc = gs[3];
+        __syncthreads();
+        double yl[24];
+        double s1[1] = {0.0};
+        {
+            int ny = 0;
+            for (int i = tid; i < n; i += PCG_THREADS, ny++) {
+                const double yv = a.ent_fixed[i / 6] ? p[i] : bf.y_rd[i] + a.mu * p[i];
+                if (ny < 24) yl[ny] = yv;
+                s1[0] = fma(p[i], yv, s1[0]);
+            }
+        }
+        block_sum<1>(s1, red);
+        const double alpha = rz / s1[0];
+        {
+            int ny = 0;
+            for (int i = tid; i < n; i += PCG_THREADS, ny++) {
+                x[i] = fma(alpha, p[i], x[i]);
+                r[i] = fma(-alpha, yl[ny < 24 ? ny : 23], r[i]);
+            }
+        }
+        __syncthreads();
+        double s2[2] = {0.0, 0.0};
+        double zloc[24];
+        int nz = 0;
+        for (int i = tid; i < n; i += PCG_THREADS, nz++) {
+            const int e = i / 6, row = i - 6 * e;
+            double z = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            if (nz < 24) zloc[nz] = z;
+            s2[0] += r[i] * z;
+            s2[1] += r[i] * r[i];
+        }
+        block_sum<2>(s2, red);
+        const double beta = s2[0] / rz;
+        rz = s2[0];
+        rr = s2[1];
+        nz = 0;
+        for (int i = tid; i < n; i += PCG_THREADS, nz++) p[i] = fma(beta, p[i], zloc[nz < 24 ? nz : 23]);
+        itc += 1.0;
+        __syncthreads();
+    }
+    const bool done = !(itc < (double)a.max_it && rr > a.eta2 * bb && bb > 0.0);
+    if (done || d.last) {
+        if (wg == 0) {
+            for (int i = tid; i < n; i += PCG_THREADS) a.x_out[i] = x[i];
+            for (int i = n + tid; i < a.n_pad; i += PCG_THREADS) a.x_out[i] = 0.0;
+            if (tid == 0) { hs[3] = itc; hs[4] = 1.0; a.iters_out[0] = (int)itc; a.iters_out[1] += (int)itc; a.iters_out[2] += 1; }
+        }
+        publish(1.0, itc);
+        return;
+    }
+    for (int i = wg * PCG_THREADS + tid; i < n; i += G * PCG_THREADS) bf.y_zero[i] = 0.0;   // the buffer of the NEXT launch (last read two launches ago)
+    pcgf_operator(a, p, yacc, red, wg, G);
+    for (int i = tid; i < n; i += PCG_THREADS) {
+        const double v = yacc[i];
+        if (v != 0.0) atomicAdd(bf.y_wr + i, v);
+    }
+    if (wg == 0) {
+        for (int i = tid; i < n; i += PCG_THREADS) { hx[i] = x[i]; hr[i] = r[i]; hp[i] = p[i]; }
+        if (d.k == 0) for (int i = tid; i < 6 * n; i += PCG_THREADS) d.minv[i] = Mi[i];
+        if (tid == 0) { hs[0] = rz; hs[1] = bb; hs[2] = rr; hs[3] = itc; hs[4] = 0.0; }
+    }
+    publish(0.0, itc);
+}
+
+size_t pcg_lds_bytes(int A) { return ((size_t)10 * 6 * A + 4 * 27 + 8) * sizeof(double); }   // x | r | p | Mi [6 n] | yacc [n] (k_pcgf) | red
 
 // the largest grid of the persistent PCG kernels that is resident as a whole (their hand-overs wait for every workgroup): what the occupancy query
 // admits per CU for the kernel with the larger footprint, times the CUs
 int pcg_max_grid(int A, int cus) {
     const size_t lds = pcg_lds_bytes(A);
     static size_t g1 = 48 * 1024, g2 = 48 * 1024;
+    static size_t g3 = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, g1);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter), lds, g2);
-    int n1 = 0, n2 = 0;
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf), lds, g3);
+    int n1 = 0, n2 = 0, n3 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, k_pcgf, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n3 = 1; }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_pcg, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n1 = 1; }
+    n1 = std::min(n1, n3);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_pcgd_iter, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n2 = 1; }
     return std::max(1, std::min(n1, n2)) * cus;
 }
@@ -650,9 +1099,15 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
     const size_t lds = pcg_lds_bytes(P.A);
-    static size_t granted = 48 * 1024;
-    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, granted);
+    static size_t granted = 48 * 1024, granted_f = 48 * 1024;
     HookScope _h(P, KID_PCG);
+    if (P.pcg_fused && !P.deterministic) {   // one pass over W and one hand-over per iteration; its atomics take the sums in any order
+        (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * P.n_pad + (size_t)28 * P.A) * sizeof(double), st);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf), lds, granted_f);
+        hipLaunchKernelGGL(k_pcgf, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * P.n_pad);
+        return;
+    }
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, granted);
     hipLaunchKernelGGL(k_pcg, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a);
 }
 
@@ -672,9 +1127,25 @@ static PcgDistArgs pcgd_args(const DeviceProblem &P, int which, double mu) {
     return d;
 }
 
+// stride (doubles) of one of the three rotating y buffers / of one of the two state buffers of the fused sharded path
+static inline size_t pcgd_y_stride(const DeviceProblem &P) { return (size_t)6 * P.A + 8; }
+static inline size_t pcgd_state_stride(const DeviceProblem &P) { return (size_t)18 * P.A + 8; }
+static inline bool pcgd_fused(const DeviceProblem &P) { return P.pcg_fused && !P.deterministic; }
+// the buffer the host all-reduces after launch k
+double *pcgd_y_of_launch(const DeviceProblem &P, int k) { return pcgd_fused(P) ? P.pcgd_y + (size_t)(k % 3) * pcgd_y_stride(P) : P.pcgd_y; }
+
 void launch_pcgd_setup(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const PcgDistArgs d = pcgd_args(P, which, mu);
     HookScope _h(P, KID_PCG);
+    if (pcgd_fused(P)) {
+        (void)hipMemsetAsync(P.pcgd_setup, 0, (size_t)28 * P.A * sizeof(double), st);
+        (void)hipMemsetAsync(P.pcgd_y, 0, 3 * pcgd_y_stride(P) * sizeof(double), st);
+        const size_t lds = (size_t)27 * P.A * sizeof(double);
+        static size_t granted = 48 * 1024;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_setup_f), lds, granted);
+        hipLaunchKernelGGL(k_pcgd_setup_f, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, d);
+        return;
+    }
     hipLaunchKernelGGL(k_pcgd_setup, dim3(P.pcg_grid), dim3(PCG_THREADS), 0, st, d);
 }
 
@@ -682,9 +1153,18 @@ void launch_pcgd_iter(const DeviceProblem &P, int which, double mu, int k, bool 
     PcgDistArgs d = pcgd_args(P, which, mu);
     d.k = k; d.last = last ? 1 : 0; d.publish_seq = publish_seq;
     const size_t lds = pcg_lds_bytes(P.A);
-    static size_t granted = 48 * 1024;
-    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter), lds, granted);
+    static size_t granted = 48 * 1024, granted_f = 48 * 1024;
     HookScope _h(P, KID_PCG);
+    if (pcgd_fused(P)) {
+        PcgDistBufs bf;
+        const size_t ys = pcgd_y_stride(P), ss = pcgd_state_stride(P);
+        bf.state_rd = P.pcgd_state + (size_t)(k % 2) * ss; bf.state_wr = P.pcgd_state + (size_t)((k + 1) % 2) * ss;
+        bf.y_rd = P.pcgd_y + (size_t)((k + 2) % 3) * ys; bf.y_wr = P.pcgd_y + (size_t)(k % 3) * ys; bf.y_zero = P.pcgd_y + (size_t)((k + 1) % 3) * ys;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter_f), lds, granted_f);
+        hipLaunchKernelGGL(k_pcgd_iter_f, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, d, bf);
+        return;
+    }
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter), lds, granted);
     hipLaunchKernelGGL(k_pcgd_iter, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, d);
 }
 

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     gather(0, bb, d1);
     SP_STAMP(4);
     SP_VAL(400, bb); SP_VAL(401, d1); SP_VAL(402, u); SP_VAL(403, r); SP_VAL(404, mv[0]); SP_VAL(405, mv[6]); SP_VAL(406, mv[7]);
-    int it = 0, status = 0;   // status: 1 converged, 2 cap, 3 not positive definite
+    int it = 0, status = 0;   // status: 1 converged, 2 cap, 3 non-positive curvature
     if (!dead) {
         w = matvec();
         double inv_g = 0.0, inv_a = 0.0;   // 1 / gamma and 1 / alpha of the previous iteration
@@ -289,8 +289,10 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             const double beta = gam * inv_g;                   // (0 in the first iteration)
             const double den = dlt - beta * gam * inv_a;       // p^T A p
             if (!(den > 0.0) || !(gam > 0.0)) {
-                // p^T A p <= 0: the damped system is not positive definite in floating point -- unless the recurrences have simply reached their floor
-                // (a forcing term below what pipelined CG can attain: |r| / |b| ~ 1e-8 .. 1e-12): then x is as good as it gets
+                // p^T A p <= 0.  Either the recurrences have reached their floor (a forcing term below what pipelined CG can attain, |r| / |b| ~ 1e-8 ..
+                // 1e-12: x is as good as it gets), or they have broken down on the way there (long runs on ill-conditioned systems), or the damped system
+                // really is not positive definite in floating point.  CG does not try to tell the last two apart: it gives up (flag 8) and the direct
+                // chain, whose pivots do tell, redoes the try
                 status = (gam <= 1e-16 * bb) ? 1 : 3;
                 break;
             }
@@ -312,13 +314,12 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     if (ra && g == 0) a.x_out[row] = x;
     if (lane == 0) {
         if (dead) atomicOr(a.flags, 4);
-        if (status == 3) atomicOr(a.flags, 2);
-        if (status == 2) atomicOr(a.flags, 8);
+        if (status == 2 || status == 3) atomicOr(a.flags, 8);
         if (e == e0) {
             a.iters[0] = dead ? SPCG_BUFS : it;   // (a timed-out launch may have dirtied any buffer: the next one clears them all)
             a.iters[1] += it;
             a.iters[2] += 1;
-            if (status == 2) a.iters[3] += 1;
+            if (status >= 2) a.iters[3] += 1;
         }
     }
 }

@@ -237,7 +237,7 @@ def test_config5_shaped_problem_against_the_oracle():
                 xs, reps = q.lm_solve(ds.x_full)
                 return q.reproj_stats(xs)[0], reps
         for rmse_r, reps in _run_ranks(4, solve):
-            assert abs(rmse_r - rmse_o) < (1e-7 if s == "direct" else 1e-5), (s, rmse_r, rmse_o)
+            assert abs(rmse_r - rmse_o) < (1e-7 if s == "direct" else 3e-5), (s, rmse_r, rmse_o)
             assert abs(reps["iterations"] - repo["iterations"]) <= 1, s
 
 
