@@ -194,6 +194,66 @@ def cpu_baseline(ds, workload, max_threads):
             "err_after_sample": rep["final_err"]}
 
 
+def scaling_workload(aar, w, world, rank, local_rank, comm, dist, steps, warmup):
+    """One more workload under the SAME communicator (N > 1 runs: configs 4 and 5, the ones BASELINE.json shards over 8 GPUs), with the solver AUTO picks:
+    LM it/s (barrier + device synchronisation on both sides, max over ranks), what AUTO resolved to, the all-reduce traffic, the split of a step into
+    replicated / sharded / collective time.  Every rank calls this; every rank gets the same dict (rank 0 prints it)."""
+    import numpy as np
+    ds = aar.synth(w)
+    problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, solver="auto")
+    params = lambda **kw: aar.lm_default_params(**kw)
+    calls0 = comm.stats()["allreduce_calls"] if comm is not None else 0
+
+    def barrier():
+        aar.lib().aar_device_synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(2):
+        problem.lm_solve(ds.x_full, params=params(), trace_cap=1)
+    run_steps(problem, ds.x_full, warmup, params)
+    barrier()
+    t0 = time.perf_counter()
+    done, trials, _, _ = run_steps(problem, ds.x_full, steps, params)
+    aar.lib().aar_device_synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+        dist.barrier()
+    x_fin, rep_fin = problem.lm_solve(ds.x_full, params=params())
+    rmse, _ = problem.reproj_stats(x_fin)
+    st = problem.solver_stats()
+    calls1 = comm.stats()["allreduce_calls"] if comm is not None else 0     # (before the instrumented pass below, which has collectives of its own)
+    amdahl = None
+    if st["solver"] != "pcg":
+        n_am = min(steps, 60)
+        problem.set_stage_timers(True)
+        acc, done_am = {}, 0
+        while done_am < n_am:
+            _, rep_am = problem.lm_solve(ds.x_full, params=params(max_iters=n_am - done_am), trace_cap=1)
+            for kk, vv in problem.stage_times().items():
+                acc[kk] = acc.get(kk, 0.0) + vv
+            done_am += rep_am["iterations"]
+        problem.set_stage_timers(False)
+        amdahl = amdahl_split(acc, done_am, world)
+    per_rank = [int(problem.local_obs)]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, int(problem.local_obs))
+    cs = comm.stats() if comm is not None else None
+    out = {"workload": WORKLOADS[w], "value": done / dt, "unit": "LM iterations/s", "ms_per_step": 1e3 * dt / done, "steps": steps, "warmup": warmup,
+           "solver_resolved": st["solver"], "cg_iterations_per_lm_step": st["total_iterations"] / max(1, st["solves"]) if st["solver"] != "direct" else None,
+           "solver_fallbacks": st["fallbacks"], "final_rmse_px": rmse, "lm_iterations_to_stop": rep_fin["iterations"], "local_obs": per_rank,
+           "ranks_seen": cs["ranks_seen"] if cs else 1, "allreduce_bytes": cs["system_allreduce_bytes"] if cs else 0,
+           "allreduce_calls_per_lm_step": ((calls1 - calls0) / float(max(1, done + warmup + 3 * rep_fin["iterations"]))) if cs else 0.0,
+           "amdahl": amdahl}
+    problem.close()
+    return out
+
+
 def self_launch(n, argv):
     """Parent of an N-GPU run: one fresh child process per GPU through torch.distributed.run.  This process never touches the GPU
     (no `import aar`, no torch.cuda call), so nothing that has initialised HIP is ever re-executed or forked."""
@@ -253,9 +313,24 @@ def plumbing_only(args, world, rank, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
         dist.barrier()
+    # the rank logic of scaling_workloads without a GPU: every rank plans the shards of the extra workloads and the ranks agree on the per-rank counts
+    scaling = None
+    if world > 1 and not args.no_scaling_workloads:
+        scaling = {}
+        for w in (4, 5):
+            if w == args.workload:
+                continue
+            dw = aar.synth(w) if w != 5 else aar.synth(5, num_frames=int(os.environ.get("AAR_BENCH_PLUMBING_FRAMES5", "5000")))
+            bw = aar.plan_shards(np.bincount(dw.obs_frame, minlength=dw.num_frames), world)
+            mine = int(np.sum((dw.obs_frame >= bw[rank]) & (dw.obs_frame < bw[rank + 1])))
+            counts = [mine]
+            if dist is not None:
+                counts = [None] * world
+                dist.all_gather_object(counts, mine)
+            scaling[str(w)] = {"workload": WORKLOADS[w], "local_obs": counts, "marker_observations": int(dw.num_obs), "frames": [int(bw[r + 1] - bw[r]) for r in range(world)]}
     if rank == 0:
         print(json.dumps({"metric": "LM iterations/sec", "value": None, "unit": "LM iterations/s", "n_gpus": world, "plumbing_only": True,
-                          "ranks_seen": world, "local_obs": per_rank, "max_rank_seconds": dt,
+                          "ranks_seen": world, "local_obs": per_rank, "max_rank_seconds": dt, "scaling_workloads": scaling,
                           "config": {"workload": WORKLOADS[args.workload], "marker_observations": int(ds.num_obs)}}))
     if dist is not None:
         dist.destroy_process_group()
@@ -275,6 +350,7 @@ def main():
     ap.add_argument("--solver", choices=("direct", "spcg", "pcg", "auto"), default="auto", help="aar_solver_options.solver: direct (Schur complement + dense LDL^T, the "
                     "reference's step to rounding), spcg (the same Schur complement, then CG on the explicit reduced system, csrc/spcg_kernels.hip), pcg (CG through "
                     "the frame blocks, no Schur complement, csrc/pcg_kernels.hip), auto (the library picks by size and rank count)")
+    ap.add_argument("--no-scaling-workloads", action="store_true", help="N > 1: skip the extra measurements of configs 4 and 5 (scaling_workloads)")
     ap.add_argument("--no-direct", action="store_true", help="skip the comparison leg through the direct solver (profiling runs: only the chosen solver's kernels in the trace)")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher / rendezvous / JSON relay only, no GPU work (CPU test of the N-rank plumbing)")
     args = ap.parse_args()
@@ -483,6 +559,14 @@ def main():
         track = {"frames": int(ds.num_frames), "seconds_per_call": dt_tr, "frames_per_s": ds.num_frames / dt_tr,
                  "mean_lm_iterations_per_frame": float(np.mean(it_t)), "max_pose_delta_vs_bundle_solution": float(np.abs(xt[ns:] - x_fin[ns:]).max())}
 
+    # ---- N > 1 (or AAR_BENCH_SCALING=1 behind a single-rank communicator): the workloads BASELINE.json shards over 8 GPUs, in the same line ----
+    scaling = None
+    if (world > 1 or os.environ.get("AAR_BENCH_SCALING") == "1") and not args.no_scaling_workloads:
+        scaling = {}
+        for w, (st_w, wu_w) in ((4, (90, 30)), (5, (45, 15))):
+            if w != args.workload:
+                scaling[str(w)] = scaling_workload(aar, w, world, rank, local_rank, comm, dist, st_w, wu_w)
+
     per_rank_obs = [int(problem.local_obs)]
     comm_stats = comm.stats() if comm is not None else None
     if dist is not None:
@@ -522,6 +606,8 @@ def main():
         "allreduce_bytes": comm_stats["system_allreduce_bytes"] if comm_stats else 0,
         "allreduce_calls": comm_stats["allreduce_calls"] if comm_stats else 0,
         "device_wakeup": wakeup,   # untimed whole solves before the W warm-up steps (see above); not part of any reported time
+        # N > 1: configs 4 and 5 under the same communicator with the solver AUTO picks for them (scaling_workload above)
+        "scaling_workloads": scaling,
     }
     if world == 1 and not args.no_cpu_baseline:
         threads = os.cpu_count() or 1

@@ -24,7 +24,7 @@ def run(args, env_extra=None, timeout=600):
 
 
 def test_two_rank_self_launch_relays_one_json_line():
-    out = run(["--gpus", "2", "--plumbing-only", "--workload", "2"])
+    out = run(["--gpus", "2", "--plumbing-only", "--workload", "2"], {"AAR_BENCH_PLUMBING_FRAMES5": "200"})
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout                      # rank 0's line and nothing else on stdout
@@ -33,6 +33,12 @@ def test_two_rank_self_launch_relays_one_json_line():
     assert len(rec["local_obs"]) == 2 and sum(rec["local_obs"]) == rec["config"]["marker_observations"]
     assert max(rec["local_obs"]) / (sum(rec["local_obs"]) / 2.0) < 1.1          # balanced by observation count
     assert abs(rec["max_rank_seconds"] - 0.002) < 1e-12                          # MAX over ranks (rank r contributed 0.001 (r + 1))
+    # N > 1: the workloads BASELINE.json shards over 8 GPUs ride in the same line (scaling_workloads): here their shard plans, agreed on by the ranks
+    sw = rec["scaling_workloads"]
+    assert set(sw) == {"4", "5"} and "2000-frame" in sw["4"]["workload"] and "16-cam" in sw["5"]["workload"]
+    for w in sw.values():
+        assert len(w["local_obs"]) == 2 and sum(w["local_obs"]) == w["marker_observations"] and max(w["local_obs"]) / (sum(w["local_obs"]) / 2.0) < 1.1
+        assert len(w["frames"]) == 2 and all(f > 0 for f in w["frames"])
 
 
 def test_child_failure_propagates_and_prints_no_result():
@@ -67,7 +73,7 @@ def test_amdahl_object_and_kernel_models():
     assert abs(b["sharded_us_one_gpu"] - 40.0) < 1e-9 and abs(b["collective_us"] - 17.0) < 1e-9
     assert abs(b["bound_at"]["2"] - 130.0 / (90.0 + 20.0 + 17.0)) < 1e-9
     # every kernel the library can time has a bound and a flop / byte model; k_ldl_panel is priced as panel solve + trailing update
-    assert bench.KERNEL_BOUND["k_ldl_panel"] == "fp64_mfma" and bench.KERNEL_BOUND["k_ldl_diag"] == "latency"
+    assert bench.KERNEL_BOUND["k_ldl_panel"] == "fp64_mfma" and bench.KERNEL_BOUND["k_ldl_diag"] == "latency" and bench.KERNEL_BOUND["k_spcg"] == "latency"
     nb3 = 96.0 ** 3
     assert bench.algorithmic_flops("k_ldl_panel", 0, 288, 0.0, True) == ((2 * nb3 + 4 * nb3) + (nb3 + nb3)) / 2      # m = 2 and m = 1
     assert bench.algorithmic_flops("k_ldl_trsm", 0, 288, 0.0, True) == 0.0                                           # no split stage at three tiles
