@@ -1,6 +1,6 @@
 // aar_find_solution: the find_solution driver for the accelerated path (apps/find_solution.cpp:28-181).
 //
-//   aar_find_solution <data_folder> <marker_size> [ignored] [-subseqs] [-exclude-cams ...] [-with-huber] [-thresh t]
+//   aar_find_solution <data_folder> <marker_size> [ignored] [-subseqs] [-exclude-cams ...] [-with-huber] [-thresh t] [-solver direct|spcg|pcg|auto]
 //
 // File contract kept from the reference (:45,99-100,146-147,162-163,175-177): reads <folder>/aruco.detections and
 // <folder>/<cam>/calib.{xml,yml,yaml}, runs the Initializer (IPPE poses, votes, spanning trees -- on the GPU, aar_initializer_run),
@@ -26,7 +26,7 @@
 using namespace std;
 
 static int print_usage(const char *a0) {
-    cout << "Usage: " << a0 << " <data_folder_path> <marker_size> [ignored] [-subseqs] [-exclude-cams <cam_id> ...] [-with-huber] [-thresh <t>] [-from-initial]" << endl;
+    cout << "Usage: " << a0 << " <data_folder_path> <marker_size> [ignored] [-subseqs] [-exclude-cams <cam_id> ...] [-with-huber] [-thresh <t>] [-from-initial] [-solver direct|spcg|pcg|auto]" << endl;
     cout << "       " << a0 << " --synth <config 1..5> <out_folder>   (write a synthetic data set in the reference's file formats)" << endl;
     return -1;
 }
@@ -68,7 +68,8 @@ int main(int argc, char *argv[]) {
     bool use_subseqs = false, with_huber = false, set_threshold = false, from_initial = false, tracking_only = false;
     double threshold = 2.0;
     set<int> excluded_cams;
-    enum ArgFlag { NONE, ExcludeCams, Threshold } arg_flag = NONE;
+    int solver = AAR_SOLVER_DIRECT;   // not an option of the reference: how the damped systems are solved (aar_solver_options); the default is the reference's step
+    enum ArgFlag { NONE, ExcludeCams, Threshold, Solver } arg_flag = NONE;
     for (int i = 4; i < argc; i++) {  // sic: the reference starts at argv[4] (apps/find_solution.cpp:47)
         const string a = argv[i];
         if (a == "-subseqs") use_subseqs = true;
@@ -77,6 +78,12 @@ int main(int argc, char *argv[]) {
         else if (a == "-from-initial") { from_initial = true; arg_flag = NONE; }
         else if (a == "-tracking-only") { tracking_only = true; arg_flag = NONE; }   // names the files only, as in the reference (:54-57,76-77)
         else if (a == "-thresh") { set_threshold = true; arg_flag = Threshold; }
+        else if (a == "-solver") arg_flag = Solver;
+        else if (arg_flag == Solver) {
+            solver = a == "spcg" ? AAR_SOLVER_SPCG : a == "pcg" ? AAR_SOLVER_PCG : a == "auto" ? AAR_SOLVER_AUTO : a == "direct" ? AAR_SOLVER_DIRECT : -1;
+            if (solver < 0) return print_usage(argv[0]);
+            arg_flag = NONE;
+        }
         else if (arg_flag == ExcludeCams) excluded_cams.insert(stoi(a));
         else if (arg_flag == Threshold) { threshold = stod(a); arg_flag = NONE; }
     }
@@ -145,6 +152,11 @@ int main(int argc, char *argv[]) {
     mcm.solver_params.verbose = true;
     mcm.set_optmize_flag_cam_intrinsics(false);  // apps/find_solution.cpp:140
     if (with_huber) mcm.set_with_huber(true);
+    if (solver != AAR_SOLVER_DIRECT) {
+        aar::MultiCamMapper::SolverOptions so;
+        so.solver = solver;
+        mcm.set_solver_options(so);
+    }
     const auto start = chrono::system_clock::now();
     try {
         mcm.solve();
@@ -156,6 +168,12 @@ int main(int argc, char *argv[]) {
     mcm.write_solution_file(final_path);
     mcm.write_text_solution_file(final_path + ".yaml");
     const aar_lm_report &r = mcm.last_report;
+    if (solver != AAR_SOLVER_DIRECT) {
+        const aar_solver_stats st = mcm.solver_stats();
+        const char *names[] = {"direct", "pcg", "spcg", "auto"};
+        cout << "solver: " << names[st.solver & 3] << ", " << st.total_iterations << " CG iterations in " << st.solves << " damped solves, " << st.fallbacks
+             << " redone by the direct chain" << endl;
+    }
     cout << "LM iterations: " << r.iterations << "  error " << r.initial_err << " -> " << r.final_err << "  (" << r.iterations / r.solve_seconds
          << " LM it/s in the solver loop)" << endl;
     const int minutes = (int)(d.count() / 60);

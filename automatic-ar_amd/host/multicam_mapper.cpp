@@ -276,9 +276,28 @@ int MultiCamMapper::ensure_problem() {
     d.residual_mode = residual_mode;
     d.with_huber = with_huber_ ? 1 : 0;
     d.device_id = device_id;
-    int rc = aar_problem_create(&d, &problem_);
+    aar_solver_options so;
+    aar_solver_default_options(&so);
+    so.solver = solver_options_.solver;
+    so.deterministic = solver_options_.deterministic ? 1 : 0;
+    so.pcg_eta = solver_options_.pcg_eta;
+    so.pcg_max_it = solver_options_.pcg_max_it;
+    int rc = aar_problem_create_ex(&d, &so, &problem_);
     if (!rc && with_huber_) rc = aar_problem_set_huber_delta(problem_, hubberDelta);
     return rc;
+}
+
+void MultiCamMapper::set_solver_options(const SolverOptions &o) {
+    solver_options_ = o;
+    drop_problem();   // (the solver is a property of the device problem: the next solve() / track() builds one with these options)
+}
+
+aar_solver_stats MultiCamMapper::solver_stats() {
+    if (!data_) throw std::runtime_error("MultiCamMapper::solver_stats: no data set");
+    if (ensure_problem()) throw std::runtime_error(aar_last_error());
+    aar_solver_stats st;
+    if (aar_problem_get_solver_stats(problem_, &st)) throw std::runtime_error(aar_last_error());
+    return st;
 }
 
 void MultiCamMapper::error_function(const eVector &input, eVector &error) {

@@ -357,6 +357,19 @@ class MultiCamMapper {
     std::vector<double> track_errors;
     int device_id = 0;
     int residual_mode = AAR_RES_F32;
+    // How the damped normal equations are solved (aar_solver_options, include/aar.h) -- the counterpart of configuring the reference's solver object
+    // through SparseLevMarq::Params (libs/sparselevmarq.h:30-50), and kept beside them: DIRECT (the default) is the reference's Eigen::SimplicialLDLT
+    // step to rounding; SPCG / PCG / AUTO are inexact LM (same fixed point, final reprojection error within 1e-4 px).  Takes effect when the device
+    // problem is (re)built: set it before solve() / track(); set_solver_options() drops a problem that exists already.
+    struct SolverOptions {
+        int solver = AAR_SOLVER_DIRECT;   // AAR_SOLVER_DIRECT | _SPCG | _PCG | _AUTO
+        bool deterministic = false;       // fixed-order sums: two runs give the same bits
+        double pcg_eta = 0.0;             // forcing term of the inexact solvers (0: the solver's default)
+        int pcg_max_it = 0;               // iteration cap of an inner CG solve (0: the solver's default)
+    };
+    void set_solver_options(const SolverOptions &o);
+    const SolverOptions &get_solver_options() const { return solver_options_; }
+    aar_solver_stats solver_stats();      // what the problem runs with (AUTO resolved) and what its inner solver has done; builds the problem if need be
 
     const aar_dataset *dataset() const { return data_; }
 
@@ -376,6 +389,7 @@ class MultiCamMapper {
     aar_problem *problem_ = nullptr;
     std::vector<aar_cam_model> cam_models_;   // per camera INDEX, when the mapper was built from calibrations (full distortion vectors)
     Config config_;
+    SolverOptions solver_options_;
     bool with_huber_ = false;
 };
 

@@ -474,7 +474,7 @@ def main():
             try:
                 tr = json.load(open(pmc)).get("workload_%d" % args.workload, {})
                 if not tr:
-                    traffic_note = "no PMC pass was collected for this workload (profiles/pmc_traffic.json holds workloads 3 and 5)"
+                    traffic_note = "no PMC pass was collected for this workload"
                 elif tr.get("_kernel_source_sha1") == src_hash:
                     traffic_tab, traffic_note = tr, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel sources (%s)" % tr.get("_source")
                     rocprof_avg = {("k_passA" if kk == "k_passAB" else kk): vv for kk, vv in tr.get("_rocprofv3_avg_us", {}).items()}
@@ -502,8 +502,11 @@ def main():
                  "hbm": {"achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": by / avg_s / 1e9 / HBM_PEAK_GBPS},
                  "fp64": {"achieved": fl / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / FP64_PEAK_TFLOPS},
                  "traffic": traffic_tab.get("k_passAB" if (k == "k_passA" and merged) else k)}
-            if k == "k_schur" and r["traffic"] is None and "k_schur_mfma" in traffic_tab:      # two kernels behind one launcher
-                r["traffic"] = traffic_tab["k_schur_mfma"] + traffic_tab.get("k_schur_fill", 0.0)
+            if k == "k_schur" and r["traffic"] is None and "k_schur_mfma" in traffic_tab:      # two kernels behind one launcher; k_schur_fill only counts when it ran
+                fill = traffic_tab.get("raw_k_schur_fill", {}).get("launches", 0) / float(max(1, traffic_tab.get("raw_k_schur_mfma", {}).get("launches", 1)))
+                r["traffic"] = traffic_tab["k_schur_mfma"] + fill * traffic_tab.get("k_schur_fill", 0.0)      # (fill launches per mfma launch: ~0.07, the steps whose damping was not the predicted one)
+            if k == "k_pcg" and r["traffic"] is None:                                            # the launcher's kernels: k_pcgf on one GPU, k_pcgd_* with ranks
+                r["traffic"] = traffic_tab.get("k_pcgf", traffic_tab.get("k_pcgd_iter_f"))
             # the contract's fields, priced against the roofline that applies to this kernel: `bound` says which -- "hbm" (GB/s),
             # "fp64_valu" / "fp64_mfma" (TFLOP/s against the 78.6 TFLOP/s fp64 peak of the vector / matrix pipes), or "latency": a
             # single-workgroup dependent chain, for which a throughput fraction says nothing -- its useful flops over its duration

@@ -1,7 +1,10 @@
 """Fold two rocprofv3 --pmc runs (FETCH_SIZE, WRITE_SIZE; separate passes, as the TCC slot budget requires) into
 profiles/pmc_traffic.json: HBM bytes per launch for every kernel.
 
-    python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <tag> [<kernel_stats.csv>]
+    python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <tag> [<kernel_stats.csv>] [--merge]
+
+--merge: the passes were taken with another solver of the same sources (the direct chain's k_ldl_* kernels beside the default solver's): kernels the
+workload's entry does not hold yet are added to it, the ones it holds stay.
 
 With the fifth argument (the rocprofv3 --kernel-trace --stats summary of the same command) the per-kernel average durations are
 recorded as well (`_rocprofv3_avg_us`); bench.py prints them beside its own HIP-event averages.
@@ -27,8 +30,10 @@ def per_kernel(path):
 
 
 def main():
-    fetch, write, workload, tag = sys.argv[1:5]
-    stats = sys.argv[5] if len(sys.argv) > 5 else None
+    merge = "--merge" in sys.argv
+    argv = [a for a in sys.argv if a != "--merge"]
+    fetch, write, workload, tag = argv[1:5]
+    stats = argv[5] if len(argv) > 5 else None
     f, w = per_kernel(fetch), per_kernel(write)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_path = os.path.join(root, "profiles", "pmc_traffic.json")
@@ -51,6 +56,16 @@ def main():
             k = row["Name"].split("(")[0].replace("void ", "").replace("aar::", "").split("<")[0]
             if k.startswith("k_"):
                 entry["_rocprofv3_avg_us"][k] = float(row["AverageNs"]) * 1e-3
+    old = data.get("workload_%s" % workload)
+    if merge and old and old.get("_kernel_source_sha1") == entry["_kernel_source_sha1"]:
+        for k, v in entry.items():
+            if k == "_rocprofv3_avg_us":
+                for kk, vv in v.items():
+                    old.setdefault("_rocprofv3_avg_us", {}).setdefault(kk, vv)
+            elif not k.startswith("_"):
+                old.setdefault(k, v)
+        old["_source"] = "%s + %s" % (old["_source"], tag)
+        entry = old
     data["workload_%s" % workload] = entry
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
     with open(os.path.join(root, "profiles", "%s_pmc_summary.csv" % tag), "w") as fh:

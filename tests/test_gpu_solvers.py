@@ -259,3 +259,24 @@ def test_init_head_start_leaves_the_trajectory_alone(monkeypatch):
     for a, b in zip(runs["1"], runs["0"]):
         assert np.array_equal(np.asarray(a), np.asarray(b))
     np.testing.assert_allclose(runs["1"][1], g["analytic_err"], rtol=1e-7)
+
+
+def test_cpp_mirror_and_driver_take_the_solver_as_an_option(tmp_path):
+    # aar::MultiCamMapper::set_solver_options (beside SparseLevMarq::Params, libs/sparselevmarq.h:30-50) through the driver: aar_find_solution -solver spcg
+    # on a 4-camera / 12-marker recording written in the reference's file formats ends where the default (direct) run ends, and says what its solver did
+    import subprocess
+    from conftest import PKG
+    exe = os.path.join(PKG, "aar_find_solution")
+    runs = {}
+    for s in ("direct", "spcg", "auto"):
+        folder = str(tmp_path / s)
+        assert subprocess.run([exe, "--synth", "2", folder], capture_output=True, text=True).returncode == 0
+        run = subprocess.run([exe, folder, "0.05", "x", "-from-initial"] + ([] if s == "direct" else ["-solver", s]), capture_output=True, text=True)
+        assert run.returncode == 0, run.stderr + run.stdout
+        fin = aar.solution_read(os.path.join(folder, "final.solution"))
+        runs[s] = (ol.Oracle(fin).reproj_stats(fin.x_full)["rmse"], run.stdout)
+    assert "solver: spcg" in runs["spcg"][1] and "CG iterations" in runs["spcg"][1] and "solver:" not in runs["direct"][1]
+    assert "solver: direct" in runs["auto"][1]                      # (one tile of unknowns: AUTO keeps the direct chain)
+    assert abs(runs["spcg"][0] - runs["direct"][0]) < 1e-5 and abs(runs["auto"][0] - runs["direct"][0]) < 1e-9
+    bad = subprocess.run([exe, str(tmp_path / "direct"), "0.05", "x", "-solver", "nonsense"], capture_output=True, text=True)
+    assert bad.returncode != 0
