@@ -1180,6 +1180,9 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         P.use_pcg = solver == AAR_SOLVER_PCG ? 1 : 0;
         P.use_spcg = solver == AAR_SOLVER_SPCG ? 1 : 0;
         if (const char *t = getenv("AAR_SPCG_TEST_DROP")) P.spcg_test_drop = atoi(t);   // test hook: see kernels.h
+        if (const char *t = getenv("AAR_SPCG_SPREAD")) P.spcg_spread = std::max(1, atoi(t));
+        // (one XCD has a thirty-second of... an eighth of the CUs: more entities than that many wavefront slots would not all be resident there)
+        if (P.n_pad / 6 > 4 * (cus / 8)) P.spcg_spread = 1;
         // forcing term: |r| <= 0.1 |b| for the CG through the frame blocks; the CG on the explicit system measures in the preconditioner's norm
         // (r^T M^-1 r, which its recurrences carry anyway), where 0.02 gives the same distance to the exact LM run
         P.pcg_eta = P.use_spcg ? 0.02 : 0.1;

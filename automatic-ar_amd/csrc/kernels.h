@@ -13,6 +13,10 @@ constexpr int PASSB_CHUNK = 256;  // max observations of one (camera, marker) ru
 constexpr int SPCG_MAX_IT = 64, SPCG_BUFS = SPCG_MAX_IT + 2, SPCG_MAX_NT = 14;
 inline int spcg_stride(int n_pad) { return 8 * (n_pad / 6); }   // doubles per hand-over buffer: one 64-byte record per entity
 
+#ifndef SPCG_PRE
+#define SPCG_PRE 0   // s_sleep units (64 cycles) between a wavefront's publish and its first poll of a hand-over (measured: 0 is best, profiles/r04_spcg_probe.txt)
+#endif
+
 // Kernel ids for the optional per-launch timing hooks (aar_get_kernel_times)
 enum KernelId { KID_UNPACK = 0, KID_RESIDUAL, KID_PASSA, KID_PASSB, KID_MAXDIAG, KID_FRAME_INV, KID_SCHUR, KID_LDL_DIAG,
                 KID_LDL_TRSM, KID_LDL_UPDATE, KID_LDL_BACKSOLVE, KID_BACKSUB, KID_REDUCE, KID_LDL_PANEL, KID_PCG, KID_SPCG, KID_COUNT };
@@ -95,6 +99,7 @@ struct DeviceProblem {
     double *pcg_yg = nullptr;             // k_pcgf: y [3][n_pad] (rotating) | the set-up's sums [A][28]
     // solver spcg (spcg_kernels.hip): CG on the explicit Schur complement, one wavefront per shared entity
     int use_spcg = 0, spcg_max_it = SPCG_MAX_IT;
+    int spcg_spread = 8;                  // AAR_SPCG_SPREAD=1: every workgroup of the grid works (the wavefronts then sit on all XCDs and hand over through memory)
     int spcg_test_drop = -1;              // test hook (AAR_SPCG_TEST_DROP=entity): that entity's wavefront never shows up -> every hand-over times out -> flag 4 -> direct chain
     double *spcg_ws = nullptr;            // [2][SPCG_BUFS][spcg_stride(n_pad)] hand-over slots (sentinel-filled when idle)
     int32_t *spcg_iters = nullptr;        // [0] iterations of the last solve, [1] running total, [2] solves, [3] solves that hit the cap (flag 8)

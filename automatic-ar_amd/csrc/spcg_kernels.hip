@@ -33,6 +33,8 @@ constexpr unsigned long long SPCG_EMPTY = 0xFFF85EEDFFF85EEDull;   // both halve
 
 __device__ __forceinline__ bool sp_empty(double v) { return (unsigned long long)__double_as_longlong(v) == SPCG_EMPTY; }
 __device__ __forceinline__ void sp_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the same store kept in the XCD's L2 (sc0 instead of sc1): for readers on the SAME XCD only, see SPCG_SPREAD
+__device__ __forceinline__ void sp_st_xcd(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ double sp_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int CTRL>
@@ -94,6 +96,7 @@ struct SpcgArgs {
     double *x_out;                    // [n_pad] delta_s
     int32_t *iters;                   // [0] iterations of this solve, [1] running total, [2] solves, [3] solves that hit the cap (flag 8)
     int32_t *flags;
+    int spread;                       // 8: every eighth workgroup works (one XCD under round-robin placement); 1: every workgroup
     int test_drop;                    // test hook (AAR_SPCG_TEST_DROP): the wavefront of this entity leaves without a word, as if it had never been scheduled
 };
 
@@ -105,7 +108,12 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     // c / 4 and holds its words 2 (lane % 4), 2 (lane % 4) + 1: lanes with lane % 4 < 3 gather entries of m, lanes with lane % 4 == 3 the two shares
     constexpr int NPAD = 96 * NT, NK = 6 * NT, NENT = 16 * NT, NL = NT, NEB = (NENT + 63) / 64;
     __shared__ __align__(16) double mv[NPAD];
-    const int lane = threadIdx.x, e = blockIdx.x, i = lane >> 3, g = lane & 7;
+    // Placement.  Workgroups are dealt round-robin over the 8 XCDs (observed, not promised): with a.spread == 8 only every eighth workgroup works, so
+    // that all wavefronts of the solve share ONE XCD and its L2.  Whether they really do is checked at run time (every wavefront publishes its
+    // XCC id in the first, placement-independent hand-over): if so, the later hand-overs keep their records in that L2 (sc0 stores; the sc1 loads
+    // are L2-served) instead of sending every store out to the fabric and every poll after it -- a hand-over then costs an L2 round trip, not a memory one.
+    if (blockIdx.x % a.spread) return;
+    const int lane = threadIdx.x, e = blockIdx.x / a.spread, i = lane >> 3, g = lane & 7;
     const int n_free_ent = a.n / 6;   // entities beyond are padding: identity rows
     auto fixed = [&](int ent) -> bool { return ent >= n_free_ent || a.ent_fixed[ent < n_free_ent ? ent : 0] != 0; };
     if (fixed(e)) {   // gauge / switched-off / padding entity: identity rows, zero right-hand side; nobody waits for this wavefront
@@ -116,12 +124,15 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     double *set = a.ws + (size_t)a.parity * a.set_len, *other = a.ws + (size_t)(1 - a.parity) * a.set_len;
     // ---- every load of the set-up is issued before the first is used: one memory latency, not one per stage ----
     const int nprev_raw = a.iters[0];
-    int e0 = -1;    // the first free entity: its wavefront reports
+    int e0 = -1, n_act = 0;    // the first free entity (its wavefront reports), the number of free entities
 #pragma unroll
     for (int k = 0; k < NEB; k++) {
         const unsigned long long fr = __ballot(lane + 64 * k < NENT && !fixed(lane + 64 * k));
         if (e0 < 0 && fr) e0 = 64 * k + __builtin_ctzll(fr);
+        n_act += __builtin_popcountll(fr);
     }
+    const double xcc = (double)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf);   // hwreg(HW_REG_XCC_ID, 0, 4)
+    bool same_xcd = false;     // until the first hand-over has told
     unsigned pact = 0;   // bit k: piece lane + 64 k belongs to a free entity (the others read as zero without being polled)
 #pragma unroll
     for (int k = 0; k < NL; k++) if (!fixed((lane + 64 * k) >> 2)) pact |= 1u << k;
@@ -192,7 +203,10 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
         sh += dpp<DPP_ROR8>(sh);
         sh = sum_across_rows(sh);
         const bool is_m = ra && g == 0, is_s = lane == 1 || lane == 2;
-        if (is_m || is_s) sp_st(rec + (is_m ? i : 5 + lane), is_m ? val : sh);
+        if (is_m || is_s) {
+            if (same_xcd) sp_st_xcd(rec + (is_m ? i : 5 + lane), is_m ? val : sh);
+            else sp_st(rec + (is_m ? i : 5 + lane), is_m ? val : sh);
+        }
     };
     // gather: buffer b -> the whole vector in mv (LDS), the two sums over all wavefronts.  The poll IS the load of the payload (16-byte sc1
     // loads: a CU's memory queue is what a hand-over costs, so as few requests as possible; every 8-byte half is validated by itself)
@@ -203,6 +217,7 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
 #pragma unroll
         for (int k = 0; k < NL; k++) cur[k] = ((pact >> k) & 1) ? make_double2(__longlong_as_double((long long)SPCG_EMPTY), __longlong_as_double((long long)SPCG_EMPTY)) : make_double2(0.0, 0.0);
         long spins = 0;
+        if (SPCG_PRE > 0) __builtin_amdgcn_s_sleep(SPCG_PRE);   // (the others publish when this wavefront does: a poll issued at once finds nothing and costs a round trip)
         for (;;) {
             sp_u32x4 t[NL];
 #pragma unroll
@@ -262,10 +277,14 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     double u = prec(r), w = 0.0, z = 0.0, q = 0.0, s = 0.0, p = 0.0;
     double bb, d1;
     SP_STAMP(2);
-    publish(0, u, r * u, 0.0);
+    publish(0, u, r * u, i == 0 ? xcc + 4096.0 * xcc * xcc : 0.0);   // (second share of this buffer: where this wavefront runs; sum of id and of id^2, exact)
     SP_STAMP(3);
     gather(0, bb, d1);
     SP_STAMP(4);
+    {
+        const double s2 = floor(d1 * (1.0 / 4096.0)), s1 = d1 - 4096.0 * s2;
+        same_xcd = a.spread > 1 && (double)n_act * s2 == s1 * s1;          // all XCC ids equal <=> n sum(id^2) == (sum id)^2
+    }
     SP_VAL(400, bb); SP_VAL(401, d1); SP_VAL(402, u); SP_VAL(403, r); SP_VAL(404, mv[0]); SP_VAL(405, mv[6]); SP_VAL(406, mv[7]);
     int it = 0, status = 0;   // status: 1 converged, 2 cap, 3 non-positive curvature
     if (!dead) {
@@ -326,7 +345,7 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
 
 template <int NT>
 static void launch_spcg_nt(const SpcgArgs &a, int n_ent, hipStream_t st) {
-    hipLaunchKernelGGL(k_spcg<NT>, dim3(n_ent), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_spcg<NT>, dim3(n_ent * a.spread), dim3(64), 0, st, a);
 }
 
 bool spcg_fits(int nT) { return nT >= 1 && nT <= SPCG_MAX_NT; }
@@ -343,6 +362,7 @@ void launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.mu = mu; a.eta2 = P.pcg_eta * P.pcg_eta; a.max_it = std::min(P.spcg_max_it, SPCG_MAX_IT);
     a.ws = P.spcg_ws; a.stride = spcg_stride(P.n_pad); a.set_len = (long long)SPCG_BUFS * a.stride; a.parity = P.spcg_parity;
     a.x_out = P.delta_s; a.iters = P.spcg_iters; a.flags = P.flags; a.test_drop = P.spcg_test_drop;
+    a.spread = P.spcg_spread;
     P.spcg_parity ^= 1;
     const int n_ent = P.n_pad / 6;
     HookScope _h(P, KID_SPCG);
