@@ -350,6 +350,7 @@ def main():
     ap.add_argument("--solver", choices=("direct", "spcg", "pcg", "auto"), default="auto", help="aar_solver_options.solver: direct (Schur complement + dense LDL^T, the "
                     "reference's step to rounding), spcg (the same Schur complement, then CG on the explicit reduced system, csrc/spcg_kernels.hip), pcg (CG through "
                     "the frame blocks, no Schur complement, csrc/pcg_kernels.hip), auto (the library picks by size and rank count)")
+    ap.add_argument("--deterministic", action="store_true", help="aar_solver_options.deterministic: fixed-order sums instead of fp64 atomics (bit-identical runs)")
     ap.add_argument("--no-scaling-workloads", action="store_true", help="N > 1: skip the extra measurements of configs 4 and 5 (scaling_workloads)")
     ap.add_argument("--no-direct", action="store_true", help="skip the comparison leg through the direct solver (profiling runs: only the chosen solver's kernels in the trace)")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher / rendezvous / JSON relay only, no GPU work (CPU test of the N-rank plumbing)")
@@ -386,7 +387,8 @@ def main():
         if dist is not None:
             dist.broadcast_object_list(uid, src=0)
         comm = aar.Comm(uid[0], world, rank, local_rank)
-    problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics, solver=args.solver)
+    problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics, solver=args.solver,
+                          deterministic=True if args.deterministic else None)
     # x_full of the default Config: the pose vector, then fx cx fy cy d0..d4 per camera (fill_io_vec_cam_intrinsics, :488-498)
     x0 = problem.x_with_intrinsics(ds.x_full) if args.intrinsics else ds.x_full
 
@@ -434,7 +436,8 @@ def main():
     # ---- the same through the direct solver (the reference's step to rounding): rate, LM steps to stop, final error -- what an inexact solver is judged against ----
     direct = None
     if solver != "direct" and not args.no_direct:
-        with aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics, solver="direct") as pdir:
+        with aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics, solver="direct",
+                         deterministic=True if (args.deterministic and ds.num_cams + ds.num_markers < 96) else None) as pdir:
             for _ in range(3):
                 pdir.lm_solve(x0, params=params(), trace_cap=1)
             n_d = min(args.steps, 200)
@@ -593,7 +596,7 @@ def main():
                    "frames": ds.num_frames, "marker_observations": int(ds.num_obs), "residual_rows": int(8 * ds.num_obs), "unknowns": int(P),
                    "reduced_unknowns": int(Ps), "parallelism": "frames sharded over %d GPU(s)" % world, "seed": 20190219 + args.workload,
                    "residual_mode": "float32-faithful", "jacobian": "analytic",
-                   "optimize_cam_intrinsics": bool(args.intrinsics), "solver": args.solver, "solver_resolved": solver},
+                   "optimize_cam_intrinsics": bool(args.intrinsics), "solver": args.solver, "solver_resolved": solver, "deterministic": bool(args.deterministic)},
         "final_rmse_px": rmse, "final_sum_sq": ss, "lm_iterations_to_stop": rep_fin["iterations"], "trial_points_per_step": t_avg,
         "iteration_hbm": {"bytes_per_iteration": b_iter, "achieved": b_iter * done / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                           "frac": b_iter * done / dt / 1e9 / HBM_PEAK_GBPS},
