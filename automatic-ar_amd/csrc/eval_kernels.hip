@@ -361,7 +361,10 @@ struct PassBArgs {
 
 // one wavefront per chunk; `scratch` = 2048 doubles of LDS per wavefront of the workgroup
 // DET: the 90 sums of the chunk are stored as the chunk's record (k_passB_reduce adds the records up in a fixed order)
-template <bool DET = false>
+// LEAN: the corner loop is NOT unrolled -- the four corners' temporaries then take turns in the same registers (274 instead of 390: with
+// __launch_bounds__(256, 2) 23 of them spill and TWO wavefronts share a SIMD).  For pass B as a launch of its own (many chunks per SIMD: config 5); inside
+// the merged launch pass A's registers set the occupancy anyway and the unrolled loop's instruction-level parallelism is worth more
+template <bool DET = false, bool LEAN = false>
 __device__ __forceinline__ void passB_body(const PassBArgs &b, double *scratch, const int first_chunk) {
     const ObsIdx *__restrict__ idx = b.idx;
     const float *__restrict__ uv = b.uv;
@@ -394,12 +397,15 @@ __device__ __forceinline__ void passB_body(const PassBArgs &b, double *scratch, 
         const float ou[8] = {uv0.x, uv0.y, uv0.z, uv0.w, uv1.x, uv1.y, uv1.z, uv1.w};
         Ent ef;
         load_ent(ent, A + id.frame, ef);
-#pragma unroll
+#pragma unroll LEAN ? 1 : 4
         for (int k = 0; k < 4; k++) {
             CornerGeom g;
             project_corner(ec, em, ef, K, h, k, g);
             double r[2];
-            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, res_f32, huber, r[0], r[1]);
+            float ox, oy;
+            if (LEAN) { const float2 t = reinterpret_cast<const float2 *>(uv)[4 * (int64_t)o + k]; ox = t.x; oy = t.y; }   // (a register array indexed by a loop counter would live in scratch)
+            else { ox = ou[2 * k]; oy = ou[2 * k + 1]; }
+            corner_residual(ox, oy, g.u, g.v, res_f32, huber, r[0], r[1]);
             double Gc[2][6], Gm[2][6], Gf[2][6];
             corner_jacobian<true, true, false>(ec, em, ef, K, g, Gc, Gm, Gf);
 #pragma unroll
@@ -455,6 +461,15 @@ __global__ void __launch_bounds__(256) k_passB(const PassBArgs b) {
 __global__ void __launch_bounds__(256) k_passB_det(const PassBArgs b) {
     __shared__ double scratch[4 * 2048];
     passB_body<true>(b, scratch, (int)blockIdx.x * 4);
+}
+// experiments (AAR_PASSB_LEAN=1 / 2): the corner loop not unrolled, with / without the register cap that lets two wavefronts share a SIMD
+__global__ void __launch_bounds__(256, 2) k_passB_lean2(const PassBArgs b) {
+    __shared__ double scratch[4 * 2048];
+    passB_body<false, true>(b, scratch, (int)blockIdx.x * 4);
+}
+__global__ void __launch_bounds__(256) k_passB_lean1(const PassBArgs b) {
+    __shared__ double scratch[4 * 2048];
+    passB_body<false, true>(b, scratch, (int)blockIdx.x * 4);
 }
 
 // Pass B for the intrinsics entities (optimize_cam_intrinsics): same chunks, the 62 values of U_kk (4x4, packed lower), W_kc
@@ -761,7 +776,12 @@ void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
         hipLaunchKernelGGL(k_passB_reduce, dim3((P.n_pbr + 3) / 4), dim3(256), 0, st, r);
         return;
     }
-    { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which)); }
+    {
+        HookScope _h(P, KID_PASSB);
+        if (P.tune.passB_lean == 1) hipLaunchKernelGGL(k_passB_lean2, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which));
+        else if (P.tune.passB_lean == 2) hipLaunchKernelGGL(k_passB_lean1, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which));
+        else hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which));
+    }
     if (P.intr) { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB_intr, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which)); }
 }
 

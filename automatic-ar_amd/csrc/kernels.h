@@ -115,6 +115,7 @@ struct DeviceProblem {
         int backsub_rides = 0;     // AAR_BACKSUB_RIDES=1: the frame back-substitution rides in the last tile's launch
         int lookahead = 1;         // AAR_LDL_LOOKAHEAD=0: tall block columns launch k_ldl_update
         int passA_variant = 0;     // AAR_PASSA_VARIANT: 1281 / 1282 / 1284 / 2564 force a pass A workgroup shape
+        int passB_lean = 0;        // AAR_PASSB_LEAN (experiment): 1 = pass B's corner loop not unrolled + two wavefronts per SIMD (28 spilled registers), 2 = not unrolled only
         int pack_system = -1;      // AAR_PACK_SYSTEM=0/1: the reduced system travels as it lies / as the packed triangle (default: by size)
         int init_headstart = 1;    // AAR_INIT_HEADSTART=0: the first step's frame inverses and Schur complement wait for the host to have read mu_0
     } tune;
