@@ -208,6 +208,10 @@ struct aar_problem {
     bool spec_chol = true;             // AAR_SPEC_CHOL=0: off
     int solver = AAR_SOLVER_DIRECT;    // what the problem runs with (aar_solver_options.solver, AUTO resolved)
     bool force_direct = false;         // solver spcg: THIS try takes the direct chain (the CG solve of the same system hit its cap / timed out)
+    // ... and so do the next tries of this solve (the damping only falls along accepted steps: the systems get harder, not easier): 8 after the first
+    // fall-back, twice as many after each further one (a 505-step -with-huber run moves its damping both ways: CG gets another chance now and then);
+    // aar_lm_init clears both
+    int spcg_skip = 0, spcg_backoff = 0;
     int64_t spcg_fallbacks = 0;
     double *h_pcg = nullptr;           // solver pcg with a communicator: pinned, mapped {done, iterations, -, sequence} the iteration launches publish
     unsigned long long pcg_seq = 0;
@@ -701,7 +705,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     pb->s_reduced = false;      // the factorisation below consumes the system
     pb->trial_reduced = false;
     bool backsub_rode = false;
-    const bool by_cg = P.use_spcg && !pb->force_direct;   // CG on the explicit reduced system instead of the LDL^T chain (S stays as it is)
+    const bool by_cg = P.use_spcg && !pb->force_direct && pb->spcg_skip == 0;
+    if (P.use_spcg && !pb->force_direct && pb->spcg_skip > 0) pb->spcg_skip--;   // CG on the explicit reduced system instead of the LDL^T chain (S stays as it is)
     if (!chol_done) {
         StageTimer t(pb, &pb->times.chol);
         // (stage timers keep the frame back-substitution in its own launch, so that it has a time of its own)
@@ -758,7 +763,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         pb->trial_reduced = true;
         if (pb->spec_chol && !pb->stage_timers && !pb->profiling) {
             StageTimer t(pb, &pb->times.chol);
-            if (P.use_spcg) launch_spcg(P, tr, mu * 0.33, pb->stream);
+            if (P.use_spcg && pb->spcg_skip == 0) launch_spcg(P, tr, mu * 0.33, pb->stream);
             else (void)launch_chol(P, tr, mu * 0.33, pb->stream);
             pb->spec_chol_blk = tr;
             pb->spec_chol_mu = mu * 0.33;
@@ -782,6 +787,8 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
             // followed it in this try is meaningless, but S was not touched.  Not an error: the caller redoes the try with the direct chain.
             if (pb->h_flags[0] & 4) spcg_ws_reset(P, pb->stream);   // (a timed-out launch leaves slots of both buffer sets in an unknown state)
             pb->spcg_fallbacks++;
+            pb->spcg_backoff = pb->spcg_backoff ? std::min(2 * pb->spcg_backoff, 1024) : 8;
+            pb->spcg_skip = pb->spcg_backoff;
             return TRY_CG_FAILED;
         }
         set_error(AAR_ERR_NUMERIC, "device flags %d at mu=%g (1: a frame block is not positive definite, 2: non-positive pivot of the reduced system, 4: back-substitution chain timed out)", pb->h_flags[0], mu);
@@ -1658,6 +1665,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     pb->vinv_mu = -1;
     pb->schur_mu = -1;
     pb->s_reduced = pb->trial_reduced = false;
+    pb->spcg_skip = pb->spcg_backoff = 0;   // (a one-off solve: the problem's own solver gets its chance whatever an earlier LM run ended with)
     if ((rc = damped_try_fb(pb, mu, false))) return rc == TRY_NOT_POSITIVE_DEFINITE ? AAR_ERR_NUMERIC : rc;
     pb->lm_ready = false;
     std::vector<double> x0(x_full, x_full + L.full_len()), x1(x0);
@@ -1680,6 +1688,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     pb->cur = 0;
     pb->trial_points = 0;
     pb->launches = 0;
+    pb->spcg_skip = pb->spcg_backoff = 0;
     if (pb->spec_chol_blk >= 0) {   // a factorisation queued ahead of the last step of the previous solve: its pivot flags mean nothing
         HIP_TRY(hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream));
         pb->spec_chol_blk = -1;

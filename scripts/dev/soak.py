@@ -1,5 +1,6 @@
-"""Scratch (GPU): soak of the fence-free hand-overs -- thousands of solves at 1-, 2-, 3-, 4- and 14-tile systems (bs rider, chained back-substitution) and
-of the PCG grid hand-overs; every solve must land on the same final error (to the atomics' noise) in the same number of iterations."""
+"""Scratch (GPU): soak of the fence-free hand-overs -- thousands of solves at 1-, 2-, 3-, 4- and 14-tile systems (bs rider, chained back-substitution), of the
+PCG grid hand-overs and of the wavefront-to-wavefront hand-overs of the CG on the explicit system (solver spcg: sentinel records, same-XCD placement); every
+solve must land on the same final error (to the atomics' noise) in the same number of iterations, and no spcg solve may fall back."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "automatic-ar_amd"), os.path.join(ROOT, "tests")]
@@ -8,7 +9,10 @@ import aar
 bad = 0
 for label, kw, reps, env in (("1 tile (cfg2)", dict(cfg=2), 1500, {}), ("3 tiles (cfg3)", dict(cfg=3), 1500, {}), ("2 tiles", dict(cfg=3, num_cams=4, num_markers=20, num_frames=60), 800, {}),
                              ("4 tiles (intr)", dict(cfg=3, intr=True), 500, {}), ("5 tiles", dict(cfg=3, num_cams=4, num_markers=62, num_frames=40), 500, {}),
-                             ("14 tiles (cfg5)", dict(cfg=5), 12, {}), ("pcg cfg3", dict(cfg=3), 600, {"AAR_SOLVER": "pcg"}), ("pcg cfg5", dict(cfg=5), 12, {"AAR_SOLVER": "pcg"})):
+                             ("14 tiles (cfg5)", dict(cfg=5), 12, {}), ("pcg cfg3", dict(cfg=3), 600, {"AAR_SOLVER": "pcg"}), ("pcg cfg5", dict(cfg=5), 12, {"AAR_SOLVER": "pcg"}),
+                             ("spcg cfg3", dict(cfg=3), 3000, {"AAR_SOLVER": "spcg"}), ("spcg cfg4", dict(cfg=4), 600, {"AAR_SOLVER": "spcg"}), ("spcg 2 tiles", dict(cfg=3, num_cams=4, num_markers=20, num_frames=60), 1500, {"AAR_SOLVER": "spcg"}),
+                             ("spcg 4 tiles (intr)", dict(cfg=3, intr=True), 800, {"AAR_SOLVER": "spcg"}), ("spcg cfg3, all XCDs", dict(cfg=3), 1000, {"AAR_SOLVER": "spcg", "AAR_SPCG_SPREAD": "1"}),
+                             ("spcg 14 tiles (cfg5)", dict(cfg=5), 10, {"AAR_SOLVER": "spcg"})):
     for k, v in env.items(): os.environ[k] = v
     cfg = kw.pop("cfg"); intr = kw.pop("intr", False)
     ds = aar.synth(cfg, **kw)
@@ -22,9 +26,13 @@ for label, kw, reps, env in (("1 tile (cfg2)", dict(cfg=2), 1500, {}), ("3 tiles
             x, rep = p.lm_solve(x0)
             dev = abs(rep["final_err"] - ref_err) / ref_err
             worst = max(worst, dev)
-            if rep["iterations"] != ref_it or not (dev < 1e-6):
+            # (an inexact solver amplifies the last-bit noise of the fp64 atomics behind S: a stopping test that flips by one CG iteration moves the final error by ~1e-6)
+            if rep["iterations"] != ref_it or not (dev < (1e-6 if "AAR_SOLVER" not in env else 2e-5)):
                 bad += 1
                 print("  DEVIATION", label, i, rep["iterations"], ref_it, dev, flush=True)
+        st = p.solver_stats()
+        if st["fallbacks"]:
+            print("  (fall-backs to the direct chain: %d in %d CG solves)" % (st["fallbacks"], st["solves"]), flush=True)
     for k in env: os.environ.pop(k)
     print("%-16s %5d solves x %d iterations: worst relative deviation of the final error %.2e  (%.1f s)" % (label, reps * int(os.environ.get("SOAK_X", "1")), ref_it, worst, time.time() - t0), flush=True)
 print("BAD", bad)
