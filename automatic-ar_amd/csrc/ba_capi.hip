@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -1286,14 +1287,34 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
                 cursor[a] = e;
             }
     } else {
+        // XCD-aware order (opt-in, AAR_SCHUR_XCD=1).  Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: with entity-major items every
+        // XCD ends up walking ALL frames and pulls the whole of W through its L2 (8 x 3.6 MB per launch at config 3 for 0.67 MB of output).  Here the frames
+        // are cut into 8 contiguous ranges instead, an item stays inside one range, and the items of range x sit at positions = x (mod 8): an XCD then
+        // only ever touches an eighth of W (holes are padded with empty items; the launch's rider shifts every range by the same XCD).  Measured (round 4,
+        // profiles/r04_attempts.txt): k_schur 20.9 -> 20.3 us at config 3, 51.7 -> 59.4 us at config 4 (more, shorter items; every one ends with an atomic
+        // flush of its row panel): the kernel is not bound by those fetches -- not the default.
+        int xcd = 1;
+        if (const char *e = getenv("AAR_SCHUR_XCD")) xcd = atoi(e) != 0 ? 8 : 1;
+        std::vector<std::vector<std::array<int32_t, 3>>> lists(xcd);
         for (int a = 0; a < A; a++) {
             const int cnt = (int)inc[a].size();
-            for (int s = 0; s < cnt; s += per_item) {
-                sw_ent.push_back(a);
-                sw_begin.push_back(pair_base[a] + s);
-                sw_end.push_back(pair_base[a] + std::min(cnt, s + per_item));
+            int s = 0;
+            for (int x = 0; x < xcd; x++) {
+                const int f_hi = (int)((int64_t)F * (x + 1) / xcd);
+                int e = s;
+                while (e < cnt && inc[a][e].first < f_hi) e++;
+                for (int c = s; c < e; c += per_item)
+                    lists[x].push_back({(int32_t)a, (int32_t)(pair_base[a] + c), (int32_t)(pair_base[a] + std::min(e, c + per_item))});
+                s = e;
             }
         }
+        size_t longest = 0;
+        for (auto &l : lists) longest = std::max(longest, l.size());
+        for (size_t k = 0; k < longest; k++)
+            for (int x = 0; x < xcd; x++) {
+                if (k < lists[x].size()) { sw_ent.push_back(lists[x][k][0]); sw_begin.push_back(lists[x][k][1]); sw_end.push_back(lists[x][k][2]); }
+                else if (xcd > 1) { sw_ent.push_back(0); sw_begin.push_back(0); sw_end.push_back(0); }   // a hole: nothing to walk, an empty panel to flush
+            }
     }
     P.n_swork = (int)sw_ent.size();
     // deterministic mode: a record per Schur work item, the items of every entity in ascending frame order; a record per
