@@ -711,7 +711,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     if (!chol_done) {
         StageTimer t(pb, &pb->times.chol);
         // (stage timers keep the frame back-substitution in its own launch, so that it has a time of its own)
-        if (by_cg) launch_spcg(P, cur, mu, pb->stream);
+        if (by_cg) backsub_rode = launch_spcg(P, cur, mu, pb->stream, pb->stage_timers ? -1 : tr);
         else backsub_rode = launch_chol(P, cur, mu, pb->stream, pb->stage_timers ? -1 : tr);
     }
     if (!backsub_rode) {
@@ -1166,7 +1166,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         auto env_int = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
         env_int("AAR_FUSED_PANEL", P.tune.fused_panel); env_int("AAR_BS_RIDES", P.tune.bs_rides); env_int("AAR_BACKSUB_RIDES", P.tune.backsub_rides);
         env_int("AAR_LDL_LOOKAHEAD", P.tune.lookahead); env_int("AAR_PASSA_VARIANT", P.tune.passA_variant); env_int("AAR_PACK_SYSTEM", P.tune.pack_system);
-        env_int("AAR_INIT_HEADSTART", P.tune.init_headstart); env_int("AAR_PASSB_LEAN", P.tune.passB_lean);
+        env_int("AAR_INIT_HEADSTART", P.tune.init_headstart); env_int("AAR_PASSB_LEAN", P.tune.passB_lean); env_int("AAR_SPCG_BACKSUB_RIDES", P.tune.spcg_backsub_rides);
     }
     { const char *e = getenv("AAR_DENSE_FROM_PASSA"); if (e) P.dense_from_passA = atoi(e) != 0 ? 1 : 0; }
     {   // which solver (aar_solver_options; AUTO: DESIGN.md section 12)
@@ -1507,7 +1507,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         }
     }
     if (P.use_spcg) {
-        AL(spcg_ws, spcg_ws_doubles(P.n_pad)); AL(spcg_iters, 4);
+        AL(spcg_ws, spcg_ws_doubles(P.n_pad)); AL(spcg_iters, 4); AL(spcg_done, 2);
         spcg_ws_reset(P, pb->stream);
     }
     if (P.n_smwork) { AL(Wd, (size_t)F * P.Ad * 36); AL(Yd, (size_t)F * P.Ad * 36); }   // zeroed here, once: absent pairs are never written

@@ -104,6 +104,8 @@ struct DeviceProblem {
     double *spcg_ws = nullptr;            // [2][SPCG_BUFS][spcg_stride(n_pad)] hand-over slots (sentinel-filled when idle)
     int32_t *spcg_iters = nullptr;        // [0] iterations of the last solve, [1] running total, [2] solves, [3] solves that hit the cap (flag 8)
     mutable int spcg_parity = 0;
+    int32_t *spcg_done = nullptr;         // [0] arrivals of CG workgroups, [1] flag: the frame back-substitution riding in k_spcg's launch waits for it
+    mutable int spcg_epoch = 0;
     // ... with frames sharded over ranks: this rank's set-up share [A][28] (all-reduced), Minv [A][36], x | r | p | scalars [3 n + 8],
     // this rank's partial y [n] (all-reduced per iteration), mapped host record {done, iterations, -, sequence}
     double *pcgd_setup = nullptr, *pcgd_minv = nullptr, *pcgd_state = nullptr, *pcgd_y = nullptr, *pcgd_host = nullptr;
@@ -115,6 +117,7 @@ struct DeviceProblem {
         int backsub_rides = 0;     // AAR_BACKSUB_RIDES=1: the frame back-substitution rides in the last tile's launch
         int lookahead = 1;         // AAR_LDL_LOOKAHEAD=0: tall block columns launch k_ldl_update
         int passA_variant = 0;     // AAR_PASSA_VARIANT: 1281 / 1282 / 1284 / 2564 force a pass A workgroup shape
+        int spcg_backsub_rides = 0; // AAR_SPCG_BACKSUB_RIDES=1 (experiment, slower: profiles/r04_attempts.txt): the frame back-substitution rides in k_spcg's launch on the XCDs the CG leaves idle
         int passB_lean = 0;        // AAR_PASSB_LEAN (experiment): 1 = pass B's corner loop not unrolled + two wavefronts per SIMD (28 spilled registers), 2 = not unrolled only
         int pack_system = -1;      // AAR_PACK_SYSTEM=0/1: the reduced system travels as it lies / as the packed triangle (default: by size)
         int init_headstart = 1;    // AAR_INIT_HEADSTART=0: the first step's frame inverses and Schur complement wait for the host to have read mu_0
@@ -200,7 +203,7 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st);  
 size_t pcg_lds_bytes(int A);
 int pcg_max_grid(int A, int cus);   // largest co-resident grid of the persistent PCG kernels
 // solver spcg: delta_s by CG on the explicit reduced system S of block set `which` (the Schur complement for mu must have been taken; S is not modified)
-void launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st);
+bool launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial = -1);   // trial >= 0: launch_backsub(which, trial) may ride (true: it did)
 bool spcg_fits(int nT);                                    // the system's rows fit the wavefronts' registers
 size_t spcg_ws_doubles(int n_pad);
 void spcg_ws_reset(const DeviceProblem &P, hipStream_t st);   // every hand-over slot back to the sentinel (at creation, after a timed-out launch)

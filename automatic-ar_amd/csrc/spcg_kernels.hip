@@ -24,6 +24,7 @@
 // each side.
 #include "geom.hpp"
 #include "kernels.h"
+#include "backsub.hpp"
 
 namespace aar {
 
@@ -97,6 +98,12 @@ struct SpcgArgs {
     int32_t *iters;                   // [0] iterations of this solve, [1] running total, [2] solves, [3] solves that hit the cap (flag 8)
     int32_t *flags;
     int spread;                       // 8: every eighth workgroup works (one XCD under round-robin placement); 1: every workgroup
+    // riders: the workgroups of the grid that are NOT CG wavefronts do the frame back-substitution of the try (backsub.hpp) -- they fetch what does not depend
+    // on delta_s (the frame's W blocks, g_f, V_f^-1) while the CG runs on the other XCD and wait for ONE flag, raised by the last CG wavefront to leave
+    int ride, n_ent_total, n_riders;
+    BacksubArgs bs;
+    int32_t *done;                    // [0] arrivals (monotonic over launches), [1] flag = done_epoch once all n_ent_total CG workgroups of this launch have left
+    int done_epoch;
     int test_drop;                    // test hook (AAR_SPCG_TEST_DROP): the wavefront of this entity leaves without a word, as if it had never been scheduled
 };
 
@@ -112,12 +119,28 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     // that all wavefronts of the solve share ONE XCD and its L2.  Whether they really do is checked at run time (every wavefront publishes its
     // XCC id in the first, placement-independent hand-over): if so, the later hand-overs keep their records in that L2 (sc0 stores; the sc1 loads
     // are L2-served) instead of sending every store out to the fabric and every poll after it -- a hand-over then costs an L2 round trip, not a memory one.
-    if (blockIdx.x % a.spread) return;
+    if (blockIdx.x % a.spread || (int)blockIdx.x >= a.n_ent_total * a.spread) {
+        if (!a.ride || blockIdx.x % 8 == 0) return;   // (position 0 mod 8 behind the CG range: the CG's XCD -- left alone)
+        __shared__ double red[32];
+        const int bx = (int)blockIdx.x, cg_range = a.n_ent_total * a.spread;
+        const int rid = bx < cg_range ? bx - bx / a.spread - 1 : a.n_ent_total * (a.spread - 1) + (bx - cg_range) - (bx - cg_range + 7) / 8;
+        for (int blk = rid; blk <= a.bs.n_frame_blocks; blk += a.n_riders) backsub_body(a.bs, blk, red, a.done + 1, a.done_epoch, a.flags);
+        return;
+    }
     const int lane = threadIdx.x, e = blockIdx.x / a.spread, i = lane >> 3, g = lane & 7;
+    auto leave = [&]() {   // this workgroup's entries of delta_s are on their way (agent-scope stores): drain them, arrive; the last one raises the riders' flag
+        if (!a.ride) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const int old = __hip_atomic_fetch_add(a.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1 == a.done_epoch * a.n_ent_total) __hip_atomic_store(a.done + 1, a.done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     const int n_free_ent = a.n / 6;   // entities beyond are padding: identity rows
     auto fixed = [&](int ent) -> bool { return ent >= n_free_ent || a.ent_fixed[ent < n_free_ent ? ent : 0] != 0; };
     if (fixed(e)) {   // gauge / switched-off / padding entity: identity rows, zero right-hand side; nobody waits for this wavefront
-        if (lane < 6) a.x_out[6 * e + lane] = 0.0;
+        if (lane < 6) sp_st(a.x_out + 6 * e + lane, 0.0);
+        leave();
         return;
     }
     if (e == a.test_drop) return;
@@ -330,7 +353,8 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
         }
     }
     SP_STAMP(5);
-    if (ra && g == 0) a.x_out[row] = x;
+    if (ra && g == 0) sp_st(a.x_out + row, x);
+    leave();
     if (lane == 0) {
         if (dead) atomicOr(a.flags, 4);
         if (status == 2 || status == 3) atomicOr(a.flags, 8);
@@ -343,19 +367,17 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     }
 }
 
-template <int NT>
-static void launch_spcg_nt(const SpcgArgs &a, int n_ent, hipStream_t st) {
-    hipLaunchKernelGGL(k_spcg<NT>, dim3(n_ent * a.spread), dim3(64), 0, st, a);
-}
-
 bool spcg_fits(int nT) { return nT >= 1 && nT <= SPCG_MAX_NT; }
 size_t spcg_ws_doubles(int n_pad) { return (size_t)2 * SPCG_BUFS * spcg_stride(n_pad); }
 void spcg_ws_reset(const DeviceProblem &P, hipStream_t st) {
     (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.spcg_ws), (int)0xFFF85EED, 2 * spcg_ws_doubles(P.n_pad), st);
+    (void)hipMemsetAsync(P.spcg_done, 0, 2 * sizeof(int32_t), st);   // the riders' arrival counter and flag start over
+    P.spcg_epoch = 0;
 }
 
-// delta_s of (S + mu I) delta_s = rhs + g0 by CG on the explicit reduced system of block set `which` (S is left as it is)
-void launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
+// delta_s of (S + mu I) delta_s = rhs + g0 by CG on the explicit reduced system of block set `which` (S is left as it is).
+// trial >= 0: the frame back-substitution z[trial] = z[which] + delta rides in the same launch (true is returned if it did: the caller then skips launch_backsub)
+bool launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial) {
     const DeviceProblem::Blocks &b = P.blk[which];
     SpcgArgs a;
     a.S = b.S; a.rhs = b.rhs; a.g0 = b.g0; a.ent_fixed = P.ent_fixed; a.n = P.n; a.n_pad = P.n_pad;
@@ -365,14 +387,29 @@ void launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.spread = P.spcg_spread;
     P.spcg_parity ^= 1;
     const int n_ent = P.n_pad / 6;
+    a.n_ent_total = n_ent;
+    // riders: only where the CG leaves seven XCDs idle anyway, and not when somebody wants the back-substitution's own time
+    a.ride = (trial >= 0 && P.tune.spcg_backsub_rides && a.spread >= 8 && !P.hook.pre && P.F > 0) ? 1 : 0;
+    a.bs = backsub_args(P, which, trial >= 0 ? trial : which, 1);
+    a.done = P.spcg_done; a.done_epoch = 0; a.n_riders = 0;
+    int grid = n_ent * a.spread;
+    if (a.ride) {
+        a.done_epoch = ++P.spcg_epoch;
+        const int base = n_ent * (a.spread - 1), want = std::min(a.bs.n_frame_blocks + 1, 4096);
+        int extra = 0;
+        if (base < want) extra = ((want - base) * 8 + 6) / 7;            // (every eighth block behind the CG range sits on the CG's XCD and is left alone)
+        grid += extra;
+        a.n_riders = base + extra - (extra + 7) / 8;
+    }
     HookScope _h(P, KID_SPCG);
     switch (P.nT) {
-#define SPCG_CASE(t) case t: launch_spcg_nt<t>(a, n_ent, st); break;
+#define SPCG_CASE(t) case t: hipLaunchKernelGGL(k_spcg<t>, dim3(grid), dim3(64), 0, st, a); break;
         SPCG_CASE(1) SPCG_CASE(2) SPCG_CASE(3) SPCG_CASE(4) SPCG_CASE(5) SPCG_CASE(6) SPCG_CASE(7) SPCG_CASE(8)
         SPCG_CASE(9) SPCG_CASE(10) SPCG_CASE(11) SPCG_CASE(12) SPCG_CASE(13) SPCG_CASE(14)
 #undef SPCG_CASE
         default: break;   // (spcg_fits() is checked when the solver is chosen)
     }
+    return a.ride != 0;
 }
 
 }  // namespace aar

@@ -8,6 +8,7 @@
 #include <vector>
 #include <random>
 using namespace aar;
+namespace aar { BacksubArgs backsub_args(const DeviceProblem &, int, int, int) { return BacksubArgs(); } }   // (the probe launches no riders; the real one lives in solve_kernels.hip)
 int main(int argc, char **argv) {
     const int nT = argc > 1 ? atoi(argv[1]) : 3;
     const double eta = argc > 2 ? atof(argv[2]) : 1e-6;

@@ -283,3 +283,24 @@ def test_cpp_mirror_and_driver_take_the_solver_as_an_option(tmp_path):
     assert abs(runs["spcg"][0] - runs["direct"][0]) < 1e-5 and abs(runs["auto"][0] - runs["direct"][0]) < 1e-9
     bad = subprocess.run([exe, str(tmp_path / "direct"), "0.05", "x", "-solver", "nonsense"], capture_output=True, text=True)
     assert bad.returncode != 0
+
+
+def test_spcg_in_deterministic_mode_gives_the_same_bits_twice():
+    # k_spcg has no atomics (every wavefront adds the same shares in the same order); with fixed-order sums in the passes and the Schur kernel the whole
+    # INEXACT run -- CG iteration counts included -- is bit-reproducible, on one rank and on two
+    ds, g = load_golden("g1_cfg3_cut")
+    def run():
+        with aar.Problem(ds, solver="spcg", deterministic=True) as p:
+            x, rep = p.lm_solve(ds.x_full)
+            return x, [t["err"] for t in rep["trace"]], [t["mu"] for t in rep["trace"]], p.solver_stats()["total_iterations"]
+    a, b = run(), run()
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2] and a[3] == b[3] > 0
+    def solve(comm, rank):
+        with aar.Problem(ds, comm=comm, solver="spcg", deterministic=True) as q:
+            xs, reps = q.lm_solve(ds.x_full)
+            return xs, [t["err"] for t in reps["trace"]]
+    r1, r2 = _run_ranks(2, solve), _run_ranks(2, solve)
+    for (xa, ea), (xb, eb) in zip(r1, r2):
+        assert np.array_equal(xa, xb) and ea == eb
+    assert np.array_equal(r1[0][0], r1[1][0])
+    np.testing.assert_allclose(r1[0][1], a[1], rtol=1e-6)
