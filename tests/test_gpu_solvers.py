@@ -93,7 +93,7 @@ def test_spcg_through_the_retry_far_start_and_huber_fixtures(name, huber):
         assert max(t["tries"] for t in rep["trace"]) > 1 and max(t["tries"] for t in rep_d["trace"]) > 1
     assert rep["trial_points"] == sum(t["tries"] for t in rep["trace"])
     # (from a far start with tau = 1e-6 the number of steps is not a stable quantity: the direct path itself is given +- 2 against the real solver there)
-    assert abs(rep["iterations"] - rep_d["iterations"]) <= max(4 if "retry" in name else 2, rep_d["iterations"] // 50)
+    assert abs(rep["iterations"] - rep_d["iterations"]) <= max(5 if "retry" in name else 2, rep_d["iterations"] // 50)
     assert 0 < st["solves"] <= rep["trial_points"] + st["fallbacks"]       # (after a fall-back the direct chain keeps the next tries)
 
 
