@@ -82,22 +82,28 @@ def test_amdahl_object_and_kernel_models():
 
 
 def test_committed_bench_lines_keep_the_contract():
-    # profiles/r03_bench_cfg{3,5}.json are bench.py's own lines from the GPU box (scripts/collect_profiles.sh): the fields the driver and the
-    # judge read must be there, with the metric of BASELINE.json, the roofline of the dominant kernel and the CPU baseline beside it
+    # profiles/r04_bench_cfg{3,5}.json are bench.py's own lines from the GPU box (scripts/collect_profiles.sh, then scripts/collect_bench_lines.sh once the PMC
+    # fold exists): the fields the driver and the judge read must be there, with the metric of BASELINE.json, the roofline of the dominant kernel with its PMC
+    # traffic, the CPU baseline beside it, and -- the default solver being AUTO -- what it resolved to and the direct solver's figures on the same problem
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    for name, workload in (("r03_bench_cfg3.json", "8-cam/40-marker/500-frame"), ("r03_bench_cfg5.json", "16-cam/200-marker/5000-frame")):
+    for name, workload, solver in (("r04_bench_cfg3.json", "8-cam/40-marker/500-frame", "spcg"), ("r04_bench_cfg5.json", "16-cam/200-marker/5000-frame", "pcg")):
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-                  "roofline", "cpu_baseline", "amdahl", "final_rmse_px"):
+                  "roofline", "cpu_baseline", "amdahl", "final_rmse_px", "direct_it_per_s", "rmse_delta_vs_direct_px", "lm_iterations_to_stop", "solver_stats"):
             assert k in d, (name, k)
         assert d["metric"].startswith("LM iterations/sec") and base["metric"].startswith("LM iterations/sec")
         assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
         assert workload in d["config"]["workload"] and "model" not in d["config"]
+        assert d["config"]["solver"] == "auto" and d["config"]["solver_resolved"] == solver == d["solver_stats"]["solver"]
         assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+        assert d["rmse_delta_vs_direct_px"] < 1e-5 and d["lm_iterations_to_stop"] == d["direct"]["lm_iterations_to_stop"] and d["value"] > 1.9 * d["direct_it_per_s"]
         r = d["roofline"]
         assert r["bound"] in ("hbm", "fp64_valu", "fp64_mfma", "latency") and r["kernel"] in r["per_kernel"]
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] is not None and r["traffic"] > 0
-        assert set(d["amdahl"]["bound_at"]) == {"1", "2", "4", "8"} and d["amdahl"]["bound_at"]["1"] == 1.0
-    d3 = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_cfg3.json")))
+    d3 = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg3.json")))
+    assert set(d3["amdahl"]["bound_at"]) == {"1", "2", "4", "8"} and d3["amdahl"]["bound_at"]["1"] == 1.0
     cb = d3["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+    # the N > 1 line's extra workloads, as measured behind a single-rank communicator
+    sw = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg3_single_rank_rccl.json")))["scaling_workloads"]
+    assert sw["4"]["solver_resolved"] == "spcg" and sw["5"]["solver_resolved"] == "pcg" and sw["5"]["value"] > 900 and sw["4"]["amdahl"]["bound_at"]["8"] > 2.5
