@@ -1507,7 +1507,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         }
     }
     if (P.use_spcg) {
-        AL(spcg_ws, spcg_ws_doubles(P.n_pad)); AL(spcg_iters, 4); AL(spcg_done, 2);
+        AL(spcg_ws, spcg_ws_doubles(P.n_pad)); AL(spcg_iters, 8); AL(spcg_done, 2);
         spcg_ws_reset(P, pb->stream);
     }
     if (P.n_smwork) { AL(Wd, (size_t)F * P.Ad * 36); AL(Yd, (size_t)F * P.Ad * 36); }   // zeroed here, once: absent pairs are never written
@@ -2042,14 +2042,15 @@ int aar_problem_get_solver_stats(aar_problem *pb, aar_solver_stats *out) {
     out->pcg_max_it = pb->P.use_spcg ? pb->P.spcg_max_it : pb->P.pcg_max_it;
     out->fallbacks = pb->spcg_fallbacks;
     if (!pb->P.use_pcg && !pb->P.use_spcg) return AAR_OK;
-    int32_t c[4] = {0, 0, 0, 0};
+    int32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipSetDevice(pb->device));
-    if (pb->P.use_spcg) HIP_TRY(hipMemcpyAsync(c, pb->P.spcg_iters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
+    if (pb->P.use_spcg) HIP_TRY(hipMemcpyAsync(c, pb->P.spcg_iters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
     else HIP_TRY(hipMemcpyAsync(c, pb->P.pcg_counter + 2, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
     HIP_TRY(hipStreamSynchronize(pb->stream));
     out->last_iterations = std::min(c[0], pb->P.use_spcg ? SPCG_MAX_IT : c[0]);
     out->total_iterations = c[1];
     out->solves = c[2];
+    out->same_xcd_solves = c[4];
     return AAR_OK;
 }
 

@@ -95,7 +95,7 @@ struct SpcgArgs {
     long long set_len;                // doubles per set
     int stride, parity;
     double *x_out;                    // [n_pad] delta_s
-    int32_t *iters;                   // [0] iterations of this solve, [1] running total, [2] solves, [3] solves that hit the cap (flag 8)
+    int32_t *iters;                   // [0] iterations of this solve, [1] running total, [2] solves, [3] solves that gave up (flag 8), [4] solves whose wavefronts all shared one XCD
     int32_t *flags;
     int spread;                       // 8: every eighth workgroup works (one XCD under round-robin placement); 1: every workgroup
     // riders: the workgroups of the grid that are NOT CG wavefronts do the frame back-substitution of the try (backsub.hpp) -- they fetch what does not depend
@@ -363,6 +363,7 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             a.iters[1] += it;
             a.iters[2] += 1;
             if (status >= 2) a.iters[3] += 1;
+            if (same_xcd) a.iters[4] += 1;
         }
     }
 }

@@ -297,6 +297,7 @@ typedef struct aar_solver_stats {
     int64_t fallbacks;                        /* SPCG: tries redone with the direct chain (iteration cap, hand-over time-out)          */
     double pcg_eta;
     int32_t pcg_max_it, reserved2;
+    int64_t same_xcd_solves;                  /* SPCG: solves whose wavefronts all ran on one XCD (hand-overs through that XCD's L2: the fast case)   */
 } aar_solver_stats;
 int aar_problem_get_solver_stats(aar_problem *, aar_solver_stats *out);
 void aar_problem_destroy(aar_problem *);
