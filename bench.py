@@ -489,8 +489,9 @@ def main():
         def roof(k):
             avg_s = kernels[k]["avg_us"] * 1e-6
             by = algorithmic_bytes(k, n_loc, A, F, n_pad)
-            if k == "k_pcg":       # one pass over the W blocks for the preconditioner, two per CG iteration (SURVEY 8d has no row for this solver)
-                by = 288.0 * float(kf.sum()) / max(1, world) * (1.0 + 2.0 * pcg_total / float(done))
+            if k == "k_pcg":       # one pass over the W blocks for the preconditioner, ONE per CG iteration (k_pcgf; two with k_pcg: deterministic mode, AAR_PCG_FUSED=0)
+                passes = 2.0 if (args.deterministic or os.environ.get("AAR_PCG_FUSED") == "0") else 1.0
+                by = 288.0 * float(kf.sum()) / max(1, world) * (1.0 + passes * pcg_total / float(done))
             if k == "k_spcg":      # both triangles of the reduced system once into registers; a 6 x n product per wavefront per iteration (+ the one of the set-up)
                 by = 8.0 * n_pad * n_pad
             if k == "k_passA" and merged:
