@@ -389,80 +389,78 @@ __device__ __forceinline__ void pcgf_setup_slots(const PcgArgs &a, double *__res
 }
 
 // this workgroup's share of  y = U p - sum_f W_f (V_f + mu I)^-1 W_f^T p  (no mu p term) into yacc [n] (LDS, zeroed here): ONE pass over the W blocks of
-// its frames -- c = W^T p, t = Vinv c, y -= W t, the frame's panel staying in registers across both uses -- and (U p)_e for the entities dealt to it.
-// p: this workgroup's copy of the search direction (LDS).
-// Nine lanes share a block: lane (b = lane / 9, q = lane % 9) of round r holds the 16-byte pieces q and q + 9 of block 7 r + b, i.e. entries (i, 2 jp), (i, 2 jp + 1)
-// and (i + 3, 2 jp), (i + 3, 2 jp + 1) with i = q / 3, jp = q % 3 -- the same (i, jp) in every round, so the piece's place in c and in y is a property of the lane.
-// A load instruction then covers seven runs of 144 consecutive bytes (14 cache lines) instead of 64 lanes x 16 bytes 288 bytes apart (64 lines): with one block per
-// lane every line went through the CU's vector cache up to eight times and the kernel sat at 2.9 TB/s with its waves waiting 65 % of their cycles.
-constexpr int PCGF_ROUNDS = 18;   // rounds of 7 blocks held in registers: 126 blocks per frame; beyond that the tail is fetched twice
+// its frames -- c = W^T p, t = Vinv c, y -= W t, the first two rounds of a frame's slot list staying in registers across both uses -- and (U p)_e for the
+// entities dealt to it.  p: this workgroup's copy of the search direction (LDS)
 __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__restrict__ p, double *__restrict__ yacc, double *__restrict__ red, int wg, int G) {
     constexpr int NW = PCG_THREADS / 64;
     const int n = 6 * a.A, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = lane / 9, q = lane - 9 * b, i = q / 3, jp = q - 3 * i;
-    const bool on = lane < 63;
-    for (int k = tid; k < n; k += PCG_THREADS) yacc[k] = 0.0;
+    for (int i = tid; i < n; i += PCG_THREADS) yacc[i] = 0.0;
     __syncthreads();
     for (int f = wg * NW + wave; f < a.F; f += G * NW) {
-        const int s0 = a.fslot_start[f], kf = a.fslot_start[f + 1] - s0;
+        const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
         const double *Vi = a.Vinv + (size_t)f * 36;
-        const double2 *panel = reinterpret_cast<const double2 *>(a.W + (size_t)s0 * 36);
-        double2 lo[PCGF_ROUNDS], hi[PCGF_ROUNDS];
-        int ent[PCGF_ROUNDS];
+        double2 w0[18], w1[18];
+        int e0 = -1, e1 = -1;
+        double c[6] = {0, 0, 0, 0, 0, 0};
+        auto gather_c = [&](const double2 (&wb)[18], int e) {
 #pragma unroll
-        for (int r = 0; r < PCGF_ROUNDS; r++) {
-            const int sl = 7 * r + b;
-            const bool have = on && sl < kf;
-            ent[r] = have ? a.fslot_ent[s0 + sl] : -1;
-            lo[r] = have ? panel[18 * sl + q] : make_double2(0.0, 0.0);
-            hi[r] = have ? panel[18 * sl + q + 9] : make_double2(0.0, 0.0);
-        }
-        double cx = 0.0, cy = 0.0;   // this lane's share of c[2 jp], c[2 jp + 1]
-#pragma unroll
-        for (int r = 0; r < PCGF_ROUNDS; r++) {
-            if (ent[r] >= 0) {
-                const double p0 = p[6 * ent[r] + i], p1 = p[6 * ent[r] + i + 3];
-                cx = fma(lo[r].x, p0, fma(hi[r].x, p1, cx));
-                cy = fma(lo[r].y, p0, fma(hi[r].y, p1, cy));
+            for (int i = 0; i < 6; i++) {
+                const double pe = p[6 * e + i];
+                c[0] = fma(wb[3 * i].x, pe, c[0]); c[1] = fma(wb[3 * i].y, pe, c[1]); c[2] = fma(wb[3 * i + 1].x, pe, c[2]);
+                c[3] = fma(wb[3 * i + 1].y, pe, c[3]); c[4] = fma(wb[3 * i + 2].x, pe, c[4]); c[5] = fma(wb[3 * i + 2].y, pe, c[5]);
             }
-        }
-        for (int sl = 7 * PCGF_ROUNDS + b; on && sl < kf; sl += 7) {
-            const int e = a.fslot_ent[s0 + sl];
-            const double2 l2 = panel[18 * sl + q], h2 = panel[18 * sl + q + 9];
-            const double p0 = p[6 * e + i], p1 = p[6 * e + i + 3];
-            cx = fma(l2.x, p0, fma(h2.x, p1, cx));
-            cy = fma(l2.y, p0, fma(h2.y, p1, cy));
-        }
-        double c[6];
+        };
+        if (s0 + lane < s1) {
+            e0 = a.fslot_ent[s0 + lane];
+            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)(s0 + lane) * 36);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { c[2 * k] = (on && jp == k) ? cx : 0.0; c[2 * k + 1] = (on && jp == k) ? cy : 0.0; }
+            for (int u = 0; u < 18; u++) w0[u] = q[u];
+        }
+        if (s0 + lane + 64 < s1) {
+            e1 = a.fslot_ent[s0 + lane + 64];
+            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)(s0 + lane + 64) * 36);
+#pragma unroll
+            for (int u = 0; u < 18; u++) w1[u] = q[u];
+        }
+        if (e0 >= 0) gather_c(w0, e0);
+        if (e1 >= 0) gather_c(w1, e1);
+        for (int s = s0 + lane + 128; s < s1; s += 64) {
+            const int e = a.fslot_ent[s];
+            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
+            double2 wt[18];
+#pragma unroll
+            for (int u = 0; u < 18; u++) wt[u] = q[u];
+            gather_c(wt, e);
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-            for (int k = 0; k < 6; k++) c[k] += __shfl_xor(c[k], off);
-        // t = Vinv c: this lane needs t[2 jp], t[2 jp + 1] only
-        double tx = 0.0, ty = 0.0;
+            for (int i = 0; i < 6; i++) c[i] += __shfl_xor(c[i], off);
+        double t[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             double tv = 0.0;
 #pragma unroll
             for (int j = 0; j < 6; j++) tv = fma(Vi[k * 6 + j], c[j], tv);
-            if (k == 2 * jp) tx = tv;
-            if (k == 2 * jp + 1) ty = tv;
+            t[k] = tv;
         }
+        auto scatter = [&](const double2 (&wb)[18], int e) {
+            if (a.ent_fixed[e]) return;
 #pragma unroll
-        for (int r = 0; r < PCGF_ROUNDS; r++) {
-            if (ent[r] >= 0 && !a.ent_fixed[ent[r]]) {
-                atomicAdd(yacc + 6 * ent[r] + i, -(lo[r].x * tx + lo[r].y * ty));
-                atomicAdd(yacc + 6 * ent[r] + i + 3, -(hi[r].x * tx + hi[r].y * ty));
+            for (int i = 0; i < 6; i++) {
+                const double v = wb[3 * i].x * t[0] + wb[3 * i].y * t[1] + wb[3 * i + 1].x * t[2] + wb[3 * i + 1].y * t[3] + wb[3 * i + 2].x * t[4] + wb[3 * i + 2].y * t[5];
+                atomicAdd(yacc + 6 * e + i, -v);
             }
-        }
-        for (int sl = 7 * PCGF_ROUNDS + b; on && sl < kf; sl += 7) {
-            const int e = a.fslot_ent[s0 + sl];
-            if (a.ent_fixed[e]) continue;
-            const double2 l2 = panel[18 * sl + q], h2 = panel[18 * sl + q + 9];
-            atomicAdd(yacc + 6 * e + i, -(l2.x * tx + l2.y * ty));
-            atomicAdd(yacc + 6 * e + i + 3, -(h2.x * tx + h2.y * ty));
+        };
+        if (e0 >= 0) scatter(w0, e0);
+        if (e1 >= 0) scatter(w1, e1);
+        for (int s = s0 + lane + 128; s < s1; s += 64) {
+            const int e = a.fslot_ent[s];
+            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
+            double2 wt[18];
+#pragma unroll
+            for (int u = 0; u < 18; u++) wt[u] = q[u];
+            scatter(wt, e);
         }
     }
     // (U p)_e for the entities dealt to this workgroup (row e of the symmetric U, lower triangle stored)
