@@ -304,3 +304,36 @@ def test_spcg_in_deterministic_mode_gives_the_same_bits_twice():
         assert np.array_equal(xa, xb) and ea == eb
     assert np.array_equal(r1[0][0], r1[1][0])
     np.testing.assert_allclose(r1[0][1], a[1], rtol=1e-6)
+
+
+def test_solver_options_struct_is_forward_compatible_and_validated():
+    # aar_solver_options carries its own size: a caller built against a shorter struct (only struct_size + solver) keeps working, the fields it does not know
+    # take their defaults; an unset struct_size and values outside the enums are refused with AAR_ERR_INVALID (no silent fall-back to another solver)
+    import ctypes as C
+    ds, g = load_golden("g1_cfg3_cut")
+    cds = ds.as_c()
+    d = aar.CProblemDesc()
+    aar.lib().aar_problem_desc_from_dataset(C.byref(cds), C.byref(d))
+    so = aar.CSolverOptions()
+    aar.lib().aar_solver_default_options(C.byref(so))
+    assert so.struct_size == C.sizeof(aar.CSolverOptions) and so.solver == aar.SOLVER_DIRECT and so.deterministic == 0
+    h = C.c_void_p()
+    so.solver, so.struct_size, so.deterministic, so.pcg_eta = aar.SOLVER_SPCG, 8, 1, 0.5      # a "short" caller: deterministic / eta lie beyond its struct
+    assert aar.lib().aar_problem_create_ex(C.byref(d), C.byref(so), C.byref(h)) == 0
+    st = aar.CSolverStats()
+    assert aar.lib().aar_problem_get_solver_stats(h, C.byref(st)) == 0
+    assert st.solver == aar.SOLVER_SPCG and st.deterministic == 0 and abs(st.pcg_eta - 0.02) < 1e-15
+    aar.lib().aar_problem_destroy(h)
+    for bad in (dict(struct_size=0), dict(solver=7), dict(pcg_eta=-1.0), dict(pcg_max_it=-3)):
+        aar.lib().aar_solver_default_options(C.byref(so))
+        for k, v in bad.items():
+            setattr(so, k, v)
+        h = C.c_void_p()
+        assert aar.lib().aar_problem_create_ex(C.byref(d), C.byref(so), C.byref(h)) == aar.AAR_ERR_INVALID, bad
+    # a solver the problem is too large for is refused, not replaced: CG on the explicit system beyond 14 tiles of unknowns
+    big = aar.synth(3, num_cams=4, num_markers=300, num_frames=12)
+    with pytest.raises(aar.AarError) as e:
+        aar.Problem(big, solver="spcg")
+    assert e.value.code == aar.AAR_ERR_UNSUPPORTED
+    with aar.Problem(big, solver="auto") as p:
+        assert p.solver_stats()["solver"] == "pcg"
