@@ -48,6 +48,12 @@ __device__ __forceinline__ void wave_sum_lds(const double (&vals)[NV], double *_
     }
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // zero_n > 0: the launch also clears zero_p[0 .. zero_n) grid-stride (aar_lm_init: the block set pass B is about to accumulate into and the
 // linear-model partials -- one launch less at the start of every solve)
@@ -120,13 +126,13 @@ __device__ __forceinline__ void load_ent_lds(const double *row, Ent &e) {
 // LDS; W_cf / W_mf blocks accumulate in LDS (ds_add_f64) at the frame-local slot of the camera / marker and leave as
 // one coalesced copy.  Nothing here is shared with another workgroup: no global atomics.  The epilogue inverts
 // V_f + mu_pred I (the damping the NEXT solve is expected to use) and clears a dead block set grid-stride.
-// LDS: [max_kf*37] W blocks | [32] V,g,err | [(max_kf+1)*25] entity rows | [nwaves * 64 * passA_sum_chunk] wave-sum scratch
+// LDS: [max_kf*37] W blocks | [64] V,g,err (+ H_f, sum w r of the wrench form) | [(max_kf+1)*25] entity rows | [nwaves * 64 * passA_sum_chunk] wave-sum scratch
 // ------------------------------------------------------------------------------------------------
 struct PassAArgs {
     const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat;   // ent: the {R, t, J_l} table of the point (k_backsub / k_unpack)
     int kstride;                                                                 // Kmat[kstride * camera + i]
     const int32_t *frame_obs_start, *fslot_start, *fslot_ent;
-    int A, F, res_f32, max_kf, frames_fixed;
+    int A, F, C, res_f32, max_kf, frames_fixed;   // C: entities below it are cameras
     float huber;
     double h, mu_pred;
     double *V, *gf, *W, *Vinv, *hf, *err_part;
@@ -144,6 +150,67 @@ constexpr int WLS = 37;   // doubles between the W blocks of consecutive frame-l
 __host__ __device__ constexpr size_t passA_w_doubles(int max_kf) { return ((size_t)max_kf * WLS + 1) & ~(size_t)1; }   // what follows stays 16-byte aligned
 __host__ __device__ constexpr int passA_sum_chunk(int block) { return block >= 128 ? 8 : 32; }
 
+// what both forms of pass A end with (W blocks, V / g / err in LDS; after a __syncthreads): the coalesced copies, (V_f + mu_pred I)^-1 and h_f on one lane,
+// the dense panels of the MFMA Schur path
+template <int BLOCK>
+__device__ __forceinline__ void passA_epilogue(const PassAArgs &a, const double *Wl, const double *acc, double *scratch, const int f, const int s0, const int kf) {
+    const int tid = threadIdx.x;
+    // coalesced write-out
+    for (int i = tid; i < kf * 36; i += BLOCK) a.W[(size_t)s0 * 36 + i] = Wl[i + i / 36];
+    for (int t = tid; t < 36; t += BLOCK) a.V[(size_t)f * 36 + t] = acc[sym6(t / 6, t % 6)];
+    for (int t = tid; t < 6; t += BLOCK) a.gf[(size_t)f * 6 + t] = acc[21 + t];
+    if (tid == 0) a.err_part[f] = acc[27];
+    const bool dense = a.Yd != nullptr && a.mu_pred >= 0.0;
+    if (a.mu_pred >= 0.0 && tid == BLOCK - 1) {  // (V_f + mu I)^-1 and h_f for the damping the next solve is expected to use
+        double out[36];
+        if (a.frames_fixed) {
+#pragma unroll
+            for (int i = 0; i < 36; i++) out[i] = 0.0;
+        } else {
+            double m[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) m[i][j] = acc[sym6(i, j)] + (i == j ? a.mu_pred : 0.0);
+            if (!spd6_inverse(m, out)) atomicOr(a.flags, 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double hv = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                a.Vinv[(size_t)f * 36 + i * 6 + j] = out[i * 6 + j];
+                hv += out[i * 6 + j] * acc[21 + j];
+                if (dense) scratch[i * 6 + j] = out[i * 6 + j];   // (the wave-sum scratch is free by now)
+            }
+            a.hf[(size_t)f * 6 + i] = hv;
+        }
+    }
+    if (dense) {   // row (slot, i) of the frame's panels: W as it is, Y = W (V_f + mu I)^-1; the pseudo entity 0 carries g_f in its row 0
+        __syncthreads();
+        double vi[36];
+#pragma unroll
+        for (int q = 0; q < 36; q++) vi[q] = scratch[q];
+        const size_t fbase = (size_t)f * a.Ad * 36;
+        for (int r = tid; r < kf * 6; r += BLOCK) {
+            const int sl = r / 6, i = r - sl * 6;
+            const double *wr = Wl + sl * WLS + i * 6;
+            double w[6], y[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 6; k++) w[k] = wr[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) y[j] = fma(w[k], vi[k * 6 + j], y[j]);
+            const size_t o = fbase + (size_t)a.slot_dense[s0 + sl] * 36 + i * 6;
+            double2 *yp = reinterpret_cast<double2 *>(a.Yd + o), *wd = reinterpret_cast<double2 *>(a.Wd + o);
+            yp[0] = make_double2(y[0], y[1]); yp[1] = make_double2(y[2], y[3]); yp[2] = make_double2(y[4], y[5]);
+            wd[0] = make_double2(w[0], w[1]); wd[1] = make_double2(w[2], w[3]); wd[2] = make_double2(w[4], w[5]);
+        }
+        if (tid < 6) a.Wd[fbase + tid] = acc[21 + tid];
+    }
+}
+
 // CPL = corners per lane: 4 = one lane per observation; 2 / 1 = two / four lanes per observation for frames with few
 // observations (the wavefront's instruction stream gets that much shorter; the sums over lanes do not care)
 // INTR: camera intrinsics are optimised -- every observation also feeds W_kf, the block of its camera's intrinsics entity
@@ -151,8 +218,8 @@ __host__ __device__ constexpr int passA_sum_chunk(int block) { return block >= 1
 template <int BLOCK, int CPL, bool INTR = false>
 __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, const int f, const int n_blocks_a) {
     double *Wl = lds;                                   // [kf][WLS]: 36 values per slot, 37 apart (an odd stride spreads the slots over all banks)
-    double *acc = lds + passA_w_doubles(a.max_kf);         // [32]
-    double *entl = acc + 32;                            // [(max_kf+1)][ENT_LDS]
+    double *acc = lds + passA_w_doubles(a.max_kf);         // [32] (+ 32 the wrench form uses)
+    double *entl = acc + 64;                            // [(max_kf+1)][ENT_LDS]
     constexpr int CH = passA_sum_chunk(BLOCK);
     double *scratch = entl + (size_t)(a.max_kf + 1) * ENT_LDS;  // [BLOCK/64][CH * 64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -287,8 +354,187 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
     // V, g, err: wave sums, then one LDS add per wave and value
     wave_sum_lds<28, CH>(vals, scratch + wave * (CH * 64), lane, [&](int i, double s) { atomicAdd(acc + i, s); });
     __syncthreads();
-    // coalesced write-out
-    for (int i = tid; i < kf * 36; i += BLOCK) a.W[(size_t)s0 * 36 + i] = Wl[i + i / 36];
+    passA_epilogue<BLOCK>(a, Wl, acc, scratch, f, s0, kf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pass A in wrench form (geom.hpp, corner_wrench): the same workgroup per frame and the same results up to rounding, but a lane only forms
+// H = sum w w^T (21 values) of its observation and adds it to the observation's camera slot and marker slot in LDS; sum w r and sum r^2 stay in
+// registers.  After the loop: H_f = the sum of the camera slots (cameras come first in a frame's ascending slot list and every observation has one),
+// V_f = F^T H_f F, g_f = F^T sum w r, and one lane per slot turns its H into the W block T^T H F and stores it.
+//   ~720 instead of ~1 500 fp64 instructions per observation, 42 instead of 72 LDS atomics, 28 accumulators instead of 100 (profiles/r04_vgpr_counts.txt);
+//   LDS holds nothing but the H slots (21 doubles each: 21 KB instead of 69 KB at config 5's 122 slots per frame -- the row form also stages the
+//   entities' {R, t, J_l} rows and the W blocks): the kernel is bound by the dependent fetches and barriers of a workgroup, i.e. by how many workgroups
+//   a CU holds, and the entity rows are L1/L2 hits fetched next to the observation's index record without a staging phase before them.
+// LDS: [max_kf*21] H slots | [32] V,g,err | [32] H_f, sum w r, sum r^2, [30] = camera slots | [24] the frame's row | [36] H_f F | [36] (V_f + mu I)^-1
+// ------------------------------------------------------------------------------------------------
+constexpr int HLS = 21;
+__host__ __device__ constexpr size_t passA_h_doubles(int max_kf) { return ((size_t)max_kf * HLS + 1) & ~(size_t)1; }
+
+template <int BLOCK, int CPL>
+__device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *lds, const int f, const int n_blocks_a) {
+    double *Hl = lds;
+    double *acc = lds + passA_h_doubles(a.max_kf);
+    double *hacc = acc + 32;
+    double *frow = acc + 64;
+    double *Yl = frow + 24;
+    double *vil = Yl + 36;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o0 = a.frame_obs_start[f], o1 = a.frame_obs_start[f + 1];
+    const int s0 = a.fslot_start[f], kf = a.fslot_start[f + 1] - s0;
+    for (int i = tid; i < kf * HLS; i += BLOCK) Hl[i] = 0.0;
+    for (int t = tid; t < 64; t += BLOCK) acc[t] = 0.0;
+    if (tid < ENT_STRIDE / 2) {
+        const double2 v = reinterpret_cast<const double2 *>(a.ent + (size_t)(a.A + f) * ENT_STRIDE)[tid];
+        frow[2 * tid] = v.x; frow[2 * tid + 1] = v.y;
+    }
+    {   // grid-stride clearing of the block set that is dead by now
+        const int64_t gid = (int64_t)f * BLOCK + tid, stride = (int64_t)n_blocks_a * BLOCK;
+        for (int64_t i = gid; i < a.zero0_n; i += stride) a.zero0[i] = 0.0;
+        for (int64_t i = gid; i < a.zero1_n; i += stride) a.zero1[i] = 0.0;
+        for (int64_t i = gid; i < a.zero2_n; i += stride) a.zero2[i] = 0.0;
+    }
+    __syncthreads();
+
+    double vals[7];  // sum w r (6), sum r^2
+#pragma unroll
+    for (int i = 0; i < 7; i++) vals[i] = 0.0;
+    Ent ef;          // wave-uniform: SGPRs
+    load_ent(a.ent, a.A + __builtin_amdgcn_readfirstlane(f), ef);
+    const int nobs = o1 - o0;
+    int stride = 1;  // consecutive lanes take observations `stride` apart (different cameras: fewer same-address LDS atomics); coprime with nobs
+    if (nobs > 16) {
+        stride = nobs / 8 + 1;
+        while (true) {
+            int x = stride, y = nobs;
+            while (y) { int t = x % y; x = y; y = t; }
+            if (x == 1) break;
+            stride++;
+        }
+    }
+    constexpr int LPO = 4 / CPL;
+    for (int t = tid; t < nobs * LPO; t += BLOCK) {
+        const int it = t / LPO, part = t - it * LPO;
+        const int o = o0 + (int)(((int64_t)it * stride) % nobs);
+        const ObsIdx id = a.idx[o];
+        const int sc = id.slots & ((1 << SLOT_C_BITS) - 1), sm = (id.slots >> SLOT_C_BITS) & ((1 << SLOT_M_BITS) - 1);
+        EntRT ec, em;
+        load_ent_rt(a.ent, id.cam, ec);
+        load_ent_rt(a.ent, id.marker, em);
+        double K[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) K[i] = a.Kmat[a.kstride * id.cam + i];
+        double H[21];
+#pragma unroll
+        for (int i = 0; i < 21; i++) H[i] = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < CPL; kk++) {
+            const int k = part * CPL + kk;
+            const float2 ouv = reinterpret_cast<const float2 *>(a.uv)[4 * (int64_t)o + k];
+            CornerGeom g;
+            project_corner(ec, em, ef, K, a.h, k, g);
+            double r[2], w[2][6];
+            corner_residual(ouv.x, ouv.y, g.u, g.v, a.res_f32, a.huber, r[0], r[1]);
+            corner_wrench(ec, K, g, w);
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                vals[6] += r[rr] * r[rr];
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    vals[i] += w[rr][i] * r[rr];
+#pragma unroll
+                    for (int j = 0; j <= i; j++) H[i * (i + 1) / 2 + j] += w[rr][i] * w[rr][j];
+                }
+            }
+        }
+        double *hc = Hl + sc * HLS, *hm = Hl + sm * HLS;
+#pragma unroll
+        for (int i = 0; i < 21; i++) atomicAdd(hc + i, H[i]);
+#pragma unroll
+        for (int i = 0; i < 21; i++) atomicAdd(hm + i, H[i]);
+    }
+    for (int t = tid; t < kf; t += BLOCK)
+        if (a.fslot_ent[s0 + t] < a.C) atomicAdd(hacc + 30, 1.0);
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const double sv = wave_sum(vals[i]);
+        if (lane == 0) atomicAdd(hacc + 21 + i, sv);
+    }
+    __syncthreads();
+    if (tid < 21) {   // H_f: the camera slots of the frame
+        const int nc = (int)hacc[30];
+        double sv = 0.0;
+        for (int t = 0; t < nc; t++) sv += Hl[t * HLS + tid];
+        hacc[tid] = sv;
+    }
+    __syncthreads();
+    if (wave == 0) {   // V_f = F^T H_f F (through Y = H_f F), g_f = F^T sum w r
+        const double *jl = frow + 12;
+        if (lane < 36) {
+            const int k = lane / 6, j = lane - 6 * k;
+            Yl[lane] = j < 3 ? hacc[sym6(k, 0)] * jl[j] + hacc[sym6(k, 1)] * jl[3 + j] + hacc[sym6(k, 2)] * jl[6 + j] : hacc[sym6(k, j)];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 28) {
+            double out;
+            if (lane < 21) {
+                int i = 0;
+                while ((i + 1) * (i + 2) / 2 <= lane) i++;
+                const int j = lane - i * (i + 1) / 2;
+                out = i < 3 ? jl[i] * Yl[j] + jl[3 + i] * Yl[6 + j] + jl[6 + i] * Yl[12 + j] : Yl[i * 6 + j];
+            } else if (lane < 27) {
+                const int i = lane - 21;
+                out = i < 3 ? jl[i] * hacc[21] + jl[3 + i] * hacc[22] + jl[6 + i] * hacc[23] : hacc[21 + i];
+            } else out = hacc[27];
+            acc[lane] = out;
+        }
+    }
+    // one lane per slot: W = T^T H F, rows stored as they come
+    for (int t = tid; t < kf; t += BLOCK) {
+        const int e = a.fslot_ent[s0 + t];
+        const double2 *rowp = reinterpret_cast<const double2 *>(a.ent + (size_t)e * ENT_STRIDE);
+        double2 rv[7];   // doubles 8 .. 21 of the entity's row: R[8] | t | J_l
+#pragma unroll
+        for (int i = 0; i < 7; i++) rv[i] = rowp[4 + i];
+        const bool cam = e < a.C;
+        const double tt[3] = {cam ? rv[0].y - ef.t[0] : rv[0].y, cam ? rv[1].x - ef.t[1] : rv[1].x, cam ? rv[1].y - ef.t[2] : rv[1].y};   // d = t_c - t_f, or t_m
+        const double Jl[9] = {rv[2].x, rv[2].y, rv[3].x, rv[3].y, rv[4].x, rv[4].y, rv[5].x, rv[5].y, rv[6].x};
+        double H[21], X[6][6];
+        const double *slot = Hl + t * HLS;
+#pragma unroll
+        for (int i = 0; i < 21; i++) H[i] = slot[i];
+        // camera: T^T = -[J_l^T, -J_l^T [d]x; 0, I]      marker: T^T = [J_l^T R_f^T, -J_l^T [t_m]x R_f^T; 0, R_f^T]
+#pragma unroll
+        for (int l = 0; l < 6; l++) {
+            double zt[3], zb[3], x[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                zt[i] = cam ? H[sym6(i, l)] : ef.R[i] * H[sym6(0, l)] + ef.R[3 + i] * H[sym6(1, l)] + ef.R[6 + i] * H[sym6(2, l)];
+                zb[i] = cam ? H[sym6(3 + i, l)] : ef.R[i] * H[sym6(3, l)] + ef.R[3 + i] * H[sym6(4, l)] + ef.R[6 + i] * H[sym6(5, l)];
+            }
+            cross3(tt, zb, x);
+            const double v[3] = {zt[0] - x[0], zt[1] - x[1], zt[2] - x[2]};
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double wt = Jl[i] * v[0] + Jl[3 + i] * v[1] + Jl[6 + i] * v[2];
+                X[i][l] = cam ? -wt : wt;
+                X[3 + i][l] = cam ? -zb[i] : zb[i];
+            }
+        }
+        double2 *wp = reinterpret_cast<double2 *>(a.W + (size_t)(s0 + t) * 36);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double wr[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) wr[j] = X[i][0] * ef.Jl[j] + X[i][1] * ef.Jl[3 + j] + X[i][2] * ef.Jl[6 + j];
+            wp[3 * i] = make_double2(wr[0], wr[1]);
+            wp[3 * i + 1] = make_double2(wr[2], X[i][3]);
+            wp[3 * i + 2] = make_double2(X[i][4], X[i][5]);
+        }
+    }
+    __syncthreads();
     for (int t = tid; t < 36; t += BLOCK) a.V[(size_t)f * 36 + t] = acc[sym6(t / 6, t % 6)];
     for (int t = tid; t < 6; t += BLOCK) a.gf[(size_t)f * 6 + t] = acc[21 + t];
     if (tid == 0) a.err_part[f] = acc[27];
@@ -313,31 +559,33 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
             for (int j = 0; j < 6; j++) {
                 a.Vinv[(size_t)f * 36 + i * 6 + j] = out[i * 6 + j];
                 hv += out[i * 6 + j] * acc[21 + j];
-                if (dense) scratch[i * 6 + j] = out[i * 6 + j];   // (the wave-sum scratch is free by now)
+                if (dense) vil[i * 6 + j] = out[i * 6 + j];
             }
             a.hf[(size_t)f * 6 + i] = hv;
         }
     }
-    if (dense) {   // row (slot, i) of the frame's panels: W as it is, Y = W (V_f + mu I)^-1; the pseudo entity 0 carries g_f in its row 0
+    if (dense) {   // the frame's panels of the MFMA Schur path: W as it is, Y = W (V_f + mu I)^-1; the pseudo entity 0 carries g_f in its row 0
         __syncthreads();
         double vi[36];
 #pragma unroll
-        for (int q = 0; q < 36; q++) vi[q] = scratch[q];
+        for (int q = 0; q < 36; q++) vi[q] = vil[q];
         const size_t fbase = (size_t)f * a.Ad * 36;
-        for (int r = tid; r < kf * 6; r += BLOCK) {
-            const int sl = r / 6, i = r - sl * 6;
-            const double *wr = Wl + sl * WLS + i * 6;
-            double w[6], y[6] = {0, 0, 0, 0, 0, 0};
+        for (int t = tid; t < kf; t += BLOCK) {   // (a lane reads back the block it has stored itself)
+            const double2 *wp = reinterpret_cast<const double2 *>(a.W + (size_t)(s0 + t) * 36);
+            const size_t o = fbase + (size_t)a.slot_dense[s0 + t] * 36;
 #pragma unroll
-            for (int k = 0; k < 6; k++) w[k] = wr[k];
+            for (int i = 0; i < 6; i++) {
+                const double2 w0 = wp[3 * i], w1 = wp[3 * i + 1], w2 = wp[3 * i + 2];
+                const double w[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+                double y[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 6; k++)
+                for (int k = 0; k < 6; k++)
 #pragma unroll
-                for (int j = 0; j < 6; j++) y[j] = fma(w[k], vi[k * 6 + j], y[j]);
-            const size_t o = fbase + (size_t)a.slot_dense[s0 + sl] * 36 + i * 6;
-            double2 *yp = reinterpret_cast<double2 *>(a.Yd + o), *wd = reinterpret_cast<double2 *>(a.Wd + o);
-            yp[0] = make_double2(y[0], y[1]); yp[1] = make_double2(y[2], y[3]); yp[2] = make_double2(y[4], y[5]);
-            wd[0] = make_double2(w[0], w[1]); wd[1] = make_double2(w[2], w[3]); wd[2] = make_double2(w[4], w[5]);
+                    for (int j = 0; j < 6; j++) y[j] = fma(w[k], vi[k * 6 + j], y[j]);
+                double2 *yp = reinterpret_cast<double2 *>(a.Yd + o + i * 6), *wd = reinterpret_cast<double2 *>(a.Wd + o + i * 6);
+                yp[0] = make_double2(y[0], y[1]); yp[1] = make_double2(y[2], y[3]); yp[2] = make_double2(y[4], y[5]);
+                wd[0] = w0; wd[1] = w1; wd[2] = w2;
+            }
         }
         if (tid < 6) a.Wd[fbase + tid] = acc[21 + tid];
     }
@@ -448,10 +696,12 @@ __device__ __forceinline__ void passB_body(const PassBArgs &b, double *scratch, 
 // The two passes as kernels of their own, and as ONE launch: workgroups [0, F) are pass A's, the rest pass B's.  They
 // are independent once the {R, t, J_l} table exists (k_backsub / k_unpack write it), so the trial evaluation of an LM step
 // runs them side by side; both are latency-bound with one wavefront per SIMD and together still fit the chip at config 3.
-template <int BLOCK, int CPL>
+// WR: the wrench form (the default without intrinsics entities); the row form stays for the intrinsics variants and as the A/B reference (AAR_PASSA_WRENCH=0)
+template <int BLOCK, int CPL, bool WR>
 __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
     extern __shared__ double lds[];
-    passA_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+    if (WR) passA_wrench_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+    else passA_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ void __launch_bounds__(256) k_passB(const PassBArgs b) {
@@ -611,11 +861,13 @@ __global__ void __launch_bounds__(BLOCK) k_passA_intr(const PassAArgs a) {
     passA_body<BLOCK, CPL, INTR>(a, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
-template <int BLOCK, int CPL>
+template <int BLOCK, int CPL, bool WR>
 __global__ void __launch_bounds__(BLOCK) k_passAB(const PassAArgs a, const PassBArgs b) {
     extern __shared__ double lds[];   // pass A's layout; pass B uses the first (BLOCK / 64) * 2048 doubles
-    if ((int)blockIdx.x < a.F) passA_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, a.F);
-    else passB_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
+    if ((int)blockIdx.x < a.F) {
+        if (WR) passA_wrench_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, a.F);
+        else passA_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, a.F);
+    } else passB_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
 }
 // the same with camera intrinsics optimised: pass A with the W_kf blocks, pass B, and pass B's intrinsics blocks (three launches before)
 template <int BLOCK, int CPL>
@@ -679,8 +931,10 @@ void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream
 
 int residual_blocks(const DeviceProblem &P) { return (int)((P.N + 255) / 256); }
 
+size_t passA_wrench_lds_bytes(int max_kf) { return (passA_h_doubles(max_kf) + 64 + 24 + 72) * sizeof(double); }
+
 size_t passA_lds_bytes(int max_kf, int block) {
-    return (passA_w_doubles(max_kf) + 32 + (size_t)(max_kf + 1) * ENT_LDS + (block / 64) * passA_sum_chunk(block) * 64) * sizeof(double);
+    return (passA_w_doubles(max_kf) + 64 + (size_t)(max_kf + 1) * ENT_LDS + (block / 64) * passA_sum_chunk(block) * 64) * sizeof(double);
 }
 
 static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, int zero_blk) {
@@ -688,7 +942,7 @@ static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, i
     a.idx = P.a_idx; a.uv = P.a_uv; a.ent = P.ent[which];
     { const KTable kt = k_table(P, which); a.Kmat = kt.base; a.kstride = kt.stride; }
     a.frame_obs_start = P.frame_obs_start; a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent;
-    a.A = P.A; a.F = P.F; a.res_f32 = P.res_f32; a.max_kf = P.max_kf; a.frames_fixed = P.frames_fixed;
+    a.A = P.A; a.F = P.F; a.C = P.C; a.res_f32 = P.res_f32; a.max_kf = P.max_kf; a.frames_fixed = P.frames_fixed;
     a.huber = P.huber;
     a.h = P.half_size; a.mu_pred = mu_pred;
     const DeviceProblem::Blocks &b = P.blk[which];
@@ -720,7 +974,7 @@ static PassBArgs passB_args(const DeviceProblem &P, int which) {
 // with_b: pass B's chunks ride in the same launch (the caller must not launch pass B again)
 template <int B, int CPL>
 static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, const PassBArgs *pbargs, hipStream_t st) {
-    size_t lds = passA_lds_bytes(P.max_kf, B);
+    size_t lds = (P.tune.passA_wrench && !P.intr) ? passA_wrench_lds_bytes(P.max_kf) : passA_lds_bytes(P.max_kf, B);
     if (pbargs) lds = std::max(lds, (size_t)(B / 64) * 2048 * sizeof(double));   // pass B's wave-sum scratch, when its chunks ride along
     static size_t granted = 48 * 1024, granted_ab = 48 * 1024;
     HookScope _h(P, KID_PASSA);
@@ -733,12 +987,20 @@ static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, const Pas
         static size_t granted_i = 48 * 1024;
         allow_dynamic_lds(reinterpret_cast<const void *>(k_passA_intr<B, CPL, true>), lds, granted_i);
         hipLaunchKernelGGL((k_passA_intr<B, CPL, true>), dim3(P.F), dim3(B), lds, st, a);
+    } else if (pbargs && P.tune.passA_wrench) {
+        static size_t granted_abw = 48 * 1024;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB<B, CPL, true>), lds, granted_abw);
+        hipLaunchKernelGGL((k_passAB<B, CPL, true>), dim3(P.F + (P.n_chunks + B / 64 - 1) / (B / 64)), dim3(B), lds, st, a, *pbargs);
     } else if (pbargs) {
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB<B, CPL>), lds, granted_ab);
-        hipLaunchKernelGGL((k_passAB<B, CPL>), dim3(P.F + (P.n_chunks + B / 64 - 1) / (B / 64)), dim3(B), lds, st, a, *pbargs);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB<B, CPL, false>), lds, granted_ab);
+        hipLaunchKernelGGL((k_passAB<B, CPL, false>), dim3(P.F + (P.n_chunks + B / 64 - 1) / (B / 64)), dim3(B), lds, st, a, *pbargs);
+    } else if (P.tune.passA_wrench) {
+        static size_t granted_w = 48 * 1024;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B, CPL, true>), lds, granted_w);
+        hipLaunchKernelGGL((k_passA<B, CPL, true>), dim3(P.F), dim3(B), lds, st, a);
     } else {
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B, CPL>), lds, granted);
-        hipLaunchKernelGGL((k_passA<B, CPL>), dim3(P.F), dim3(B), lds, st, a);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passA<B, CPL, false>), lds, granted);
+        hipLaunchKernelGGL((k_passA<B, CPL, false>), dim3(P.F), dim3(B), lds, st, a);
     }
 }
 
@@ -815,11 +1077,6 @@ void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st) {
 // ================================================================================================
 namespace aar {
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
 
 struct TrackArgs {
     const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat; const int32_t *frame_obs_start;
