@@ -1154,6 +1154,14 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         fslot_start[F] = (int32_t)fslot_ent.size();
     }
     P.total_slots = (int)fslot_ent.size();
+    std::vector<int32_t> frame_stride(F, 1);   // the observations of a frame are camera-major: a stride of ~ n / 8, coprime with n, puts different cameras into neighbouring lanes
+    for (int f = 0; f < F; f++) {
+        const int n = frame_obs_start[f + 1] - frame_obs_start[f];
+        if (n <= 16) continue;
+        int st = n / 8 + 1;
+        while (std::gcd(st, n) != 1) st++;
+        frame_stride[f] = st;
+    }
     const size_t ldsA = passA_lds_bytes(P.max_kf, 256) > passA_lds_bytes(P.max_kf, 64) ? passA_lds_bytes(P.max_kf, 256) : passA_lds_bytes(P.max_kf, 64);
     if (ldsA > 160 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers; the frame-block kernel holds them in LDS (limit ~ %d)", P.max_kf, (160 * 1024 / 8 - 58 - 2048) / 62);
     // Which Schur kernel (solve_kernels.hip): the MFMA kernel works on dense per-frame panels and is the default from 96 shared
@@ -1436,7 +1444,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
 
     // ---- upload ----
 #define UP(field, vec) if ((rc = dev_upload(pb, &P.field, vec))) return fail(rc)
-    UP(K, Kh); UP(a_idx, a_idx); UP(a_uv, a_uv); UP(frame_obs_start, frame_obs_start);
+    UP(K, Kh); UP(a_idx, a_idx); UP(a_uv, a_uv); UP(frame_obs_start, frame_obs_start); UP(frame_stride, frame_stride);
     UP(fslot_start, fslot_start); UP(fslot_ent, fslot_ent); UP(b_idx, b_idx); UP(b_uv, b_uv);
     UP(chunk_start, chunk_start); UP(ent_fixed, ent_fixed);
     UP(sw_ent, sw_ent); UP(sw_begin, sw_begin); UP(sw_end, sw_end); UP(pair_rec, pair_rec);

@@ -9,8 +9,10 @@
 // fp64 throughout.  No atomics on frame-owned data; shared blocks get one fp64 atomic per value per
 // (camera, marker) chunk.
 #include <algorithm>
+#include <vector>
 #include "geom.hpp"
 #include "kernels.h"
+#include "wave.hpp"
 
 namespace aar {
 
@@ -131,7 +133,8 @@ __device__ __forceinline__ void load_ent_lds(const double *row, Ent &e) {
 struct PassAArgs {
     const ObsIdx *idx; const float *uv; const double *ent; const double *Kmat;   // ent: the {R, t, J_l} table of the point (k_backsub / k_unpack)
     int kstride;                                                                 // Kmat[kstride * camera + i]
-    const int32_t *frame_obs_start, *fslot_start, *fslot_ent;
+    const int32_t *frame_obs_start, *fslot_start, *fslot_ent, *frame_stride;
+    unsigned long long *stamps;   // AAR_PASSA_STAMPS builds only
     int A, F, C, res_f32, max_kf, frames_fixed;   // C: entities below it are cameras
     float huber;
     double h, mu_pred;
@@ -371,6 +374,12 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
 constexpr int HLS = 21;
 __host__ __device__ constexpr size_t passA_h_doubles(int max_kf) { return ((size_t)max_kf * HLS + 1) & ~(size_t)1; }
 
+#ifdef AAR_PASSA_STAMPS   // diagnostic build (make HIPFLAGS+=-DAAR_PASSA_STAMPS; AAR_STAMPS_A=<file>; scripts/dev/passA_stamps_report.py): cycle stamps of a workgroup's phases
+#define PA_STAMP(n) do { if (a.stamps && f < 512 && tid == 0) a.stamps[f * 16 + (n)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PA_STAMP(n) do { } while (0)
+#endif
+
 template <int BLOCK, int CPL>
 __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *lds, const int f, const int n_blocks_a) {
     double *Hl = lds;
@@ -380,61 +389,71 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
     double *Yl = frow + 24;
     double *vil = Yl + 36;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int o0 = a.frame_obs_start[f], o1 = a.frame_obs_start[f + 1];
+    const int o0 = a.frame_obs_start[f], nobs = a.frame_obs_start[f + 1] - o0;
     const int s0 = a.fslot_start[f], kf = a.fslot_start[f + 1] - s0;
-    for (int i = tid; i < kf * HLS; i += BLOCK) Hl[i] = 0.0;
-    for (int t = tid; t < 64; t += BLOCK) acc[t] = 0.0;
-    if (tid < ENT_STRIDE / 2) {
-        const double2 v = reinterpret_cast<const double2 *>(a.ent + (size_t)(a.A + f) * ENT_STRIDE)[tid];
-        frow[2 * tid] = v.x; frow[2 * tid + 1] = v.y;
+    PA_STAMP(0);
+    // A workgroup is a chain of dependent fetches (index record -> entity rows ... slot entity -> its row) and barriers; everything that does not depend
+    // on LDS is issued up front: the frame's own row (SGPRs: wave-uniform), the first observation's index record and corners, the slot's entity
+    Ent ef;
+    load_ent(a.ent, a.A + __builtin_amdgcn_readfirstlane(f), ef);
+    // Consecutive lanes take observations `stride` apart (a permutation of the frame: the host picks stride coprime with nobs) so that the lanes of a
+    // wavefront mostly hold different cameras -- the order inside a frame is camera-major, and same-address ds_add_f64 serialise (+50 % at config 5).
+    constexpr int LPO = 4 / CPL;   // lanes per observation
+    const int stride = a.frame_stride[f];
+    const int part = tid % LPO;
+    int pos = 0, step = 0;
+    if (nobs > 0) {
+        pos = (int)(((unsigned long long)(tid / LPO) * (unsigned)stride) % (unsigned)nobs);
+        step = (int)(((unsigned long long)(BLOCK / LPO) * (unsigned)stride) % (unsigned)nobs);
     }
+    int t = tid;
+    bool have = t < nobs * LPO;
+    ObsIdx id = {0, 0, 0, 0};
+    float2 ouv[CPL];
+    EntRT ec, em;
+    double K[9];
+    auto fetch_obs = [&]() {
+        const int o = o0 + pos;
+        id = a.idx[o];
+#pragma unroll
+        for (int kk = 0; kk < CPL; kk++) ouv[kk] = reinterpret_cast<const float2 *>(a.uv)[4 * (int64_t)o + part * CPL + kk];
+    };
+    auto fetch_rows = [&]() {
+        load_ent_rt(a.ent, id.cam, ec);
+        load_ent_rt(a.ent, id.marker, em);
+#pragma unroll
+        for (int i = 0; i < 9; i++) K[i] = a.Kmat[a.kstride * id.cam + i];
+    };
+    if (have) fetch_obs();
+    const int e_slot = tid < kf ? a.fslot_ent[s0 + tid] : -1;
+    double2 frv = make_double2(0.0, 0.0);
+    if (tid < ENT_STRIDE / 2) frv = reinterpret_cast<const double2 *>(a.ent + (size_t)(a.A + f) * ENT_STRIDE)[tid];
+    for (int i = tid; i < kf * HLS; i += BLOCK) Hl[i] = 0.0;
+    for (int i = tid; i < 64; i += BLOCK) acc[i] = 0.0;
+    if (have) fetch_rows();
     {   // grid-stride clearing of the block set that is dead by now
-        const int64_t gid = (int64_t)f * BLOCK + tid, stride = (int64_t)n_blocks_a * BLOCK;
-        for (int64_t i = gid; i < a.zero0_n; i += stride) a.zero0[i] = 0.0;
-        for (int64_t i = gid; i < a.zero1_n; i += stride) a.zero1[i] = 0.0;
-        for (int64_t i = gid; i < a.zero2_n; i += stride) a.zero2[i] = 0.0;
+        const int64_t gid = (int64_t)f * BLOCK + tid, gstride = (int64_t)n_blocks_a * BLOCK;
+        for (int64_t i = gid; i < a.zero0_n; i += gstride) a.zero0[i] = 0.0;
+        for (int64_t i = gid; i < a.zero1_n; i += gstride) a.zero1[i] = 0.0;
+        for (int64_t i = gid; i < a.zero2_n; i += gstride) a.zero2[i] = 0.0;
     }
     __syncthreads();
+    PA_STAMP(1);
 
     double vals[7];  // sum w r (6), sum r^2
 #pragma unroll
     for (int i = 0; i < 7; i++) vals[i] = 0.0;
-    Ent ef;          // wave-uniform: SGPRs
-    load_ent(a.ent, a.A + __builtin_amdgcn_readfirstlane(f), ef);
-    const int nobs = o1 - o0;
-    int stride = 1;  // consecutive lanes take observations `stride` apart (different cameras: fewer same-address LDS atomics); coprime with nobs
-    if (nobs > 16) {
-        stride = nobs / 8 + 1;
-        while (true) {
-            int x = stride, y = nobs;
-            while (y) { int t = x % y; x = y; y = t; }
-            if (x == 1) break;
-            stride++;
-        }
-    }
-    constexpr int LPO = 4 / CPL;
-    for (int t = tid; t < nobs * LPO; t += BLOCK) {
-        const int it = t / LPO, part = t - it * LPO;
-        const int o = o0 + (int)(((int64_t)it * stride) % nobs);
-        const ObsIdx id = a.idx[o];
+    while (have) {
         const int sc = id.slots & ((1 << SLOT_C_BITS) - 1), sm = (id.slots >> SLOT_C_BITS) & ((1 << SLOT_M_BITS) - 1);
-        EntRT ec, em;
-        load_ent_rt(a.ent, id.cam, ec);
-        load_ent_rt(a.ent, id.marker, em);
-        double K[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) K[i] = a.Kmat[a.kstride * id.cam + i];
         double H[21];
 #pragma unroll
         for (int i = 0; i < 21; i++) H[i] = 0.0;
 #pragma unroll
         for (int kk = 0; kk < CPL; kk++) {
-            const int k = part * CPL + kk;
-            const float2 ouv = reinterpret_cast<const float2 *>(a.uv)[4 * (int64_t)o + k];
             CornerGeom g;
-            project_corner(ec, em, ef, K, a.h, k, g);
+            project_corner(ec, em, ef, K, a.h, part * CPL + kk, g);
             double r[2], w[2][6];
-            corner_residual(ouv.x, ouv.y, g.u, g.v, a.res_f32, a.huber, r[0], r[1]);
+            corner_residual(ouv[kk].x, ouv[kk].y, g.u, g.v, a.res_f32, a.huber, r[0], r[1]);
             corner_wrench(ec, K, g, w);
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
@@ -447,28 +466,49 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
                 }
             }
         }
+        t += BLOCK;
+        have = t < nobs * LPO;
+        if (have) {   // the next observation's fetches go out before this one's LDS additions
+            pos += step;
+            if (pos >= nobs) pos -= nobs;
+            fetch_obs();
+        }
         double *hc = Hl + sc * HLS, *hm = Hl + sm * HLS;
 #pragma unroll
         for (int i = 0; i < 21; i++) atomicAdd(hc + i, H[i]);
 #pragma unroll
         for (int i = 0; i < 21; i++) atomicAdd(hm + i, H[i]);
+        if (have) fetch_rows();
     }
-    for (int t = tid; t < kf; t += BLOCK)
-        if (a.fslot_ent[s0 + t] < a.C) atomicAdd(hacc + 30, 1.0);
+    PA_STAMP(2);
+    // the slot's entity row (doubles 8 .. 21: R[8] | t | J_l) is on its way during the sums and barriers below
+    double2 rv[7];
+    if (e_slot >= 0) {
+        const double2 *rowp = reinterpret_cast<const double2 *>(a.ent + (size_t)e_slot * ENT_STRIDE);
+#pragma unroll
+        for (int i = 0; i < 7; i++) rv[i] = rowp[4 + i];
+        if (e_slot < a.C) atomicAdd(hacc + 30, 1.0);
+    }
+    for (int ts = tid + BLOCK; ts < kf; ts += BLOCK)
+        if (a.fslot_ent[s0 + ts] < a.C) atomicAdd(hacc + 30, 1.0);
+    if (tid < ENT_STRIDE / 2) { frow[2 * tid] = frv.x; frow[2 * tid + 1] = frv.y; }
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        const double sv = wave_sum(vals[i]);
+        const double sv = wave_sum_dpp(vals[i]);
         if (lane == 0) atomicAdd(hacc + 21 + i, sv);
     }
+    PA_STAMP(3);
     __syncthreads();
+    PA_STAMP(4);
     if (tid < 21) {   // H_f: the camera slots of the frame
         const int nc = (int)hacc[30];
         double sv = 0.0;
-        for (int t = 0; t < nc; t++) sv += Hl[t * HLS + tid];
+        for (int ts = 0; ts < nc; ts++) sv += Hl[ts * HLS + tid];
         hacc[tid] = sv;
     }
     __syncthreads();
-    if (wave == 0) {   // V_f = F^T H_f F (through Y = H_f F), g_f = F^T sum w r
+    PA_STAMP(5);
+    if (wave == BLOCK / 64 - 1) {   // V_f = F^T H_f F (through Y = H_f F), g_f = F^T sum w r -- on the LAST wavefront: the slots' lanes start with the first
         const double *jl = frow + 12;
         if (lane < 36) {
             const int k = lane / 6, j = lane - 6 * k;
@@ -491,18 +531,21 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
             acc[lane] = out;
         }
     }
+    PA_STAMP(6);
     // one lane per slot: W = T^T H F, rows stored as they come
-    for (int t = tid; t < kf; t += BLOCK) {
-        const int e = a.fslot_ent[s0 + t];
-        const double2 *rowp = reinterpret_cast<const double2 *>(a.ent + (size_t)e * ENT_STRIDE);
-        double2 rv[7];   // doubles 8 .. 21 of the entity's row: R[8] | t | J_l
+    for (int ts = tid; ts < kf; ts += BLOCK) {
+        int e = e_slot;
+        if (ts != tid) {   // (frames with more slots than lanes)
+            e = a.fslot_ent[s0 + ts];
+            const double2 *rowp = reinterpret_cast<const double2 *>(a.ent + (size_t)e * ENT_STRIDE);
 #pragma unroll
-        for (int i = 0; i < 7; i++) rv[i] = rowp[4 + i];
+            for (int i = 0; i < 7; i++) rv[i] = rowp[4 + i];
+        }
         const bool cam = e < a.C;
         const double tt[3] = {cam ? rv[0].y - ef.t[0] : rv[0].y, cam ? rv[1].x - ef.t[1] : rv[1].x, cam ? rv[1].y - ef.t[2] : rv[1].y};   // d = t_c - t_f, or t_m
         const double Jl[9] = {rv[2].x, rv[2].y, rv[3].x, rv[3].y, rv[4].x, rv[4].y, rv[5].x, rv[5].y, rv[6].x};
         double H[21], X[6][6];
-        const double *slot = Hl + t * HLS;
+        const double *slot = Hl + ts * HLS;
 #pragma unroll
         for (int i = 0; i < 21; i++) H[i] = slot[i];
         // camera: T^T = -[J_l^T, -J_l^T [d]x; 0, I]      marker: T^T = [J_l^T R_f^T, -J_l^T [t_m]x R_f^T; 0, R_f^T]
@@ -523,7 +566,7 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
                 X[3 + i][l] = cam ? -zb[i] : zb[i];
             }
         }
-        double2 *wp = reinterpret_cast<double2 *>(a.W + (size_t)(s0 + t) * 36);
+        double2 *wp = reinterpret_cast<double2 *>(a.W + (size_t)(s0 + ts) * 36);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             double wr[3];
@@ -534,9 +577,11 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
             wp[3 * i + 2] = make_double2(X[i][4], X[i][5]);
         }
     }
+    PA_STAMP(7);
     __syncthreads();
-    for (int t = tid; t < 36; t += BLOCK) a.V[(size_t)f * 36 + t] = acc[sym6(t / 6, t % 6)];
-    for (int t = tid; t < 6; t += BLOCK) a.gf[(size_t)f * 6 + t] = acc[21 + t];
+    PA_STAMP(8);
+    for (int q = tid; q < 36; q += BLOCK) a.V[(size_t)f * 36 + q] = acc[sym6(q / 6, q % 6)];
+    for (int q = tid; q < 6; q += BLOCK) a.gf[(size_t)f * 6 + q] = acc[21 + q];
     if (tid == 0) a.err_part[f] = acc[27];
     const bool dense = a.Yd != nullptr && a.mu_pred >= 0.0;
     if (a.mu_pred >= 0.0 && tid == BLOCK - 1) {  // (V_f + mu I)^-1 and h_f for the damping the next solve is expected to use
@@ -564,15 +609,16 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
             a.hf[(size_t)f * 6 + i] = hv;
         }
     }
+    PA_STAMP(9);
     if (dense) {   // the frame's panels of the MFMA Schur path: W as it is, Y = W (V_f + mu I)^-1; the pseudo entity 0 carries g_f in its row 0
         __syncthreads();
         double vi[36];
 #pragma unroll
         for (int q = 0; q < 36; q++) vi[q] = vil[q];
         const size_t fbase = (size_t)f * a.Ad * 36;
-        for (int t = tid; t < kf; t += BLOCK) {   // (a lane reads back the block it has stored itself)
-            const double2 *wp = reinterpret_cast<const double2 *>(a.W + (size_t)(s0 + t) * 36);
-            const size_t o = fbase + (size_t)a.slot_dense[s0 + t] * 36;
+        for (int ts = tid; ts < kf; ts += BLOCK) {   // (a lane reads back the block it has stored itself)
+            const double2 *wp = reinterpret_cast<const double2 *>(a.W + (size_t)(s0 + ts) * 36);
+            const size_t o = fbase + (size_t)a.slot_dense[s0 + ts] * 36;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const double2 w0 = wp[3 * i], w1 = wp[3 * i + 1], w2 = wp[3 * i + 2];
@@ -941,7 +987,20 @@ static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, i
     PassAArgs a;
     a.idx = P.a_idx; a.uv = P.a_uv; a.ent = P.ent[which];
     { const KTable kt = k_table(P, which); a.Kmat = kt.base; a.kstride = kt.stride; }
-    a.frame_obs_start = P.frame_obs_start; a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent;
+    a.frame_obs_start = P.frame_obs_start; a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.frame_stride = P.frame_stride;
+    a.stamps = nullptr;
+#ifdef AAR_PASSA_STAMPS
+    {
+        static unsigned long long *st = nullptr;
+        if (!st && getenv("AAR_STAMPS_A")) {
+            (void)hipMalloc(&st, 512 * 16 * 8); (void)hipMemset(st, 0, 512 * 16 * 8);
+            static unsigned long long *keep = st;
+            atexit([] { std::vector<unsigned long long> h(512 * 16); (void)hipMemcpy(h.data(), keep, 512 * 16 * 8, hipMemcpyDeviceToHost);
+                        FILE *fp = fopen(getenv("AAR_STAMPS_A"), "w"); for (int i = 0; i < 512; i++) { for (int j = 0; j < 16; j++) fprintf(fp, "%llu ", h[i * 16 + j]); fprintf(fp, "\n"); } fclose(fp); });
+        }
+        a.stamps = st;
+    }
+#endif
     a.A = P.A; a.F = P.F; a.C = P.C; a.res_f32 = P.res_f32; a.max_kf = P.max_kf; a.frames_fixed = P.frames_fixed;
     a.huber = P.huber;
     a.h = P.half_size; a.mu_pred = mu_pred;

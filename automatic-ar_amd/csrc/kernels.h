@@ -49,6 +49,7 @@ struct DeviceProblem {
     ObsIdx *a_idx = nullptr;          // ordering A = reference order (frame, camera, detection order)
     float *a_uv = nullptr;            // [N][8]
     int32_t *frame_obs_start = nullptr;   // [F+1]
+    int32_t *frame_stride = nullptr;      // [F] pass A (wrench form): lane i of a frame's workgroup starts at observation (i * stride) mod n, stride coprime with n
     int32_t *fslot_start = nullptr;       // [F+1] first W block of each frame
     int32_t *fslot_ent = nullptr;         // [total_slots] shared entity of each W block (ascending inside a frame)
     ObsIdx *b_idx = nullptr;          // ordering B = (camera, marker, frame)
