@@ -1255,6 +1255,28 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
     P.n_chunks = (int)chunk_start.size();
     chunk_start.push_back((int32_t)N);
 
+    // ---- which off-diagonal blocks of U exist: entities that share an observation (camera x marker; with intrinsics entities also those of the camera) ----
+    std::vector<int32_t> up_start(A + 1, 0), up_ent;
+    {
+        std::vector<std::vector<int32_t>> nb(A);
+        for (int ch = 0; ch < P.n_chunks; ch++) {
+            const ObsIdx &h = b_idx[chunk_start[ch]];
+            if (ch > 0 && b_idx[chunk_start[ch - 1]].cam == h.cam && b_idx[chunk_start[ch - 1]].marker == h.marker) continue;
+            int ents[3] = {h.cam, h.marker, L.oi ? C + M + h.cam : -1};
+            for (int x = 0; x < 3; x++)
+                for (int y = 0; y < 3; y++)
+                    if (x != y && ents[x] >= 0 && ents[y] >= 0) nb[ents[x]].push_back(ents[y]);
+        }
+        for (int a = 0; a < A; a++) {
+            std::sort(nb[a].begin(), nb[a].end());
+            nb[a].erase(std::unique(nb[a].begin(), nb[a].end()), nb[a].end());
+            up_start[a] = (int32_t)up_ent.size();
+            up_ent.insert(up_ent.end(), nb[a].begin(), nb[a].end());
+        }
+        up_start[A] = (int32_t)up_ent.size();
+        if (up_ent.empty()) up_ent.push_back(0);
+    }
+
     // ---- (entity, frame) incidence for the Schur complement ----
     std::vector<std::vector<std::pair<int32_t, int32_t>>> inc(A);
     for (int f = 0; f < F; f++)
@@ -1446,7 +1468,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
 #define UP(field, vec) if ((rc = dev_upload(pb, &P.field, vec))) return fail(rc)
     UP(K, Kh); UP(a_idx, a_idx); UP(a_uv, a_uv); UP(frame_obs_start, frame_obs_start); UP(frame_stride, frame_stride);
     UP(fslot_start, fslot_start); UP(fslot_ent, fslot_ent); UP(b_idx, b_idx); UP(b_uv, b_uv);
-    UP(chunk_start, chunk_start); UP(ent_fixed, ent_fixed);
+    UP(chunk_start, chunk_start); UP(ent_fixed, ent_fixed); UP(up_start, up_start); UP(up_ent, up_ent);
     UP(sw_ent, sw_ent); UP(sw_begin, sw_begin); UP(sw_end, sw_end); UP(pair_rec, pair_rec);
     if (P.use_pcg) {   // balanced work items: at most `chunk` incidences of one entity each, 1 .. 8 items per entity (PCG_MAX_ITEMS)
         hipDeviceProp_t prop;

@@ -97,6 +97,7 @@ struct DeviceProblem {
     int32_t *pcg_counter = nullptr;       // [0..1] grid-barrier counters (alternating), [2] iterations of the last solve, [3] running total
     mutable int pcg_parity = 0;
     int pcg_fused = 1;                    // AAR_PCG_FUSED=0: k_pcg (two passes over W and two hand-overs per iteration) instead of k_pcgf
+    int32_t *up_start = nullptr, *up_ent = nullptr;   // [A + 1], [..]: entity -> the OTHER entities whose block of U can be non-zero (seen together in an observation); the CG operator skips the rest
     double *pcg_yg = nullptr;             // k_pcgf: y [3][n_pad] (rotating) | the set-up's sums [A][28]
     // solver spcg (spcg_kernels.hip): CG on the explicit Schur complement, one wavefront per shared entity
     int use_spcg = 0, spcg_max_it = SPCG_MAX_IT;

@@ -29,6 +29,7 @@ struct PcgArgs {
     int n_items;
     const int4 *pair_rec;                        // {frame, W block, first W block of the frame, 0}
     const int32_t *ent_fixed;
+    const int32_t *up_start, *up_ent;            // entity -> the other entities whose block of U can be non-zero (k_pcgf's operator; the others walk all of U)
     int A, F, n_pad;
     double mu, eta2;                             // damping; eta^2
     int max_it;
@@ -396,6 +397,49 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
     const int n = 6 * a.A, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < n; i += PCG_THREADS) yacc[i] = 0.0;
     __syncthreads();
+    // (U p) for the block rows dealt to this workgroup, FIRST (the wavefronts without blocks go straight to their frames): one thread per stored block
+    // U_eb, b < e, of the blocks that exist (U is block-sparse: entities that share an observation -- camera x marker; at config 5, 16 of a marker's 216),
+    // read row-wise in 16-byte pieces, used twice -- y_e += U_eb p_b and y_b += U_eb^T p_e -- and added to the workgroup's y in LDS like the frames'
+    // contributions: no reduction, no barrier.  (p of a gauge entity is zero and its y is overridden later.)
+    for (int e = wg; e < a.A; e += G) {
+        if (a.ent_fixed[e]) continue;   // (uniform per workgroup)
+        const int n0 = a.up_start[e], n1 = a.up_start[e + 1];
+        for (int q = n0 - 1 + tid; q < n1; q += PCG_THREADS) {
+            if (q < n0) {   // the diagonal block (lower triangle stored)
+                double acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        const double u = j <= i ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] : a.U[(size_t)(6 * e + j) * a.n_pad + 6 * e + i];
+                        acc[i] = fma(u, p[6 * e + j], acc[i]);
+                    }
+#pragma unroll
+                for (int i = 0; i < 6; i++) atomicAdd(yacc + 6 * e + i, acc[i]);
+                continue;
+            }
+            const int b = a.up_ent[q];
+            if (b >= e || a.ent_fixed[b]) continue;
+            double2 u[6][3];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double2 *row = reinterpret_cast<const double2 *>(a.U + (size_t)(6 * e + i) * a.n_pad + 6 * b);
+                u[i][0] = row[0]; u[i][1] = row[1]; u[i][2] = row[2];
+            }
+            double pb[6], pe[6], yb[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 6; k++) { pb[k] = p[6 * b + k]; pe[k] = p[6 * e + k]; }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double ye = u[i][0].x * pb[0] + u[i][0].y * pb[1] + u[i][1].x * pb[2] + u[i][1].y * pb[3] + u[i][2].x * pb[4] + u[i][2].y * pb[5];
+                atomicAdd(yacc + 6 * e + i, ye);
+                yb[0] = fma(u[i][0].x, pe[i], yb[0]); yb[1] = fma(u[i][0].y, pe[i], yb[1]); yb[2] = fma(u[i][1].x, pe[i], yb[2]);
+                yb[3] = fma(u[i][1].y, pe[i], yb[3]); yb[4] = fma(u[i][2].x, pe[i], yb[4]); yb[5] = fma(u[i][2].y, pe[i], yb[5]);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) atomicAdd(yacc + 6 * b + j, yb[j]);
+        }
+    }
     for (int f = wg * NW + wave; f < a.F; f += G * NW) {
         const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
         const double *Vi = a.Vinv + (size_t)f * 36;
@@ -462,25 +506,6 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
             for (int u = 0; u < 18; u++) wt[u] = q[u];
             scatter(wt, e);
         }
-    }
-    // (U p)_e for the entities dealt to this workgroup (row e of the symmetric U, lower triangle stored)
-    for (int e = wg; e < a.A; e += G) {
-        if (a.ent_fixed[e]) continue;   // (uniform per workgroup)
-        double acc[6] = {0, 0, 0, 0, 0, 0};
-        for (int bq = tid; bq < a.A; bq += PCG_THREADS) {
-            if (a.ent_fixed[bq]) continue;
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    const double u = bq < e ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * bq + j]
-                                            : (bq > e ? a.U[(size_t)(6 * bq + j) * a.n_pad + 6 * e + i]
-                                                      : (j <= i ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] : a.U[(size_t)(6 * e + j) * a.n_pad + 6 * e + i]));
-                    acc[i] = fma(u, p[6 * bq + j], acc[i]);
-                }
-        }
-        block_sum<6>(acc, red);
-        if (tid < 6) atomicAdd(yacc + 6 * e + tid, acc[tid]);
     }
     __syncthreads();
 }
@@ -1092,7 +1117,7 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const DeviceProblem::Blocks &b = P.blk[which];
     PcgArgs a;
     a.U = b.S; a.g0 = b.g0; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf;
-    a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed;
+    a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed; a.up_start = P.up_start; a.up_ent = P.up_ent;
     a.it_ent = P.pcg_it_ent; a.it_begin = P.pcg_it_begin; a.it_end = P.pcg_it_end; a.ent_item_start = P.pcg_ent_item_start; a.n_items = P.pcg_n_items;
     a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta * P.pcg_eta; a.max_it = P.pcg_max_it;
     a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
@@ -1116,7 +1141,7 @@ static PcgDistArgs pcgd_args(const DeviceProblem &P, int which, double mu) {
     PcgDistArgs d;
     PcgArgs &a = d.a;
     a.U = b.S; a.g0 = b.g0; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf;
-    a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed;
+    a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed; a.up_start = P.up_start; a.up_ent = P.up_ent;
     a.it_ent = P.pcg_it_ent; a.it_begin = P.pcg_it_begin; a.it_end = P.pcg_it_end; a.ent_item_start = P.pcg_ent_item_start; a.n_items = P.pcg_n_items;
     a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta * P.pcg_eta; a.max_it = P.pcg_max_it;
     a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
