@@ -17,6 +17,7 @@
 // same numbers in the same order: all leave in the same iteration.
 #include "geom.hpp"
 #include "kernels.h"
+#include "wave.hpp"
 
 namespace aar {
 
@@ -73,6 +74,9 @@ __device__ __forceinline__ bool grid_hop(int32_t *counter, int &round, int G, in
 }
 
 // sum of NV per-thread values over the 256 threads, fixed order; result in out[0..NV) on every thread.  lds: 4 * NV doubles
+constexpr int PCG_THREADS = 256;
+constexpr int PCG_NW = PCG_THREADS / 64;
+
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -88,10 +92,14 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *lds) {
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NV; i++) v[i] = (lds[i] + lds[NV + i]) + (lds[2 * NV + i] + lds[3 * NV + i]);
+    for (int i = 0; i < NV; i++) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < PCG_NW; w++) t += lds[w * NV + i];   // (the same order in every thread: the same bits)
+        v[i] = t;
+    }
 }
 
-constexpr int PCG_THREADS = 256;
 
 // Work items of the two entity-side passes: a range of at most `chunk` (entity, frame) incidences of ONE entity, at most PCG_MAX_ITEMS per
 // entity.  A workgroup per entity leaves the pass waiting for the cameras (a camera is seen in every frame: 5000 W blocks = 1.4 MB through
@@ -477,9 +485,7 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
             gather_c(wt, e);
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-            for (int i = 0; i < 6; i++) c[i] += __shfl_xor(c[i], off);
+        for (int i = 0; i < 6; i++) c[i] = wave_sum_dpp(c[i]);   // (DPP + row swaps: no LDS round trips)
         double t[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -707,7 +713,7 @@ __device__ __forceinline__ void pcgd_items_setup(const PcgArgs &a, double *red, 
 }
 
 __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_setup(const PcgDistArgs d) {
-    __shared__ double red[4 * 27];
+    __shared__ double red[PCG_NW * 27];
     const PcgArgs &a = d.a;
     const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
     int32_t *counter = a.counter + a.parity;
@@ -1094,7 +1100,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
     publish(0.0, itc);
 }
 
-size_t pcg_lds_bytes(int A) { return ((size_t)10 * 6 * A + 4 * 27 + 8) * sizeof(double); }   // x | r | p | Mi [6 n] | yacc [n] (k_pcgf) | red
+size_t pcg_lds_bytes(int A) { return ((size_t)10 * 6 * A + PCG_NW * 27 + 8) * sizeof(double); }   // x | r | p | Mi [6 n] | yacc [n] (k_pcgf) | red
 
 // the largest grid of the persistent PCG kernels that is resident as a whole (their hand-overs wait for every workgroup): what the occupancy query
 // admits per CU for the kernel with the larger footprint, times the CUs
