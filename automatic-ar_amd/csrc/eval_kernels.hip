@@ -739,6 +739,179 @@ __device__ __forceinline__ void passB_body(const PassBArgs &b, double *scratch, 
     });
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pass B in wrench form.  A row's wrench in CAMERA coordinates about the camera's origin is w = (pc x beta, beta), beta = d(u,v)_r / d(pc) -- no entity
+// enters it -- and both Jacobian blocks of the row are images of it:  G_c = w^T T_c,  T_c = -[R_c^T J_l(c) 0; 0 R_c^T]  (the same for the whole chunk),
+// G_m = (X w)^T [J_l(m) 0; 0 I]  with the observation's transport  X = [Q [e]x Q; 0 Q],  Q = R_f^T R_c,  e = R_f^T (t_c - t_f) - t_m  (the camera-frame
+// wrench seen from the marker's origin in object coordinates).  So an observation costs its Gram matrix H = sum w w^T (21 + 6 values from 8 rows instead of
+// 90), H X^T and X H X^T column by column (~330 fp64 instructions), and the lane's 90 sums are kept in wrench coordinates; the chunk's 90 values get their
+// entity matrices once, after the wave sum, on the lanes that issue the atomics.  ~1 000 instead of ~1 400 fp64 instructions per observation; same results
+// up to rounding.
+// ------------------------------------------------------------------------------------------------
+template <bool DET = false>
+__device__ __forceinline__ void passB_wrench_body(const PassBArgs &b, double *scratch, const int first_chunk) {
+    __shared__ double pb_red[4][128];   // per wavefront: the chunk's 90 sums | [90, 126): the entity matrices F_c top / bottom, F_m top / bottom (3x3 each)
+    const ObsIdx *__restrict__ idx = b.idx;
+    const float *__restrict__ uv = b.uv;
+    const double *__restrict__ ent = b.ent, *__restrict__ Kmat = b.Kmat;
+    const int32_t *__restrict__ chunk_start = b.chunk_start;
+    const int n_chunks = b.n_chunks, A = b.A, res_f32 = b.res_f32, n_pad = b.n_pad;
+    const float huber = b.huber;
+    const double h = b.h;
+    double *__restrict__ U0 = b.U0, *__restrict__ g0 = b.g0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the chunk's rows arrive in SGPRs
+    const int chunk = first_chunk + wave;
+    if (chunk >= n_chunks) return;
+    const int o0 = chunk_start[chunk], o1 = chunk_start[chunk + 1];
+    double vals[90];   // H_c (21) | H_m (21) | H_cm (36) | b_c (6) | b_m (6), in wrench coordinates
+#pragma unroll
+    for (int i = 0; i < 90; i++) vals[i] = 0.0;
+    const ObsIdx head = idx[o0];
+    Ent ec, em;
+    load_ent(ent, head.cam, ec);
+    load_ent(ent, head.marker, em);
+    double K[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) K[i] = Kmat[b.kstride * head.cam + i];
+    for (int o = o0 + lane; o < o1; o += 64) {
+        const ObsIdx id = idx[o];
+        const float4 uv0 = reinterpret_cast<const float4 *>(uv)[2 * (int64_t)o];
+        const float4 uv1 = reinterpret_cast<const float4 *>(uv)[2 * (int64_t)o + 1];
+        const float ou[8] = {uv0.x, uv0.y, uv0.z, uv0.w, uv1.x, uv1.y, uv1.z, uv1.w};
+        EntRT ef;
+        load_ent_rt(ent, A + id.frame, ef);
+        double H[21], bw[6];
+#pragma unroll
+        for (int i = 0; i < 21; i++) H[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) bw[i] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            CornerGeom g;
+            project_corner(ec, em, ef, K, h, k, g);
+            double r[2];
+            corner_residual(ou[2 * k], ou[2 * k + 1], g.u, g.v, res_f32, huber, r[0], r[1]);
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                double w[6];
+#pragma unroll
+                for (int j = 0; j < 3; j++) w[3 + j] = (K[3 * rr + j] - (rr ? g.v : g.u) * K[6 + j]) * g.iw;
+                cross3(g.pc, &w[3], &w[0]);
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    bw[i] += w[i] * r[rr];
+#pragma unroll
+                    for (int j = 0; j <= i; j++) H[i * (i + 1) / 2 + j] += w[i] * w[j];
+                }
+            }
+        }
+        // the observation's transport X = [Q E; 0 Q]
+        double Q[3][3], E[3][3], e3[3];
+        {
+            const double d[3] = {ec.t[0] - ef.t[0], ec.t[1] - ef.t[1], ec.t[2] - ef.t[2]};
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) Q[i][j] = ef.R[i] * ec.R[j] + ef.R[3 + i] * ec.R[3 + j] + ef.R[6 + i] * ec.R[6 + j];
+                e3[i] = ef.R[i] * d[0] + ef.R[3 + i] * d[1] + ef.R[6 + i] * d[2] - em.t[i];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double qc[3] = {Q[0][j], Q[1][j], Q[2][j]};
+                double x[3];
+                cross3(e3, qc, x);
+                E[0][j] = x[0]; E[1][j] = x[1]; E[2][j] = x[2];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 21; i++) vals[i] += H[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) vals[78 + i] += bw[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {   // b_m += X b
+            vals[84 + i] += Q[i][0] * bw[0] + Q[i][1] * bw[1] + Q[i][2] * bw[2] + E[i][0] * bw[3] + E[i][1] * bw[4] + E[i][2] * bw[5];
+            vals[87 + i] += Q[i][0] * bw[3] + Q[i][1] * bw[4] + Q[i][2] * bw[5];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {   // column j of H X^T (x = row j of X), then of X H X^T (rows i >= j)
+            double p[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                if (j < 3) p[i] = H[sym6(i, 0)] * Q[j][0] + H[sym6(i, 1)] * Q[j][1] + H[sym6(i, 2)] * Q[j][2] + H[sym6(i, 3)] * E[j][0] + H[sym6(i, 4)] * E[j][1] + H[sym6(i, 5)] * E[j][2];
+                else p[i] = H[sym6(i, 3)] * Q[j - 3][0] + H[sym6(i, 4)] * Q[j - 3][1] + H[sym6(i, 5)] * Q[j - 3][2];
+                vals[42 + i * 6 + j] += p[i];
+            }
+#pragma unroll
+            for (int i = j; i < 6; i++) {
+                double q;
+                if (i < 3) q = Q[i][0] * p[0] + Q[i][1] * p[1] + Q[i][2] * p[2] + E[i][0] * p[3] + E[i][1] * p[4] + E[i][2] * p[5];
+                else q = Q[i - 3][0] * p[3] + Q[i - 3][1] * p[4] + Q[i - 3][2] * p[5];
+                vals[21 + i * (i + 1) / 2 + j] += q;
+            }
+        }
+    }
+    double *red = pb_red[wave & 3];
+    wave_sum_lds<90>(vals, scratch + wave * 2048, lane, [&](int v, double s) { red[v] = s; });
+    if (lane == 0) {   // F_c = [R_c^T J_l(c) 0; 0 R_c^T] (the minus sign goes to g_c and W_cm), F_m = [J_l(m) 0; 0 I]; entry [k][i]: wrench component k, parameter i
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                red[90 + 3 * k + i] = ec.R[k] * ec.Jl[i] + ec.R[3 + k] * ec.Jl[3 + i] + ec.R[6 + k] * ec.Jl[6 + i];
+                red[99 + 3 * k + i] = ec.R[3 * i + k];
+                red[108 + 3 * k + i] = em.Jl[3 * k + i];
+                red[117 + 3 * k + i] = k == i ? 1.0 : 0.0;
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int rc = 6 * head.cam, rm = 6 * head.marker;  // first row of the camera / marker block
+    for (int v = lane; v < 90; v += 64) {
+        double out = 0.0;
+        double *dst;
+        if (v < 78) {   // out(i, j) = sum_{a, c < 3} FA[3 bi + a][i] M[3 bi + a][3 bj + c] FB[3 bj + c][j]: FA / FB block-diagonal
+            int i, j, mbase, fa, fb;
+            bool sym;
+            if (v < 42) {
+                const int p = v < 21 ? v : v - 21;
+                i = 0;
+                while ((i + 1) * (i + 2) / 2 <= p) i++;
+                j = p - i * (i + 1) / 2;
+                mbase = v < 21 ? 0 : 21; fa = fb = v < 21 ? 90 : 108; sym = true;
+                const int base = v < 21 ? rc : rm;
+                dst = U0 + (size_t)(base + i) * n_pad + base + j;
+            } else {
+                i = (v - 42) / 6; j = (v - 42) % 6;
+                mbase = 42; fa = 90; fb = 108; sym = false;
+                dst = U0 + (size_t)(rm + j) * n_pad + rc + i;   // W_cm[i][j] -> row of the marker (below the cameras), column of the camera
+            }
+            const int bi = i / 3, bj = j / 3;
+            const double *FA = red + fa + 9 * bi + (i - 3 * bi), *FB = red + fb + 9 * bj + (j - 3 * bj);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                double t = 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int k = 3 * bi + a, l = 3 * bj + c;
+                    t += red[mbase + (sym ? sym6(k, l) : k * 6 + l)] * FB[3 * c];
+                }
+                out += FA[3 * a] * t;
+            }
+            if (!sym) out = -out;
+        } else {        // g_c = -F_c^T b_c,  g_m = F_m^T b_m
+            const bool cam = v < 84;
+            const int i = cam ? v - 78 : v - 84, bi = i / 3;
+            const double *F = red + (cam ? 90 : 108) + 9 * bi + (i - 3 * bi), *bv = red + (cam ? 78 : 84) + 3 * bi;
+            out = F[0] * bv[0] + F[3] * bv[1] + F[6] * bv[2];
+            if (cam) out = -out;
+            dst = g0 + (cam ? rc : rm) + i;
+        }
+        if (DET) b.part[(size_t)chunk * b.part_stride + v] = out;
+        else atomicAdd(dst, out);
+    }
+}
+
 // The two passes as kernels of their own, and as ONE launch: workgroups [0, F) are pass A's, the rest pass B's.  They
 // are independent once the {R, t, J_l} table exists (k_backsub / k_unpack write it), so the trial evaluation of an LM step
 // runs them side by side; both are latency-bound with one wavefront per SIMD and together still fit the chip at config 3.
@@ -750,13 +923,17 @@ __global__ void __launch_bounds__(BLOCK) k_passA(const PassAArgs a) {
     else passA_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
+template <bool WR>
 __global__ void __launch_bounds__(256) k_passB(const PassBArgs b) {
     __shared__ double scratch[4 * 2048];
-    passB_body(b, scratch, (int)blockIdx.x * 4);
+    if (WR) passB_wrench_body(b, scratch, (int)blockIdx.x * 4);
+    else passB_body(b, scratch, (int)blockIdx.x * 4);
 }
+template <bool WR>
 __global__ void __launch_bounds__(256) k_passB_det(const PassBArgs b) {
     __shared__ double scratch[4 * 2048];
-    passB_body<true>(b, scratch, (int)blockIdx.x * 4);
+    if (WR) passB_wrench_body<true>(b, scratch, (int)blockIdx.x * 4);
+    else passB_body<true>(b, scratch, (int)blockIdx.x * 4);
 }
 // experiments (AAR_PASSB_LEAN=1 / 2): the corner loop not unrolled, with / without the register cap that lets two wavefronts share a SIMD
 __global__ void __launch_bounds__(256, 2) k_passB_lean2(const PassBArgs b) {
@@ -913,7 +1090,8 @@ __global__ void __launch_bounds__(BLOCK) k_passAB(const PassAArgs a, const PassB
     if ((int)blockIdx.x < a.F) {
         if (WR) passA_wrench_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, a.F);
         else passA_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, a.F);
-    } else passB_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
+    } else if (WR) passB_wrench_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
+    else passB_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
 }
 // the same with camera intrinsics optimised: pass A with the W_kf blocks, pass B, and pass B's intrinsics blocks (three launches before)
 template <int BLOCK, int CPL>
@@ -1089,7 +1267,8 @@ void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
     if (P.deterministic) {   // per-chunk records, then their fixed-order sums (stored: the block set is clear)
         HookScope _h(P, KID_PASSB);
         const PassBArgs b = passB_args(P, which);
-        hipLaunchKernelGGL(k_passB_det, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, b);
+        if (P.tune.passA_wrench) hipLaunchKernelGGL(k_passB_det<true>, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, b);
+        else hipLaunchKernelGGL(k_passB_det<false>, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, b);
         if (P.intr) hipLaunchKernelGGL(k_passB_intr_det, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, b);
         PassBReduceArgs r;
         r.start = P.pbr_start; r.chunk = P.pbr_chunk; r.kind = P.pbr_kind; r.ea = P.pbr_a; r.eb = P.pbr_b; r.part = P.pb_part;
@@ -1101,7 +1280,8 @@ void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
         HookScope _h(P, KID_PASSB);
         if (P.tune.passB_lean == 1) hipLaunchKernelGGL(k_passB_lean2, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which));
         else if (P.tune.passB_lean == 2) hipLaunchKernelGGL(k_passB_lean1, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which));
-        else hipLaunchKernelGGL(k_passB, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which));
+        else if (P.tune.passA_wrench) hipLaunchKernelGGL(k_passB<true>, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which));
+        else hipLaunchKernelGGL(k_passB<false>, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which));
     }
     if (P.intr) { HookScope _h(P, KID_PASSB); hipLaunchKernelGGL(k_passB_intr, dim3((P.n_chunks + 3) / 4), dim3(256), 0, st, passB_args(P, which)); }
 }
