@@ -1028,14 +1028,16 @@ def test_deterministic_mode_gives_the_same_bits_twice(name, kw):
 
 def test_deterministic_mode_tightens_the_retry_trace():
     # the same run as test_huber_schedule_with_a_rejected_try: with fixed-order sums the damping follows the real solver's to
-    # 1e-9 over the first 60 steps (2e-4 is what the default path's atomics allow: their order moves mu between runs)
+    # 1e-8 over the first 60 steps (2e-4 is what the default path's atomics allow: their order moves mu between runs)
     ds, g = load_golden("g1_cfg2_huber_retry")
     prm = aar.lm_default_params(tau=float(g["tau"][0]))
     with aar.Problem(ds, with_huber=True, deterministic=True) as p:
         x, rep = p.lm_solve(ds.x_full, params=prm, trace_cap=600)
     k = 60
     assert max(t["tries"] for t in rep["trace"]) > 1
-    np.testing.assert_allclose([t["mu"] for t in rep["trace"]][:k], g["analytic_mu"][:k], rtol=1e-9)
+    # (observed: 2.7e-10 with the observation passes in wrench form, 6e-12 in row form -- the same blocks, products associated differently;
+    #  scripts/dev/det_margin.py prints it)
+    np.testing.assert_allclose([t["mu"] for t in rep["trace"]][:k], g["analytic_mu"][:k], rtol=1e-8)
     np.testing.assert_allclose([t["err"] for t in rep["trace"]][:k], g["analytic_err"][:k], rtol=1e-6)
     n = min(len(rep["trace"]), len(g["analytic_err"]))
     np.testing.assert_allclose([t["err"] for t in rep["trace"]][:n], g["analytic_err"][:n], rtol=2e-6)
