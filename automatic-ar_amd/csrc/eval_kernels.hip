@@ -530,6 +530,37 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
             } else out = hacc[27];
             acc[lane] = out;
         }
+        // ... and (V_f + mu I)^-1, h_f for the damping the next solve is expected to use, on this wavefront's last lane -- with more than one wavefront
+        // per workgroup that is beside the slots' lanes, not after them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (a.mu_pred >= 0.0 && lane == 63) {
+            double out[36];
+            if (a.frames_fixed) {
+#pragma unroll
+                for (int i = 0; i < 36; i++) out[i] = 0.0;
+            } else {
+                double m[6][6];
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) m[i][j] = acc[sym6(i, j)] + (i == j ? a.mu_pred : 0.0);
+                if (!spd6_inverse(m, out)) atomicOr(a.flags, 1);
+            }
+            const bool dense_ = a.Yd != nullptr;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                double hv = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    a.Vinv[(size_t)f * 36 + i * 6 + j] = out[i * 6 + j];
+                    hv += out[i * 6 + j] * acc[21 + j];
+                    if (dense_) vil[i * 6 + j] = out[i * 6 + j];
+                }
+                a.hf[(size_t)f * 6 + i] = hv;
+            }
+        }
     }
     PA_STAMP(6);
     // one lane per slot: W = T^T H F, rows stored as they come
@@ -584,31 +615,6 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
     for (int q = tid; q < 6; q += BLOCK) a.gf[(size_t)f * 6 + q] = acc[21 + q];
     if (tid == 0) a.err_part[f] = acc[27];
     const bool dense = a.Yd != nullptr && a.mu_pred >= 0.0;
-    if (a.mu_pred >= 0.0 && tid == BLOCK - 1) {  // (V_f + mu I)^-1 and h_f for the damping the next solve is expected to use
-        double out[36];
-        if (a.frames_fixed) {
-#pragma unroll
-            for (int i = 0; i < 36; i++) out[i] = 0.0;
-        } else {
-            double m[6][6];
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int j = 0; j < 6; j++) m[i][j] = acc[sym6(i, j)] + (i == j ? a.mu_pred : 0.0);
-            if (!spd6_inverse(m, out)) atomicOr(a.flags, 1);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            double hv = 0.0;
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                a.Vinv[(size_t)f * 36 + i * 6 + j] = out[i * 6 + j];
-                hv += out[i * 6 + j] * acc[21 + j];
-                if (dense) vil[i * 6 + j] = out[i * 6 + j];
-            }
-            a.hf[(size_t)f * 6 + i] = hv;
-        }
-    }
     PA_STAMP(9);
     if (dense) {   // the frame's panels of the MFMA Schur path: W as it is, Y = W (V_f + mu I)^-1; the pseudo entity 0 carries g_f in its row 0
         __syncthreads();
