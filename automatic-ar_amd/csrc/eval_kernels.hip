@@ -1293,7 +1293,7 @@ void launch_passB(const DeviceProblem &P, int which, hipStream_t st) {
 }
 
 bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st) {
-    if (P.F == 0 || P.n_chunks == 0 || P.deterministic || !P.tune.passAB_merge) return false;   // nothing to merge (or the deterministic variants): the caller launches what there is
+    if (P.F == 0 || P.n_chunks == 0 || P.deterministic) return false;   // nothing to merge (or the deterministic variants): the caller launches what there is
     // Side by side pays while the two passes together are a few wavefronts per SIMD (configs 2-4: -45 % / -11 % of their
     // summed time at configs 3 / 4); once either fills the chip on its own (config 5: +7 %, pass B's workgroups then carry
     // pass A's LDS allocation) they go one after the other

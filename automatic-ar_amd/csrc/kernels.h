@@ -121,7 +121,6 @@ struct DeviceProblem {
         int passA_variant = 0;     // AAR_PASSA_VARIANT: 1281 / 1282 / 1284 / 2564 force a pass A workgroup shape
         int spcg_backsub_rides = 0; // AAR_SPCG_BACKSUB_RIDES=1 (experiment, slower: profiles/r04_attempts.txt): the frame back-substitution rides in k_spcg's launch on the XCDs the CG leaves idle
         int passA_wrench = 1;      // AAR_PASSA_WRENCH=0: pass A in its row form (three Jacobian blocks per row, 100 accumulators per lane) -- the A/B reference of the wrench form
-        int passAB_merge = 1;      // AAR_PASSAB_MERGE=0: the two observation passes always as launches of their own
         int passB_lean = 0;        // AAR_PASSB_LEAN (experiment): 1 = pass B's corner loop not unrolled + two wavefronts per SIMD (28 spilled registers), 2 = not unrolled only
         int pack_system = -1;      // AAR_PACK_SYSTEM=0/1: the reduced system travels as it lies / as the packed triangle (default: by size)
         int init_headstart = 1;    // AAR_INIT_HEADSTART=0: the first step's frame inverses and Schur complement wait for the host to have read mu_0

@@ -1173,3 +1173,43 @@ def test_randomized_shapes_in_the_optional_modes(mode):
         if done >= 8:
             break
     assert done >= 6
+
+
+@pytest.mark.parametrize("shape", ["cfg2", "cfg3_cut", "cfg5_shaped", "few_obs_per_frame", "huber_f64"])
+def test_observation_passes_wrench_form_equals_row_form(shape, monkeypatch):
+    # The default observation passes reach the frame blocks (V_f, g_f, W_cf, W_mf) and the shared blocks (U, g) through the observation's 6x6 Gram matrix of
+    # wrenches (csrc/geom.hpp corner_wrench; csrc/eval_kernels.hip passA_wrench_body / passB_wrench_body); AAR_PASSA_WRENCH=0 keeps the row form that
+    # multiplies the three 2x6 Jacobian blocks of every row (libs/multicam_mapper.cpp:976-994 in closed form).  Same algebra, different association:
+    # the full normal equations, the gradient, the error and a damped step agree to rounding -- in every workgroup shape the launcher picks
+    # (one / two / four lanes per observation, one or two wavefronts per frame), with the dense panels of the MFMA Schur path, in both modes.
+    kw = {}
+    if shape == "cfg2":
+        ds = load_golden("g1_cfg2")[0]
+    elif shape == "cfg3_cut":
+        ds = load_golden("g1_cfg3_cut")[0]
+    elif shape == "cfg5_shaped":
+        ds = aar.synth(5, num_frames=40)                      # 16 cameras / 200 markers: ~250 observations per frame, two wavefronts per frame, MFMA Schur panels
+    elif shape == "few_obs_per_frame":
+        ds = aar.synth(3, num_cams=3, num_markers=6, num_frames=60)   # <= 14 observations per frame: four lanes per observation
+    else:
+        ds = load_golden("g1_cfg2_huber")[0]
+        kw = dict(with_huber=True, residual_mode=aar.RES_F64)
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("AAR_PASSA_WRENCH", form)
+        for det in (False, True):
+            with aar.Problem(ds, deterministic=det, solver="direct", **kw) as p:
+                H, B, ss = p.eval_normal_equations(ds.x_full)
+                d = p.eval_damped_step(ds.x_full, 1e2)
+            out[form, det] = (H, B, ss, d)
+    for det in (False, True):
+        (H1, B1, s1, d1), (H0, B0, s0, d0) = out["1", det], out["0", det]
+        assert np.abs(H1 - H0).max() / np.abs(H0).max() < 1e-13
+        assert np.abs(B1 - B0).max() / np.abs(B0).max() < 1e-12
+        assert abs(s1 - s0) <= 1e-13 * s0
+        assert np.abs(d1 - d0).max() / np.abs(d0).max() < 1e-8        # (the small problem is the ill-conditioned one: 1.5e-9; the others 1e-11)
+    # the deterministic mode of the wrench form gives the same bits twice
+    monkeypatch.setenv("AAR_PASSA_WRENCH", "1")
+    with aar.Problem(ds, deterministic=True, solver="direct", **kw) as p:
+        H, B, ss = p.eval_normal_equations(ds.x_full)
+    assert np.array_equal(H, out["1", True][0]) and np.array_equal(B, out["1", True][1]) and ss == out["1", True][2]
