@@ -92,7 +92,7 @@ class CSolverOptions(C.Structure):
 class CSolverStats(C.Structure):
     _fields_ = [("solver", C.c_int32), ("deterministic", C.c_int32), ("last_iterations", C.c_int32), ("reserved", C.c_int32),
                 ("total_iterations", C.c_int64), ("solves", C.c_int64), ("fallbacks", C.c_int64), ("pcg_eta", C.c_double),
-                ("pcg_max_it", C.c_int32), ("reserved2", C.c_int32), ("same_xcd_solves", C.c_int64)]
+                ("pcg_max_it", C.c_int32), ("reserved2", C.c_int32), ("same_xcd_solves", C.c_int64), ("pcg_eta_loose", C.c_double)]
 
 
 class CLmParams(C.Structure):
@@ -784,7 +784,7 @@ class Problem:
         _check(lib().aar_problem_get_solver_stats(self.handle, C.byref(st)))
         return dict(solver=SOLVER_NAMES[st.solver], deterministic=bool(st.deterministic), last_iterations=st.last_iterations,
                     total_iterations=st.total_iterations, solves=st.solves, fallbacks=st.fallbacks, pcg_eta=st.pcg_eta, pcg_max_it=st.pcg_max_it,
-                    same_xcd_solves=st.same_xcd_solves)
+                    same_xcd_solves=st.same_xcd_solves, pcg_eta_loose=st.pcg_eta_loose)
 
     def set_stage_timers(self, on):
         _check(lib().aar_set_stage_timers(self.handle, int(on)))

@@ -184,6 +184,7 @@ struct aar_problem {
     aar_lm_params prm;
     int cur = 0;                       // pose buffer / block set of curr_z
     double mu = -1, v = 2, currErr = 0, prevErr = 0;
+    double rel_drop = -1;              // share of the error the last accepted LM step took away (-1: none yet); the PCG forcing sequence looks at it
     bool lm_ready = false;
     bool with_huber = false;
     float hubber_delta = 2.5f;         // MultiCamMapper::hubberDelta (libs/multicam_mapper.h:41)
@@ -1202,7 +1203,14 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         // forcing term: |r| <= 0.1 |b| for the CG through the frame blocks; the CG on the explicit system measures in the preconditioner's norm
         // (r^T M^-1 r, which its recurrences carry anyway), where 0.02 gives the same distance to the exact LM run
         P.pcg_eta = P.use_spcg ? 0.02 : 0.1;
+        P.pcg_eta_loose = 0.0;
         if (so.pcg_eta > 0) P.pcg_eta = so.pcg_eta;
+        else if (P.use_pcg && so.solver == AAR_SOLVER_AUTO) {   // AUTO's PCG with the default forcing term: a forcing sequence (kernels.h, include/aar.h)
+            P.pcg_eta_loose = 0.3;
+            if (const char *e = getenv("AAR_PCG_ETA_LOOSE")) P.pcg_eta_loose = atof(e);
+            if (const char *e = getenv("AAR_PCG_ETA_SWITCH")) P.pcg_eta_switch = atof(e);
+        }
+        P.pcg_eta_now = P.pcg_eta;
         if (so.pcg_max_it > 0) { P.pcg_max_it = so.pcg_max_it; P.spcg_max_it = std::min(so.pcg_max_it, SPCG_MAX_IT); }
         if (P.use_pcg && !pcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_PCG keeps the CG vectors and the preconditioner of %d unknowns in LDS: too many shared entities", 6 * A);
         if (P.use_spcg && !spcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_SPCG keeps the reduced system in the registers of one wavefront per shared entity: %d unknowns are too many (limit %d, and at most %d entities)", 6 * A, 96 * SPCG_MAX_NT, cus);
@@ -1717,6 +1725,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     pb->schur_mu = -1;
     pb->s_reduced = pb->trial_reduced = false;
     pb->spcg_skip = pb->spcg_backoff = 0;   // (a one-off solve: the problem's own solver gets its chance whatever an earlier LM run ended with)
+    pb->P.pcg_eta_now = pb->P.pcg_eta;      // (... and the forcing term itself, not the LM's forcing sequence)
     if ((rc = damped_try_fb(pb, mu, false))) return rc == TRY_NOT_POSITIVE_DEFINITE ? AAR_ERR_NUMERIC : rc;
     pb->lm_ready = false;
     std::vector<double> x0(x_full, x_full + L.full_len()), x1(x0);
@@ -1775,6 +1784,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     if ((rc = wait_result(pb))) return rc;
     if (!pb->comm) { pb->mu_seed = pb->h_scal[4]; pb->mu_seed_valid = true; }
     pb->currErr = pb->prevErr = pb->h_scal[0];
+    pb->rel_drop = -1;
     pb->blocks_valid = true;
     pb->vinv_mu = -1;
     pb->schur_mu = -1;
@@ -1815,6 +1825,8 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
     do {
         if (!pb->blocks_valid && (rc = rebuild_current(pb))) return rc;  // a rejected try consumed them
         const double mu_used = pb->mu;
+        if (pb->P.use_pcg)   // (every rank sees the same errors: the same choice)
+            pb->P.pcg_eta_now = (pb->P.pcg_eta_loose > pb->P.pcg_eta && (pb->rel_drop < 0 || pb->rel_drop > pb->P.pcg_eta_switch)) ? pb->P.pcg_eta_loose : pb->P.pcg_eta;
         if ((rc = damped_try_fb(pb, mu_used, true))) {
             if (rc != TRY_NOT_POSITIVE_DEFINITE) return rc;
             // J^T J + mu I came out indefinite in floating point: the reference's LDL^T would hand back the stationary point
@@ -1838,6 +1850,7 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
         if (gain > 0 && ((err - pb->prevErr) < 0)) {  // :409-415
             pb->mu = mu_used * std::max(0.33, 1. - std::pow(2 * gain - 1, 3));
             pb->v = 2.f;
+            pb->rel_drop = pb->prevErr > 0 ? (pb->prevErr - err) / pb->prevErr : 0.0;
             pb->currErr = err;
             pb->cur = 1 - pb->cur;  // curr_z = estimated_z; its blocks were built speculatively by the try
             pb->huber_of_blocks = pb->P.huber;
@@ -2070,6 +2083,7 @@ int aar_problem_get_solver_stats(aar_problem *pb, aar_solver_stats *out) {
     out->deterministic = pb->P.deterministic;
     out->pcg_eta = pb->P.pcg_eta;
     out->pcg_max_it = pb->P.use_spcg ? pb->P.spcg_max_it : pb->P.pcg_max_it;
+    out->pcg_eta_loose = pb->P.pcg_eta_loose;
     out->fallbacks = pb->spcg_fallbacks;
     if (!pb->P.use_pcg && !pb->P.use_spcg) return AAR_OK;
     int32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -1125,7 +1125,7 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.U = b.S; a.g0 = b.g0; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf;
     a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed; a.up_start = P.up_start; a.up_ent = P.up_ent;
     a.it_ent = P.pcg_it_ent; a.it_begin = P.pcg_it_begin; a.it_end = P.pcg_it_end; a.ent_item_start = P.pcg_ent_item_start; a.n_items = P.pcg_n_items;
-    a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta * P.pcg_eta; a.max_it = P.pcg_max_it;
+    a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.max_it = P.pcg_max_it;
     a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
     a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
@@ -1149,7 +1149,7 @@ static PcgDistArgs pcgd_args(const DeviceProblem &P, int which, double mu) {
     a.U = b.S; a.g0 = b.g0; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf;
     a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed; a.up_start = P.up_start; a.up_ent = P.up_ent;
     a.it_ent = P.pcg_it_ent; a.it_begin = P.pcg_it_begin; a.it_end = P.pcg_it_end; a.ent_item_start = P.pcg_ent_item_start; a.n_items = P.pcg_n_items;
-    a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta * P.pcg_eta; a.max_it = P.pcg_max_it;
+    a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.max_it = P.pcg_max_it;
     a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
     a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;

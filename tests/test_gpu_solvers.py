@@ -337,3 +337,26 @@ def test_solver_options_struct_is_forward_compatible_and_validated():
     assert e.value.code == aar.AAR_ERR_UNSUPPORTED
     with aar.Problem(big, solver="auto") as p:
         assert p.solver_stats()["solver"] == "pcg"
+
+
+def test_auto_pcg_forcing_sequence():
+    # AUTO resolving to the frame-block PCG (>= 96 shared entities) with the forcing term left at its default solves the early LM steps to 0.3 and the
+    # steps near the stopping rule to 0.1 (include/aar.h, profiles/r04_pcg_eta_sweep.txt): same LM step count as the direct solver (+- 1), final RMSE
+    # within 1e-5 px of it, fewer CG iterations than the fixed 0.1; an explicit solver or an explicit forcing term switches the sequence off
+    ds = aar.synth(5, num_frames=120)
+    with aar.Problem(ds, solver="direct") as p:
+        xd, rd = p.lm_solve(ds.x_full)
+        rmse_d = p.reproj_stats(xd)[0]
+    runs = {}
+    for name, kw in (("auto", dict(solver="auto")), ("pcg", dict(solver="pcg")), ("auto_eta", dict(solver="auto", pcg_eta=0.1))):
+        with aar.Problem(ds, **kw) as p:
+            st = p.solver_stats()
+            assert st["solver"] == "pcg" and st["pcg_eta"] == 0.1
+            assert st["pcg_eta_loose"] == (0.3 if name == "auto" else 0.0)
+            x, rep = p.lm_solve(ds.x_full)
+            runs[name] = (p.reproj_stats(x)[0], rep["iterations"], p.solver_stats()["total_iterations"])
+    for name, (rmse, its, cg) in runs.items():
+        assert abs(rmse - rmse_d) < 1e-5, (name, rmse, rmse_d)
+        assert abs(its - rd["iterations"]) <= 1, (name, its, rd["iterations"])
+    assert runs["auto"][2] < runs["pcg"][2]
+    assert runs["auto_eta"][2] == runs["pcg"][2]
