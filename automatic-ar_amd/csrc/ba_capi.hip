@@ -1205,8 +1205,8 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         P.pcg_eta = P.use_spcg ? 0.02 : 0.1;
         P.pcg_eta_loose = 0.0;
         if (so.pcg_eta > 0) P.pcg_eta = so.pcg_eta;
-        else if (P.use_pcg && so.solver == AAR_SOLVER_AUTO) {   // AUTO's PCG with the default forcing term: a forcing sequence (kernels.h, include/aar.h)
-            P.pcg_eta_loose = 0.3;
+        else if ((P.use_pcg || P.use_spcg) && so.solver == AAR_SOLVER_AUTO) {   // AUTO's inexact solvers with the default forcing term: a forcing sequence (kernels.h, include/aar.h)
+            P.pcg_eta_loose = P.use_pcg ? 0.3 : 0.1;
             if (const char *e = getenv("AAR_PCG_ETA_LOOSE")) P.pcg_eta_loose = atof(e);
             if (const char *e = getenv("AAR_PCG_ETA_SWITCH")) P.pcg_eta_switch = atof(e);
         }
@@ -1825,7 +1825,7 @@ int aar_lm_step(aar_problem *pb, aar_lm_iter *out) {
     do {
         if (!pb->blocks_valid && (rc = rebuild_current(pb))) return rc;  // a rejected try consumed them
         const double mu_used = pb->mu;
-        if (pb->P.use_pcg)   // (every rank sees the same errors: the same choice)
+        if (pb->P.use_pcg || pb->P.use_spcg)   // (every rank sees the same errors: the same choice)
             pb->P.pcg_eta_now = (pb->P.pcg_eta_loose > pb->P.pcg_eta && (pb->rel_drop < 0 || pb->rel_drop > pb->P.pcg_eta_switch)) ? pb->P.pcg_eta_loose : pb->P.pcg_eta;
         if ((rc = damped_try_fb(pb, mu_used, true))) {
             if (rc != TRY_NOT_POSITIVE_DEFINITE) return rc;

@@ -91,7 +91,7 @@ struct DeviceProblem {
     // AAR_SOLVER=pcg (opt-in, pcg_kernels.hip): the reduced system solved by preconditioned CG through the frame blocks
     int use_pcg = 0, pcg_grid = 0, pcg_max_it = 200;
     double pcg_eta = 0.1;                 // |r| <= eta |b| stops an inner solve (AAR_PCG_ETA)
-    // the frame-block PCG's forcing SEQUENCE when the caller left the forcing term at its default: while the LM is still far from its stopping rule (the last
+    // the inexact solvers' forcing SEQUENCE when AUTO chose them and the caller left the forcing term at its default: while the LM is still far from its stopping rule (the last
     // accepted step took more than pcg_eta_switch of the error away) the inner solve stops at pcg_eta_loose, afterwards at pcg_eta -- the steps that decide
     // the stopping rule are solved as tightly as before (profiles/r04_pcg_eta_sweep.txt).  pcg_eta_now is what the next launch uses.
     double pcg_eta_loose = 0.0, pcg_eta_switch = 0.01, pcg_eta_now = 0.1;

@@ -352,7 +352,7 @@ bool launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st, i
     const DeviceProblem::Blocks &b = P.blk[which];
     SpcgArgs a;
     a.S = b.S; a.rhs = b.rhs; a.g0 = b.g0; a.ent_fixed = P.ent_fixed; a.n = P.n; a.n_pad = P.n_pad;
-    a.mu = mu; a.eta2 = P.pcg_eta * P.pcg_eta; a.max_it = std::min(P.spcg_max_it, SPCG_MAX_IT);
+    a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.max_it = std::min(P.spcg_max_it, SPCG_MAX_IT);
     a.ws = P.spcg_ws; a.stride = spcg_stride(P.n_pad); a.set_len = (long long)SPCG_BUFS * a.stride; a.parity = P.spcg_parity;
     a.x_out = P.delta_s; a.iters = P.spcg_iters; a.flags = P.flags; a.test_drop = P.spcg_test_drop;
     a.spread = P.spcg_spread;

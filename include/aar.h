@@ -272,9 +272,10 @@ int aar_problem_create(const aar_problem_desc *, aar_problem **out);   /* = aar_
  *   AAR_SOLVER_PCG     no Schur complement at all: CG THROUGH the frame blocks (csrc/pcg_kernels.hip); with a communicator the frames'
  *                      blocks stay on their ranks and every CG iteration all-reduces 8 n bytes (nothing O(n^3) is replicated)
  *   AAR_SOLVER_AUTO    the fastest of the three for the problem's size and rank count as measured on MI355X.  When it
- *                      resolves to PCG and pcg_eta is left at 0, the inner solves follow a forcing SEQUENCE: 0.3 while the last accepted LM step
- *                      still took more than 1 % of the error away, 0.1 afterwards (the steps that decide the stopping rule are solved as
- *                      tightly as with AAR_SOLVER_PCG; aar_solver_stats.pcg_eta_loose reports it)
+ *                      resolves to an inexact solver and pcg_eta is left at 0, the inner solves follow a forcing SEQUENCE: PCG 0.3 / SPCG 0.1
+ *                      while the last accepted LM step still took more than 1 % of the error away, the solver's own default (0.1 / 0.02)
+ *                      afterwards -- the steps that decide the stopping rule are solved as tightly as with the solver named explicitly
+ *                      (aar_solver_stats.pcg_eta_loose reports it)
  * deterministic: every sum the default path leaves to fp64 atomics is taken in a fixed order (as the reference's ascending-row
  * accumulation is, libs/sparselevmarq.h:291-303): two runs give the same bits; slower.
  * Environment variables AAR_SOLVER (direct|spcg|pcg|auto), AAR_DETERMINISTIC, AAR_PCG_ETA, AAR_PCG_MAX_IT override the options of every
@@ -301,7 +302,7 @@ typedef struct aar_solver_stats {
     double pcg_eta;
     int32_t pcg_max_it, reserved2;
     int64_t same_xcd_solves;                  /* SPCG: solves whose wavefronts all ran on one XCD (hand-overs through that XCD's L2: the fast case)   */
-    double pcg_eta_loose;                     /* PCG chosen by AUTO with the default forcing term: what the early LM steps are solved to (0: pcg_eta throughout) */
+    double pcg_eta_loose;                     /* PCG / SPCG chosen by AUTO with the default forcing term: what the early LM steps are solved to (0: pcg_eta throughout) */
 } aar_solver_stats;
 int aar_problem_get_solver_stats(aar_problem *, aar_solver_stats *out);
 void aar_problem_destroy(aar_problem *);

@@ -360,3 +360,23 @@ def test_auto_pcg_forcing_sequence():
         assert abs(its - rd["iterations"]) <= 1, (name, its, rd["iterations"])
     assert runs["auto"][2] < runs["pcg"][2]
     assert runs["auto_eta"][2] == runs["pcg"][2]
+
+
+def test_auto_spcg_forcing_sequence():
+    # the same for AUTO resolving to the CG on the explicit reduced system (two tiles and more, below 96 entities): 0.1 early, the solver's 0.02 near the
+    # stopping rule (measured in the preconditioner's norm); full-size config 3: the direct solver's 15 LM steps, final RMSE within 1e-5 px of it
+    ds = aar.synth(3)
+    with aar.Problem(ds, solver="direct") as p:
+        xd, rd = p.lm_solve(ds.x_full)
+        rmse_d = p.reproj_stats(xd)[0]
+    out = {}
+    for name, kw in (("auto", dict(solver="auto")), ("spcg", dict(solver="spcg"))):
+        with aar.Problem(ds, **kw) as p:
+            st = p.solver_stats()
+            assert st["solver"] == "spcg" and abs(st["pcg_eta"] - 0.02) < 1e-15 and st["pcg_eta_loose"] == (0.1 if name == "auto" else 0.0)
+            x, rep = p.lm_solve(ds.x_full)
+            st = p.solver_stats()
+            out[name] = (p.reproj_stats(x)[0], rep["iterations"], st["total_iterations"], st["fallbacks"])
+    for name, (rmse, its, cg, fb) in out.items():
+        assert abs(rmse - rmse_d) < 1e-5 and its == rd["iterations"] and fb == 0, (name, rmse, rmse_d, its)
+    assert out["auto"][2] < out["spcg"][2]
