@@ -41,8 +41,12 @@ for w in 3 5; do
       python3 "$ROOT/bench.py" --workload $w $pm --solver direct --no-cpu-baseline --no-kernel-profile --no-amdahl > "$OUT/pmc${w}direct_$c.log" 2>&1
   done
 done
-# register counts of every kernel (occupancy, spills)
+# hardware counters of the observation passes at config 5 (VALU busy, waiting, LDS): scripts/kernel_pmc.sh prints per-launch averages
 cd "$ROOT"
+bash scripts/kernel_pmc.sh k_passA 5 12 > "$OUT/kpmc_passA_cfg5.txt" 2>&1
+bash scripts/kernel_pmc.sh k_passB 5 12 > "$OUT/kpmc_passB_cfg5.txt" 2>&1
+bash scripts/kernel_pmc.sh k_pcg 5 12 > "$OUT/kpmc_pcg_cfg5.txt" 2>&1
+rm -rf "$ROOT/gpurun_out/kpmc"
 # keep what is judged, drop the bulky traces
 find "$OUT" -name '*kernel_trace.csv' -delete
 find "$OUT" -name '*agent_info.csv' -delete
