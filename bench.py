@@ -95,12 +95,18 @@ def algorithmic_flops(kernel, N, n_pad, sum_kf2, merged_passes):
     NB = 96.0
     split, fused = _stages(n_pad)
     avg = lambda v: (sum(v) / len(v)) if v else 0.0
+    # look-ahead (default; AAR_LDL_LOOKAHEAD=0 switches it off): a tall block column's trailing update rides in the NEXT diagonal tile's launch, k_ldl_update is launched
+    # only for the last split column -- the riders' flops are k_ldl_diag's then (averaged over its nT launches)
+    lookahead = os.environ.get("AAR_LDL_LOOKAHEAD", "1") != "0" and len(split) > 1
+    nT = max(1, n_pad // 96)
+    ride = sum((m * NB) ** 2 * NB for m in split[:-1]) if lookahead else 0.0
+    upd = [(m * NB) ** 2 * NB for m in (split[-1:] if lookahead else split)]
     tab = {
         "k_passA": (4800.0 if merged_passes else 2600.0) * N, "k_passB": 2200.0 * N, "k_residual": 400.0 * N,
         "k_schur": 216.0 * sum_kf2,
-        "k_ldl_diag": NB ** 3 / 3.0,
+        "k_ldl_diag": NB ** 3 / 3.0 + ride / nT,
         "k_ldl_trsm": avg([m * NB * NB * NB for m in split]),
-        "k_ldl_update": avg([(m * NB) ** 2 * NB for m in split]),
+        "k_ldl_update": avg(upd),
         "k_ldl_panel": avg([m * NB * NB * NB + (m * NB) ** 2 * NB for m in fused]),
         "k_ldl_backsolve": 2.0 * n_pad * n_pad / 2.0,
     }
@@ -121,9 +127,9 @@ def algorithmic_bytes(kernel, N, A, F, n_pad):
         "k_residual": rec + 8 * P,
         "k_unpack": 8 * P,
         "k_schur": 8 * (n_pad * n_pad // 2 + n_pad),  # frame-owned W/V traffic is overhead, not algorithmic
-        "k_ldl_diag": tile,                           # lower triangle of the diagonal tile in, lower triangle of its factor out
+        "k_ldl_diag": tile + (sum(tile * m + 2 * tile * m * (m + 1) / 2 for m in split[:-1]) / max(1, n_pad // 96) if (os.environ.get("AAR_LDL_LOOKAHEAD", "1") != "0" and len(split) > 1) else 0),   # lower triangle of the diagonal tile in / out (+ the look-ahead riders' block column and trailing tiles)
         "k_ldl_trsm": avg([2 * tile * m + tile for m in split]),                   # the block column below the diagonal in/out + L_ss
-        "k_ldl_update": avg([tile * m + 2 * tile * m * (m + 1) / 2 for m in split]),   # the block column in, the trailing tiles in/out
+        "k_ldl_update": avg([tile * m + 2 * tile * m * (m + 1) / 2 for m in (split[-1:] if (os.environ.get("AAR_LDL_LOOKAHEAD", "1") != "0" and len(split) > 1) else split)]),   # the block column in, the trailing tiles in/out
         "k_ldl_panel": avg([2 * tile * m + tile + 2 * tile * m * (m + 1) / 2 for m in fused]),   # both of the above in one launch
         "k_ldl_backsolve": 8 * (n_pad * n_pad // 2 + 2 * n_pad),
         "k_frame_inv": 8 * 48 * F * 2, "k_backsub": 8 * P * 2, "k_reduce_scalars": 8 * 3 * F, "k_maxdiag": 8 * (n_pad + 6 * F),
@@ -500,6 +506,8 @@ def main():
             if k == "k_spcg":
                 fl = 2.0 * n_pad * n_pad * (1.0 + pcg_total / float(done))
             kind = KERNEL_BOUND.get(k, "hbm")
+            if k == "k_ldl_diag" and os.environ.get("AAR_LDL_LOOKAHEAD", "1") != "0" and len(_stages(n_pad)[0]) > 1:
+                kind = "fp64_mfma"     # (its launches carry the tall block columns' trailing updates as riders: matrix-pipe work, not a lone tile's chain)
             if k == "k_schur" and (A >= 96 or os.environ.get("AAR_SCHUR_MFMA") == "1") and os.environ.get("AAR_SCHUR_MFMA") != "0":
                 kind = "fp64_mfma"     # from 96 shared entities on: dense panels through the fp64 matrix pipes (k_schur_fill + k_schur_mfma)
             r = {"kernel": k, "avg_us": kernels[k]["avg_us"], "bytes_per_launch": by, "flops_per_launch": fl,
