@@ -1175,7 +1175,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         auto env_int = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
         env_int("AAR_FUSED_PANEL", P.tune.fused_panel); env_int("AAR_BS_RIDES", P.tune.bs_rides); env_int("AAR_BACKSUB_RIDES", P.tune.backsub_rides);
         env_int("AAR_LDL_LOOKAHEAD", P.tune.lookahead); env_int("AAR_PASSA_VARIANT", P.tune.passA_variant); env_int("AAR_PACK_SYSTEM", P.tune.pack_system);
-        env_int("AAR_INIT_HEADSTART", P.tune.init_headstart); env_int("AAR_PASSB_LEAN", P.tune.passB_lean); env_int("AAR_PASSA_WRENCH", P.tune.passA_wrench); env_int("AAR_SPCG_BACKSUB_RIDES", P.tune.spcg_backsub_rides);
+        env_int("AAR_INIT_HEADSTART", P.tune.init_headstart); env_int("AAR_PASSB_LEAN", P.tune.passB_lean); env_int("AAR_PASSA_WRENCH", P.tune.passA_wrench); env_int("AAR_PASSB_WRENCH_MERGED", P.tune.passB_wrench_merged); env_int("AAR_SPCG_BACKSUB_RIDES", P.tune.spcg_backsub_rides);
     }
     { const char *e = getenv("AAR_DENSE_FROM_PASSA"); if (e) P.dense_from_passA = atoi(e) != 0 ? 1 : 0; }
     {   // which solver (aar_solver_options; AUTO: DESIGN.md section 12)

@@ -1090,13 +1090,13 @@ __global__ void __launch_bounds__(BLOCK) k_passA_intr(const PassAArgs a) {
     passA_body<BLOCK, CPL, INTR>(a, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
-template <int BLOCK, int CPL, bool WR>
+template <int BLOCK, int CPL, bool WR, bool WRB = WR>
 __global__ void __launch_bounds__(BLOCK) k_passAB(const PassAArgs a, const PassBArgs b) {
     extern __shared__ double lds[];   // pass A's layout; pass B uses the first (BLOCK / 64) * 2048 doubles
     if ((int)blockIdx.x < a.F) {
         if (WR) passA_wrench_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, a.F);
         else passA_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, a.F);
-    } else if (WR) passB_wrench_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
+    } else if (WRB) passB_wrench_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
     else passB_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
 }
 // the same with camera intrinsics optimised: pass A with the W_kf blocks, pass B, and pass B's intrinsics blocks (three launches before)
@@ -1230,6 +1230,10 @@ static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, const Pas
         static size_t granted_i = 48 * 1024;
         allow_dynamic_lds(reinterpret_cast<const void *>(k_passA_intr<B, CPL, true>), lds, granted_i);
         hipLaunchKernelGGL((k_passA_intr<B, CPL, true>), dim3(P.F), dim3(B), lds, st, a);
+    } else if (pbargs && P.tune.passA_wrench && !P.tune.passB_wrench_merged) {   // (the default: pass A in wrench form, pass B's chunks in row form)
+        static size_t granted_abr = 48 * 1024;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB<B, CPL, true, false>), lds, granted_abr);
+        hipLaunchKernelGGL((k_passAB<B, CPL, true, false>), dim3(P.F + (P.n_chunks + B / 64 - 1) / (B / 64)), dim3(B), lds, st, a, *pbargs);
     } else if (pbargs && P.tune.passA_wrench) {
         static size_t granted_abw = 48 * 1024;
         allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB<B, CPL, true>), lds, granted_abw);

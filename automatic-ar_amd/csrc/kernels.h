@@ -125,6 +125,8 @@ struct DeviceProblem {
         int passA_variant = 0;     // AAR_PASSA_VARIANT: 1281 / 1282 / 1284 / 2564 force a pass A workgroup shape
         int spcg_backsub_rides = 0; // AAR_SPCG_BACKSUB_RIDES=1 (experiment, slower: profiles/r04_attempts.txt): the frame back-substitution rides in k_spcg's launch on the XCDs the CG leaves idle
         int passA_wrench = 1;      // AAR_PASSA_WRENCH=0: pass A in its row form (three Jacobian blocks per row, 100 accumulators per lane) -- the A/B reference of the wrench form
+        int passB_wrench_merged = 0;   // AAR_PASSB_WRENCH_MERGED=1: pass B in wrench form also inside the merged launch of small problems (there a lane has one observation and the
+                                       // stage after the wave sum costs more than the rows save: -1.5 % LM it/s at config 3); as a launch of its own pass B is always in pass A's form
         int passB_lean = 0;        // AAR_PASSB_LEAN (experiment): 1 = pass B's corner loop not unrolled + two wavefronts per SIMD (28 spilled registers), 2 = not unrolled only
         int pack_system = -1;      // AAR_PACK_SYSTEM=0/1: the reduced system travels as it lies / as the packed triangle (default: by size)
         int init_headstart = 1;    // AAR_INIT_HEADSTART=0: the first step's frame inverses and Schur complement wait for the host to have read mu_0
