@@ -1195,21 +1195,23 @@ def test_observation_passes_wrench_form_equals_row_form(shape, monkeypatch):
         ds = load_golden("g1_cfg2_huber")[0]
         kw = dict(with_huber=True, residual_mode=aar.RES_F64)
     out = {}
-    for form in ("1", "0"):
-        monkeypatch.setenv("AAR_PASSA_WRENCH", form)
+    for form in ("1", "1b", "0"):   # "1": the default (inside the merged launch of a small problem pass B's chunks stay in row form); "1b": wrench form there too
+        monkeypatch.setenv("AAR_PASSA_WRENCH", form[0])
+        monkeypatch.setenv("AAR_PASSB_WRENCH_MERGED", "1" if form == "1b" else "0")
         for det in (False, True):
             with aar.Problem(ds, deterministic=det, solver="direct", **kw) as p:
                 H, B, ss = p.eval_normal_equations(ds.x_full)
                 d = p.eval_damped_step(ds.x_full, 1e2)
             out[form, det] = (H, B, ss, d)
-    for det in (False, True):
-        (H1, B1, s1, d1), (H0, B0, s0, d0) = out["1", det], out["0", det]
+    for det, form in ((False, "1"), (True, "1"), (False, "1b"), (True, "1b")):
+        (H1, B1, s1, d1), (H0, B0, s0, d0) = out[form, det], out["0", det]
         assert np.abs(H1 - H0).max() / np.abs(H0).max() < 1e-13
         assert np.abs(B1 - B0).max() / np.abs(B0).max() < 1e-12
         assert abs(s1 - s0) <= 1e-13 * s0
         assert np.abs(d1 - d0).max() / np.abs(d0).max() < 1e-8        # (the small problem is the ill-conditioned one: 1.5e-9; the others 1e-11)
     # the deterministic mode of the wrench form gives the same bits twice
     monkeypatch.setenv("AAR_PASSA_WRENCH", "1")
+    monkeypatch.setenv("AAR_PASSB_WRENCH_MERGED", "0")
     with aar.Problem(ds, deterministic=True, solver="direct", **kw) as p:
         H, B, ss = p.eval_normal_equations(ds.x_full)
     assert np.array_equal(H, out["1", True][0]) and np.array_equal(B, out["1", True][1]) and ss == out["1", True][2]
