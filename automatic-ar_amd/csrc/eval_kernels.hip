@@ -1257,6 +1257,9 @@ static void launch_passA_any(const DeviceProblem &P, const PassAArgs &a, const P
     const double avg = (double)P.N / (double)P.F;
     if (P.deterministic && avg > 96) return launch_passA_t<64, 4>(P, a, pbargs, st);   // ONE wavefront per frame: its LDS additions come in program order
     const int var = P.tune.passA_variant;   // experiments (AAR_PASSA_VARIANT): 1281 / 1282 / 1284 / 2564
+    if (var == 641) return launch_passA_t<64, 1>(P, a, pbargs, st);
+    if (var == 642) return launch_passA_t<64, 2>(P, a, pbargs, st);
+    if (var == 644) return launch_passA_t<64, 4>(P, a, pbargs, st);
     if (var == 1281) return launch_passA_t<128, 1>(P, a, pbargs, st);
     if (var == 1282) return launch_passA_t<128, 2>(P, a, pbargs, st);
     if (var == 1284) return launch_passA_t<128, 4>(P, a, pbargs, st);

@@ -122,7 +122,7 @@ struct DeviceProblem {
         int bs_rides = 1;          // AAR_BS_RIDES=0: the back-substitution of 2-3 tile systems as its own chained launch
         int backsub_rides = 0;     // AAR_BACKSUB_RIDES=1: the frame back-substitution rides in the last tile's launch
         int lookahead = 1;         // AAR_LDL_LOOKAHEAD=0: tall block columns launch k_ldl_update
-        int passA_variant = 0;     // AAR_PASSA_VARIANT: 1281 / 1282 / 1284 / 2564 force a pass A workgroup shape
+        int passA_variant = 0;     // AAR_PASSA_VARIANT: 641 / 642 / 644 / 1281 / 1282 / 1284 / 2564 force a pass A workgroup shape (threads, corners per lane)
         int spcg_backsub_rides = 0; // AAR_SPCG_BACKSUB_RIDES=1 (experiment, slower: profiles/r04_attempts.txt): the frame back-substitution rides in k_spcg's launch on the XCDs the CG leaves idle
         int passA_wrench = 1;      // AAR_PASSA_WRENCH=0: pass A in its row form (three Jacobian blocks per row, 100 accumulators per lane) -- the A/B reference of the wrench form
         int passB_wrench_merged = 0;   // AAR_PASSB_WRENCH_MERGED=1: pass B in wrench form also inside the merged launch of small problems (there a lane has one observation and the
