@@ -1251,8 +1251,11 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         b_idx[i] = a_idx[perm[i]];
         memcpy(&b_uv[8 * i], &a_uv[8 * (size_t)perm[i]], 8 * sizeof(float));
     }
-    int chunk_len = (int)((N / 4096 + 63) / 64 * 64);
-    chunk_len = std::min(std::max(chunk_len, 64), PASSB_CHUNK);
+    // (a wavefront pays a wave sum of 90 values and 90 atomics per chunk whatever its length: config 5's runs of ~390 observations as ONE chunk each, 3 200 wavefronts,
+    //  run 11 % faster than cut at 256 -- profiles/r04_attempts.txt section 17; small problems keep 64 and the parallelism)
+    int chunk_len = (int)((N / 2048 + 63) / 64 * 64);
+    chunk_len = std::min(std::max(chunk_len, 64), 512);
+    if (const char *e = getenv("AAR_PASSB_CHUNK")) chunk_len = std::min(std::max(atoi(e) / 64 * 64, 64), PASSB_CHUNK);   // tuning knob (observations of a run per wavefront)
     std::vector<int32_t> chunk_start;
     for (int64_t i = 0; i < N;) {
         int64_t e = i;

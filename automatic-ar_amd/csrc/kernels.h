@@ -7,7 +7,7 @@
 namespace aar {
 
 constexpr int CHOL_NB = 96;       // dense LDL^T tile (16 entity blocks of 6)
-constexpr int PASSB_CHUNK = 256;  // max observations of one (camera, marker) run handled by one wavefront
+constexpr int PASSB_CHUNK = 1024;  // upper limit of AAR_PASSB_CHUNK (observations of one (camera, marker) run handled by one wavefront; the default rule stops at 512)
 // CG on the explicit reduced system (spcg_kernels.hip): iteration cap (sizes the hand-over buffers: one per iteration plus the
 // start-up and the final one), largest system (tiles of 96 unknowns: the six rows of an entity live in one wavefront's registers)
 constexpr int SPCG_MAX_IT = 64, SPCG_BUFS = SPCG_MAX_IT + 2, SPCG_MAX_NT = 14;
