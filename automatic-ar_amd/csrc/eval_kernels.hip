@@ -135,6 +135,7 @@ struct PassAArgs {
     int kstride;                                                                 // Kmat[kstride * camera + i]
     const int32_t *frame_obs_start, *fslot_start, *fslot_ent, *frame_stride;
     unsigned long long *stamps;   // AAR_PASSA_STAMPS builds only
+    int k_ent0;                   // first intrinsics entity (C + M); = A without them
     int A, F, C, res_f32, max_kf, frames_fixed;   // C: entities below it are cameras
     float huber;
     double h, mu_pred;
@@ -371,8 +372,8 @@ __device__ __forceinline__ void passA_body(const PassAArgs &a, double *lds, cons
 //   a CU holds, and the entity rows are L1/L2 hits fetched next to the observation's index record without a staging phase before them.
 // LDS: [max_kf*21] H slots | [32] V,g,err | [32] H_f, sum w r, sum r^2, [30] = camera slots | [24] the frame's row | [36] H_f F | [36] (V_f + mu I)^-1
 // ------------------------------------------------------------------------------------------------
-constexpr int HLS = 21;
-__host__ __device__ constexpr size_t passA_h_doubles(int max_kf) { return ((size_t)max_kf * HLS + 1) & ~(size_t)1; }
+constexpr int HLS = 21, HLS_INTR = 25;   // doubles per slot: H (21); with intrinsics entities their slots hold M = sum G_k^T w^T (4 x 6 = 24)
+__host__ __device__ constexpr size_t passA_h_doubles(int max_kf, int hls = HLS) { return ((size_t)max_kf * hls + 1) & ~(size_t)1; }
 
 #ifdef AAR_PASSA_STAMPS   // diagnostic build (make HIPFLAGS+=-DAAR_PASSA_STAMPS; AAR_STAMPS_A=<file>; scripts/dev/passA_stamps_report.py): cycle stamps of a workgroup's phases
 #define PA_STAMP(n) do { if (a.stamps && f < 512 && tid == 0) a.stamps[f * 16 + (n)] = __builtin_readcyclecounter(); } while (0)
@@ -380,10 +381,13 @@ __host__ __device__ constexpr size_t passA_h_doubles(int max_kf) { return ((size
 #define PA_STAMP(n) do { } while (0)
 #endif
 
-template <int BLOCK, int CPL>
+// INTR: camera intrinsics are optimised -- the observation's block against its camera's intrinsics entity is W_kf = sum G_k^T G_f = (sum G_k^T w^T) F: the slot of that
+// entity collects M = sum G_k^T w^T (4 x 6) and gets F once, like the others
+template <int BLOCK, int CPL, bool INTR = false>
 __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *lds, const int f, const int n_blocks_a) {
+    constexpr int SL = INTR ? HLS_INTR : HLS;
     double *Hl = lds;
-    double *acc = lds + passA_h_doubles(a.max_kf);
+    double *acc = lds + passA_h_doubles(a.max_kf, SL);
     double *hacc = acc + 32;
     double *frow = acc + 64;
     double *Yl = frow + 24;
@@ -428,7 +432,7 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
     const int e_slot = tid < kf ? a.fslot_ent[s0 + tid] : -1;
     double2 frv = make_double2(0.0, 0.0);
     if (tid < ENT_STRIDE / 2) frv = reinterpret_cast<const double2 *>(a.ent + (size_t)(a.A + f) * ENT_STRIDE)[tid];
-    for (int i = tid; i < kf * HLS; i += BLOCK) Hl[i] = 0.0;
+    for (int i = tid; i < kf * SL; i += BLOCK) Hl[i] = 0.0;
     for (int i = tid; i < 64; i += BLOCK) acc[i] = 0.0;
     if (have) fetch_rows();
     {   // grid-stride clearing of the block set that is dead by now
@@ -445,9 +449,14 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
     for (int i = 0; i < 7; i++) vals[i] = 0.0;
     while (have) {
         const int sc = id.slots & ((1 << SLOT_C_BITS) - 1), sm = (id.slots >> SLOT_C_BITS) & ((1 << SLOT_M_BITS) - 1);
-        double H[21];
+        const int sk = (id.slots >> (SLOT_C_BITS + SLOT_M_BITS)) & ((1 << SLOT_M_BITS) - 1);
+        double H[21], Mk[INTR ? 24 : 1];
 #pragma unroll
         for (int i = 0; i < 21; i++) H[i] = 0.0;
+        if (INTR) {
+#pragma unroll
+            for (int i = 0; i < 24; i++) Mk[i] = 0.0;
+        }
 #pragma unroll
         for (int kk = 0; kk < CPL; kk++) {
             CornerGeom g;
@@ -455,6 +464,16 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
             double r[2], w[2][6];
             corner_residual(ouv[kk].x, ouv[kk].y, g.u, g.v, a.res_f32, a.huber, r[0], r[1]);
             corner_wrench(ec, K, g, w);
+            if (INTR) {
+                double Gk[2][4];
+                corner_jacobian_intr(g, Gk);
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 6; j++) Mk[i * 6 + j] += Gk[rr][i] * w[rr][j];
+            }
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
                 vals[6] += r[rr] * r[rr];
@@ -473,11 +492,16 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
             if (pos >= nobs) pos -= nobs;
             fetch_obs();
         }
-        double *hc = Hl + sc * HLS, *hm = Hl + sm * HLS;
+        double *hc = Hl + sc * SL, *hm = Hl + sm * SL;
 #pragma unroll
         for (int i = 0; i < 21; i++) atomicAdd(hc + i, H[i]);
 #pragma unroll
         for (int i = 0; i < 21; i++) atomicAdd(hm + i, H[i]);
+        if (INTR) {
+            double *hk = Hl + sk * SL;
+#pragma unroll
+            for (int i = 0; i < 24; i++) atomicAdd(hk + i, Mk[i]);
+        }
         if (have) fetch_rows();
     }
     PA_STAMP(2);
@@ -503,7 +527,7 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
     if (tid < 21) {   // H_f: the camera slots of the frame
         const int nc = (int)hacc[30];
         double sv = 0.0;
-        for (int ts = 0; ts < nc; ts++) sv += Hl[ts * HLS + tid];
+        for (int ts = 0; ts < nc; ts++) sv += Hl[ts * SL + tid];
         hacc[tid] = sv;
     }
     __syncthreads();
@@ -572,11 +596,29 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
 #pragma unroll
             for (int i = 0; i < 7; i++) rv[i] = rowp[4 + i];
         }
+        if (INTR && e >= a.k_ent0) {   // an intrinsics entity's slot: W = M F (rows fx, cx, fy, cy; the entity's two idle rows are zero)
+            const double *mk = Hl + ts * SL;
+            double2 *wp = reinterpret_cast<double2 *>(a.W + (size_t)(s0 + ts) * 36);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                double m6[6], wr[3];
+#pragma unroll
+                for (int j = 0; j < 6; j++) m6[j] = mk[i * 6 + j];
+#pragma unroll
+                for (int j = 0; j < 3; j++) wr[j] = m6[0] * ef.Jl[j] + m6[1] * ef.Jl[3 + j] + m6[2] * ef.Jl[6 + j];
+                wp[3 * i] = make_double2(wr[0], wr[1]);
+                wp[3 * i + 1] = make_double2(wr[2], m6[3]);
+                wp[3 * i + 2] = make_double2(m6[4], m6[5]);
+            }
+#pragma unroll
+            for (int q = 12; q < 18; q++) wp[q] = make_double2(0.0, 0.0);
+            continue;
+        }
         const bool cam = e < a.C;
         const double tt[3] = {cam ? rv[0].y - ef.t[0] : rv[0].y, cam ? rv[1].x - ef.t[1] : rv[1].x, cam ? rv[1].y - ef.t[2] : rv[1].y};   // d = t_c - t_f, or t_m
         const double Jl[9] = {rv[2].x, rv[2].y, rv[3].x, rv[3].y, rv[4].x, rv[4].y, rv[5].x, rv[5].y, rv[6].x};
         double H[21], X[6][6];
-        const double *slot = Hl + ts * HLS;
+        const double *slot = Hl + ts * SL;
 #pragma unroll
         for (int i = 0; i < 21; i++) H[i] = slot[i];
         // camera: T^T = -[J_l^T, -J_l^T [d]x; 0, I]      marker: T^T = [J_l^T R_f^T, -J_l^T [t_m]x R_f^T; 0, R_f^T]
@@ -1084,10 +1126,11 @@ __global__ void __launch_bounds__(256) k_passB_reduce(const PassBReduceArgs r) {
     }
 }
 
-template <int BLOCK, int CPL, bool INTR>
+template <int BLOCK, int CPL, bool WR>
 __global__ void __launch_bounds__(BLOCK) k_passA_intr(const PassAArgs a) {
     extern __shared__ double lds[];
-    passA_body<BLOCK, CPL, INTR>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+    if (WR) passA_wrench_body<BLOCK, CPL, true>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+    else passA_body<BLOCK, CPL, true>(a, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <int BLOCK, int CPL, bool WR, bool WRB = WR>
@@ -1100,11 +1143,14 @@ __global__ void __launch_bounds__(BLOCK) k_passAB(const PassAArgs a, const PassB
     else passB_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
 }
 // the same with camera intrinsics optimised: pass A with the W_kf blocks, pass B, and pass B's intrinsics blocks (three launches before)
-template <int BLOCK, int CPL>
+template <int BLOCK, int CPL, bool WR>
 __global__ void __launch_bounds__(BLOCK) k_passAB_intr(const PassAArgs a, const PassBArgs b, int nb) {
     extern __shared__ double lds[];
     const int blk = (int)blockIdx.x;
-    if (blk < a.F) passA_body<BLOCK, CPL, true>(a, lds, blk, a.F);
+    if (blk < a.F) {
+        if (WR) passA_wrench_body<BLOCK, CPL, true>(a, lds, blk, a.F);
+        else passA_body<BLOCK, CPL, true>(a, lds, blk, a.F);
+    }
     else if (blk < a.F + nb) passB_body(b, lds, (blk - a.F) * (BLOCK / 64));
     else passB_intr_body(b, lds, (blk - a.F - nb) * (BLOCK / 64));
 }
@@ -1161,7 +1207,7 @@ void launch_residual(const DeviceProblem &P, int which, double *r_out, hipStream
 
 int residual_blocks(const DeviceProblem &P) { return (int)((P.N + 255) / 256); }
 
-size_t passA_wrench_lds_bytes(int max_kf) { return (passA_h_doubles(max_kf) + 64 + 24 + 72) * sizeof(double); }
+size_t passA_wrench_lds_bytes(int max_kf, bool intr) { return (passA_h_doubles(max_kf, intr ? HLS_INTR : HLS) + 64 + 24 + 72) * sizeof(double); }
 
 size_t passA_lds_bytes(int max_kf, int block) {
     return (passA_w_doubles(max_kf) + 64 + (size_t)(max_kf + 1) * ENT_LDS + (block / 64) * passA_sum_chunk(block) * 64) * sizeof(double);
@@ -1172,7 +1218,7 @@ static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, i
     a.idx = P.a_idx; a.uv = P.a_uv; a.ent = P.ent[which];
     { const KTable kt = k_table(P, which); a.Kmat = kt.base; a.kstride = kt.stride; }
     a.frame_obs_start = P.frame_obs_start; a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.frame_stride = P.frame_stride;
-    a.stamps = nullptr;
+    a.stamps = nullptr; a.k_ent0 = P.intr ? P.C + P.M : P.A;
 #ifdef AAR_PASSA_STAMPS
     {
         static unsigned long long *st = nullptr;
@@ -1217,19 +1263,31 @@ static PassBArgs passB_args(const DeviceProblem &P, int which) {
 // with_b: pass B's chunks ride in the same launch (the caller must not launch pass B again)
 template <int B, int CPL>
 static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, const PassBArgs *pbargs, hipStream_t st) {
-    size_t lds = (P.tune.passA_wrench && !P.intr) ? passA_wrench_lds_bytes(P.max_kf) : passA_lds_bytes(P.max_kf, B);
+    size_t lds = P.tune.passA_wrench ? passA_wrench_lds_bytes(P.max_kf, P.intr != 0) : passA_lds_bytes(P.max_kf, B);
     if (pbargs) lds = std::max(lds, (size_t)(B / 64) * 2048 * sizeof(double));   // pass B's wave-sum scratch, when its chunks ride along
     static size_t granted = 48 * 1024, granted_ab = 48 * 1024;
     HookScope _h(P, KID_PASSA);
     if (P.intr && pbargs) {
         static size_t granted_abi = 48 * 1024;
         const int nb = (P.n_chunks + B / 64 - 1) / (B / 64);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB_intr<B, CPL>), lds, granted_abi);
-        hipLaunchKernelGGL((k_passAB_intr<B, CPL>), dim3(P.F + 2 * nb), dim3(B), lds, st, a, *pbargs, nb);
+        if (P.tune.passA_wrench) {
+            static size_t granted_abiw = 48 * 1024;
+            allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB_intr<B, CPL, true>), lds, granted_abiw);
+            hipLaunchKernelGGL((k_passAB_intr<B, CPL, true>), dim3(P.F + 2 * nb), dim3(B), lds, st, a, *pbargs, nb);
+        } else {
+            allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB_intr<B, CPL, false>), lds, granted_abi);
+            hipLaunchKernelGGL((k_passAB_intr<B, CPL, false>), dim3(P.F + 2 * nb), dim3(B), lds, st, a, *pbargs, nb);
+        }
     } else if (P.intr) {
         static size_t granted_i = 48 * 1024;
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_passA_intr<B, CPL, true>), lds, granted_i);
-        hipLaunchKernelGGL((k_passA_intr<B, CPL, true>), dim3(P.F), dim3(B), lds, st, a);
+        if (P.tune.passA_wrench) {
+            static size_t granted_iw = 48 * 1024;
+            allow_dynamic_lds(reinterpret_cast<const void *>(k_passA_intr<B, CPL, true>), lds, granted_iw);
+            hipLaunchKernelGGL((k_passA_intr<B, CPL, true>), dim3(P.F), dim3(B), lds, st, a);
+        } else {
+            allow_dynamic_lds(reinterpret_cast<const void *>(k_passA_intr<B, CPL, false>), lds, granted_i);
+            hipLaunchKernelGGL((k_passA_intr<B, CPL, false>), dim3(P.F), dim3(B), lds, st, a);
+        }
     } else if (pbargs && P.tune.passA_wrench && !P.tune.passB_wrench_merged) {   // (the default: pass A in wrench form, pass B's chunks in row form)
         static size_t granted_abr = 48 * 1024;
         allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB<B, CPL, true, false>), lds, granted_abr);

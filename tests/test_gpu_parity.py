@@ -1175,7 +1175,7 @@ def test_randomized_shapes_in_the_optional_modes(mode):
     assert done >= 6
 
 
-@pytest.mark.parametrize("shape", ["cfg2", "cfg3_cut", "cfg5_shaped", "few_obs_per_frame", "huber_f64"])
+@pytest.mark.parametrize("shape", ["cfg2", "cfg3_cut", "cfg5_shaped", "few_obs_per_frame", "huber_f64", "intrinsics", "intrinsics_cfg5_shaped"])
 def test_observation_passes_wrench_form_equals_row_form(shape, monkeypatch):
     # The default observation passes reach the frame blocks (V_f, g_f, W_cf, W_mf) and the shared blocks (U, g) through the observation's 6x6 Gram matrix of
     # wrenches (csrc/geom.hpp corner_wrench; csrc/eval_kernels.hip passA_wrench_body / passB_wrench_body); AAR_PASSA_WRENCH=0 keeps the row form that
@@ -1191,17 +1191,25 @@ def test_observation_passes_wrench_form_equals_row_form(shape, monkeypatch):
         ds = aar.synth(5, num_frames=40)                      # 16 cameras / 200 markers: ~250 observations per frame, two wavefronts per frame, MFMA Schur panels
     elif shape == "few_obs_per_frame":
         ds = aar.synth(3, num_cams=3, num_markers=6, num_frames=60)   # <= 14 observations per frame: four lanes per observation
-    else:
+    elif shape == "huber_f64":
         ds = load_golden("g1_cfg2_huber")[0]
         kw = dict(with_huber=True, residual_mode=aar.RES_F64)
+    elif shape == "intrinsics":                               # optimize_cam_intrinsics: the intrinsics entities' slots collect sum G_k^T w^T
+        ds = load_golden("g1_cfg2_intr")[0]
+        kw = dict(intrinsics=True)
+    else:
+        ds = aar.synth(5, num_frames=30)
+        kw = dict(intrinsics=True)
+    x_eval = None
     out = {}
     for form in ("1", "1b", "0"):   # "1": the default (inside the merged launch of a small problem pass B's chunks stay in row form); "1b": wrench form there too
         monkeypatch.setenv("AAR_PASSA_WRENCH", form[0])
         monkeypatch.setenv("AAR_PASSB_WRENCH_MERGED", "1" if form == "1b" else "0")
         for det in (False, True):
             with aar.Problem(ds, deterministic=det, solver="direct", **kw) as p:
-                H, B, ss = p.eval_normal_equations(ds.x_full)
-                d = p.eval_damped_step(ds.x_full, 1e2)
+                x_eval = p.x_with_intrinsics(ds.x_full) if kw.get("intrinsics") else ds.x_full
+                H, B, ss = p.eval_normal_equations(x_eval)
+                d = p.eval_damped_step(x_eval, 1e2)
             out[form, det] = (H, B, ss, d)
     for det, form in ((False, "1"), (True, "1"), (False, "1b"), (True, "1b")):
         (H1, B1, s1, d1), (H0, B0, s0, d0) = out[form, det], out["0", det]
@@ -1213,5 +1221,5 @@ def test_observation_passes_wrench_form_equals_row_form(shape, monkeypatch):
     monkeypatch.setenv("AAR_PASSA_WRENCH", "1")
     monkeypatch.setenv("AAR_PASSB_WRENCH_MERGED", "0")
     with aar.Problem(ds, deterministic=True, solver="direct", **kw) as p:
-        H, B, ss = p.eval_normal_equations(ds.x_full)
+        H, B, ss = p.eval_normal_equations(x_eval)
     assert np.array_equal(H, out["1", True][0]) and np.array_equal(B, out["1", True][1]) and ss == out["1", True][2]
