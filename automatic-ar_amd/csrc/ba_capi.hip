@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 
 #include <algorithm>
@@ -1027,17 +1028,18 @@ void aar_solver_default_options(aar_solver_options *o) {
 
 int aar_problem_create(const aar_problem_desc *d, aar_problem **out) { return aar_problem_create_ex(d, nullptr, out); }
 
-// AAR_ABORT_BACKTRACE=1 (diagnostics): the native stack of whoever raises SIGABRT in this process (a runtime library giving up) goes to stderr before the default action
+// AAR_ABORT_BACKTRACE=<file> (diagnostics): the native stack of whoever raises SIGABRT in this process (a runtime library giving up) is appended to the file before the default action
+static int abort_bt_fd = 2;
 static void abort_backtrace(int sig) {
     void *bt[64];
     const int n = backtrace(bt, 64);
-    backtrace_symbols_fd(bt, n, 2);
+    backtrace_symbols_fd(bt, n, abort_bt_fd);
     signal(sig, SIG_DFL);
     raise(sig);
 }
 
 int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *opts, aar_problem **out) {
-    { static bool once = false; if (!once && getenv("AAR_ABORT_BACKTRACE")) { once = true; signal(SIGABRT, abort_backtrace); } }
+    { static bool once = false; if (!once && getenv("AAR_ABORT_BACKTRACE")) { once = true; const int fd = open(getenv("AAR_ABORT_BACKTRACE"), O_WRONLY | O_CREAT | O_APPEND, 0644); if (fd >= 0) abort_bt_fd = fd; signal(SIGABRT, abort_backtrace); } }
     if (!d || !out) return set_error(AAR_ERR_INVALID, "aar_problem_create: null argument");
     aar_solver_options so;
     aar_solver_default_options(&so);
