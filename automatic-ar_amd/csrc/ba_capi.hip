@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <execinfo.h>
 #include <fcntl.h>
+#include <unistd.h>
 #include <signal.h>
 
 #include <algorithm>
@@ -1032,6 +1033,7 @@ int aar_problem_create(const aar_problem_desc *d, aar_problem **out) { return aa
 static int abort_bt_fd = 2;
 static void abort_backtrace(int sig) {
     void *bt[64];
+    { char msg[64]; const int k = aar::g_last_kernel_id; int n = 0; const char *t = "last kernel id "; while (t[n]) { msg[n] = t[n]; n++; } if (k < 0) msg[n++] = '-'; else { if (k >= 10) msg[n++] = '0' + k / 10; msg[n++] = '0' + k % 10; } msg[n++] = '\n'; (void)!write(abort_bt_fd, msg, n); }
     const int n = backtrace(bt, 64);
     backtrace_symbols_fd(bt, n, abort_bt_fd);
     signal(sig, SIG_DFL);

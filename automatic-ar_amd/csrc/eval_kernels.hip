@@ -16,6 +16,8 @@
 
 namespace aar {
 
+volatile int g_last_kernel_id = -1;   // (kernels.h: diagnostics)
+
 // ------------------------------------------------------------------------------------------------
 // wave-level sum of NV per-lane values through LDS, result handed to `sink(i, total)` on one lane.
 // scratch: CH*64 doubles per wave.  Values are processed CH at a time; 64/CH lanes share a value, each sums CH of its 64

@@ -181,10 +181,11 @@ inline KTable k_table(const DeviceProblem &P, int which) {
 constexpr int SLOT_C_BITS = 10, SLOT_M_BITS = 11;   // ObsIdx::slots
 inline int pack_slots(int sc, int sm, int sk) { return sc | (sm << SLOT_C_BITS) | (sk << (SLOT_C_BITS + SLOT_M_BITS)); }
 
+extern volatile int g_last_kernel_id;   // the kernel id of the most recent launch of this process (diagnostics: AAR_ABORT_BACKTRACE prints it)
 struct HookScope {  // RAII: pre/post around one launch
     const DeviceProblem &P;
     int kid;
-    HookScope(const DeviceProblem &p, int k) : P(p), kid(k) { if (P.hook.pre) P.hook.pre(P.hook.ctx, kid); }
+    HookScope(const DeviceProblem &p, int k) : P(p), kid(k) { g_last_kernel_id = k; if (P.hook.pre) P.hook.pre(P.hook.ctx, kid); }
     ~HookScope() { if (P.hook.post) P.hook.post(P.hook.ctx, kid); }
 };
 
