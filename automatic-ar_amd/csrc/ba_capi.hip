@@ -1627,8 +1627,8 @@ int aar_eval_residuals(aar_problem *pb, const double *x_full, double *r, double 
     if (rc) { if (d_r) (void)hipFree(d_r); return rc; }
     pb->seq++;
     launch_publish(P, pb->seq, pb->stream);
-    if (r) HIP_TRY(hipMemcpyAsync(r, d_r, 8 * (size_t)P.N * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
     HIP_TRY(hipStreamSynchronize(pb->stream));
+    if (r) HIP_TRY(hipMemcpy(r, d_r, 8 * (size_t)P.N * sizeof(double), hipMemcpyDeviceToHost));   // (blocking: a large pageable destination, see aar_eval_normal_equations)
     if ((rc = wait_result(pb))) { if (d_r) (void)hipFree(d_r); return rc; }
     if (d_r) (void)hipFree(d_r);
     if (sum_sq) *sum_sq = pb->h_scal[0];
@@ -1665,15 +1665,17 @@ int aar_eval_normal_equations(aar_problem *pb, const double *x_full, double *JtJ
     const int A = P.A, F = P.F, np = P.n_pad;
     const DeviceProblem::Blocks &bk = P.blk[pb->cur];
     std::vector<double> U0((size_t)np * np), g0(np), V((size_t)F * 36), gf((size_t)F * 6), W((size_t)P.total_slots * 36), ep(F);
-    HIP_TRY(hipMemcpyAsync(U0.data(), bk.S, U0.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-    HIP_TRY(hipMemcpyAsync(g0.data(), bk.g0, g0.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-    if (F) {
-        HIP_TRY(hipMemcpyAsync(V.data(), bk.V, V.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-        HIP_TRY(hipMemcpyAsync(gf.data(), bk.gf, gf.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-        HIP_TRY(hipMemcpyAsync(W.data(), bk.W, W.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-        HIP_TRY(hipMemcpyAsync(ep.data(), P.err_part, ep.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
-    }
+    // Blocking copies after the stream has drained: with asynchronous copies into these pageable vectors (14 MB for U0 at 216 entities) the GPU faulted on a host
+    // address once in ~8 runs of the test suite (the runtime pins pageable destinations of asynchronous copies on the fly); this is a checking API, not a hot path.
     HIP_TRY(hipStreamSynchronize(pb->stream));
+    HIP_TRY(hipMemcpy(U0.data(), bk.S, U0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(g0.data(), bk.g0, g0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (F) {
+        HIP_TRY(hipMemcpy(V.data(), bk.V, V.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(gf.data(), bk.gf, gf.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(W.data(), bk.W, W.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ep.data(), P.err_part, ep.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
     pb->lm_ready = false;
     // reference column of each device parameter (or -1): roots, non-optimised groups and the two idle parameters of an
     // intrinsics entity have none
