@@ -1610,6 +1610,23 @@ int aar_problem_set_huber_delta(aar_problem *pb, float delta) {
 }
 float aar_problem_get_huber_delta(const aar_problem *pb) { return pb ? pb->hubber_delta : 0.f; }
 
+// Device-to-host copy of a LARGE block into pageable memory (the checking APIs: dense normal equations, residual vector) through a pinned staging buffer.
+// Handing the pageable destination to hipMemcpy itself makes the runtime pin those heap pages on the fly; a range it had pinned before for an upload (read-only for
+// the GPU) and that malloc has handed out again then takes the GPU's write as "write access to a read-only page" -- seen once in ~6 runs of the test suite.
+static int d2h_staged(void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return AAR_OK;
+    const size_t chunk = std::min<size_t>(bytes, (size_t)8 << 20);
+    void *stg = nullptr;
+    HIP_TRY(hipHostMalloc(&stg, chunk, hipHostMallocDefault));
+    for (size_t off = 0; off < bytes; off += chunk) {
+        const size_t n = std::min(chunk, bytes - off);
+        if (hipMemcpy(stg, (const char *)src + off, n, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipHostFree(stg); return set_error(AAR_ERR_HIP, "device-to-host copy failed"); }
+        memcpy((char *)dst + off, stg, n);
+    }
+    (void)hipHostFree(stg);
+    return AAR_OK;
+}
+
 int aar_eval_residuals(aar_problem *pb, const double *x_full, double *r, double *sum_sq) {
     if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_eval_residuals: null argument");
     if (r && pb->comm) return set_error(AAR_ERR_UNSUPPORTED, "residual vector output is single-GPU only");
@@ -1628,7 +1645,7 @@ int aar_eval_residuals(aar_problem *pb, const double *x_full, double *r, double 
     pb->seq++;
     launch_publish(P, pb->seq, pb->stream);
     HIP_TRY(hipStreamSynchronize(pb->stream));
-    if (r) HIP_TRY(hipMemcpy(r, d_r, 8 * (size_t)P.N * sizeof(double), hipMemcpyDeviceToHost));   // (blocking: a large pageable destination, see aar_eval_normal_equations)
+    if (r && (rc = d2h_staged(r, d_r, 8 * (size_t)P.N * sizeof(double)))) { (void)hipFree(d_r); return rc; }
     if ((rc = wait_result(pb))) { if (d_r) (void)hipFree(d_r); return rc; }
     if (d_r) (void)hipFree(d_r);
     if (sum_sq) *sum_sq = pb->h_scal[0];
@@ -1665,16 +1682,12 @@ int aar_eval_normal_equations(aar_problem *pb, const double *x_full, double *JtJ
     const int A = P.A, F = P.F, np = P.n_pad;
     const DeviceProblem::Blocks &bk = P.blk[pb->cur];
     std::vector<double> U0((size_t)np * np), g0(np), V((size_t)F * 36), gf((size_t)F * 6), W((size_t)P.total_slots * 36), ep(F);
-    // Blocking copies after the stream has drained: with asynchronous copies into these pageable vectors (14 MB for U0 at 216 entities) the GPU faulted on a host
-    // address once in ~8 runs of the test suite (the runtime pins pageable destinations of asynchronous copies on the fly); this is a checking API, not a hot path.
+    // (copies through a pinned staging buffer after the stream has drained: d2h_staged)
     HIP_TRY(hipStreamSynchronize(pb->stream));
-    HIP_TRY(hipMemcpy(U0.data(), bk.S, U0.size() * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(g0.data(), bk.g0, g0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if ((rc = d2h_staged(U0.data(), bk.S, U0.size() * sizeof(double))) || (rc = d2h_staged(g0.data(), bk.g0, g0.size() * sizeof(double)))) return rc;
     if (F) {
-        HIP_TRY(hipMemcpy(V.data(), bk.V, V.size() * sizeof(double), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(gf.data(), bk.gf, gf.size() * sizeof(double), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(W.data(), bk.W, W.size() * sizeof(double), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(ep.data(), P.err_part, ep.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if ((rc = d2h_staged(V.data(), bk.V, V.size() * sizeof(double))) || (rc = d2h_staged(gf.data(), bk.gf, gf.size() * sizeof(double))) ||
+            (rc = d2h_staged(W.data(), bk.W, W.size() * sizeof(double))) || (rc = d2h_staged(ep.data(), P.err_part, ep.size() * sizeof(double)))) return rc;
     }
     pb->lm_ready = false;
     // reference column of each device parameter (or -1): roots, non-optimised groups and the two idle parameters of an
