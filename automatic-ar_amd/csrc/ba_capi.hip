@@ -379,6 +379,23 @@ int collective_status(aar_problem *pb, int local_rc, int *agreed) {
 // side_stream: the copy goes through the problem's second stream and only THAT is waited for.  z[which] must be complete already (the host has
 // seen the scalars of the step that wrote it); what is still running on the main stream -- the speculative Schur complement of a step that
 // turned out to be the last, ~20 us -- then overlaps with the caller's own work instead of being waited for.  Single GPU only.
+// Device-to-host copy of a LARGE block into pageable memory (the checking APIs: dense normal equations, residual vector) through a pinned staging buffer.
+// Handing the pageable destination to hipMemcpy itself makes the runtime pin those heap pages on the fly; a range it had pinned before for an upload (read-only for
+// the GPU) and that malloc has handed out again then takes the GPU's write as "write access to a read-only page" -- seen once in ~6 runs of the test suite.
+static int d2h_staged(void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return AAR_OK;
+    const size_t chunk = std::min<size_t>(bytes, (size_t)8 << 20);
+    void *stg = nullptr;
+    HIP_TRY(hipHostMalloc(&stg, chunk, hipHostMallocDefault));
+    for (size_t off = 0; off < bytes; off += chunk) {
+        const size_t n = std::min(chunk, bytes - off);
+        if (hipMemcpy(stg, (const char *)src + off, n, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipHostFree(stg); return set_error(AAR_ERR_HIP, "device-to-host copy failed"); }
+        memcpy((char *)dst + off, stg, n);
+    }
+    (void)hipHostFree(stg);
+    return AAR_OK;
+}
+
 int download_z(aar_problem *pb, int which, double *x_full, bool side_stream = false) {
     const PoseLayout &L = pb->L;
     const int A = pb->P.A, F = pb->P.F;
@@ -407,8 +424,8 @@ int download_z(aar_problem *pb, int which, double *x_full, bool side_stream = fa
                                        (size_t)6 * F * sizeof(double), hipMemcpyDeviceToDevice, pb->stream));
             int rc = allreduce(pb, pb->d_frames_all, cnt, NCCL_SUM);
             if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(x_full + L.full_fr0(), pb->d_frames_all, cnt * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
             HIP_TRY(hipStreamSynchronize(pb->stream));
+            if ((rc = d2h_staged(x_full + L.full_fr0(), pb->d_frames_all, cnt * sizeof(double)))) return rc;   // (the caller's pageable vector: through pinned memory)
         }
     }
     return AAR_OK;
@@ -1609,23 +1626,6 @@ int aar_problem_set_huber_delta(aar_problem *pb, float delta) {
     return AAR_OK;
 }
 float aar_problem_get_huber_delta(const aar_problem *pb) { return pb ? pb->hubber_delta : 0.f; }
-
-// Device-to-host copy of a LARGE block into pageable memory (the checking APIs: dense normal equations, residual vector) through a pinned staging buffer.
-// Handing the pageable destination to hipMemcpy itself makes the runtime pin those heap pages on the fly; a range it had pinned before for an upload (read-only for
-// the GPU) and that malloc has handed out again then takes the GPU's write as "write access to a read-only page" -- seen once in ~6 runs of the test suite.
-static int d2h_staged(void *dst, const void *src, size_t bytes) {
-    if (bytes == 0) return AAR_OK;
-    const size_t chunk = std::min<size_t>(bytes, (size_t)8 << 20);
-    void *stg = nullptr;
-    HIP_TRY(hipHostMalloc(&stg, chunk, hipHostMallocDefault));
-    for (size_t off = 0; off < bytes; off += chunk) {
-        const size_t n = std::min(chunk, bytes - off);
-        if (hipMemcpy(stg, (const char *)src + off, n, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipHostFree(stg); return set_error(AAR_ERR_HIP, "device-to-host copy failed"); }
-        memcpy((char *)dst + off, stg, n);
-    }
-    (void)hipHostFree(stg);
-    return AAR_OK;
-}
 
 int aar_eval_residuals(aar_problem *pb, const double *x_full, double *r, double *sum_sq) {
     if (!pb || !x_full) return set_error(AAR_ERR_INVALID, "aar_eval_residuals: null argument");
