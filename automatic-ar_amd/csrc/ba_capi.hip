@@ -179,6 +179,7 @@ struct aar_problem {
     double *d_status = nullptr;      // multi-GPU: one double for collective status decisions
     std::vector<double> h_z;    // staging [6A + 6F_loc]; page-locked (hipHostRegister) once it has its size, so uploads need no sync
     bool h_z_pinned = false;
+    double *h_gather = nullptr; size_t h_gather_n = 0;   // multi-rank: pinned landing zone of the gathered frame poses (download_z)
     hipEvent_t up_ev = nullptr;  // the last upload from h_z (it must have left before h_z is packed again)
     bool mu_seed_valid = false;  // max diag(J^T J) of the start point, published together with its sum r^2 (aar_lm_init)
     double mu_seed = 0;
@@ -424,8 +425,15 @@ int download_z(aar_problem *pb, int which, double *x_full, bool side_stream = fa
                                        (size_t)6 * F * sizeof(double), hipMemcpyDeviceToDevice, pb->stream));
             int rc = allreduce(pb, pb->d_frames_all, cnt, NCCL_SUM);
             if (rc) return rc;
+            if (pb->h_gather_n < cnt) {   // (the caller's vector is pageable: the copy lands in pinned memory of the problem's own, allocated once)
+                if (pb->h_gather) (void)hipHostFree(pb->h_gather);
+                pb->h_gather = nullptr; pb->h_gather_n = 0;
+                HIP_TRY(hipHostMalloc((void **)&pb->h_gather, cnt * sizeof(double), hipHostMallocDefault));
+                pb->h_gather_n = cnt;
+            }
+            HIP_TRY(hipMemcpyAsync(pb->h_gather, pb->d_frames_all, cnt * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
             HIP_TRY(hipStreamSynchronize(pb->stream));
-            if ((rc = d2h_staged(x_full + L.full_fr0(), pb->d_frames_all, cnt * sizeof(double)))) return rc;   // (the caller's pageable vector: through pinned memory)
+            memcpy(x_full + L.full_fr0(), pb->h_gather, cnt * sizeof(double));
         }
     }
     return AAR_OK;
@@ -1026,6 +1034,7 @@ void aar_problem_destroy(aar_problem *pb) {
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
     if (pb->h_pcg) (void)hipHostFree(pb->h_pcg);
     if (pb->h_z_pinned) (void)hipHostUnregister(pb->h_z.data());
+    if (pb->h_gather) (void)hipHostFree(pb->h_gather);
     if (pb->up_ev) (void)hipEventDestroy(pb->up_ev);
     if (pb->ev[0]) (void)hipEventDestroy(pb->ev[0]);
     if (pb->ev[1]) (void)hipEventDestroy(pb->ev[1]);
