@@ -16,6 +16,7 @@ B --workload 3 --solver direct --no-cpu-baseline > "$OUT/bench_cfg3_direct.json"
 B --workload 5 --solver direct --steps 45 --warmup 15 --no-cpu-baseline > "$OUT/bench_cfg5_direct.json"
 B --workload 5 --solver spcg --steps 45 --warmup 15 --no-cpu-baseline > "$OUT/bench_cfg5_spcg.json"
 B --workload 3 --solver pcg --no-cpu-baseline > "$OUT/bench_cfg3_pcg.json"
+B --workload 5 --solver pcg --steps 45 --warmup 15 --no-cpu-baseline > "$OUT/bench_cfg5_pcg.json"   # (the solver named explicitly: fixed forcing term 0.1)
 B --workload 3 --intrinsics --no-cpu-baseline > "$OUT/bench_cfg3_intrinsics.json"
 B --workload 5 --intrinsics --steps 45 --warmup 15 --no-cpu-baseline > "$OUT/bench_cfg5_intrinsics.json"
 B --workload 3 --deterministic --no-cpu-baseline > "$OUT/bench_cfg3_deterministic.json"
