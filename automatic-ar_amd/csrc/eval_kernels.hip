@@ -459,7 +459,7 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
 #pragma unroll
             for (int i = 0; i < 24; i++) Mk[i] = 0.0;
         }
-#pragma unroll
+#pragma unroll (INTR && CPL == 4 ? 2 : CPL)
         for (int kk = 0; kk < CPL; kk++) {
             CornerGeom g;
             project_corner(ec, em, ef, K, a.h, part * CPL + kk, g);
