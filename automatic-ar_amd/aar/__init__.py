@@ -34,10 +34,12 @@ SYMBOLS = [
     "aar_vote_transforms", "aar_init_default_params", "aar_initializer_run", "aar_initializer_object_poses",
     "aar_comm_get_stats", "aar_lm_set_step_callback", "aar_lm_set_stop_function", "aar_problem_extract_z", "aar_problem_merge_z",
     "aar_solution_read_ex", "aar_cam_configs_read_ex", "aar_set_stage_timers", "aar_problem_pcg_iterations",
-    "aar_solver_default_options", "aar_problem_create_ex", "aar_problem_get_solver_stats",
+    "aar_solver_default_options", "aar_problem_create_ex", "aar_problem_get_solver_stats", "aar_problem_set_test_hook",
 ]
 NUM_KERNELS = 16
 SOLVER_DIRECT, SOLVER_PCG, SOLVER_SPCG, SOLVER_AUTO = 0, 1, 2, 3
+TEST_HOOK_SPCG_DROP = 1
+ENV_SOLVER, ENV_DETERMINISTIC, ENV_PCG_ETA, ENV_PCG_MAX_IT = 1, 2, 4, 8
 SOLVERS = {"direct": SOLVER_DIRECT, "pcg": SOLVER_PCG, "spcg": SOLVER_SPCG, "auto": SOLVER_AUTO}
 SOLVER_NAMES = {v: k for k, v in SOLVERS.items()}
 
@@ -86,13 +88,14 @@ class CProblemDesc(C.Structure):
 
 class CSolverOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("solver", C.c_int32), ("deterministic", C.c_int32), ("pcg_max_it", C.c_int32),
-                ("pcg_eta", C.c_double)]
+                ("pcg_eta", C.c_double), ("pcg_eta_loose", C.c_double), ("pcg_eta_switch", C.c_double)]
 
 
 class CSolverStats(C.Structure):
-    _fields_ = [("solver", C.c_int32), ("deterministic", C.c_int32), ("last_iterations", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("solver", C.c_int32), ("deterministic", C.c_int32), ("last_iterations", C.c_int32),
                 ("total_iterations", C.c_int64), ("solves", C.c_int64), ("fallbacks", C.c_int64), ("pcg_eta", C.c_double),
-                ("pcg_max_it", C.c_int32), ("reserved2", C.c_int32), ("same_xcd_solves", C.c_int64), ("pcg_eta_loose", C.c_double)]
+                ("pcg_max_it", C.c_int32), ("env_overrides", C.c_int32), ("same_xcd_solves", C.c_int64), ("pcg_eta_loose", C.c_double),
+                ("pcg_eta_switch", C.c_double)]
 
 
 class CLmParams(C.Structure):
@@ -183,6 +186,7 @@ def lib():
     L.aar_solver_default_options.argtypes = [C.POINTER(CSolverOptions)]
     L.aar_solver_default_options.restype = None
     L.aar_problem_get_solver_stats.argtypes = [C.c_void_p, C.POINTER(CSolverStats)]
+    L.aar_problem_set_test_hook.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.aar_problem_destroy.argtypes = [C.c_void_p]
     L.aar_problem_destroy.restype = None
     for n in ("aar_problem_full_len", "aar_problem_num_vars", "aar_problem_local_obs"):
@@ -605,9 +609,10 @@ class Problem:
     """aar_problem: the bundle-adjustment problem resident on one GPU."""
 
     def __init__(self, ds, residual_mode=RES_F32, device=0, comm=None, optimize=None, with_huber=False, intrinsics=False,
-                 solver=None, deterministic=None, pcg_eta=None, pcg_max_it=None):
+                 solver=None, deterministic=None, pcg_eta=None, pcg_max_it=None, pcg_eta_loose=None, pcg_eta_switch=None):
         """intrinsics=True: Config::optimize_cam_intrinsics -- every vector ends with 9 per camera (x_with_intrinsics builds one)
-        solver ("direct" | "spcg" | "pcg" | "auto"), deterministic, pcg_eta, pcg_max_it: aar_solver_options (None = the library's default)"""
+        solver ("direct" | "spcg" | "pcg" | "auto"), deterministic, pcg_eta, pcg_max_it, pcg_eta_loose, pcg_eta_switch: aar_solver_options
+        (None = the library's default: solver AUTO with its forcing sequence)"""
         self.ds = ds
         self._cds = ds.as_c()
         d = CProblemDesc()
@@ -620,7 +625,7 @@ class Problem:
         d.device_id = device
         d.comm = comm.handle if comm is not None else None
         self.handle = C.c_void_p()
-        if solver is None and deterministic is None and pcg_eta is None and pcg_max_it is None:
+        if all(v is None for v in (solver, deterministic, pcg_eta, pcg_max_it, pcg_eta_loose, pcg_eta_switch)):
             _check(lib().aar_problem_create(C.byref(d), C.byref(self.handle)))
         else:
             so = CSolverOptions()
@@ -633,6 +638,10 @@ class Problem:
                 so.pcg_eta = float(pcg_eta)
             if pcg_max_it is not None:
                 so.pcg_max_it = int(pcg_max_it)
+            if pcg_eta_loose is not None:
+                so.pcg_eta_loose = float(pcg_eta_loose)
+            if pcg_eta_switch is not None:
+                so.pcg_eta_switch = float(pcg_eta_switch)
             _check(lib().aar_problem_create_ex(C.byref(d), C.byref(so), C.byref(self.handle)))
         self.full_len = lib().aar_problem_full_len(self.handle)
         self.num_vars = lib().aar_problem_num_vars(self.handle)
@@ -781,10 +790,15 @@ class Problem:
     def solver_stats(self):
         """aar_problem_get_solver_stats: the solver the problem runs with (AUTO resolved) and what its inner CG has done so far"""
         st = CSolverStats()
+        st.struct_size = C.sizeof(CSolverStats)
         _check(lib().aar_problem_get_solver_stats(self.handle, C.byref(st)))
         return dict(solver=SOLVER_NAMES[st.solver], deterministic=bool(st.deterministic), last_iterations=st.last_iterations,
                     total_iterations=st.total_iterations, solves=st.solves, fallbacks=st.fallbacks, pcg_eta=st.pcg_eta, pcg_max_it=st.pcg_max_it,
-                    same_xcd_solves=st.same_xcd_solves, pcg_eta_loose=st.pcg_eta_loose)
+                    same_xcd_solves=st.same_xcd_solves, pcg_eta_loose=st.pcg_eta_loose, pcg_eta_switch=st.pcg_eta_switch, env_overrides=st.env_overrides)
+
+    def set_test_hook(self, hook, value):
+        """aar_problem_set_test_hook (testing only): fault injection for the solvers' fall-back paths"""
+        _check(lib().aar_problem_set_test_hook(self.handle, int(hook), int(value)))
 
     def set_stage_timers(self, on):
         _check(lib().aar_set_stage_timers(self.handle, int(on)))

@@ -24,6 +24,7 @@
 
 #include "../host/internal.h"
 #include "geom.hpp"
+#include "hostcopy.h"
 #include "kernels.h"
 
 using namespace aar;
@@ -177,8 +178,7 @@ struct aar_problem {
     double *d_diag = nullptr;        // [n_pad]
     double *d_pack = nullptr;        // multi-GPU: packed lower triangle of S | rhs | g0 | scalars, the all-reduce payload
     double *d_status = nullptr;      // multi-GPU: one double for collective status decisions
-    std::vector<double> h_z;    // staging [6A + 6F_loc]; page-locked (hipHostRegister) once it has its size, so uploads need no sync
-    bool h_z_pinned = false;
+    PinnedBuf h_z;              // pose staging [6A + 6F_loc]: page-locked memory of the problem's own (hostcopy.h), so uploads need no sync
     double *h_gather = nullptr; size_t h_gather_n = 0;   // multi-rank: pinned landing zone of the gathered frame poses (download_z)
     hipEvent_t up_ev = nullptr;  // the last upload from h_z (it must have left before h_z is packed again)
     bool mu_seed_valid = false;  // max diag(J^T J) of the start point, published together with its sum r^2 (aar_lm_init)
@@ -214,6 +214,7 @@ struct aar_problem {
     // turn-around hides behind it as it hides behind the Schur kernel on one GPU; any other outcome rebuilds the system anyway
     bool spec_chol = true;             // AAR_SPEC_CHOL=0: off
     int solver = AAR_SOLVER_DIRECT;    // what the problem runs with (aar_solver_options.solver, AUTO resolved)
+    int env_overrides = 0;             // AAR_ENV_* bits: option fields an environment variable changed (aar_solver_stats.env_overrides)
     bool force_direct = false;         // solver spcg: THIS try takes the direct chain (the CG solve of the same system hit its cap / timed out)
     // ... and so do the next tries of this solve (the damping only falls along accepted steps: the systems get harder, not easier): 8 after the first
     // fall-back, twice as many after each further one (a 505-step -with-huber run moves its damping both ways: CG gets another chance now and then);
@@ -254,12 +255,23 @@ int dev_alloc(aar_problem *pb, T **ptr, size_t count) {
     return AAR_OK;
 }
 
+// host <-> device through the library's page-locked staging (hostcopy.h): the runtime never sees a pageable pointer
+int copy_h2d(aar_problem *pb, void *dst, const void *src, size_t bytes) {
+    const char *what = "";
+    const int e = h2d(dst, src, bytes, pb->stream, &what);
+    return e ? set_error(AAR_ERR_HIP, "%s failed: %s", what, hipGetErrorString((hipError_t)e)) : AAR_OK;
+}
+int copy_d2h(aar_problem *pb, void *dst, const void *src, size_t bytes) {
+    const char *what = "";
+    const int e = d2h(dst, src, bytes, pb->stream, &what);
+    return e ? set_error(AAR_ERR_HIP, "%s failed: %s", what, hipGetErrorString((hipError_t)e)) : AAR_OK;
+}
+
 template <class T>
 int dev_upload(aar_problem *pb, T **ptr, const std::vector<T> &h) {
     int rc = dev_alloc(pb, ptr, h.size());
     if (rc) return rc;
-    if (!h.empty()) HIP_TRY(hipMemcpyAsync(*ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, pb->stream));
-    return AAR_OK;
+    return h.empty() ? AAR_OK : copy_h2d(pb, *ptr, h.data(), h.size() * sizeof(T));
 }
 
 int ensure_device(int device_id) {
@@ -274,10 +286,10 @@ int ensure_device(int device_id) {
 }
 
 // x_full (reference packing, roots skipped) -> device pose vector [A entities | local frames]
-void pack_z(const aar_problem *pb, const double *x_full, std::vector<double> &z) {
+void pack_z(const aar_problem *pb, const double *x_full, double *z) {
     const PoseLayout &L = pb->L;
     const int A = pb->P.A, F = pb->P.F;
-    z.assign((size_t)6 * (A + F), 0.0);
+    memset(z, 0, (size_t)6 * (A + F) * sizeof(double));
     for (int c = 0; c < L.C; c++)
         if (c != L.rc) memcpy(&z[6 * (size_t)c], x_full + L.full_cam0() + 6LL * L.cam_slot(c), 6 * sizeof(double));
     for (int m = 0; m < L.M; m++)
@@ -288,16 +300,14 @@ void pack_z(const aar_problem *pb, const double *x_full, std::vector<double> &z)
 }
 
 int upload_z(aar_problem *pb, const double *x_full, int which) {
-    if (pb->up_ev) HIP_TRY(hipEventSynchronize(pb->up_ev));   // the previous upload has left the staging vector (it normally has long ago)
-    pack_z(pb, x_full, pb->h_z);
-    if (!pb->h_z_pinned && !pb->h_z.empty()) {   // page-lock the staging vector once (its size never changes: pack_z re-assigns in place)
-        if (hipHostRegister(pb->h_z.data(), pb->h_z.size() * sizeof(double), hipHostRegisterDefault) == hipSuccess) pb->h_z_pinned = true;
-        else (void)hipGetLastError();
-        if (pb->h_z_pinned && !pb->up_ev && hipEventCreateWithFlags(&pb->up_ev, hipEventDisableTiming) != hipSuccess) { pb->up_ev = nullptr; (void)hipGetLastError(); }
-    }
-    HIP_TRY(hipMemcpyAsync(pb->P.z[which], pb->h_z.data(), pb->h_z.size() * sizeof(double), hipMemcpyHostToDevice, pb->stream));
-    if (pb->h_z_pinned && pb->up_ev) HIP_TRY(hipEventRecord(pb->up_ev, pb->stream));
-    else HIP_TRY(hipStreamSynchronize(pb->stream));   // pageable staging: the copy must complete before the vector can be reused
+    if (pb->up_ev) HIP_TRY(hipEventSynchronize(pb->up_ev));   // the previous upload has left the staging buffer (it normally has long ago)
+    const size_t cnt = (size_t)6 * (pb->P.A + pb->P.F);
+    if (pb->h_z.reserve(cnt)) return set_error(AAR_ERR_HIP, "hipHostMalloc(pose staging) failed");
+    pack_z(pb, x_full, pb->h_z.data());
+    if (!pb->up_ev && hipEventCreateWithFlags(&pb->up_ev, hipEventDisableTiming) != hipSuccess) { pb->up_ev = nullptr; (void)hipGetLastError(); }
+    if (cnt) HIP_TRY(hipMemcpyAsync(pb->P.z[which], pb->h_z.data(), cnt * sizeof(double), hipMemcpyHostToDevice, pb->stream));   // (page-locked source)
+    if (pb->up_ev) HIP_TRY(hipEventRecord(pb->up_ev, pb->stream));
+    else HIP_TRY(hipStreamSynchronize(pb->stream));
     return AAR_OK;
 }
 
@@ -316,7 +326,7 @@ int allreduce(aar_problem *pb, double *buf, size_t count, int op) {
         g->ptrs[c->rank] = buf;
         if (!g->barrier()) return set_error(AAR_ERR_COMM, "local group: a rank did not reach the collective");   // ... and so is everybody else's
         const double **d_ptrs = reinterpret_cast<const double **>(c->tmp + count);
-        HIP_TRY(hipMemcpyAsync(d_ptrs, g->ptrs.data(), sizeof(double *) * g->world, hipMemcpyHostToDevice, pb->stream));
+        { int rc = copy_h2d(pb, (void *)d_ptrs, g->ptrs.data(), sizeof(double *) * g->world); if (rc) return rc; }
         hipLaunchKernelGGL(k_local_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, pb->stream, c->tmp, d_ptrs, g->world, count,
                            op == NCCL_MAX ? 1 : 0);
         HIP_TRY(hipStreamSynchronize(pb->stream));
@@ -365,13 +375,11 @@ int collective_status(aar_problem *pb, int local_rc, int *agreed) {
     *agreed = local_rc;
     if (!pb->comm) return AAR_OK;
     const double v = (double)(-local_rc);
-    HIP_TRY(hipMemcpyAsync(pb->d_status, &v, sizeof v, hipMemcpyHostToDevice, pb->stream));
-    HIP_TRY(hipStreamSynchronize(pb->stream));     // (v is a stack variable)
-    int rc = allreduce(pb, pb->d_status, 1, NCCL_MAX);
+    int rc = copy_h2d(pb, pb->d_status, &v, sizeof v);
     if (rc) return rc;
+    if ((rc = allreduce(pb, pb->d_status, 1, NCCL_MAX))) return rc;
     double w = 0;
-    HIP_TRY(hipMemcpyAsync(&w, pb->d_status, sizeof w, hipMemcpyDeviceToHost, pb->stream));
-    HIP_TRY(hipStreamSynchronize(pb->stream));
+    if ((rc = copy_d2h(pb, &w, pb->d_status, sizeof w))) return rc;
     *agreed = -(int)w;
     return AAR_OK;
 }
@@ -380,30 +388,15 @@ int collective_status(aar_problem *pb, int local_rc, int *agreed) {
 // side_stream: the copy goes through the problem's second stream and only THAT is waited for.  z[which] must be complete already (the host has
 // seen the scalars of the step that wrote it); what is still running on the main stream -- the speculative Schur complement of a step that
 // turned out to be the last, ~20 us -- then overlaps with the caller's own work instead of being waited for.  Single GPU only.
-// Device-to-host copy of a LARGE block into pageable memory (the checking APIs: dense normal equations, residual vector) through a pinned staging buffer.
-// Handing the pageable destination to hipMemcpy itself makes the runtime pin those heap pages on the fly; a range it had pinned before for an upload (read-only for
-// the GPU) and that malloc has handed out again then takes the GPU's write as "write access to a read-only page" -- seen once in ~6 runs of the test suite.
-static int d2h_staged(void *dst, const void *src, size_t bytes) {
-    if (bytes == 0) return AAR_OK;
-    const size_t chunk = std::min<size_t>(bytes, (size_t)8 << 20);
-    void *stg = nullptr;
-    HIP_TRY(hipHostMalloc(&stg, chunk, hipHostMallocDefault));
-    for (size_t off = 0; off < bytes; off += chunk) {
-        const size_t n = std::min(chunk, bytes - off);
-        if (hipMemcpy(stg, (const char *)src + off, n, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipHostFree(stg); return set_error(AAR_ERR_HIP, "device-to-host copy failed"); }
-        memcpy((char *)dst + off, stg, n);
-    }
-    (void)hipHostFree(stg);
-    return AAR_OK;
-}
-
 int download_z(aar_problem *pb, int which, double *x_full, bool side_stream = false) {
     const PoseLayout &L = pb->L;
     const int A = pb->P.A, F = pb->P.F;
-    std::vector<double> &z = pb->h_z;
-    z.resize((size_t)6 * (A + F));
+    if (pb->up_ev) HIP_TRY(hipEventSynchronize(pb->up_ev));   // (the staging buffer is shared with the uploads)
+    const size_t zcnt = (size_t)6 * (A + F);
+    if (pb->h_z.reserve(zcnt)) return set_error(AAR_ERR_HIP, "hipHostMalloc(pose staging) failed");
+    const double *z = pb->h_z.data();
     hipStream_t st = (side_stream && !pb->comm && pb->stream2) ? pb->stream2 : pb->stream;
-    HIP_TRY(hipMemcpyAsync(z.data(), pb->P.z[which], z.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (zcnt) HIP_TRY(hipMemcpyAsync(pb->h_z.data(), pb->P.z[which], zcnt * sizeof(double), hipMemcpyDeviceToHost, st));   // (page-locked destination)
     HIP_TRY(hipStreamSynchronize(st));
     if (L.oc)
         for (int c = 0; c < L.C; c++)
@@ -1033,7 +1026,6 @@ void aar_problem_destroy(aar_problem *pb) {
     for (void *p : pb->allocs) (void)hipFree(p);
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
     if (pb->h_pcg) (void)hipHostFree(pb->h_pcg);
-    if (pb->h_z_pinned) (void)hipHostUnregister(pb->h_z.data());
     if (pb->h_gather) (void)hipHostFree(pb->h_gather);
     if (pb->up_ev) (void)hipEventDestroy(pb->up_ev);
     if (pb->ev[0]) (void)hipEventDestroy(pb->ev[0]);
@@ -1050,7 +1042,7 @@ void aar_solver_default_options(aar_solver_options *o) {
     if (!o) return;
     memset(o, 0, sizeof *o);
     o->struct_size = (uint32_t)sizeof *o;
-    o->solver = AAR_SOLVER_DIRECT;
+    o->solver = AAR_SOLVER_AUTO;
 }
 
 int aar_problem_create(const aar_problem_desc *d, aar_problem **out) { return aar_problem_create_ex(d, nullptr, out); }
@@ -1076,18 +1068,23 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         memcpy(&so, opts, std::min<size_t>(opts->struct_size, sizeof so));
         so.struct_size = (uint32_t)sizeof so;
     }
-    // environment overrides (tuning / bisecting only: the options struct is the interface)
+    // environment overrides (tuning / bisecting only: the options struct is the interface): they apply to fields the caller left at their defaults
+    // -- an explicitly chosen solver, forcing term or cap always wins -- and are reported (aar_solver_stats.env_overrides)
+    int env_over = 0;
     if (const char *e = getenv("AAR_SOLVER")) {
-        if (!strcmp(e, "direct")) so.solver = AAR_SOLVER_DIRECT;
-        else if (!strcmp(e, "pcg")) so.solver = AAR_SOLVER_PCG;
-        else if (!strcmp(e, "spcg")) so.solver = AAR_SOLVER_SPCG;
-        else if (!strcmp(e, "auto")) so.solver = AAR_SOLVER_AUTO;
+        if (so.solver == AAR_SOLVER_AUTO) {
+            int v = -1;
+            if (!strcmp(e, "direct")) v = AAR_SOLVER_DIRECT;
+            else if (!strcmp(e, "pcg")) v = AAR_SOLVER_PCG;
+            else if (!strcmp(e, "spcg")) v = AAR_SOLVER_SPCG;
+            if (v >= 0) { so.solver = v; env_over |= AAR_ENV_SOLVER; }
+        }
     }
-    if (const char *e = getenv("AAR_DETERMINISTIC")) so.deterministic = atoi(e) != 0 ? 1 : 0;
-    if (const char *e = getenv("AAR_PCG_ETA")) so.pcg_eta = atof(e);
-    if (const char *e = getenv("AAR_PCG_MAX_IT")) so.pcg_max_it = atoi(e);
+    if (const char *e = getenv("AAR_DETERMINISTIC")) if (!so.deterministic && atoi(e) != 0) { so.deterministic = 1; env_over |= AAR_ENV_DETERMINISTIC; }
+    if (const char *e = getenv("AAR_PCG_ETA")) if (so.pcg_eta == 0 && atof(e) > 0) { so.pcg_eta = atof(e); env_over |= AAR_ENV_PCG_ETA; }
+    if (const char *e = getenv("AAR_PCG_MAX_IT")) if (so.pcg_max_it == 0 && atoi(e) > 0) { so.pcg_max_it = atoi(e); env_over |= AAR_ENV_PCG_MAX_IT; }
     if (so.solver < AAR_SOLVER_DIRECT || so.solver > AAR_SOLVER_AUTO) return set_error(AAR_ERR_INVALID, "aar_solver_options.solver %d is not one of AAR_SOLVER_*", so.solver);
-    if (so.pcg_eta < 0 || so.pcg_max_it < 0) return set_error(AAR_ERR_INVALID, "aar_solver_options: negative pcg_eta / pcg_max_it");
+    if (so.pcg_eta < 0 || so.pcg_max_it < 0 || so.pcg_eta_loose < 0 || so.pcg_eta_switch < 0) return set_error(AAR_ERR_INVALID, "aar_solver_options: negative pcg_eta / pcg_eta_loose / pcg_eta_switch / pcg_max_it");
     const int C = d->num_cams, M = d->num_markers, Fg = d->num_frames;
     const int64_t Ng = d->num_obs;
     if (C < 1 || M < 1 || Fg < 0 || Ng < 0) return set_error(AAR_ERR_INVALID, "aar_problem_create: bad sizes");
@@ -1205,20 +1202,22 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         while (std::gcd(st, n) != 1) st++;
         frame_stride[f] = st;
     }
-    const size_t ldsA = passA_lds_bytes(P.max_kf, 256) > passA_lds_bytes(P.max_kf, 64) ? passA_lds_bytes(P.max_kf, 256) : passA_lds_bytes(P.max_kf, 64);
-    if (ldsA > 160 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers; the frame-block kernel holds them in LDS (limit ~ %d)", P.max_kf, (160 * 1024 / 8 - 58 - 2048) / 62);
-    // Which Schur kernel (solve_kernels.hip): the MFMA kernel works on dense per-frame panels and is the default from 96 shared
-    // entities, where the output-stationary kernel's re-reads of W dominate (config 5); AAR_SCHUR_MFMA=0 / 1 forces it (tests
-    // force it on small problems).  Its panels cost 2 F Ad 288 bytes -- tens of GB for long sequences with many rarely seen
-    // entities -- so they must fit a budget (half of the free device memory; AAR_SCHUR_PANEL_MB overrides), else the
-    // output-stationary kernel, which needs none of this, takes over.  Only THAT kernel keeps a row panel of all entities in LDS.
-    P.deterministic = so.deterministic ? 1 : 0;
     {   // tuning switches of this problem (kernels.h, DeviceProblem::Tuning)
         auto env_int = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
         env_int("AAR_FUSED_PANEL", P.tune.fused_panel); env_int("AAR_BS_RIDES", P.tune.bs_rides); env_int("AAR_BACKSUB_RIDES", P.tune.backsub_rides);
         env_int("AAR_LDL_LOOKAHEAD", P.tune.lookahead); env_int("AAR_PASSA_VARIANT", P.tune.passA_variant); env_int("AAR_PACK_SYSTEM", P.tune.pack_system);
         env_int("AAR_INIT_HEADSTART", P.tune.init_headstart); env_int("AAR_PASSB_LEAN", P.tune.passB_lean); env_int("AAR_PASSA_WRENCH", P.tune.passA_wrench); env_int("AAR_PASSB_WRENCH_MERGED", P.tune.passB_wrench_merged); env_int("AAR_SPCG_BACKSUB_RIDES", P.tune.spcg_backsub_rides);
     }
+    // the frame-block kernel keeps a frame's slots in LDS: sized by the form that is actually launched (wrench form: 21 + 4 doubles per slot; row form: 62)
+    const size_t ldsA = P.tune.passA_wrench ? passA_wrench_lds_bytes(P.max_kf, L.oi)
+                                            : std::max(passA_lds_bytes(P.max_kf, 256), passA_lds_bytes(P.max_kf, 64));
+    if (ldsA > 160 * 1024 && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "a frame touches %d cameras+markers: %zu bytes of LDS in the frame-block kernel (%s form), the CU has 160 KiB", P.max_kf, ldsA, P.tune.passA_wrench ? "wrench" : "row");
+    // Which Schur kernel (solve_kernels.hip): the MFMA kernel works on dense per-frame panels and is the default from 96 shared
+    // entities, where the output-stationary kernel's re-reads of W dominate (config 5); AAR_SCHUR_MFMA=0 / 1 forces it (tests
+    // force it on small problems).  Its panels cost 2 F Ad 288 bytes -- tens of GB for long sequences with many rarely seen
+    // entities -- so they must fit a budget (half of the free device memory; AAR_SCHUR_PANEL_MB overrides), else the
+    // output-stationary kernel, which needs none of this, takes over.  Only THAT kernel keeps a row panel of all entities in LDS.
+    P.deterministic = so.deterministic ? 1 : 0;
     { const char *e = getenv("AAR_DENSE_FROM_PASSA"); if (e) P.dense_from_passA = atoi(e) != 0 ? 1 : 0; }
     {   // which solver (aar_solver_options; AUTO: DESIGN.md section 12)
         hipDeviceProp_t prop;
@@ -1236,22 +1235,23 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
             else solver = AAR_SOLVER_DIRECT;
         }
         pb->solver = solver;
+        pb->env_overrides = env_over;
         P.use_pcg = solver == AAR_SOLVER_PCG ? 1 : 0;
         P.use_spcg = solver == AAR_SOLVER_SPCG ? 1 : 0;
-        if (const char *t = getenv("AAR_SPCG_TEST_DROP")) P.spcg_test_drop = atoi(t);   // test hook: see kernels.h
         if (const char *t = getenv("AAR_SPCG_SPREAD")) P.spcg_spread = std::max(1, atoi(t));
-        // (one XCD has a thirty-second of... an eighth of the CUs: more entities than that many wavefront slots would not all be resident there)
+        // (one XCD has an eighth of the CUs: more entities than that many wavefront slots would not all be resident there)
         if (P.n_pad / 6 > 4 * (cus / 8)) P.spcg_spread = 1;
-        // forcing term: |r| <= 0.1 |b| for the CG through the frame blocks; the CG on the explicit system measures in the preconditioner's norm
-        // (r^T M^-1 r, which its recurrences carry anyway), where 0.02 gives the same distance to the exact LM run
-        P.pcg_eta = P.use_spcg ? 0.02 : 0.1;
-        P.pcg_eta_loose = 0.0;
+        // Forcing term of the inexact solvers (include/aar.h; defaults and why: kernels.h).  The CG through the frame blocks measures |r| / |b|; the CG on the
+        // explicit system measures in the preconditioner's norm (r^T M^-1 r, which its recurrences carry anyway).  pcg_eta_loose > pcg_eta: a forcing sequence (opt-in).
+        P.pcg_eta = P.use_spcg ? SPCG_ETA_DEFAULT : PCG_ETA_DEFAULT;
         if (so.pcg_eta > 0) P.pcg_eta = so.pcg_eta;
-        else if ((P.use_pcg || P.use_spcg) && so.solver == AAR_SOLVER_AUTO) {   // AUTO's inexact solvers with the default forcing term: a forcing sequence (kernels.h, include/aar.h)
-            P.pcg_eta_loose = P.use_pcg ? 0.3 : 0.1;
-            if (const char *e = getenv("AAR_PCG_ETA_LOOSE")) P.pcg_eta_loose = atof(e);
-            if (const char *e = getenv("AAR_PCG_ETA_SWITCH")) P.pcg_eta_switch = atof(e);
-        }
+        P.pcg_eta_loose = 0.0;
+        if (so.pcg_eta_loose > 0) P.pcg_eta_loose = so.pcg_eta_loose;
+        else if (so.pcg_eta == 0 && (P.use_pcg || P.use_spcg)) P.pcg_eta_loose = P.use_pcg ? PCG_ETA_LOOSE_DEFAULT : SPCG_ETA_LOOSE_DEFAULT;   // (0: none)
+        if (const char *e = getenv("AAR_PCG_ETA_LOOSE")) if (so.pcg_eta_loose == 0) P.pcg_eta_loose = atof(e);
+        if (P.pcg_eta_loose <= P.pcg_eta) P.pcg_eta_loose = 0.0;   // (no sequence: one forcing term throughout)
+        if (so.pcg_eta_switch > 0) P.pcg_eta_switch = so.pcg_eta_switch;
+        else if (const char *e = getenv("AAR_PCG_ETA_SWITCH")) P.pcg_eta_switch = atof(e);
         P.pcg_eta_now = P.pcg_eta;
         if (so.pcg_max_it > 0) { P.pcg_max_it = so.pcg_max_it; P.spcg_max_it = std::min(so.pcg_max_it, SPCG_MAX_IT); }
         if (P.use_pcg && !pcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_PCG keeps the CG vectors and the preconditioner of %d unknowns in LDS: too many shared entities", 6 * A);
@@ -1610,11 +1610,9 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
     if (hipStreamSynchronize(pb->stream) != hipSuccess) return fail(set_error(AAR_ERR_HIP, "upload failed"));
     {   // the runtime brings its device-to-host copy path up on first use (8-13 ms, once per process: scripts/probe/outlier2.py):
         // better here than inside the caller's first solve
-        pb->h_z.assign((size_t)6 * (A + F), 0.0);
-        if (!pb->h_z.empty() && hipHostRegister(pb->h_z.data(), pb->h_z.size() * sizeof(double), hipHostRegisterDefault) == hipSuccess) pb->h_z_pinned = true;
-        else (void)hipGetLastError();
-        if (pb->h_z_pinned && hipEventCreateWithFlags(&pb->up_ev, hipEventDisableTiming) != hipSuccess) { pb->up_ev = nullptr; (void)hipGetLastError(); }
-        if (hipMemcpyAsync(pb->h_z.data(), P.z[0], pb->h_z.size() * sizeof(double), hipMemcpyDeviceToHost, pb->stream) != hipSuccess ||
+        if (pb->h_z.reserve((size_t)6 * (A + F))) return fail(set_error(AAR_ERR_HIP, "hipHostMalloc(pose staging) failed"));
+        if (hipEventCreateWithFlags(&pb->up_ev, hipEventDisableTiming) != hipSuccess) { pb->up_ev = nullptr; (void)hipGetLastError(); }
+        if (hipMemcpyAsync(pb->h_z.data(), P.z[0], (size_t)6 * (A + F) * sizeof(double), hipMemcpyDeviceToHost, pb->stream) != hipSuccess ||
             hipStreamSynchronize(pb->stream) != hipSuccess)
             return fail(set_error(AAR_ERR_HIP, "device-to-host copy failed"));
     }
@@ -1654,7 +1652,7 @@ int aar_eval_residuals(aar_problem *pb, const double *x_full, double *r, double 
     pb->seq++;
     launch_publish(P, pb->seq, pb->stream);
     HIP_TRY(hipStreamSynchronize(pb->stream));
-    if (r && (rc = d2h_staged(r, d_r, 8 * (size_t)P.N * sizeof(double)))) { (void)hipFree(d_r); return rc; }
+    if (r && (rc = copy_d2h(pb, r, d_r, 8 * (size_t)P.N * sizeof(double)))) { (void)hipFree(d_r); return rc; }
     if ((rc = wait_result(pb))) { if (d_r) (void)hipFree(d_r); return rc; }
     if (d_r) (void)hipFree(d_r);
     if (sum_sq) *sum_sq = pb->h_scal[0];
@@ -1691,12 +1689,12 @@ int aar_eval_normal_equations(aar_problem *pb, const double *x_full, double *JtJ
     const int A = P.A, F = P.F, np = P.n_pad;
     const DeviceProblem::Blocks &bk = P.blk[pb->cur];
     std::vector<double> U0((size_t)np * np), g0(np), V((size_t)F * 36), gf((size_t)F * 6), W((size_t)P.total_slots * 36), ep(F);
-    // (copies through a pinned staging buffer after the stream has drained: d2h_staged)
+    // (copies through the library's page-locked staging, hostcopy.h)
     HIP_TRY(hipStreamSynchronize(pb->stream));
-    if ((rc = d2h_staged(U0.data(), bk.S, U0.size() * sizeof(double))) || (rc = d2h_staged(g0.data(), bk.g0, g0.size() * sizeof(double)))) return rc;
+    if ((rc = copy_d2h(pb, U0.data(), bk.S, U0.size() * sizeof(double))) || (rc = copy_d2h(pb, g0.data(), bk.g0, g0.size() * sizeof(double)))) return rc;
     if (F) {
-        if ((rc = d2h_staged(V.data(), bk.V, V.size() * sizeof(double))) || (rc = d2h_staged(gf.data(), bk.gf, gf.size() * sizeof(double))) ||
-            (rc = d2h_staged(W.data(), bk.W, W.size() * sizeof(double))) || (rc = d2h_staged(ep.data(), P.err_part, ep.size() * sizeof(double)))) return rc;
+        if ((rc = copy_d2h(pb, V.data(), bk.V, V.size() * sizeof(double))) || (rc = copy_d2h(pb, gf.data(), bk.gf, gf.size() * sizeof(double))) ||
+            (rc = copy_d2h(pb, W.data(), bk.W, W.size() * sizeof(double))) || (rc = copy_d2h(pb, ep.data(), P.err_part, ep.size() * sizeof(double)))) return rc;
     }
     pb->lm_ready = false;
     // reference column of each device parameter (or -1): roots, non-optimised groups and the two idle parameters of an
@@ -2052,12 +2050,11 @@ int aar_track(aar_problem *pb, double *x_full, const aar_lm_params *prm, int32_t
     launch_track(P, pb->cur, p.max_iters, p.min_error, p.min_step_error_diff, p.min_average_step_error_diff, p.tau, d_it, d_err, pb->stream);
     std::vector<int32_t> h_it(std::max(F, 1));
     std::vector<double> h_err(std::max(F, 1));
-    hipError_t e1 = hipMemcpyAsync(h_it.data(), d_it, std::max(F, 1) * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream);
-    hipError_t e2 = hipMemcpyAsync(h_err.data(), d_err, std::max(F, 1) * sizeof(double), hipMemcpyDeviceToHost, pb->stream);
-    hipError_t e3 = hipStreamSynchronize(pb->stream);
+    rc = copy_d2h(pb, h_it.data(), d_it, std::max(F, 1) * sizeof(int32_t));
+    if (!rc) rc = copy_d2h(pb, h_err.data(), d_err, std::max(F, 1) * sizeof(double));
     (void)hipFree(d_it);
     (void)hipFree(d_err);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return set_error(AAR_ERR_HIP, "aar_track: %s", hipGetErrorString(e3 != hipSuccess ? e3 : (e1 != hipSuccess ? e1 : e2)));
+    if (rc) return rc;
     if ((rc = check_async("track kernel"))) return rc;
     // only the frame poses move; download_z honours the Config flags, so force "frames on, shared off" for this call
     PoseLayout keep = pb->L;
@@ -2113,32 +2110,45 @@ int aar_problem_pcg_iterations(aar_problem *pb, int32_t out[2]) {
     out[0] = out[1] = 0;
     if (!pb->P.use_pcg && !pb->P.use_spcg) return AAR_OK;
     HIP_TRY(hipSetDevice(pb->device));
-    HIP_TRY(hipMemcpyAsync(out, pb->P.use_pcg ? pb->P.pcg_counter + 2 : pb->P.spcg_iters, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
-    HIP_TRY(hipStreamSynchronize(pb->stream));
+    { int rc = copy_d2h(pb, out, pb->P.use_pcg ? pb->P.pcg_counter + 2 : pb->P.spcg_iters, 2 * sizeof(int32_t)); if (rc) return rc; }
     if (out[0] > SPCG_MAX_IT && pb->P.use_spcg) out[0] = SPCG_MAX_IT;   // (a timed-out launch records SPCG_BUFS)
     return AAR_OK;
 }
 
 int aar_problem_get_solver_stats(aar_problem *pb, aar_solver_stats *out) {
     if (!pb || !out) return set_error(AAR_ERR_INVALID, "aar_problem_get_solver_stats: null argument");
-    memset(out, 0, sizeof *out);
-    out->solver = pb->solver;
-    out->deterministic = pb->P.deterministic;
-    out->pcg_eta = pb->P.pcg_eta;
-    out->pcg_max_it = pb->P.use_spcg ? pb->P.spcg_max_it : pb->P.pcg_max_it;
-    out->pcg_eta_loose = pb->P.pcg_eta_loose;
-    out->fallbacks = pb->spcg_fallbacks;
-    if (!pb->P.use_pcg && !pb->P.use_spcg) return AAR_OK;
-    int32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipSetDevice(pb->device));
-    if (pb->P.use_spcg) HIP_TRY(hipMemcpyAsync(c, pb->P.spcg_iters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
-    else HIP_TRY(hipMemcpyAsync(c, pb->P.pcg_counter + 2, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, pb->stream));
-    HIP_TRY(hipStreamSynchronize(pb->stream));
-    out->last_iterations = std::min(c[0], pb->P.use_spcg ? SPCG_MAX_IT : c[0]);
-    out->total_iterations = c[1];
-    out->solves = c[2];
-    out->same_xcd_solves = c[4];
+    // the caller says how large ITS struct is (a caller built against an older header has a shorter one): never write beyond it
+    const size_t cap = out->struct_size;
+    if (cap < 4 * sizeof(int32_t) || cap > 4096) return set_error(AAR_ERR_INVALID, "aar_solver_stats.struct_size is not set (sizeof(aar_solver_stats) of the caller)");
+    aar_solver_stats st;
+    memset(&st, 0, sizeof st);
+    st.solver = pb->solver;
+    st.deterministic = pb->P.deterministic;
+    st.pcg_eta = pb->P.pcg_eta;
+    st.pcg_max_it = pb->P.use_spcg ? pb->P.spcg_max_it : pb->P.pcg_max_it;
+    st.pcg_eta_loose = pb->P.pcg_eta_loose;
+    st.pcg_eta_switch = pb->P.pcg_eta_switch;
+    st.env_overrides = pb->env_overrides;
+    st.fallbacks = pb->spcg_fallbacks;
+    if (pb->P.use_pcg || pb->P.use_spcg) {
+        int32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipSetDevice(pb->device));
+        int rc = copy_d2h(pb, c, pb->P.use_spcg ? pb->P.spcg_iters : pb->P.pcg_counter + 2, (pb->P.use_spcg ? 8 : 3) * sizeof(int32_t));
+        if (rc) return rc;
+        st.last_iterations = std::min(c[0], pb->P.use_spcg ? SPCG_MAX_IT : c[0]);
+        st.total_iterations = c[1];
+        st.solves = c[2];
+        st.same_xcd_solves = c[4];
+    }
+    st.struct_size = (uint32_t)std::min(cap, sizeof st);
+    memcpy(out, &st, std::min(cap, sizeof st));
     return AAR_OK;
+}
+
+int aar_problem_set_test_hook(aar_problem *pb, int32_t hook, int32_t value) {
+    if (!pb) return set_error(AAR_ERR_INVALID, "aar_problem_set_test_hook: null argument");
+    if (hook == AAR_TEST_HOOK_SPCG_DROP) { pb->P.spcg_test_drop = value; return AAR_OK; }
+    return set_error(AAR_ERR_INVALID, "aar_problem_set_test_hook: unknown hook %d", hook);
 }
 
 int aar_set_stage_timers(aar_problem *pb, int on) {

@@ -12,6 +12,7 @@
 #include <vector>
 #include "geom.hpp"
 #include "kernels.h"
+#include "hostcopy.h"
 #include "wave.hpp"
 
 namespace aar {
@@ -1227,7 +1228,7 @@ static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, i
         if (!st && getenv("AAR_STAMPS_A")) {
             (void)hipMalloc(&st, 512 * 16 * 8); (void)hipMemset(st, 0, 512 * 16 * 8);
             static unsigned long long *keep = st;
-            atexit([] { std::vector<unsigned long long> h(512 * 16); (void)hipMemcpy(h.data(), keep, 512 * 16 * 8, hipMemcpyDeviceToHost);
+            atexit([] { std::vector<unsigned long long> h(512 * 16); (void)d2h(h.data(), keep, 512 * 16 * 8, nullptr);
                         FILE *fp = fopen(getenv("AAR_STAMPS_A"), "w"); for (int i = 0; i < 512; i++) { for (int j = 0; j < 16; j++) fprintf(fp, "%llu ", h[i * 16 + j]); fprintf(fp, "\n"); } fclose(fp); });
         }
         a.stamps = st;

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../host/init_device.h"
+#include "hostcopy.h"
 
 namespace aar {
 
@@ -358,7 +359,7 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)); }
     hipError_t upload(const T *h, size_t n) {
         hipError_t e = alloc(n);
-        if (e == hipSuccess && n) e = hipMemcpy(p, h, sizeof(T) * n, hipMemcpyHostToDevice);
+        if (e == hipSuccess && n) e = (hipError_t)h2d(p, h, sizeof(T) * n, nullptr);   // (through page-locked staging: hostcopy.h)
         return e;
     }
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -420,9 +421,9 @@ int initdev_ippe(InitDevice *D, const aar_cam_model *cams, int32_t n_cams, float
     hipLaunchKernelGGL(k_ippe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, (long long)n, d_uv.p, d_cam.p, d_tab.p,
                        marker_size / 2.0f, D->poses, d_e1.p, d_e2.p, d_uvK.p);
     HIPCHK(hipGetLastError(), "k_ippe");
-    HIPCHK(hipMemcpy(e1, d_e1.p, sizeof(float) * n, hipMemcpyDeviceToHost), "download(e1)");
-    HIPCHK(hipMemcpy(e2, d_e2.p, sizeof(float) * n, hipMemcpyDeviceToHost), "download(e2)");
-    HIPCHK(hipMemcpy(uv_undistorted, d_uvK.p, sizeof(float) * 8 * n, hipMemcpyDeviceToHost), "download(corners)");
+    HIPCHK((hipError_t)d2h(e1, d_e1.p, sizeof(float) * n, nullptr), "download(e1)");
+    HIPCHK((hipError_t)d2h(e2, d_e2.p, sizeof(float) * n, nullptr), "download(e2)");
+    HIPCHK((hipError_t)d2h(uv_undistorted, d_uvK.p, sizeof(float) * 8 * n, nullptr), "download(corners)");
     return AAR_OK;
 }
 
@@ -441,7 +442,7 @@ static int vote_sets(int64_t n_cand, const double *Tc, const double *BJ, int64_t
         HIPCHK(d_cost.alloc((size_t)n_cand), "hipMalloc(cost)");
         hipLaunchKernelGGL(k_vote, dim3((unsigned)items.size()), dim3(64), 0, 0, d_items.p, Tc, BJ, marker_size / 2, d_cost.p);
         HIPCHK(hipGetLastError(), "k_vote");
-        HIPCHK(hipMemcpy(cost.data(), d_cost.p, sizeof(double) * n_cand, hipMemcpyDeviceToHost), "download(cost)");
+        HIPCHK((hipError_t)d2h(cost.data(), d_cost.p, sizeof(double) * n_cand, nullptr), "download(cost)");
     }
     if (cost_out && n_cand) memcpy(cost_out, cost.data(), sizeof(double) * n_cand);
     std::vector<int> bidx((size_t)n_sets);
@@ -461,7 +462,7 @@ static int vote_sets(int64_t n_cand, const double *Tc, const double *BJ, int64_t
         HIPCHK(d_out.alloc(12 * (size_t)n_sets), "hipMalloc(best_T)");
         hipLaunchKernelGGL(k_gather12, dim3((unsigned)((12 * n_sets + 255) / 256)), dim3(256), 0, 0, (int)n_sets, d_idx.p, Tc, d_out.p);
         HIPCHK(hipGetLastError(), "k_gather12");
-        HIPCHK(hipMemcpy(best_T, d_out.p, sizeof(double) * 12 * n_sets, hipMemcpyDeviceToHost), "download(best_T)");
+        HIPCHK((hipError_t)d2h(best_T, d_out.p, sizeof(double) * 12 * n_sets, nullptr), "download(best_T)");
     }
     return AAR_OK;
 }
@@ -535,7 +536,7 @@ extern "C" int aar_ippe_square(double marker_size, const aar_cam_model *cam, int
     int rc = initdev_ippe(D, cam, 1, (float)marker_size, n, uv, dc.data(), e1.data(), e2.data(), uvK.data());
     std::vector<double> P(24 * (size_t)n);
     if (!rc && n) {
-        hipError_t e = hipMemcpy(P.data(), D->poses, sizeof(double) * 24 * n, hipMemcpyDeviceToHost);
+        hipError_t e = (hipError_t)d2h(P.data(), D->poses, sizeof(double) * 24 * n, nullptr);
         if (e != hipSuccess) rc = hip_fail("download(poses)", e);
     }
     initdev_destroy(D);

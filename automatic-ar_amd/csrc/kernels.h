@@ -11,6 +11,13 @@ constexpr int PASSB_CHUNK = 1024;  // upper limit of AAR_PASSB_CHUNK (observatio
 // CG on the explicit reduced system (spcg_kernels.hip): iteration cap (sizes the hand-over buffers: one per iteration plus the
 // start-up and the final one), largest system (tiles of 96 unknowns: the six rows of an entity live in one wavefront's registers)
 constexpr int SPCG_MAX_IT = 64, SPCG_BUFS = SPCG_MAX_IT + 2, SPCG_MAX_NT = 14;
+// Default forcing terms of the inexact solvers (include/aar.h: aar_solver_options.pcg_eta; DESIGN.md section 12, profiles/r05_eta_pose_sweep.txt).  Chosen for the
+// final POSES: with these the poses of a run agree with the direct solver's to ~2e-6 (rotation-matrix entries) / ~1e-6 m at configs 3-5 -- 100x closer than the
+// direct path is to the reference-faithful CPU run (analytic against central-difference Jacobian), 1000x closer than the reference's own last LM step moves them.
+// Measured, uniform eta -> largest pose difference against the direct run (config 3, SPCG): 0.02 -> 2e-4, 3e-3 -> 2e-5, 1e-3 -> 1e-5, 3e-4 -> 2e-6, 1e-4 -> 6e-7;
+// (config 5, PCG): 0.1 -> 9e-5, 0.03 -> 2e-5, 0.01 -> 5e-6, 3e-3 -> 1e-6.  A loose-then-tight SEQUENCE buys nothing at equal cost: the early steps' errors along
+// weakly determined directions are never corrected by the later ones (round 4's 0.1 -> 0.02 sequence: 6e-4), so the default is ONE forcing term.
+constexpr double SPCG_ETA_DEFAULT = 3e-4, SPCG_ETA_LOOSE_DEFAULT = 0.0, PCG_ETA_DEFAULT = 5e-3, PCG_ETA_LOOSE_DEFAULT = 0.0;
 inline int spcg_stride(int n_pad) { return 8 * (n_pad / 6); }   // doubles per hand-over buffer: one 64-byte record per entity
 
 #ifndef SPCG_PRE
@@ -90,7 +97,7 @@ struct DeviceProblem {
     int32_t *se_start = nullptr, *se_items = nullptr;   // [A+1], [n_swork]: the work items of every entity, frame-ascending
     // AAR_SOLVER=pcg (opt-in, pcg_kernels.hip): the reduced system solved by preconditioned CG through the frame blocks
     int use_pcg = 0, pcg_grid = 0, pcg_max_it = 200;
-    double pcg_eta = 0.1;                 // |r| <= eta |b| stops an inner solve (AAR_PCG_ETA)
+    double pcg_eta = 0.1;                 // |r| <= eta |b| stops an inner solve of a LATE LM step (aar_solver_options.pcg_eta)
     // the inexact solvers' forcing SEQUENCE when AUTO chose them and the caller left the forcing term at its default: while the LM is still far from its stopping rule (the last
     // accepted step took more than pcg_eta_switch of the error away) the inner solve stops at pcg_eta_loose, afterwards at pcg_eta -- the steps that decide
     // the stopping rule are solved as tightly as before (profiles/r04_pcg_eta_sweep.txt).  pcg_eta_now is what the next launch uses.
@@ -198,7 +205,8 @@ void launch_passA(const DeviceProblem &P, int which, double mu_pred, int zero_bl
 void launch_passB(const DeviceProblem &P, int which, hipStream_t st);              // accumulates into blk[which].S, .g0 (must be zero); with intrinsics: their shared blocks too
 // both passes in one launch (they only share the entity table ent[which], which must be complete); false = nothing launched
 bool launch_passAB(const DeviceProblem &P, int which, double mu_pred, int zero_blk, hipStream_t st);
-size_t passA_lds_bytes(int max_kf, int block);   // dynamic LDS of the frame-block kernel (block = 64 or 256 threads)
+size_t passA_lds_bytes(int max_kf, int block);   // dynamic LDS of the frame-block kernel in row form (block = 64 or 256 threads)
+size_t passA_wrench_lds_bytes(int max_kf, bool intr);   // ... in wrench form (the default)
 void launch_maxdiag(const DeviceProblem &P, int which, hipStream_t st);            // scal[4] = max free diagonal
 void launch_frame_inv(const DeviceProblem &P, int which, double mu, hipStream_t st, const double *mu_dev = nullptr, double mu_scale = 0.0);   // mu_dev: mu = mu_scale * mu_dev[0], read on the device
 // S -= sign * W (V+mu I)^-1 W^T (sign -1 takes it back).  ride_seq != 0: the reduction of the step's scalars rides in the same

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../host/internal.h"
+#include "hostcopy.h"
 
 namespace aar {
 
@@ -63,13 +64,13 @@ extern "C" int aar_undistort_points(const double K[9], const double *dist, int32
     const size_t bytes = sizeof(float) * 2 * (size_t)n_points;
     hipError_t e = hipMalloc((void **)&d_in, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, bytes);
-    if (e == hipSuccess) e = hipMemcpy(d_in, uv_in, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = (hipError_t)h2d(d_in, uv_in, bytes, nullptr);   // (page-locked staging: hostcopy.h)
     if (e == hipSuccess) {
         a.in = d_in; a.out = d_out;
         hipLaunchKernelGGL(k_undistort, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, 0, a);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(uv_out, d_out, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = (hipError_t)d2h(uv_out, d_out, bytes, nullptr);
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return set_error(AAR_ERR_HIP, "aar_undistort_points: %s", hipGetErrorString(e));

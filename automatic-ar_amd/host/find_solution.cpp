@@ -68,7 +68,7 @@ int main(int argc, char *argv[]) {
     bool use_subseqs = false, with_huber = false, set_threshold = false, from_initial = false, tracking_only = false;
     double threshold = 2.0;
     set<int> excluded_cams;
-    int solver = AAR_SOLVER_DIRECT;   // not an option of the reference: how the damped systems are solved (aar_solver_options); the default is the reference's step
+    int solver = AAR_SOLVER_AUTO;   // not an option of the reference: how the damped systems are solved (aar_solver_options); `-solver direct` = the reference's every step
     enum ArgFlag { NONE, ExcludeCams, Threshold, Solver } arg_flag = NONE;
     for (int i = 4; i < argc; i++) {  // sic: the reference starts at argv[4] (apps/find_solution.cpp:47)
         const string a = argv[i];
@@ -152,7 +152,7 @@ int main(int argc, char *argv[]) {
     mcm.solver_params.verbose = true;
     mcm.set_optmize_flag_cam_intrinsics(false);  // apps/find_solution.cpp:140
     if (with_huber) mcm.set_with_huber(true);
-    if (solver != AAR_SOLVER_DIRECT) {
+    {
         aar::MultiCamMapper::SolverOptions so;
         so.solver = solver;
         mcm.set_solver_options(so);
@@ -168,7 +168,7 @@ int main(int argc, char *argv[]) {
     mcm.write_solution_file(final_path);
     mcm.write_text_solution_file(final_path + ".yaml");
     const aar_lm_report &r = mcm.last_report;
-    if (solver != AAR_SOLVER_DIRECT) {
+    {
         const aar_solver_stats st = mcm.solver_stats();
         const char *names[] = {"direct", "pcg", "spcg", "auto"};
         cout << "solver: " << names[st.solver & 3] << ", " << st.total_iterations << " CG iterations in " << st.solves << " damped solves, " << st.fallbacks

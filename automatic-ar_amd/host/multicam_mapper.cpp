@@ -282,6 +282,8 @@ int MultiCamMapper::ensure_problem() {
     so.deterministic = solver_options_.deterministic ? 1 : 0;
     so.pcg_eta = solver_options_.pcg_eta;
     so.pcg_max_it = solver_options_.pcg_max_it;
+    so.pcg_eta_loose = solver_options_.pcg_eta_loose;
+    so.pcg_eta_switch = solver_options_.pcg_eta_switch;
     int rc = aar_problem_create_ex(&d, &so, &problem_);
     if (!rc && with_huber_) rc = aar_problem_set_huber_delta(problem_, hubberDelta);
     return rc;
@@ -296,6 +298,7 @@ aar_solver_stats MultiCamMapper::solver_stats() {
     if (!data_) throw std::runtime_error("MultiCamMapper::solver_stats: no data set");
     if (ensure_problem()) throw std::runtime_error(aar_last_error());
     aar_solver_stats st;
+    st.struct_size = (uint32_t)sizeof st;
     if (aar_problem_get_solver_stats(problem_, &st)) throw std::runtime_error(aar_last_error());
     return st;
 }

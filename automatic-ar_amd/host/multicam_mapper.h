@@ -358,14 +358,18 @@ class MultiCamMapper {
     int device_id = 0;
     int residual_mode = AAR_RES_F32;
     // How the damped normal equations are solved (aar_solver_options, include/aar.h) -- the counterpart of configuring the reference's solver object
-    // through SparseLevMarq::Params (libs/sparselevmarq.h:30-50), and kept beside them: DIRECT (the default) is the reference's Eigen::SimplicialLDLT
-    // step to rounding; SPCG / PCG / AUTO are inexact LM (same fixed point, final reprojection error within 1e-4 px).  Takes effect when the device
-    // problem is (re)built: set it before solve() / track(); set_solver_options() drops a problem that exists already.
+    // through SparseLevMarq::Params (libs/sparselevmarq.h:30-50), and kept beside them.  AUTO (the default) picks by size: the direct chain for one tile of
+    // unknowns, CG on the explicit reduced system (SPCG) below 96 cameras + markers, CG through the frame blocks (PCG) from there -- inexact LM with a forcing
+    // sequence (loose early, tight for the late steps the final poses are made of); DIRECT is the reference's Eigen::SimplicialLDLT step to rounding, for
+    // callers who want the reference's every step.  Takes effect when the device problem is (re)built: set it before solve() / track();
+    // set_solver_options() drops a problem that exists already.
     struct SolverOptions {
-        int solver = AAR_SOLVER_DIRECT;   // AAR_SOLVER_DIRECT | _SPCG | _PCG | _AUTO
+        int solver = AAR_SOLVER_AUTO;     // AAR_SOLVER_AUTO | _DIRECT | _SPCG | _PCG
         bool deterministic = false;       // fixed-order sums: two runs give the same bits
-        double pcg_eta = 0.0;             // forcing term of the inexact solvers (0: the solver's default)
+        double pcg_eta = 0.0;             // forcing term of the late LM steps (0: the solver's default)
         int pcg_max_it = 0;               // iteration cap of an inner CG solve (0: the solver's default)
+        double pcg_eta_loose = 0.0;       // forcing term of the early LM steps (0: default; <= pcg_eta: no sequence)
+        double pcg_eta_switch = 0.0;      // "early" = the last accepted step took more than this share of the error away (0: default 0.01)
     };
     void set_solver_options(const SolverOptions &o);
     const SolverOptions &get_solver_options() const { return solver_options_; }

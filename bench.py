@@ -200,6 +200,160 @@ def cpu_baseline(ds, workload, max_threads):
             "err_after_sample": rep["final_err"]}
 
 
+def kernel_profile(problem, ds, workload, x0, steps, params, world, intrinsics=False, deterministic=False):
+    """Per-kernel device time of `steps` LM iterations of `problem` (an instrumented pass: every launch bracketed by HIP events on the library's own stream) and the
+    roofline of the dominant kernel: algorithmic bytes / flops per launch (SURVEY.md 8d's unit) over the measured average duration, with the PMC
+    traffic of the same kernel sources attached when profiles/pmc_traffic.json holds it.  Returns (kernels, roofline)."""
+    import numpy as np
+    A = ds.num_cams + ds.num_markers + (ds.num_cams if intrinsics else 0)     # an intrinsics entity per camera (fx cx fy cy + 2 idle)
+    F, n_pad = ds.num_frames, ((6 * A + 95) // 96) * 96
+    pcg0 = problem.pcg_iterations()[1]
+    problem.set_kernel_profiling(True)
+    done, _, _, _ = run_steps(problem, x0, steps, params)
+    kt = problem.kernel_times()
+    problem.set_kernel_profiling(False)
+    pcg_total = problem.pcg_iterations()[1] - pcg0
+    kernels = {k: {"total_ms": 1e3 * s, "launches": c, "avg_us": (1e6 * s / c if c else None)} for k, (s, c) in kt.items() if c}
+    dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+    n_loc = problem.local_obs
+    merged = "k_passB" not in kernels                      # both observation passes ride in k_passA's launch
+    kf = np.array([len(set(ds.obs_cam[a:b].tolist())) + len(set(ds.obs_marker[a:b].tolist()))
+                   for a, b in zip(*(lambda st: (st[:-1], st[1:]))(np.searchsorted(ds.obs_frame, np.arange(ds.num_frames + 1))))], dtype=np.float64)
+    sum_kf2 = float((kf ** 2).sum()) / max(1, world)
+    pmc, traffic_tab, src_hash, rocprof_avg = os.path.join(ROOT, "profiles", "pmc_traffic.json"), {}, kernel_source_hash(), {}
+    traffic_note = "no PMC collection for this build (profiles/pmc_traffic.json absent)"
+    if os.path.exists(pmc):
+        try:
+            tr = json.load(open(pmc)).get("workload_%d" % workload, {})
+            if not tr:
+                traffic_note = "no PMC pass was collected for this workload"
+            elif tr.get("_kernel_source_sha1") == src_hash:
+                traffic_tab, traffic_note = tr, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel sources (%s)" % tr.get("_source")
+                rocprof_avg = {("k_passA" if kk == "k_passAB" else kk): vv for kk, vv in tr.get("_rocprofv3_avg_us", {}).items()}
+            else:
+                traffic_note = "profiles/pmc_traffic.json was collected for other kernel sources (%s): not attached" % str(tr.get("_kernel_source_sha1"))[:12]
+        except Exception as e:
+            traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
+
+    def roof(k):
+        avg_s = kernels[k]["avg_us"] * 1e-6
+        by = algorithmic_bytes(k, n_loc, A, F, n_pad)
+        extra = {}
+        if k == "k_pcg":
+            # SURVEY 8d's accounting: the frame-owned W blocks are NOT algorithmic bytes (an ideal implementation keeps them on chip); what the solver must move per
+            # launch is the reduced system once (8 (n^2/2 + n), 8d's "writes then reads the reduced system once").  `utilisation` is the kernel's own byte model instead:
+            # one pass over the W blocks for the preconditioner, ONE per CG iteration (k_pcgf; two with k_pcg: deterministic mode, AAR_PCG_FUSED=0), 288 B per incidence
+            passes = 2.0 if (deterministic or os.environ.get("AAR_PCG_FUSED") == "0") else 1.0
+            util_by = 288.0 * float(kf.sum()) / max(1, world) * (1.0 + passes * pcg_total / float(done))
+            by = 8.0 * (n_pad * n_pad / 2 + n_pad)
+            extra["utilisation"] = {"bytes_per_launch": util_by, "achieved": util_by / avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": util_by / avg_s / 1e9 / HBM_PEAK_GBPS,
+                                    "model": "288 B per (entity, frame) incidence per pass over W: the kernel's own traffic model (frame-owned blocks: overhead by SURVEY 8d, not algorithmic bytes)"}
+        if k == "k_spcg":      # both triangles of the reduced system once into registers; a 6 x n product per wavefront per iteration (+ the one of the set-up)
+            by = 8.0 * n_pad * n_pad
+        if k == "k_passA" and merged:
+            by += algorithmic_bytes("k_passB", n_loc, A, F, n_pad)
+        fl = algorithmic_flops(k, n_loc, n_pad, sum_kf2, merged)
+        if k == "k_spcg":
+            fl = 2.0 * n_pad * n_pad * (1.0 + pcg_total / float(done))
+        kind = KERNEL_BOUND.get(k, "hbm")
+        if k == "k_ldl_diag" and os.environ.get("AAR_LDL_LOOKAHEAD", "1") != "0" and len(_stages(n_pad)[0]) > 1:
+            kind = "fp64_mfma"     # (its launches carry the tall block columns' trailing updates as riders: matrix-pipe work, not a lone tile's chain)
+        if k == "k_schur" and (A >= 96 or os.environ.get("AAR_SCHUR_MFMA") == "1") and os.environ.get("AAR_SCHUR_MFMA") != "0":
+            kind = "fp64_mfma"     # from 96 shared entities on: dense panels through the fp64 matrix pipes (k_schur_fill + k_schur_mfma)
+        r = {"kernel": k, "avg_us": kernels[k]["avg_us"], "bytes_per_launch": by, "flops_per_launch": fl,
+             "hbm": {"achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": by / avg_s / 1e9 / HBM_PEAK_GBPS},
+             "fp64": {"achieved": fl / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / FP64_PEAK_TFLOPS},
+             "traffic": traffic_tab.get("k_passAB" if (k == "k_passA" and merged) else k)}
+        r.update(extra)
+        if k == "k_schur" and r["traffic"] is None and "k_schur_mfma" in traffic_tab:      # two kernels behind one launcher; k_schur_fill only counts when it ran
+            fill = traffic_tab.get("raw_k_schur_fill", {}).get("launches", 0) / float(max(1, traffic_tab.get("raw_k_schur_mfma", {}).get("launches", 1)))
+            r["traffic"] = traffic_tab["k_schur_mfma"] + fill * traffic_tab.get("k_schur_fill", 0.0)      # (fill launches per mfma launch: ~0.07, the steps whose damping was not the predicted one)
+        if k == "k_pcg" and r["traffic"] is None:                                            # the launcher's kernels: k_pcgf on one GPU, k_pcgd_* with ranks
+            r["traffic"] = traffic_tab.get("k_pcgf", traffic_tab.get("k_pcgd_iter_f"))
+        # the contract's fields, priced against the roofline that applies to this kernel: `bound` says which -- "hbm" (GB/s),
+        # "fp64_valu" / "fp64_mfma" (TFLOP/s against the 78.6 TFLOP/s fp64 peak of the vector / matrix pipes), or "latency": a
+        # single-workgroup dependent chain, for which a throughput fraction says nothing -- its useful flops over its duration
+        # are reported when it has any (k_ldl_diag), and `frac` is left out when it has none
+        view = r["hbm"] if kind == "hbm" else r["fp64"]
+        r.update(bound=kind, achieved=view["achieved"], peak=view["peak"], unit=view["unit"], frac=view["frac"])
+        if kind == "latency" and fl == 0.0:
+            for f in ("achieved", "peak", "unit", "frac"):
+                r.pop(f)
+        if k in rocprof_avg:
+            r["avg_us_rocprofv3"] = rocprof_avg[k]     # the same kernel under rocprofv3 --kernel-trace --stats (profiles/, same sources)
+        elif k == "k_schur" and "k_schur_mfma" in rocprof_avg:
+            r["avg_us_rocprofv3"] = rocprof_avg["k_schur_mfma"]     # (k_schur_fill only runs when the damping was not the predicted one)
+        return r
+    roofline = roof(dom)
+    roofline["traffic_source"] = traffic_note
+    roofline["kernel_source_sha1"] = src_hash
+    roofline["observation_pass"] = roof("k_passA")     # the streaming scan the north star prices against HBM
+    roofline["per_kernel"] = {k: {f: v for f, v in roof(k).items() if f in ("bound", "achieved", "peak", "unit", "frac", "avg_us", "avg_us_rocprofv3", "traffic", "utilisation")}
+                              for k in kernels if k in KERNEL_BOUND}
+    tj = (kernels["k_passA"]["avg_us"] + (kernels["k_passB"]["avg_us"] if "k_passB" in kernels else 0.0)) * 1e-6
+    roofline["fp64_valu"] = {"kernels": "k_passA+k_passB" if not merged else "k_passA (passes A and B in one launch)", "achieved": 4800.0 * n_loc / tj / 1e12,
+                             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 4800.0 * n_loc / tj / 1e12 / FP64_PEAK_TFLOPS, "flops_per_observation": 4800,
+                             # SURVEY 8d's unit (rows x Jacobian blocks).  The passes in wrench form reach the same blocks through the observation's 6x6 Gram
+                             # matrix: ~1 500 (pass A, slot images included) + ~1 700 (pass B) executed flops per observation (DESIGN.md section 4)
+                             "executed_flops_per_observation": 3200, "executed_frac": 3200.0 * n_loc / tj / 1e12 / FP64_PEAK_TFLOPS}
+    roofline["sum_kernel_us_per_step"] = sum(v["total_ms"] for v in kernels.values()) * 1e3 / float(done)     # all launches of the pass / its LM steps
+    return kernels, roofline
+
+
+def iteration_hbm(ds, trials_per_step, it_per_s):
+    """algorithmic bytes of one LM iteration with t trial points over the measured rate"""
+    P = ds.full_len
+    Ps = 6 * (ds.num_cams - 1 + ds.num_markers - 1)
+    b_iter = 44 * ds.num_obs * (1 + trials_per_step) + 8 * (2 * P + Ps * Ps + Ps)
+    return {"bytes_per_iteration": b_iter, "achieved": b_iter * it_per_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_iter * it_per_s / 1e9 / HBM_PEAK_GBPS}
+
+
+def other_workload(aar, w, device, steps, warmup):
+    """One more workload on ONE GPU in the same bench line (`other_workloads`): configs 4 and 5 -- the configurations where a roofline means something (config 3's
+    step is 1.8 MB of algorithmic bytes: a latency chain) -- through the library's default solver: LM it/s over exactly `steps` steps after `warmup` (device
+    synchronised on both sides), what AUTO resolved to, CG iterations per LM step, final error and POSES against the direct solver on the same problem,
+    SURVEY 8d's whole-iteration HBM figure, the dominant kernel's roofline (PMC traffic attached when collected for these sources) and the observation
+    passes' fp64 fraction."""
+    from pose_metrics import pose_delta_max
+    ds = aar.synth(w)
+    params = lambda **kw: aar.lm_default_params(**kw)
+    out = {"workload": WORKLOADS[w], "survey_config": w, "marker_observations": int(ds.num_obs), "steps": steps, "warmup": warmup, "unit": "LM iterations/s"}
+    with aar.Problem(ds, residual_mode=aar.RES_F32, device=device) as problem:          # the library's default options: solver AUTO
+        for _ in range(2):
+            problem.lm_solve(ds.x_full, params=params(), trace_cap=1)
+        run_steps(problem, ds.x_full, warmup, params)
+        st0 = problem.solver_stats()
+        aar.lib().aar_device_synchronize()
+        t0 = time.perf_counter()
+        done, trials, _, _ = run_steps(problem, ds.x_full, steps, params)
+        aar.lib().aar_device_synchronize()
+        dt = time.perf_counter() - t0
+        st1 = problem.solver_stats()
+        x_fin, rep_fin = problem.lm_solve(ds.x_full, params=params())
+        rmse, _ = problem.reproj_stats(x_fin)
+        kernels, roofline = kernel_profile(problem, ds, w, ds.x_full, steps, params, 1)
+        out.update(value=done / dt, ms_per_step=1e3 * dt / done, solver_resolved=st1["solver"], solver_fallbacks=st1["fallbacks"],
+                   cg_iterations_per_lm_step=((st1["total_iterations"] - st0["total_iterations"]) / float(done)) if st1["solver"] != "direct" else None,
+                   forcing_sequence={"pcg_eta_loose": st1["pcg_eta_loose"], "pcg_eta": st1["pcg_eta"], "pcg_eta_switch": st1["pcg_eta_switch"]},
+                   final_rmse_px=rmse, lm_iterations_to_stop=rep_fin["iterations"], trial_points_per_step=trials / float(done),
+                   iteration_hbm=iteration_hbm(ds, trials / float(done), done / dt), roofline=roofline, kernels=kernels)
+    if out["solver_resolved"] != "direct":
+        with aar.Problem(ds, residual_mode=aar.RES_F32, device=device, solver="direct") as pdir:
+            pdir.lm_solve(ds.x_full, params=params(), trace_cap=1)
+            n_d = min(steps, 30)
+            aar.lib().aar_device_synchronize()
+            t0 = time.perf_counter()
+            run_steps(pdir, ds.x_full, n_d, params)
+            aar.lib().aar_device_synchronize()
+            dt_d = time.perf_counter() - t0
+            x_d, rep_d = pdir.lm_solve(ds.x_full, params=params())
+            rmse_d, _ = pdir.reproj_stats(x_d)
+        dR, dT = pose_delta_max(ds, x_fin, x_d)
+        out.update(direct={"it_per_s": n_d / dt_d, "steps": n_d, "lm_iterations_to_stop": rep_d["iterations"], "final_rmse_px": rmse_d},
+                   rmse_delta_vs_direct_px=abs(rmse - rmse_d), pose_delta_vs_direct={"rotation_matrix_entries": dR, "translation_m": dT})
+    return out
+
+
 def scaling_workload(aar, w, world, rank, local_rank, comm, dist, steps, warmup):
     """One more workload under the SAME communicator (N > 1 runs: configs 4 and 5, the ones BASELINE.json shards over 8 GPUs), with the solver AUTO picks:
     LM it/s (barrier + device synchronisation on both sides, max over ranks), what AUTO resolved to, the all-reduce traffic, the split of a step into
@@ -353,11 +507,13 @@ def main():
     ap.add_argument("--intrinsics", action="store_true", help="the reference's default Config: optimize_cam_intrinsics on (9 more parameters per camera, "
                     "libs/multicam_mapper.h:75-81); the headline metric is quoted WITHOUT it (SURVEY.md section 8 row f4)")
     ap.add_argument("--no-amdahl", action="store_true", help="skip the stage-timer pass behind the `amdahl` object")
-    ap.add_argument("--solver", choices=("direct", "spcg", "pcg", "auto"), default="auto", help="aar_solver_options.solver: direct (Schur complement + dense LDL^T, the "
-                    "reference's step to rounding), spcg (the same Schur complement, then CG on the explicit reduced system, csrc/spcg_kernels.hip), pcg (CG through "
-                    "the frame blocks, no Schur complement, csrc/pcg_kernels.hip), auto (the library picks by size and rank count)")
+    ap.add_argument("--solver", choices=("direct", "spcg", "pcg", "auto"), default=None, help="aar_solver_options.solver.  Not given: the problem is created with a NULL "
+                    "options pointer, i.e. THE LIBRARY'S DEFAULT (AUTO: picks by size) -- what aar_find_solution and MultiCamMapper run.  direct (Schur complement + dense "
+                    "LDL^T, the reference's step to rounding), spcg (the same Schur complement, then CG on the explicit reduced system, csrc/spcg_kernels.hip), pcg (CG "
+                    "through the frame blocks, no Schur complement, csrc/pcg_kernels.hip)")
     ap.add_argument("--deterministic", action="store_true", help="aar_solver_options.deterministic: fixed-order sums instead of fp64 atomics (bit-identical runs)")
     ap.add_argument("--no-scaling-workloads", action="store_true", help="N > 1: skip the extra measurements of configs 4 and 5 (scaling_workloads)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="N = 1: skip the extra measurements of configs 4 and 5 (other_workloads)")
     ap.add_argument("--no-direct", action="store_true", help="skip the comparison leg through the direct solver (profiling runs: only the chosen solver's kernels in the trace)")
     ap.add_argument("--plumbing-only", action="store_true", help="launcher / rendezvous / JSON relay only, no GPU work (CPU test of the N-rank plumbing)")
     args = ap.parse_args()
@@ -439,6 +595,7 @@ def main():
     # ---- full solve for the accuracy half of the metric ----
     x_fin, rep_fin = problem.lm_solve(x0, params=params())
     rmse, ss = problem.reproj_stats(x_fin)
+    pose_delta = None
     # ---- the same through the direct solver (the reference's step to rounding): rate, LM steps to stop, final error -- what an inexact solver is judged against ----
     direct = None
     if solver != "direct" and not args.no_direct:
@@ -460,91 +617,14 @@ def main():
             x_d, rep_d = pdir.lm_solve(x0, params=params())
             rmse_d, _ = pdir.reproj_stats(x_d)
             direct = {"it_per_s": n_d / dt_d, "steps": n_d, "lm_iterations_to_stop": rep_d["iterations"], "final_rmse_px": rmse_d}
+            from pose_metrics import pose_delta_max
+            dR, dT = pose_delta_max(ds, x_fin, x_d)        # final POSES as transforms: largest rotation-matrix-entry / translation difference against the direct solver's
+            pose_delta = {"rotation_matrix_entries": dR, "translation_m": dT}
 
     # ---- per-kernel device time: a second, instrumented pass over the same steps (HIP events on the library's stream) ----
     roofline, kernels = None, None
-    A = ds.num_cams + ds.num_markers + (ds.num_cams if args.intrinsics else 0)     # an intrinsics entity per camera (fx cx fy cy + 2 idle)
-    F, n_pad = ds.num_frames, ((6 * A + 95) // 96) * 96
     if not args.no_kernel_profile:
-        problem.set_kernel_profiling(True)
-        run_steps(problem, x0, args.steps, params)
-        kt = problem.kernel_times()
-        problem.set_kernel_profiling(False)
-        kernels = {k: {"total_ms": 1e3 * s, "launches": c, "avg_us": (1e6 * s / c if c else None)} for k, (s, c) in kt.items() if c}
-        dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
-        n_loc = problem.local_obs
-        merged = "k_passB" not in kernels                      # both observation passes ride in k_passA's launch
-        kf = np.array([len(set(ds.obs_cam[a:b].tolist())) + len(set(ds.obs_marker[a:b].tolist()))
-                       for a, b in zip(*(lambda st: (st[:-1], st[1:]))(np.searchsorted(ds.obs_frame, np.arange(ds.num_frames + 1))))], dtype=np.float64)
-        sum_kf2 = float((kf ** 2).sum()) / max(1, world)
-        pmc, traffic_tab, src_hash, rocprof_avg = os.path.join(ROOT, "profiles", "pmc_traffic.json"), {}, kernel_source_hash(), {}
-        traffic_note = "no PMC collection for this build (profiles/pmc_traffic.json absent)"
-        if os.path.exists(pmc):
-            try:
-                tr = json.load(open(pmc)).get("workload_%d" % args.workload, {})
-                if not tr:
-                    traffic_note = "no PMC pass was collected for this workload"
-                elif tr.get("_kernel_source_sha1") == src_hash:
-                    traffic_tab, traffic_note = tr, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel sources (%s)" % tr.get("_source")
-                    rocprof_avg = {("k_passA" if kk == "k_passAB" else kk): vv for kk, vv in tr.get("_rocprofv3_avg_us", {}).items()}
-                else:
-                    traffic_note = "profiles/pmc_traffic.json was collected for other kernel sources (%s): not attached" % str(tr.get("_kernel_source_sha1"))[:12]
-            except Exception as e:
-                traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
-
-        def roof(k):
-            avg_s = kernels[k]["avg_us"] * 1e-6
-            by = algorithmic_bytes(k, n_loc, A, F, n_pad)
-            if k == "k_pcg":       # one pass over the W blocks for the preconditioner, ONE per CG iteration (k_pcgf; two with k_pcg: deterministic mode, AAR_PCG_FUSED=0)
-                passes = 2.0 if (args.deterministic or os.environ.get("AAR_PCG_FUSED") == "0") else 1.0
-                by = 288.0 * float(kf.sum()) / max(1, world) * (1.0 + passes * pcg_total / float(done))
-            if k == "k_spcg":      # both triangles of the reduced system once into registers; a 6 x n product per wavefront per iteration (+ the one of the set-up)
-                by = 8.0 * n_pad * n_pad
-            if k == "k_passA" and merged:
-                by += algorithmic_bytes("k_passB", n_loc, A, F, n_pad)
-            fl = algorithmic_flops(k, n_loc, n_pad, sum_kf2, merged)
-            if k == "k_spcg":
-                fl = 2.0 * n_pad * n_pad * (1.0 + pcg_total / float(done))
-            kind = KERNEL_BOUND.get(k, "hbm")
-            if k == "k_ldl_diag" and os.environ.get("AAR_LDL_LOOKAHEAD", "1") != "0" and len(_stages(n_pad)[0]) > 1:
-                kind = "fp64_mfma"     # (its launches carry the tall block columns' trailing updates as riders: matrix-pipe work, not a lone tile's chain)
-            if k == "k_schur" and (A >= 96 or os.environ.get("AAR_SCHUR_MFMA") == "1") and os.environ.get("AAR_SCHUR_MFMA") != "0":
-                kind = "fp64_mfma"     # from 96 shared entities on: dense panels through the fp64 matrix pipes (k_schur_fill + k_schur_mfma)
-            r = {"kernel": k, "avg_us": kernels[k]["avg_us"], "bytes_per_launch": by, "flops_per_launch": fl,
-                 "hbm": {"achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": by / avg_s / 1e9 / HBM_PEAK_GBPS},
-                 "fp64": {"achieved": fl / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / FP64_PEAK_TFLOPS},
-                 "traffic": traffic_tab.get("k_passAB" if (k == "k_passA" and merged) else k)}
-            if k == "k_schur" and r["traffic"] is None and "k_schur_mfma" in traffic_tab:      # two kernels behind one launcher; k_schur_fill only counts when it ran
-                fill = traffic_tab.get("raw_k_schur_fill", {}).get("launches", 0) / float(max(1, traffic_tab.get("raw_k_schur_mfma", {}).get("launches", 1)))
-                r["traffic"] = traffic_tab["k_schur_mfma"] + fill * traffic_tab.get("k_schur_fill", 0.0)      # (fill launches per mfma launch: ~0.07, the steps whose damping was not the predicted one)
-            if k == "k_pcg" and r["traffic"] is None:                                            # the launcher's kernels: k_pcgf on one GPU, k_pcgd_* with ranks
-                r["traffic"] = traffic_tab.get("k_pcgf", traffic_tab.get("k_pcgd_iter_f"))
-            # the contract's fields, priced against the roofline that applies to this kernel: `bound` says which -- "hbm" (GB/s),
-            # "fp64_valu" / "fp64_mfma" (TFLOP/s against the 78.6 TFLOP/s fp64 peak of the vector / matrix pipes), or "latency": a
-            # single-workgroup dependent chain, for which a throughput fraction says nothing -- its useful flops over its duration
-            # are reported when it has any (k_ldl_diag), and `frac` is left out when it has none
-            view = r["hbm"] if kind == "hbm" else r["fp64"]
-            r.update(bound=kind, achieved=view["achieved"], peak=view["peak"], unit=view["unit"], frac=view["frac"])
-            if kind == "latency" and fl == 0.0:
-                for f in ("achieved", "peak", "unit", "frac"):
-                    r.pop(f)
-            if k in rocprof_avg:
-                r["avg_us_rocprofv3"] = rocprof_avg[k]     # the same kernel under rocprofv3 --kernel-trace --stats (profiles/, same sources)
-            elif k == "k_schur" and "k_schur_mfma" in rocprof_avg:
-                r["avg_us_rocprofv3"] = rocprof_avg["k_schur_mfma"]     # (k_schur_fill only runs when the damping was not the predicted one)
-            return r
-        roofline = roof(dom)
-        roofline["traffic_source"] = traffic_note
-        roofline["kernel_source_sha1"] = src_hash
-        roofline["observation_pass"] = roof("k_passA")     # the streaming scan the north star prices against HBM
-        roofline["per_kernel"] = {k: {f: v for f, v in roof(k).items() if f in ("bound", "achieved", "peak", "unit", "frac", "avg_us", "avg_us_rocprofv3", "traffic")}
-                                  for k in kernels if k in KERNEL_BOUND}
-        tj = (kernels["k_passA"]["avg_us"] + (kernels["k_passB"]["avg_us"] if "k_passB" in kernels else 0.0)) * 1e-6
-        roofline["fp64_valu"] = {"kernels": "k_passA+k_passB" if not merged else "k_passA (passes A and B in one launch)", "achieved": 4800.0 * n_loc / tj / 1e12,
-                                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 4800.0 * n_loc / tj / 1e12 / FP64_PEAK_TFLOPS, "flops_per_observation": 4800,
-                                 # SURVEY 8d's unit (rows x Jacobian blocks).  The passes in wrench form reach the same blocks through the observation's 6x6 Gram
-                                 # matrix: ~1 500 (pass A, slot images included) + ~1 700 (pass B) executed flops per observation
-                                 "executed_flops_per_observation": 3200, "executed_frac": 3200.0 * n_loc / tj / 1e12 / FP64_PEAK_TFLOPS}
+        kernels, roofline = kernel_profile(problem, ds, args.workload, x0, args.steps, params, world, intrinsics=args.intrinsics, deterministic=args.deterministic)
 
     # ---- where the step's time goes by how it scales with the rank count: a third, stage-timed pass ----
     amdahl = None
@@ -577,6 +657,14 @@ def main():
         track = {"frames": int(ds.num_frames), "seconds_per_call": dt_tr, "frames_per_s": ds.num_frames / dt_tr,
                  "mean_lm_iterations_per_frame": float(np.mean(it_t)), "max_pose_delta_vs_bundle_solution": float(np.abs(xt[ns:] - x_fin[ns:]).max())}
 
+    # ---- N = 1: configs 4 and 5 on this GPU in the same line (the configurations with a meaningful roofline) ----
+    others = None
+    if world == 1 and comm is None and not args.no_other_workloads and not args.intrinsics and args.solver is None and not args.deterministic:
+        others = {}
+        for w, (st_w, wu_w) in ((4, (90, 30)), (5, (45, 15))):
+            if w != args.workload:
+                others[str(w)] = other_workload(aar, w, local_rank, st_w, wu_w)
+
     # ---- N > 1 (or AAR_BENCH_SCALING=1 behind a single-rank communicator): the workloads BASELINE.json shards over 8 GPUs, in the same line ----
     scaling = None
     if (world > 1 or os.environ.get("AAR_BENCH_SCALING") == "1") and not args.no_scaling_workloads:
@@ -599,7 +687,6 @@ def main():
     P = ds.full_len
     Ps = 6 * (ds.num_cams - 1 + ds.num_markers - 1)
     t_avg = trials / float(done)
-    b_iter = 44 * ds.num_obs * (1 + t_avg) + 8 * (2 * P + Ps * Ps + Ps)
     out = {
         "metric": "LM iterations/sec", "value": done / dt, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / done, "higher_is_better": True, "scaling": "strong",
@@ -608,16 +695,17 @@ def main():
                    "frames": ds.num_frames, "marker_observations": int(ds.num_obs), "residual_rows": int(8 * ds.num_obs), "unknowns": int(P),
                    "reduced_unknowns": int(Ps), "parallelism": "frames sharded over %d GPU(s)" % world, "seed": 20190219 + args.workload,
                    "residual_mode": "float32-faithful", "jacobian": "analytic",
-                   "optimize_cam_intrinsics": bool(args.intrinsics), "solver": args.solver, "solver_resolved": solver, "deterministic": bool(args.deterministic)},
+                   "optimize_cam_intrinsics": bool(args.intrinsics), "solver": args.solver or "library default (NULL options: auto)", "solver_resolved": solver, "deterministic": bool(args.deterministic)},
         "final_rmse_px": rmse, "final_sum_sq": ss, "lm_iterations_to_stop": rep_fin["iterations"], "trial_points_per_step": t_avg,
-        "iteration_hbm": {"bytes_per_iteration": b_iter, "achieved": b_iter * done / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                          "frac": b_iter * done / dt / 1e9 / HBM_PEAK_GBPS},
+        "iteration_hbm": iteration_hbm(ds, t_avg, done / dt),
         "roofline": roofline, "kernels": kernels, "amdahl": amdahl, "track": track,
         "pcg_iterations_per_lm_step": (pcg_total / float(done)) if solver != "direct" else None,
         "solver_stats": problem.solver_stats(),
         # the direct solver on the same problem (the reference's step to rounding): what the inexact default is judged against
         "direct_it_per_s": direct["it_per_s"] if direct else None, "direct": direct,
-        "rmse_delta_vs_direct_px": abs(rmse - direct["final_rmse_px"]) if direct else None,
+        "rmse_delta_vs_direct_px": abs(rmse - direct["final_rmse_px"]) if direct else None, "pose_delta_vs_direct": pose_delta,
+        # N = 1: configs 4 and 5 on the same GPU through the same default path (other_workload above)
+        "other_workloads": others,
         # multi-GPU bookkeeping: ranks RCCL itself reports for the communicator, observations per rank (frame-range shards
         # balanced by observation count), payload of ONE all-reduce of the reduced system (packed lower triangle | rhs | g0 | scalars)
         "ranks_seen": comm_stats["ranks_seen"] if comm_stats else 1, "local_obs": per_rank_obs,

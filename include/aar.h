@@ -257,54 +257,71 @@ typedef struct aar_problem_desc {
 } aar_problem_desc;
 
 void aar_problem_desc_from_dataset(const aar_dataset *, aar_problem_desc *);
-int aar_problem_create(const aar_problem_desc *, aar_problem **out);   /* = aar_problem_create_ex(desc, NULL, out) */
+int aar_problem_create(const aar_problem_desc *, aar_problem **out);   /* = aar_problem_create_ex(desc, NULL, out): solver AUTO */
 
 /* How the damped normal equations of a try are solved -- the counterpart of configuring the reference's solver object through
  * SparseLevMarq::Params / setParams (libs/sparselevmarq.h:30-50,60-66): PER PROBLEM, fixed when the problem is created; two problems
  * of one process may differ.  The reference itself knows one way only (Eigen::SimplicialLDLT, :394-400): AAR_SOLVER_DIRECT is that
- * step to rounding and is what a NULL options pointer means.
+ * step to rounding.
  *   AAR_SOLVER_DIRECT  per-frame elimination (Schur complement) + dense blocked LDL^T of the reduced system: the reference's step
  *   AAR_SOLVER_SPCG    the same Schur complement, then block-Jacobi-preconditioned CG on the EXPLICIT reduced system, one wavefront
- *                      per camera / marker (csrc/spcg_kernels.hip), stopped at a relative residual pcg_eta: an inexact LM step -- the trajectory is
- *                      no longer the reference's step for step, its fixed point is (final reprojection error within 1e-5 px in every
- *                      measured case; bar 1e-4).  A solve that needs more than pcg_max_it iterations (cap 64) or whose hand-over times out
- *                      (device shared with another process) is redone with the direct chain automatically.  Needs 6 (C + M [+ C]) <= 1344.
+ *                      per camera / marker (csrc/spcg_kernels.hip), stopped at a relative residual pcg_eta: an inexact LM step.  A solve
+ *                      that needs more than pcg_max_it iterations (cap 64) or whose hand-over times out (device shared with another
+ *                      process) is redone with the direct chain automatically.  Needs 6 (C + M [+ C]) <= 1344.
  *   AAR_SOLVER_PCG     no Schur complement at all: CG THROUGH the frame blocks (csrc/pcg_kernels.hip); with a communicator the frames'
  *                      blocks stay on their ranks and every CG iteration all-reduces 8 n bytes (nothing O(n^3) is replicated)
- *   AAR_SOLVER_AUTO    the fastest of the three for the problem's size and rank count as measured on MI355X.  When it
- *                      resolves to an inexact solver and pcg_eta is left at 0, the inner solves follow a forcing SEQUENCE: PCG 0.3 / SPCG 0.1
- *                      while the last accepted LM step still took more than 1 % of the error away, the solver's own default (0.1 / 0.02)
- *                      afterwards -- the steps that decide the stopping rule are solved as tightly as with the solver named explicitly
- *                      (aar_solver_stats.pcg_eta_loose reports it)
+ *   AAR_SOLVER_AUTO    THE DEFAULT (a NULL options pointer, aar_solver_default_options): the fastest of the three for the problem's
+ *                      size as measured on MI355X (profiles/r05_auto_crossover.txt): one tile of unknowns (up to
+ *                      16 cameras + markers) DIRECT, below 96 shared entities SPCG, from 96 on PCG.
+ * Inexact solvers stop an inner solve at a relative residual pcg_eta (PCG: |r| <= eta |b|; SPCG: sqrt(r^T M^-1 r) <= eta sqrt(b^T M^-1 b), M = the
+ * block-Jacobi preconditioner).  The LM trajectory is then not the reference's step for step, and -- the reference's stopping rule being loose (its own
+ * last step still moves the poses by ~3e-3) -- where a run ends along weakly determined directions depends on every step's accuracy.  The DEFAULT forcing
+ * terms (SPCG 3e-4, PCG 5e-3) are therefore chosen for the final POSES: as transforms they agree with the DIRECT solver's to ~2e-6 in the rotation-matrix
+ * entries and ~1e-6 m in the translations at BASELINE.json's configurations (tests/test_gpu_solvers.py asserts 1e-5), final reprojection error within
+ * 1e-7 px; the direct path itself is ~1e-4 away from the reference-faithful CPU run (analytic against central-difference float Jacobian).
+ * pcg_eta_loose > pcg_eta makes a forcing SEQUENCE (pcg_eta_loose while the last accepted LM step still took more than pcg_eta_switch of the error
+ * away): faster, and measurably further from the direct run's poses (0.1 -> 0.02, round 4's default: 6e-4) -- opt-in.
+ * AAR_SOLVER_DIRECT is the opt-out for callers who want the reference's every step (trace parity).
  * deterministic: every sum the default path leaves to fp64 atomics is taken in a fixed order (as the reference's ascending-row
  * accumulation is, libs/sparselevmarq.h:291-303): two runs give the same bits; slower.
- * Environment variables AAR_SOLVER (direct|spcg|pcg|auto), AAR_DETERMINISTIC, AAR_PCG_ETA, AAR_PCG_MAX_IT override the options of every
- * problem created afterwards: tuning and bisecting only. */
+ * Environment variables AAR_SOLVER (direct|spcg|pcg|auto), AAR_DETERMINISTIC, AAR_PCG_ETA, AAR_PCG_MAX_IT apply to problems whose caller
+ * left the corresponding field at its default (NULL options, or AUTO / 0): tuning and bisecting only; aar_solver_stats.env_overrides
+ * reports what they changed.  An explicitly set field always wins. */
 enum { AAR_SOLVER_DIRECT = 0, AAR_SOLVER_PCG = 1, AAR_SOLVER_SPCG = 2, AAR_SOLVER_AUTO = 3 };
 typedef struct aar_solver_options {
     uint32_t struct_size;                     /* sizeof(aar_solver_options) of the caller: fields beyond it keep their defaults      */
     int32_t solver;                           /* AAR_SOLVER_*                                                                        */
     int32_t deterministic;                    /* 0 | 1                                                                               */
     int32_t pcg_max_it;                       /* iteration cap of an inner CG solve; 0 = default (PCG 200; SPCG 64, also its maximum)  */
-    double pcg_eta;                           /* forcing term of the inexact solvers; 0 = default: PCG |r| <= 0.1 |b|, SPCG
-                                                 sqrt(r^T M^-1 r) <= 0.02 sqrt(b^T M^-1 b) (M = the block-Jacobi preconditioner)        */
+    double pcg_eta;                           /* forcing term of the inner solves; 0 = default (SPCG 3e-4, PCG 5e-3; aar_solver_stats.pcg_eta reports it)  */
+    double pcg_eta_loose;                     /* > pcg_eta: forcing term of the EARLY LM steps (a forcing sequence); 0 = none (default)            */
+    double pcg_eta_switch;                    /* an LM step is "early" while the last accepted step took more than this share of the error
+                                                 away; 0 = default (0.01)                                                              */
 } aar_solver_options;
-void aar_solver_default_options(aar_solver_options *);   /* struct_size set, DIRECT, not deterministic, default eta / cap */
+void aar_solver_default_options(aar_solver_options *);   /* struct_size set, AUTO, not deterministic, default forcing sequence / cap */
 int aar_problem_create_ex(const aar_problem_desc *, const aar_solver_options *, aar_problem **out);
-/* what the problem runs with (AUTO resolved), and what its inner solver has done so far */
+/* what the problem runs with (AUTO resolved), and what its inner solver has done so far.  The CALLER sets struct_size = sizeof(aar_solver_stats)
+ * before the call; the library fills at most that many bytes (a caller built against an older, shorter struct keeps working). */
+enum { AAR_ENV_SOLVER = 1, AAR_ENV_DETERMINISTIC = 2, AAR_ENV_PCG_ETA = 4, AAR_ENV_PCG_MAX_IT = 8 };
 typedef struct aar_solver_stats {
+    uint32_t struct_size;                     /* in: sizeof(aar_solver_stats) of the caller                                            */
     int32_t solver;                           /* AAR_SOLVER_DIRECT | _PCG | _SPCG: never AUTO                                         */
     int32_t deterministic;
     int32_t last_iterations;                  /* CG iterations of the last damped solve (0 for DIRECT)                                */
-    int32_t reserved;
     int64_t total_iterations, solves;         /* since the problem was created                                                        */
     int64_t fallbacks;                        /* SPCG: tries redone with the direct chain (iteration cap, hand-over time-out)          */
-    double pcg_eta;
-    int32_t pcg_max_it, reserved2;
+    double pcg_eta;                           /* forcing term of the inner solves                                                      */
+    int32_t pcg_max_it;
+    int32_t env_overrides;                    /* AAR_ENV_* bits: fields an environment variable changed for this problem               */
     int64_t same_xcd_solves;                  /* SPCG: solves whose wavefronts all ran on one XCD (hand-overs through that XCD's L2: the fast case)   */
-    double pcg_eta_loose;                     /* PCG / SPCG chosen by AUTO with the default forcing term: what the early LM steps are solved to (0: pcg_eta throughout) */
+    double pcg_eta_loose;                     /* forcing term of the early LM steps (0: pcg_eta throughout)                            */
+    double pcg_eta_switch;
 } aar_solver_stats;
 int aar_problem_get_solver_stats(aar_problem *, aar_solver_stats *out);
+/* TESTING ONLY: fault injection for the solvers' fall-back paths.  AAR_TEST_HOOK_SPCG_DROP: the CG wavefront of shared entity `value` never
+ * shows up (what a device shared with another process can do): every hand-over times out, the try is redone by the direct chain; -1 clears. */
+enum { AAR_TEST_HOOK_SPCG_DROP = 1 };
+int aar_problem_set_test_hook(aar_problem *, int32_t hook, int32_t value);
 void aar_problem_destroy(aar_problem *);
 int64_t aar_problem_full_len(const aar_problem *);    /* length of x_full (+ 9 per camera with optimize_cam_intrinsics) */
 int64_t aar_problem_num_vars(const aar_problem *);    /* length of the reference's z for the Config  */

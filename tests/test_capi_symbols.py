@@ -76,3 +76,11 @@ def test_invalid_problems_are_rejected_before_touching_the_device():
 def test_default_lm_params_are_the_mappers():
     p = aar.lm_default_params()   # libs/multicam_mapper.cpp:326-330 over libs/sparselevmarq.h:41-49
     assert (p.max_iters, p.min_error, p.min_step_error_diff, p.min_average_step_error_diff, p.tau) == (10000, 1e-5, 0.0, 1e-4, 1.0)
+
+
+def test_default_solver_options_are_auto_with_one_forcing_term():
+    # what a NULL options pointer means (include/aar.h): solver AUTO, not deterministic, every forcing-term field at "default"
+    so = aar.CSolverOptions()
+    aar.lib().aar_solver_default_options(C.byref(so))
+    assert so.struct_size == C.sizeof(aar.CSolverOptions) and so.solver == aar.SOLVER_AUTO and so.deterministic == 0
+    assert so.pcg_eta == 0.0 and so.pcg_eta_loose == 0.0 and so.pcg_eta_switch == 0.0 and so.pcg_max_it == 0

@@ -17,6 +17,13 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
+
+def Problem(ds, **kw):
+    # This file pins the reference's STEP (Eigen::SimplicialLDLT to rounding: traces, damped steps, blocks): the direct solver, named explicitly.
+    # The library's default -- solver AUTO -- is pinned in tests/test_gpu_solvers.py (final poses and errors against this path and the reference).
+    kw.setdefault("solver", "direct")
+    return aar.Problem(ds, **kw)
+
 G1 = ["g1_cfg2", "g1_cfg3_cut", "g1_cfg2_far"]
 
 
@@ -30,20 +37,20 @@ def _need_gpu():
 def test_residual_rows(name):
     ds, g = load_golden(name)
     o = ol.Oracle(ds)
-    with aar.Problem(ds, residual_mode=aar.RES_F32) as p:
+    with Problem(ds, residual_mode=aar.RES_F32) as p:
         r, ss = p.eval_residuals(ds.x_full)
         assert np.array_equal(r, o.residuals(ds.x_full, res_mode=ol.RES_F32))      # bit-exact, float-faithful
         if "r0_f32" in g:
             assert np.array_equal(r, g["r0_f32"])
         np.testing.assert_allclose(ss, float((r ** 2).sum()), rtol=1e-13)
-    with aar.Problem(ds, residual_mode=aar.RES_F64) as p:
+    with Problem(ds, residual_mode=aar.RES_F64) as p:
         r, _ = p.eval_residuals(ds.x_full)
         assert np.abs(r - o.residuals(ds.x_full, res_mode=ol.RES_F64)).max() < 1e-9  # px
 
 
 def test_block_normal_equations_vs_eigen_golden():
     ds, g = load_golden("g2_small")
-    with aar.Problem(ds, residual_mode=aar.RES_F64) as p:
+    with Problem(ds, residual_mode=aar.RES_F64) as p:
         H, B, ss = p.eval_normal_equations(ds.x_full)
         scale = np.abs(g["analytic_JtJ"]).max()
         assert np.abs(H - g["analytic_JtJ"]).max() / scale < 1e-12
@@ -60,7 +67,7 @@ def test_block_normal_equations_vs_oracle(name):
     ds, _ = load_golden(name)
     o = ol.Oracle(ds)
     for mode, om in ((aar.RES_F64, ol.RES_F64), (aar.RES_F32, ol.RES_F32)):
-        with aar.Problem(ds, residual_mode=mode) as p:
+        with Problem(ds, residual_mode=mode) as p:
             H, B, _ = p.eval_normal_equations(ds.x_full)
             Ho, Bo = o.normal_equations(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=om)
             assert np.abs(H - Ho).max() / np.abs(Ho).max() < 1e-12
@@ -75,7 +82,7 @@ def test_fixed_parameter_groups(opt):
     # MultiCamMapper::Config with a group switched off: its columns disappear and its poses do not move
     ds, _ = load_golden("g2_small")
     o = ol.Oracle(ds, optimize=opt)
-    with aar.Problem(ds, residual_mode=aar.RES_F64, optimize=opt) as p:
+    with Problem(ds, residual_mode=aar.RES_F64, optimize=opt) as p:
         assert p.num_vars == o.num_vars
         H, B, _ = p.eval_normal_equations(ds.x_full)
         Ho, Bo = o.normal_equations(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F64)
@@ -98,7 +105,7 @@ def test_fixed_parameter_groups(opt):
 @pytest.mark.parametrize("name", G1)
 def test_lm_trace_equals_real_solver_with_same_jacobian(name):
     ds, g = load_golden(name)
-    with aar.Problem(ds, residual_mode=aar.RES_F32) as p:
+    with Problem(ds, residual_mode=aar.RES_F32) as p:
         x, rep = p.lm_solve(ds.x_full)
         assert rep["iterations"] == int(g["analytic_iterations"][0])
         err = np.array([t["err"] for t in rep["trace"]])
@@ -119,7 +126,7 @@ def test_lm_retry_branch():
     # far start + tau = 1e-6: some first tries are rejected (mu *= v; v *= 5, libs/sparselevmarq.h:416-419)
     ds, g = load_golden("g1_cfg2_retry")
     prm = aar.lm_default_params(tau=float(g["tau"][0]))
-    with aar.Problem(ds, residual_mode=aar.RES_F32) as p:
+    with Problem(ds, residual_mode=aar.RES_F32) as p:
         x, rep = p.lm_solve(ds.x_full, params=prm)
         tries = [t["tries"] for t in rep["trace"]]
         assert max(tries) > 1
@@ -134,7 +141,7 @@ def test_lm_retry_branch():
     # an exactly repeated error.  Which of the two, and after how many steps, depends on last-bit rounding, so the
     # checks are structural.
     ds2, g2 = load_golden("g1_cfg2")
-    with aar.Problem(ds2, residual_mode=aar.RES_F64) as p:
+    with Problem(ds2, residual_mode=aar.RES_F64) as p:
         x, rep = p.lm_solve(ds2.x_full, params=aar.lm_default_params(min_average_step_error_diff=0.0, max_iters=200))
         assert rep["iterations"] < 200 and rep["stop_code"] == 2
         last = rep["trace"][-1]
@@ -153,7 +160,7 @@ def test_huber_rows_and_schedule():
     # libs/multicam_mapper.cpp:11-24,1014-1019 (weights) and :412-417,425 (delta schedule driven by the step callback)
     ds, g = load_golden("g1_cfg2_huber")
     o = ol.Oracle(ds, with_huber=True, huber_delta=10.0)
-    with aar.Problem(ds, with_huber=True) as p:
+    with Problem(ds, with_huber=True) as p:
         p.set_huber_delta(10.0)
         r, _ = p.eval_residuals(ds.x_full)
         assert np.array_equal(r, g["r0_f32"])                       # weighted rows, bit-exact
@@ -183,7 +190,7 @@ def test_track_frames_vs_real_solver(name):
     # MultiCamMapper::track(): per-frame 6-DoF LM, cameras / markers fixed; golden = the real solver's own solve(z, f)
     ds, g = load_golden(name)
     hub = bool(g["with_huber"][0])
-    with aar.Problem(ds, with_huber=hub) as p:
+    with Problem(ds, with_huber=hub) as p:
         if hub:
             p.set_huber_delta(10.0)            # track() sets hubberDelta = 10 and installs no schedule (:439)
         x, it, err = p.track(g["track_x0"])
@@ -211,7 +218,7 @@ def test_track_frames_vs_real_solver(name):
 
 def test_step_api_matches_solve():
     ds, g = load_golden("g1_cfg2")
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         p.lm_init(ds.x_full, aar.lm_default_params())
         its = [p.lm_step() for _ in range(3)]
         np.testing.assert_allclose([i["err"] for i in its], g["analytic_err"][:3], rtol=1e-7)
@@ -224,7 +231,7 @@ def test_step_api_matches_solve():
 def test_known_answer_noise_free():
     # G3: no corner noise -> the optimum is the ground truth (gauge fixed by the root camera / marker)
     ds = aar.synth(2, noise_px=0.0)
-    with aar.Problem(ds, residual_mode=aar.RES_F64) as p:
+    with Problem(ds, residual_mode=aar.RES_F64) as p:
         x, rep = p.lm_solve(ds.x_full, params=aar.lm_default_params(min_average_step_error_diff=1e-14))
         assert rep["final_err"] < 1e-3 * ds.num_obs   # float32-rounded detections leave ~1e-5 px of noise
         rmse, _ = p.reproj_stats(x)
@@ -253,7 +260,7 @@ def test_ragged_and_degenerate_inputs():
         setattr(sub, k, getattr(ds, k)[keep])
     sub.num_obs = int(keep.sum())
     os_ = ol.Oracle(sub)
-    with aar.Problem(sub, residual_mode=aar.RES_F64) as p:
+    with Problem(sub, residual_mode=aar.RES_F64) as p:
         r, _ = p.eval_residuals(sub.x_full)
         assert np.abs(r - os_.residuals(sub.x_full, res_mode=ol.RES_F64)).max() < 1e-9
         H, B, _ = p.eval_normal_equations(sub.x_full)
@@ -270,7 +277,7 @@ def test_ragged_and_degenerate_inputs():
         setattr(empty, k, np.zeros(0, dtype=np.int32))
     empty.obs_uv = np.zeros((0, 8), dtype=np.float32)
     empty.num_obs = 0
-    with aar.Problem(empty) as p:
+    with Problem(empty) as p:
         r, ss = p.eval_residuals(empty.x_full)
         assert len(r) == 0 and ss == 0.0
 
@@ -278,7 +285,7 @@ def test_ragged_and_degenerate_inputs():
 def test_full_size_config3_properties():
     # BASELINE.json configs[2] (8 cameras / 40 markers / 500 frames): size-independent properties
     ds = aar.synth(3)
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         x, rep = p.lm_solve(ds.x_full)
         err = [t["err"] for t in rep["trace"]]
         assert all(b < a for a, b in zip([rep["initial_err"]] + err[:-1], err))     # monotone decrease
@@ -303,7 +310,7 @@ def test_config4_size_against_oracle():
     # bit-exact, one damped step against the oracle's sparse LDL^T (12 276 unknowns), three reduced-system tiles
     ds = aar.synth(4)
     o = ol.Oracle(ds)
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         r, ss = p.eval_residuals(ds.x_full)
         assert np.array_equal(r, o.residuals(ds.x_full, res_mode=ol.RES_F32))
         mu = 1e6
@@ -321,7 +328,7 @@ def test_full_size_config5_properties():
     ds = aar.synth(5)
     assert ds.num_obs > 1_200_000
     o = ol.Oracle(ds)
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         # residual rows bit-exact against the oracle (a pure streaming pass on the CPU)
         r, ss = p.eval_residuals(ds.x_full)
         ro = o.residuals(ds.x_full, res_mode=ol.RES_F32)
@@ -343,7 +350,7 @@ def test_full_size_config5_properties():
 
     # the same solve sharded over four ranks (frame ranges, one all-reduce of S | rhs | g0 per try): identical trace
     def run(comm, rank):
-        with aar.Problem(ds, comm=comm) as q:
+        with Problem(ds, comm=comm) as q:
             xs, reps = q.lm_solve(ds.x_full)
             return xs, reps, q.local_obs
     out = _run_ranks(4, run)
@@ -361,13 +368,13 @@ def test_schur_mfma_kernel_forced_on_small_problems(name, split, monkeypatch):
     o = ol.Oracle(ds)
     monkeypatch.setenv("AAR_SCHUR_MFMA", "1")
     monkeypatch.setenv("AAR_SCHUR_SPLIT", split)
-    with aar.Problem(ds, residual_mode=aar.RES_F64) as p:
+    with Problem(ds, residual_mode=aar.RES_F64) as p:
         Ho, _ = o.normal_equations(ds.x_full, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F64)
         for mu in (float(np.diag(Ho).max()) * 1e-3, 1.0):
             d = p.eval_damped_step(ds.x_full, mu)
             do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F64)
             assert np.abs(d - do).max() / np.abs(do).max() < 1e-8, mu
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         x, rep = p.lm_solve(ds.x_full)
         np.testing.assert_allclose([t["err"] for t in rep["trace"]], g["analytic_err"], rtol=1e-7)
         np.testing.assert_allclose(x, g["analytic_x"], atol=1e-7)
@@ -380,7 +387,7 @@ def test_tile_counts_and_schur_kernels_against_oracle(mfma, cams, markers, frame
     monkeypatch.setenv("AAR_SCHUR_MFMA", mfma)
     ds = aar.synth(3, num_cams=cams, num_markers=markers, num_frames=frames)
     o = ol.Oracle(ds)
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         r, ss = p.eval_residuals(ds.x_full)
         assert np.array_equal(r, o.residuals(ds.x_full, res_mode=ol.RES_F32))
         for mu in (1e6, 1e2):
@@ -399,7 +406,7 @@ def test_gauge_rows_in_trailing_tiles_of_a_three_tile_system(opt):
     # first touch inside the fused panel kernel (slabs, output blocks, right-hand side) instead of the diagonal-tile kernel
     ds = aar.synth(3, num_cams=18, num_markers=20, num_frames=40)
     o = ol.Oracle(ds, optimize=opt)
-    with aar.Problem(ds, optimize=opt) as p:
+    with Problem(ds, optimize=opt) as p:
         assert p.num_vars == o.num_vars
         for mu in (1e5, 10.0):
             d = p.eval_damped_step(ds.x_full, mu)
@@ -426,7 +433,7 @@ def test_dense_solve_path_switches(env):
         for cams, markers, frames in ((4, 20, 60), (8, 40, 60), (4, 62, 40)):
             ds = aar.synth(3, num_cams=cams, num_markers=markers, num_frames=frames)
             o = ol.Oracle(ds)
-            with aar.Problem(ds) as p:
+            with aar.Problem(ds, solver="direct") as p:
                 for mu in (1e6, 1e2):
                     d = p.eval_damped_step(ds.x_full, mu)
                     do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
@@ -456,7 +463,7 @@ def test_dense_lookahead_seven_tiles(lookahead):
         ds = aar.synth(3, num_cams=16, num_markers=92, num_frames=120)
         o = ol.Oracle(ds)
         worst = 0.0
-        with aar.Problem(ds) as p:
+        with aar.Problem(ds, solver="direct") as p:
             for mu in (1e4, 1e-2):
                 d = p.eval_damped_step(ds.x_full, mu)
                 do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
@@ -487,7 +494,7 @@ def test_randomized_shapes_against_oracle():
             continue
         opt = [(True, True, True), (True, True, True), (False, True, True), (True, False, True)][k % 4]
         o = ol.Oracle(ds, optimize=opt)
-        with aar.Problem(ds, optimize=opt) as p:
+        with Problem(ds, optimize=opt) as p:
             r, ss = p.eval_residuals(ds.x_full)
             assert np.array_equal(r, o.residuals(ds.x_full, res_mode=ol.RES_F32)), (C, M, F)
             mu = float(10.0 ** rng.integers(0, 7))
@@ -500,7 +507,7 @@ def test_randomized_shapes_against_oracle():
         np.testing.assert_allclose(rep["final_err"], repo["final_err"], rtol=1e-5, err_msg=str((C, M, F)))
         if k % 3 == 0 and opt == (True, True, True):
             def solve(comm, rank, ds=ds):
-                with aar.Problem(ds, comm=comm) as q:
+                with Problem(ds, comm=comm) as q:
                     return q.lm_solve(ds.x_full)
             for xs, reps in _run_ranks(2 + k % 2, solve):
                 assert reps["iterations"] == rep["iterations"], (C, M, F)
@@ -516,7 +523,7 @@ def test_single_rank_communicator_path():
     ds, g = load_golden("g1_cfg2")
     comm = aar.Comm(aar.Comm.make_id(), 1, 0, 0)
     try:
-        with aar.Problem(ds, comm=comm) as p:
+        with Problem(ds, comm=comm) as p:
             x, rep = p.lm_solve(ds.x_full)
             np.testing.assert_allclose([t["err"] for t in rep["trace"]], g["analytic_err"], rtol=1e-7)
             np.testing.assert_allclose(x, g["analytic_x"], atol=1e-7)
@@ -542,7 +549,7 @@ def test_remove_distortions_kernel_equals_oracle():
 def _run_rank(group, rank, ds, out, with_huber=False):
     comm = aar.Comm.local(group, rank, 0)
     try:
-        with aar.Problem(ds, comm=comm, with_huber=with_huber) as p:
+        with Problem(ds, comm=comm, with_huber=with_huber) as p:
             x, rep = p.lm_solve(ds.x_full)
             out[rank] = (x, rep, p.local_obs)
     except Exception as e:   # a rank that dies would leave the others waiting at a barrier: report, do not hang the test
@@ -607,11 +614,11 @@ def test_sharded_huber_schedule_and_idle_rank():
     # (1) -with-huber on 4 ranks: the weights and optCallBack's delta schedule give the single-GPU result;
     # (2) more ranks than frames: a rank that owns no frame still takes part in every collective
     ds, g = load_golden("g1_cfg2_huber")
-    with aar.Problem(ds, with_huber=True) as p:
+    with Problem(ds, with_huber=True) as p:
         x1, rep1 = p.lm_solve(ds.x_full)
 
     def solve_h(comm, r):
-        with aar.Problem(ds, comm=comm, with_huber=True) as p:
+        with Problem(ds, comm=comm, with_huber=True) as p:
             return p.lm_solve(ds.x_full)
     for x, rep in _run_ranks(4, solve_h):
         assert rep["iterations"] == rep1["iterations"]
@@ -620,11 +627,11 @@ def test_sharded_huber_schedule_and_idle_rank():
         np.testing.assert_allclose(x, x1, atol=1e-5)
 
     small = aar.synth(2, num_cams=3, num_markers=8, num_frames=2)
-    with aar.Problem(small) as p:
+    with Problem(small) as p:
         xs, reps = p.lm_solve(small.x_full)
 
     def solve_s(comm, r):
-        with aar.Problem(small, comm=comm) as p:
+        with Problem(small, comm=comm) as p:
             return p.lm_solve(small.x_full) + (p.local_obs,)
     outs = _run_ranks(3, solve_s)
     assert sorted(o[2] for o in outs)[0] == 0            # one rank has nothing
@@ -643,7 +650,7 @@ def test_sharded_retry_and_mispredicted_damping():
     ds_r, g = load_golden("g1_cfg2_retry")
     ds_h, gh = load_golden("g1_cfg2_huber")
     for ds, prm_kw, hub in ((ds_r, dict(tau=float(g["tau"][0])), False), (ds_h, dict(), True)):
-        with aar.Problem(ds, with_huber=hub) as p:
+        with Problem(ds, with_huber=hub) as p:
             x1, rep1 = p.lm_solve(ds.x_full, params=aar.lm_default_params(**prm_kw), trace_cap=600)
         tries1 = np.array([t["tries"] for t in rep1["trace"]])
         mu1 = np.array([t["mu"] for t in rep1["trace"]])
@@ -657,7 +664,7 @@ def test_sharded_retry_and_mispredicted_damping():
             k = 6
 
         def solve(comm, r):
-            with aar.Problem(ds, comm=comm, with_huber=hub) as q:
+            with Problem(ds, comm=comm, with_huber=hub) as q:
                 return q.lm_solve(ds.x_full, params=aar.lm_default_params(**prm_kw), trace_cap=600)
         for fused in ("1", "0"):
             os.environ["AAR_FUSED_COMM"] = fused
@@ -701,7 +708,7 @@ def test_config1_box_like_find_solution_vs_compiled_reference(tmp_path):
     assert rmse_gpu < rmse_init
     assert abs(rmse_gpu - rmse_ref) < 1e-4, (rmse_gpu, rmse_ref)        # the north star's bar
     # the same solve through the C ABI from the file: same iteration count as the driver printed, same final error
-    with aar.Problem(init) as p:
+    with Problem(init) as p:
         x, rep = p.lm_solve(init.x_full)
         assert ("LM iterations: %d " % rep["iterations"]) in run.stdout
         assert abs(p.reproj_stats(x)[0] - rmse_gpu) < 1e-7               # final.solution stores vec -> mat -> vec
@@ -717,7 +724,7 @@ def test_full_size_config3_against_compiled_reference():
     o = ol.Oracle(ds)
     solve = o.ref_lm_solve if ol.have_ref() else o.lm_solve
     x_ref, rep_ref = solve(ds.x_full, jac_mode=ol.JAC_NUMERIC_F32, res_mode=ol.RES_F32, threads=min(32, os.cpu_count() or 1))
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         mu = 1e5
         d = p.eval_damped_step(ds.x_full, mu)
         do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
@@ -736,7 +743,7 @@ def test_solver_seam_step_callback_and_stop_function():
     # ucoslam::SparseLevMarq<T>::setStepCallBackFunc / setStopFunction (libs/sparselevmarq.h:121-123) through the C ABI: the step
     # callback sees curr_z after every step (:463); with a stop function the loop is do { step; callback } while (!stop) (:444-450)
     ds, g = load_golden("g1_cfg2")
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         seen = []
         p.set_step_callback(lambda z: seen.append(z))
         x, rep = p.lm_solve(ds.x_full)
@@ -762,7 +769,7 @@ def test_huber_schedule_through_the_step_callback():
     # MultiCamMapper::solve installs optCallBack as the solver's step callback and sets hubberDelta = 10 itself
     # (libs/multicam_mapper.cpp:412-425); a caller doing the same through the seam gets the built-in schedule's trace
     ds, g = load_golden("g1_cfg2_huber")
-    with aar.Problem(ds, with_huber=True) as p:
+    with Problem(ds, with_huber=True) as p:
         delta = [np.float32(10.0)]
 
         def opt_callback(z):
@@ -836,26 +843,26 @@ def test_unsupported_sizes_are_refused_collectively():
         ds.optimize_cam_intrinsics = False
         return ds
     with pytest.raises(aar.AarError) as e:
-        aar.Problem(dataset(400, 340))
+        Problem(dataset(400, 340))
     assert e.value.code == aar.AAR_ERR_UNSUPPORTED and "touches" in str(e.value)
     # > ~560 cameras+markers: only the OUTPUT-STATIONARY Schur kernel keeps a row panel of all of them in LDS; the MFMA kernel
     # (the default from 96 entities) has no such panel, so the problem is fine unless that kernel is ruled out -- switched off,
     # or its dense panels over the memory budget
-    aar.Problem(dataset(700, 3)).close()
+    Problem(dataset(700, 3)).close()
     for knob, val in (("AAR_SCHUR_MFMA", "0"), ("AAR_SCHUR_PANEL_MB", "0")):
         os.environ[knob] = val
         try:
             with pytest.raises(aar.AarError) as e:
-                aar.Problem(dataset(700, 3))
+                Problem(dataset(700, 3))
             assert e.value.code == aar.AAR_ERR_UNSUPPORTED and "exceed" in str(e.value)
         finally:
             del os.environ[knob]
-    aar.Problem(dataset(400, 280)).close()                 # inside both limits
+    Problem(dataset(400, 280)).close()                 # inside both limits
 
     wide = dataset(400, 340)
     def create(comm, rank):
         try:
-            aar.Problem(wide, comm=comm).close()
+            Problem(wide, comm=comm).close()
             return "created"
         except aar.AarError as err:
             return err.code
@@ -870,7 +877,7 @@ def test_intrinsics_block_against_oracle_and_real_solver():
     ds, g = load_golden("g1_cfg2_intr")
     o = ol.Oracle(ds, intrinsics=True)
     i0 = ds.full_len
-    with aar.Problem(ds, intrinsics=True) as p:
+    with Problem(ds, intrinsics=True) as p:
         assert p.full_len == ds.full_len + 9 * ds.num_cams and p.num_vars == o.num_vars
         x0 = p.x_with_intrinsics(ds.x_full)
         np.testing.assert_array_equal(p.extract_z(x0), o.extract_z(ds.x_full))
@@ -898,13 +905,13 @@ def test_intrinsics_block_against_oracle_and_real_solver():
         assert abs(rmse - g["faithful_rmse"][0]) < 1e-3
 
     def solve(comm, rank):
-        with aar.Problem(ds, intrinsics=True, comm=comm) as q:
+        with Problem(ds, intrinsics=True, comm=comm) as q:
             return q.lm_solve(q.x_with_intrinsics(ds.x_full))
     for xs, reps in _run_ranks(3, solve):                                           # sharded: intrinsics entities are shared ones
         np.testing.assert_allclose([t["err"] for t in reps["trace"]], [t["err"] for t in rep["trace"]], rtol=1e-8)
         np.testing.assert_allclose(xs, x, atol=1e-7)
     # a fixed-intrinsics problem on the same data keeps the calibration's skew: other rows, other optimum
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         assert not np.array_equal(p.eval_residuals(ds.x_full)[0], g["r0_f32"])
 
 
@@ -916,7 +923,7 @@ def test_huber_schedule_with_a_rejected_try():
     ds, g = load_golden("g1_cfg2_huber_retry")
     o = ol.Oracle(ds, with_huber=True)
     prm = aar.lm_default_params(tau=float(g["tau"][0]))
-    with aar.Problem(ds, with_huber=True) as p:
+    with Problem(ds, with_huber=True) as p:
         x, rep = p.lm_solve(ds.x_full, params=prm, trace_cap=600)
     xo, repo = o.lm_solve(ds.x_full, params=ol.mapper_params(tau=float(g["tau"][0])), jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
     tries = [t["tries"] for t in rep["trace"]]
@@ -936,7 +943,7 @@ def test_600_entities_take_the_mfma_schur_path_and_match_the_oracle(monkeypatch)
     # limit is that kernel's alone -- the dense-panel MFMA kernel (default from 96 entities) solves the problem, 38 tiles of LDL^T
     ds = aar.synth(3, num_cams=4, num_markers=596, num_frames=24)
     o = ol.Oracle(ds)
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         r, ss = p.eval_residuals(ds.x_full)
         assert np.array_equal(r, o.residuals(ds.x_full, res_mode=ol.RES_F32))
         for mu in (1e5, 1e2):
@@ -949,13 +956,13 @@ def test_600_entities_take_the_mfma_schur_path_and_match_the_oracle(monkeypatch)
     # kernel can hold falls back to it silently and gives the same step
     monkeypatch.setenv("AAR_SCHUR_PANEL_MB", "0")
     with pytest.raises(aar.AarError) as e:
-        aar.Problem(ds)
+        Problem(ds)
     assert e.value.code == aar.AAR_ERR_UNSUPPORTED
     ds2 = aar.synth(3, num_cams=4, num_markers=120, num_frames=24)
-    with aar.Problem(ds2) as p:       # budget 0 -> output-stationary kernel
+    with Problem(ds2) as p:       # budget 0 -> output-stationary kernel
         d_os = p.eval_damped_step(ds2.x_full, 1e3)
     monkeypatch.delenv("AAR_SCHUR_PANEL_MB")
-    with aar.Problem(ds2) as p:       # default: MFMA kernel (A = 124 >= 96)
+    with Problem(ds2) as p:       # default: MFMA kernel (A = 124 >= 96)
         d_mf = p.eval_damped_step(ds2.x_full, 1e3)
     assert np.abs(d_os - d_mf).max() / np.abs(d_mf).max() < 1e-9
 
@@ -980,7 +987,7 @@ def test_reference_shaped_solver_calls_compile_and_run_against_the_mirror(tmp_pa
     assert float(kv["shaped_return"]) == float(kv["shaped_final_err"]) and float(kv["shaped_vs_own_max_abs_z"]) < 1e-7
     assert "initial_error: " in run.stdout and "error size: %d" % (8 * ds.num_obs) in run.stdout        # libs/multicam_mapper.cpp:424
     # step-by-step: four steps from the start equal the first four iterations of a solve
-    with aar.Problem(ds, with_huber=False) as p:
+    with Problem(ds, with_huber=False) as p:
         _, rep = p.lm_solve(ds.x_full, params=aar.lm_default_params(max_iters=4), trace_cap=8)
     assert int(kv["steps_accepted"]) == 4 and int(kv["steps_zlen"]) == ds.full_len
     np.testing.assert_allclose(float(kv["steps_err"]), rep["trace"][3]["err"], rtol=1e-7)
@@ -999,7 +1006,7 @@ def test_reference_shaped_solver_calls_compile_and_run_against_the_mirror(tmp_pa
 
 
 def _det_run(ds, det, with_huber=False, intrinsics=False, **solve_kw):
-    with aar.Problem(ds, with_huber=with_huber, intrinsics=intrinsics, deterministic=det) as p:
+    with Problem(ds, with_huber=with_huber, intrinsics=intrinsics, deterministic=det) as p:
         x0 = p.x_with_intrinsics(ds.x_full) if intrinsics else ds.x_full
         H, B, ss = p.eval_normal_equations(x0)
         d = p.eval_damped_step(x0, 1e3)
@@ -1031,7 +1038,7 @@ def test_deterministic_mode_tightens_the_retry_trace():
     # 1e-8 over the first 60 steps (2e-4 is what the default path's atomics allow: their order moves mu between runs)
     ds, g = load_golden("g1_cfg2_huber_retry")
     prm = aar.lm_default_params(tau=float(g["tau"][0]))
-    with aar.Problem(ds, with_huber=True, deterministic=True) as p:
+    with Problem(ds, with_huber=True, deterministic=True) as p:
         x, rep = p.lm_solve(ds.x_full, params=prm, trace_cap=600)
     k = 60
     assert max(t["tries"] for t in rep["trace"]) > 1
@@ -1048,17 +1055,17 @@ def test_deterministic_mode_on_a_many_entity_problem():
     # 124 shared entities: the default path would take the MFMA Schur kernel; deterministic mode keeps the output-stationary one
     # (fixed-order sums exist for it only) -- same step to rounding, same bits twice; beyond its LDS row panel the mode is refused
     ds = aar.synth(3, num_cams=4, num_markers=120, num_frames=24)
-    with aar.Problem(ds, deterministic=True) as p:
+    with Problem(ds, deterministic=True) as p:
         d1 = p.eval_damped_step(ds.x_full, 1e3)
         assert p.solver_stats()["deterministic"]
-    with aar.Problem(ds, deterministic=True) as p:
+    with Problem(ds, deterministic=True) as p:
         d2 = p.eval_damped_step(ds.x_full, 1e3)
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         d0 = p.eval_damped_step(ds.x_full, 1e3)
         assert not p.solver_stats()["deterministic"]
     assert np.array_equal(d1, d2) and np.abs(d1 - d0).max() / np.abs(d0).max() < 1e-9
     with pytest.raises(aar.AarError) as e:
-        aar.Problem(aar.synth(3, num_cams=4, num_markers=596, num_frames=24), deterministic=True)
+        Problem(aar.synth(3, num_cams=4, num_markers=596, num_frames=24), deterministic=True)
     assert e.value.code == aar.AAR_ERR_UNSUPPORTED
 
 
@@ -1068,12 +1075,12 @@ def test_pcg_solver_mode_against_the_direct_path():
     # Newton -- another trajectory to the same fixed point: final RMSE within the north star's 1e-4 px (observed: 1e-6), no more LM steps
     ds = aar.synth(3, num_frames=120)
     o = ol.Oracle(ds)
-    with aar.Problem(ds) as p:
+    with Problem(ds) as p:
         d_direct = p.eval_damped_step(ds.x_full, 1e3)
         x_d, rep_d = p.lm_solve(ds.x_full)
         rmse_d, _ = p.reproj_stats(x_d)
         assert p.pcg_iterations() == (0, 0)
-    with aar.Problem(ds, solver="pcg", pcg_eta=1e-11) as p:
+    with Problem(ds, solver="pcg", pcg_eta=1e-11) as p:
         d_pcg = p.eval_damped_step(ds.x_full, 1e3)
         last, total = p.pcg_iterations()
         assert 5 < last == total < 200
@@ -1081,7 +1088,7 @@ def test_pcg_solver_mode_against_the_direct_path():
     assert np.abs(d_pcg - d_direct).max() / np.abs(d_direct).max() < 1e-7
     assert np.abs(d_pcg - do).max() / np.abs(do).max() < 1e-7
     for opt in ((True, True, True), (False, True, True), (True, False, True)):      # gauge / switched-off groups are identity rows of the operator
-        with aar.Problem(ds, optimize=opt, solver="pcg") as p:
+        with Problem(ds, optimize=opt, solver="pcg") as p:
             assert p.solver_stats()["pcg_eta"] == 0.1
             x_p, rep_p = p.lm_solve(ds.x_full)
             rmse_p, _ = p.reproj_stats(x_p)
@@ -1090,25 +1097,25 @@ def test_pcg_solver_mode_against_the_direct_path():
             assert abs(rmse_p - rmse_d) < 1e-4 and abs(rmse_p - rmse_d) < 1e-5
             assert rep_p["iterations"] <= rep_d["iterations"] + 2 and 0 < its < 40 * rep_p["iterations"]
         else:
-            with aar.Problem(ds, optimize=opt) as q:
+            with Problem(ds, optimize=opt) as q:
                 x_q, _ = q.lm_solve(ds.x_full)
                 rmse_q, _ = q.reproj_stats(x_q)
             assert abs(rmse_p - rmse_q) < 1e-4
     # the reference's default Config (intrinsics entities are shared entities like any other) and -with-huber go through the same operator
-    with aar.Problem(ds, intrinsics=True, solver="pcg") as p:
+    with Problem(ds, intrinsics=True, solver="pcg") as p:
         x_i, rep_i = p.lm_solve(p.x_with_intrinsics(ds.x_full))
         rmse_i, _ = p.reproj_stats(x_i)
-    with aar.Problem(ds, intrinsics=True) as q:
+    with Problem(ds, intrinsics=True) as q:
         x_j, rep_j = q.lm_solve(q.x_with_intrinsics(ds.x_full))
         rmse_j, _ = q.reproj_stats(x_j)
     assert abs(rmse_i - rmse_j) < 1e-4
     # frames sharded over ranks: the operator is a sum over ranks (one all-reduce of 8 n bytes per CG iteration, queued by the host between two
     # launches); same LM steps, the same solution and (almost) the same CG iteration counts as on one GPU
-    with aar.Problem(ds, solver="pcg") as p:
+    with Problem(ds, solver="pcg") as p:
         x_1, rep_1 = p.lm_solve(ds.x_full)
         its_1 = p.pcg_iterations()[1]
     def solve(comm, rank):
-        with aar.Problem(ds, comm=comm, solver="pcg") as q:
+        with Problem(ds, comm=comm, solver="pcg") as q:
             xs, reps = q.lm_solve(ds.x_full)
             return xs, reps, q.pcg_iterations()[1]
     for world in (2, 3):
@@ -1124,7 +1131,7 @@ def test_deterministic_mode_with_two_ranks():
     # fixed-order sums rank by rank, the in-process group adds the ranks' systems in rank order: two sharded runs give the same bits
     ds, g = load_golden("g1_cfg2")
     def solve(comm, rank):
-        with aar.Problem(ds, comm=comm, deterministic=True) as q:
+        with Problem(ds, comm=comm, deterministic=True) as q:
             return q.lm_solve(ds.x_full)
     a = _run_ranks(2, solve)
     b = _run_ranks(2, solve)
@@ -1154,7 +1161,7 @@ def test_randomized_shapes_in_the_optional_modes(mode):
         o = ol.Oracle(ds, optimize=opt)
         mu = float(10.0 ** rng.integers(2, 7))
         do = o.damped_solve(ds.x_full, mu, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
-        with aar.Problem(ds, optimize=opt, **kw) as p:
+        with Problem(ds, optimize=opt, **kw) as p:
             d = p.eval_damped_step(ds.x_full, mu)
             assert np.abs(d - do).max() / np.abs(do).max() < 1e-6, (mode, C, M, F, mu)
             x, rep = p.lm_solve(ds.x_full)
@@ -1164,7 +1171,7 @@ def test_randomized_shapes_in_the_optional_modes(mode):
         np.testing.assert_allclose(rep["final_err"], repo["final_err"], rtol=2e-4 if mode == "spcg" else 1e-5, err_msg=str((mode, C, M, F)))
         if k % 3 == 0 and opt == (True, True, True):
             def solve(comm, rank, ds=ds):
-                with aar.Problem(ds, comm=comm, **kw) as q:
+                with Problem(ds, comm=comm, **kw) as q:
                     return q.lm_solve(ds.x_full)
             for xs, reps in _run_ranks(2 + k % 2, solve):
                 assert abs(reps["iterations"] - rep["iterations"]) <= 1, (mode, C, M, F)
@@ -1206,7 +1213,7 @@ def test_observation_passes_wrench_form_equals_row_form(shape, monkeypatch):
         monkeypatch.setenv("AAR_PASSA_WRENCH", form[0])
         monkeypatch.setenv("AAR_PASSB_WRENCH_MERGED", "1" if form == "1b" else "0")
         for det in (False, True):
-            with aar.Problem(ds, deterministic=det, solver="direct", **kw) as p:
+            with Problem(ds, deterministic=det, solver="direct", **kw) as p:
                 x_eval = p.x_with_intrinsics(ds.x_full) if kw.get("intrinsics") else ds.x_full
                 H, B, ss = p.eval_normal_equations(x_eval)
                 d = p.eval_damped_step(x_eval, 1e2)
@@ -1220,6 +1227,6 @@ def test_observation_passes_wrench_form_equals_row_form(shape, monkeypatch):
     # the deterministic mode of the wrench form gives the same bits twice
     monkeypatch.setenv("AAR_PASSA_WRENCH", "1")
     monkeypatch.setenv("AAR_PASSB_WRENCH_MERGED", "0")
-    with aar.Problem(ds, deterministic=True, solver="direct", **kw) as p:
+    with Problem(ds, deterministic=True, solver="direct", **kw) as p:
         H, B, ss = p.eval_normal_equations(x_eval)
     assert np.array_equal(H, out["1", True][0]) and np.array_equal(B, out["1", True][1]) and ss == out["1", True][2]
