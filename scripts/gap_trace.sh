@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd); W=$1; ST=$2
 OUT=$ROOT/gpurun_out/gaps; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/t" -- python3 "$ROOT/bench.py" --workload $W --steps $ST --warmup 20 --no-cpu-baseline --no-kernel-profile > "$OUT/run.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/t" -- python3 "$ROOT/bench.py" --workload $W --steps $ST --warmup 20 --no-cpu-baseline --no-kernel-profile --no-other-workloads --no-amdahl --no-direct > "$OUT/run.log" 2>&1
 f=$(find "$OUT/t" -name '*kernel_trace.csv' | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, re, collections

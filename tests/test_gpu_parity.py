@@ -818,7 +818,8 @@ def test_cpp_mirror_constructor_init_and_solver_seam(tmp_path):
 
 def test_unsupported_sizes_are_refused_collectively():
     # the two LDS-resident structures bound what a problem may look like: a frame that touches more than
-    # ~300 cameras+markers, more than ~560 cameras+markers in all ON THE OUTPUT-STATIONARY KERNEL -> AAR_ERR_UNSUPPORTED, never a wrong answer; on a sharded
+    # ~800 cameras+markers (pass A in wrench form keeps 25 doubles per frame-local slot in LDS: the guard is sized by the form that is launched; the row
+    # form of rounds 1-3 stopped at ~300), more than ~560 cameras+markers in all ON THE OUTPUT-STATIONARY KERNEL -> AAR_ERR_UNSUPPORTED, never a wrong answer; on a sharded
     # problem EVERY rank gets the status, also the ranks whose own frames are fine (nobody is left waiting in a collective)
     def dataset(num_markers, wide_frame):
         ds = aar.Dataset()
@@ -843,8 +844,16 @@ def test_unsupported_sizes_are_refused_collectively():
         ds.optimize_cam_intrinsics = False
         return ds
     with pytest.raises(aar.AarError) as e:
-        Problem(dataset(400, 340))
+        Problem(dataset(1100, 1000))
     assert e.value.code == aar.AAR_ERR_UNSUPPORTED and "touches" in str(e.value)
+    Problem(dataset(400, 340)).close()                 # (refused until round 4, when the guard still priced the row form: 340 slots are 68 KB in wrench form)
+    os.environ["AAR_PASSA_WRENCH"] = "0"
+    try:
+        with pytest.raises(aar.AarError) as e:
+            Problem(dataset(400, 340))                 # ... and still refused when the row form is what would be launched
+        assert e.value.code == aar.AAR_ERR_UNSUPPORTED and "touches" in str(e.value)
+    finally:
+        del os.environ["AAR_PASSA_WRENCH"]
     # > ~560 cameras+markers: only the OUTPUT-STATIONARY Schur kernel keeps a row panel of all of them in LDS; the MFMA kernel
     # (the default from 96 entities) has no such panel, so the problem is fine unless that kernel is ruled out -- switched off,
     # or its dense panels over the memory budget
@@ -859,7 +868,7 @@ def test_unsupported_sizes_are_refused_collectively():
             del os.environ[knob]
     Problem(dataset(400, 280)).close()                 # inside both limits
 
-    wide = dataset(400, 340)
+    wide = dataset(1100, 1000)
     def create(comm, rank):
         try:
             Problem(wide, comm=comm).close()
@@ -1089,13 +1098,13 @@ def test_pcg_solver_mode_against_the_direct_path():
     assert np.abs(d_pcg - do).max() / np.abs(do).max() < 1e-7
     for opt in ((True, True, True), (False, True, True), (True, False, True)):      # gauge / switched-off groups are identity rows of the operator
         with Problem(ds, optimize=opt, solver="pcg") as p:
-            assert p.solver_stats()["pcg_eta"] == 0.1
+            assert p.solver_stats()["pcg_eta"] == 5e-3 and p.solver_stats()["pcg_eta_loose"] == 0.0
             x_p, rep_p = p.lm_solve(ds.x_full)
             rmse_p, _ = p.reproj_stats(x_p)
             its = p.pcg_iterations()[1]
         if opt == (True, True, True):
-            assert abs(rmse_p - rmse_d) < 1e-4 and abs(rmse_p - rmse_d) < 1e-5
-            assert rep_p["iterations"] <= rep_d["iterations"] + 2 and 0 < its < 40 * rep_p["iterations"]
+            assert abs(rmse_p - rmse_d) < 1e-6
+            assert rep_p["iterations"] <= rep_d["iterations"] + 1 and 0 < its < 60 * rep_p["iterations"]
         else:
             with Problem(ds, optimize=opt) as q:
                 x_q, _ = q.lm_solve(ds.x_full)
@@ -1124,7 +1133,7 @@ def test_pcg_solver_mode_against_the_direct_path():
             assert reps["iterations"] == rep_1["iterations"] and abs(its - its_1) <= 0.05 * its_1
             np.testing.assert_allclose([t["err"] for t in reps["trace"]], [t["err"] for t in rep_1["trace"]], rtol=1e-4)
             assert abs(reps["final_err"] - rep_1["final_err"]) < 2e-5 * rep_1["final_err"]     # (1.2e-6 seen = 2.5e-7 px of RMSE: an inexact solve stopped one iteration apart)
-            np.testing.assert_allclose(xs, x_1, atol=1e-5)
+            np.testing.assert_allclose(xs, x_1, atol=3e-5)      # (two inexact runs stopped an iteration apart: the scale of the forcing term's own effect on the poses)
 
 
 def test_deterministic_mode_with_two_ranks():
