@@ -225,6 +225,7 @@ struct aar_problem {
     unsigned long long pcg_seq = 0;
     int spec_chol_blk = -1;            // block set whose S a speculative factorisation has consumed (-1: none pending)
     double spec_chol_mu = -1;
+    double spec_chol_eta = 0;          // ... and the forcing term it was solved to (inexact solvers: a speculative solve is only consumed by a try that wants the same)
     hipStream_t stream2 = nullptr;     // pass B of the trial point runs here, beside the speculative Schur complement
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = false;              // AAR_OVERLAP=1: pass B of the trial point on a second stream beside the Schur complement
@@ -629,7 +630,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     const int cur = pb->cur, tr = 1 - cur;
     bool chol_done = false;
     if (pb->spec_chol_blk >= 0) {   // a factorisation was queued ahead of the host's decision (multi-GPU, see aar_problem::spec_chol)
-        if (pb->spec_chol_blk == cur && pb->spec_chol_mu == mu && pb->schur_mu == mu && pb->s_reduced) {
+        if (pb->spec_chol_blk == cur && pb->spec_chol_mu == mu && pb->schur_mu == mu && pb->s_reduced && (!P.use_spcg || pb->spec_chol_eta == P.pcg_eta_now)) {
             chol_done = true;       // the step was accepted with the predicted damping: this try's factorisation is already running
         } else {
             // rejected (the trial's block set is rebuilt from scratch) or accepted with another damping (s_reduced: the system is
@@ -791,6 +792,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
             else (void)launch_chol(P, tr, mu * 0.33, pb->stream);
             pb->spec_chol_blk = tr;
             pb->spec_chol_mu = mu * 0.33;
+            pb->spec_chol_eta = P.pcg_eta_now;   // (a forcing SEQUENCE may switch to the tight term for the next try: that try then solves again)
             pb->launches += 3 * P.nT;
         }
     } else {
@@ -1226,12 +1228,19 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         const bool spcg_ok = spcg_fits(P.nT) && P.n_pad / 6 <= cus;   // one wavefront per entity, every one of them resident
         int solver = so.solver;
         if (solver == AAR_SOLVER_AUTO) {
-            // measured on MI355X (profiles/r04_auto_crossover.txt): from ~96 shared entities on the Schur complement itself is the
-            // largest kernel of a step and CG through the frame blocks, which never forms it, wins; below, CG on the explicit
-            // complement replaces the LDL^T chain; a system neither fits takes the direct chain
-            if (A >= 96 && pcg_ok) solver = AAR_SOLVER_PCG;
-            else if (spcg_ok && P.nT >= 2) solver = AAR_SOLVER_SPCG;   // (one tile: the direct chain is a single 25 us launch, about what 10 CG iterations cost)
-            else if (P.nT >= 2 && pcg_ok) solver = AAR_SOLVER_PCG;
+            // Measured on MI355X at the default forcing terms (profiles/r05_auto_crossover.txt; scripts/dev/auto_crossover.py):
+            //  * one tile of unknowns (up to 16 cameras + markers): the direct chain is a single 25-us launch -- about what 10 CG iterations cost;
+            //  * CG on the EXPLICIT Schur complement (SPCG) beats both the LDL^T chain and the CG through the frame blocks wherever it fits (up to 224 shared
+            //    entities), 48 .. 216 entities x 500 frames: 1.6x .. 1.4x the direct chain, 3.2x .. 1.1x PCG;
+            //  * PCG never forms the complement: its step costs (CG iterations) x (a pass over the frames' W blocks), SPCG's one Schur complement (work ~ slots x
+            //    slots-per-frame) + CG iterations of ~1.7 us.  PCG overtakes on long sequences of frames that each see many entities: measured crossovers at
+            //    ~100 k (entity, frame) incidences for 122 per frame (216 entities), ~230 k for 92 (160 entities), beyond 320 k for 64 (112 entities) -- fitted by
+            //    incidences x (incidences per frame - 55) >= 7e6.  (Per rank: a sharded problem's ranks see their own frames only.)
+            const double kf_avg = P.F > 0 ? (double)P.total_slots / (double)P.F : 0.0;
+            const bool pcg_pays = A >= 96 && pcg_ok && (double)P.total_slots * (kf_avg - 55.0) >= 7e6;
+            if (P.nT < 2) solver = AAR_SOLVER_DIRECT;
+            else if (spcg_ok && !pcg_pays) solver = AAR_SOLVER_SPCG;
+            else if (pcg_ok) solver = AAR_SOLVER_PCG;
             else solver = AAR_SOLVER_DIRECT;
         }
         pb->solver = solver;
