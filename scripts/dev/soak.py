@@ -1,4 +1,6 @@
-"""Scratch (GPU): soak of the fence-free hand-overs -- thousands of solves at 1-, 2-, 3-, 4- and 14-tile systems (bs rider, chained back-substitution), of the
+"""GPU soak.  `python scripts/dev/soak.py --suite [N]`: N (default 30) back-to-back runs of the GPU tests that move large blocks between host and device (Initializer, track(),
+dense normal equations, residual vectors, the primitives pin) with AAR_ABORT_BACKTRACE set: zero failures, zero runtime aborts expected now that every transfer goes through
+page-locked staging (csrc/hostcopy.h; round 4 saw "write access to a read-only page" about once per six suite runs).  Without --suite: soak of the fence-free hand-overs -- thousands of solves at 1-, 2-, 3-, 4- and 14-tile systems (bs rider, chained back-substitution), of the
 PCG grid hand-overs and of the wavefront-to-wavefront hand-overs of the CG on the explicit system (solver spcg: sentinel records, same-XCD placement); every
 solve must land on the same final error (to the atomics' noise) in the same number of iterations, and no spcg solve may fall back."""
 import os, sys, time
@@ -6,6 +8,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [os.path.join(ROOT, "automatic-ar_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 import aar
+if "--suite" in sys.argv:
+    import subprocess
+    k = sys.argv.index("--suite")
+    n = int(sys.argv[k + 1]) if len(sys.argv) > k + 1 else 30
+    bt = "/tmp/aar_abort_backtrace.txt"
+    if os.path.exists(bt):
+        os.remove(bt)
+    env = dict(os.environ, AAR_ABORT_BACKTRACE=bt)
+    sel = "initializer or track or normal_eq or residual_rows or damped or primitives or undistort or ippe or vote or full_size"
+    fails, t0 = 0, time.time()
+    for i in range(n):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "-m", "gpu", "-k", sel, "-x", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env)
+        tail = (r.stdout.strip().splitlines() or ["?"])[-1]
+        print("run %2d: rc %d  %s" % (i + 1, r.returncode, tail), flush=True)
+        if r.returncode != 0:
+            fails += 1
+            print(r.stdout[-1500:], r.stderr[-500:], flush=True)
+    aborts = os.path.getsize(bt) if os.path.exists(bt) else 0
+    print("SUITE SOAK: %d runs, %d failed, runtime aborts recorded: %s (%d bytes of backtraces)  [%.0f s]" % (n, fails, "none" if aborts == 0 else "YES", aborts, time.time() - t0))
+    if aborts:
+        print(open(bt).read()[-3000:])
+    sys.exit(1 if (fails or aborts) else 0)
 bad = 0
 for label, kw, reps, env in (("1 tile (cfg2)", dict(cfg=2), 1500, {}), ("3 tiles (cfg3)", dict(cfg=3), 1500, {}), ("2 tiles", dict(cfg=3, num_cams=4, num_markers=20, num_frames=60), 800, {}),
                              ("4 tiles (intr)", dict(cfg=3, intr=True), 500, {}), ("5 tiles", dict(cfg=3, num_cams=4, num_markers=62, num_frames=40), 500, {}),
@@ -13,11 +37,12 @@ for label, kw, reps, env in (("1 tile (cfg2)", dict(cfg=2), 1500, {}), ("3 tiles
                              ("spcg cfg3", dict(cfg=3), 3000, {"AAR_SOLVER": "spcg"}), ("spcg cfg4", dict(cfg=4), 600, {"AAR_SOLVER": "spcg"}), ("spcg 2 tiles", dict(cfg=3, num_cams=4, num_markers=20, num_frames=60), 1500, {"AAR_SOLVER": "spcg"}),
                              ("spcg 4 tiles (intr)", dict(cfg=3, intr=True), 800, {"AAR_SOLVER": "spcg"}), ("spcg cfg3, all XCDs", dict(cfg=3), 1000, {"AAR_SOLVER": "spcg", "AAR_SPCG_SPREAD": "1"}),
                              ("spcg 14 tiles (cfg5)", dict(cfg=5), 10, {"AAR_SOLVER": "spcg"})):
-    for k, v in env.items(): os.environ[k] = v
+    for k, v in env.items():
+        if k != "AAR_SOLVER": os.environ[k] = v
     cfg = kw.pop("cfg"); intr = kw.pop("intr", False)
     ds = aar.synth(cfg, **kw)
     t0 = time.time()
-    with aar.Problem(ds, intrinsics=intr) as p:
+    with aar.Problem(ds, intrinsics=intr, solver=env.get("AAR_SOLVER", "direct")) as p:
         x0 = p.x_with_intrinsics(ds.x_full) if intr else ds.x_full
         x, rep = p.lm_solve(x0)
         ref_err, ref_it = rep["final_err"], rep["iterations"]
@@ -33,6 +58,6 @@ for label, kw, reps, env in (("1 tile (cfg2)", dict(cfg=2), 1500, {}), ("3 tiles
         st = p.solver_stats()
         if st["fallbacks"]:
             print("  (fall-backs to the direct chain: %d in %d CG solves)" % (st["fallbacks"], st["solves"]), flush=True)
-    for k in env: os.environ.pop(k)
+    for k in env: os.environ.pop(k, None)
     print("%-16s %5d solves x %d iterations: worst relative deviation of the final error %.2e  (%.1f s)" % (label, reps * int(os.environ.get("SOAK_X", "1")), ref_it, worst, time.time() - t0), flush=True)
 print("BAD", bad)
