@@ -17,6 +17,8 @@ for w in 3 5; do
 done
 NAMES="bench_cfg3_driver_flags bench_cfg3_direct bench_cfg5_direct bench_cfg5_spcg bench_cfg3_pcg bench_cfg5_pcg bench_cfg3_intrinsics bench_cfg5_intrinsics bench_cfg3_single_rank_rccl bench_cfg3_deterministic bench_cfg5_deterministic"
 [ -f $C/bench_cfg3_deterministic.json ] || NAMES=$(echo $NAMES | sed "s/ bench_cfg3_deterministic bench_cfg5_deterministic//")
+[ -f $C/bench_cfg5_pcg.json ] || NAMES=$(echo $NAMES | sed "s/ bench_cfg5_pcg//")
+[ -f $C/bench_cfg3_round4_forcing_sequence.json ] && NAMES="$NAMES bench_cfg3_round4_forcing_sequence"
 [ -f $C/bench_cfg3_driver_flags_repeats.txt ] && cp $C/bench_cfg3_driver_flags_repeats.txt profiles/${R}_bench_cfg3_driver_flags_repeats.txt
 for f in $NAMES; do cp $C/$f.json profiles/${R}_$f.json; done
 python - <<PY

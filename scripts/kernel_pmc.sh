@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/kpmc; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
 for grp in "MfmaUtil" "VALUBusy" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/$tag" -- python3 "$ROOT/bench.py" --workload $W --steps $ST --warmup 4 --no-cpu-baseline --no-kernel-profile --no-amdahl --no-direct > "$OUT/$tag.log" 2>&1
+  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/$tag" -- python3 "$ROOT/bench.py" --workload $W --steps $ST --warmup 4 --no-cpu-baseline --no-kernel-profile --no-amdahl --no-direct --no-other-workloads > "$OUT/$tag.log" 2>&1
   f=$(find "$OUT/$tag" -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python3 - "$f" "$K" <<'PY'
 import csv, sys, collections

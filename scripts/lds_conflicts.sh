@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd); W=$1; ST=$2
 OUT=$ROOT/gpurun_out/ldsc; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
-timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/p" -- python3 "$ROOT/bench.py" --workload $W --steps $ST --warmup 4 --no-cpu-baseline --no-kernel-profile > "$OUT/run.log" 2>&1
+timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/p" -- python3 "$ROOT/bench.py" --workload $W --steps $ST --warmup 4 --no-cpu-baseline --no-kernel-profile --no-other-workloads > "$OUT/run.log" 2>&1
 f=$(find "$OUT/p" -name '*counter_collection.csv' | head -1)
 [ -n "$f" ] && python3 - "$f" <<'PY'
 import csv, sys, collections, re

@@ -12,7 +12,7 @@ for w in 3 5; do
   extra="--steps 60 --warmup 10"; [ $w = 5 ] && extra="--steps 12 --warmup 3"
   for c in VALUBusy $MF; do
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/w${w}_$c" -- \
-      python3 "$ROOT/bench.py" --workload $w $extra --no-cpu-baseline --no-kernel-profile > "$OUT/w${w}_$c.log" 2>&1
+      python3 "$ROOT/bench.py" --workload $w $extra --no-cpu-baseline --no-kernel-profile --no-other-workloads > "$OUT/w${w}_$c.log" 2>&1
   done
 done
 find "$OUT" -name '*kernel_trace.csv' -delete; find "$OUT" -name '*agent_info.csv' -delete
