@@ -209,11 +209,23 @@ def kernel_profile(problem, ds, workload, x0, steps, params, world, intrinsics=F
     F, n_pad = ds.num_frames, ((6 * A + 95) // 96) * 96
     pcg0 = problem.pcg_iterations()[1]
     problem.set_kernel_profiling(True)
-    done, _, _, _ = run_steps(problem, x0, steps, params)
-    kt = problem.kernel_times()
+    # in up to eight chunks: a kernel's average is the MEDIAN of its per-chunk averages -- the boxes of this pool stall for tens of milliseconds once in a while
+    # (seen: one 75-ms and one 400-ms bracket in 1000-step passes), and one such bracket would otherwise be some kernel's "average"
+    n_chunks = max(1, min(8, steps // 15))
+    done, prev, per_chunk = 0, {}, {}
+    for c in range(n_chunks):
+        d, _, _, _ = run_steps(problem, x0, steps // n_chunks + (1 if c < steps % n_chunks else 0), params)
+        done += d
+        kt = problem.kernel_times()
+        for k, (sec, cnt) in kt.items():
+            s0, c0 = prev.get(k, (0.0, 0))
+            if cnt > c0:
+                per_chunk.setdefault(k, []).append((sec - s0) / (cnt - c0))
+        prev = kt
     problem.set_kernel_profiling(False)
     pcg_total = problem.pcg_iterations()[1] - pcg0
-    kernels = {k: {"total_ms": 1e3 * s, "launches": c, "avg_us": (1e6 * s / c if c else None)} for k, (s, c) in kt.items() if c}
+    med = lambda v: sorted(v)[len(v) // 2] if len(v) % 2 else 0.5 * (sorted(v)[len(v) // 2 - 1] + sorted(v)[len(v) // 2])
+    kernels = {k: {"total_ms": 1e3 * med(per_chunk[k]) * c, "launches": c, "avg_us": 1e6 * med(per_chunk[k]), "avg_us_mean": 1e6 * s / c} for k, (s, c) in kt.items() if c}
     dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
     n_loc = problem.local_obs
     merged = "k_passB" not in kernels                      # both observation passes ride in k_passA's launch
