@@ -82,28 +82,41 @@ def test_amdahl_object_and_kernel_models():
 
 
 def test_committed_bench_lines_keep_the_contract():
-    # profiles/r04_bench_cfg{3,5}.json are bench.py's own lines from the GPU box (scripts/collect_profiles.sh, then scripts/collect_bench_lines.sh once the PMC
-    # fold exists): the fields the driver and the judge read must be there, with the metric of BASELINE.json, the roofline of the dominant kernel with its PMC
-    # traffic, the CPU baseline beside it, and -- the default solver being AUTO -- what it resolved to and the direct solver's figures on the same problem
+    # profiles/r05_bench_cfg{3,5}.json and r05_bench_cfg3_driver_flags.json are bench.py's own lines from the GPU box (scripts/collect_profiles.sh, then scripts/collect_bench_lines.sh
+    # once the PMC fold exists): the fields the driver and the judge read must be there, with the metric of BASELINE.json, the roofline of the dominant kernel with its PMC traffic, the CPU
+    # baseline beside it, what the library's DEFAULT options resolved to, and the direct solver's figures -- error AND poses -- on the same problem
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    for name, workload, solver in (("r04_bench_cfg3.json", "8-cam/40-marker/500-frame", "spcg"), ("r04_bench_cfg5.json", "16-cam/200-marker/5000-frame", "pcg")):
+    for name, workload, solver in (("r05_bench_cfg3.json", "8-cam/40-marker/500-frame", "spcg"), ("r05_bench_cfg5.json", "16-cam/200-marker/5000-frame", "pcg")):
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-                  "roofline", "cpu_baseline", "amdahl", "final_rmse_px", "direct_it_per_s", "rmse_delta_vs_direct_px", "lm_iterations_to_stop", "solver_stats"):
+                  "roofline", "cpu_baseline", "amdahl", "final_rmse_px", "direct_it_per_s", "rmse_delta_vs_direct_px", "pose_delta_vs_direct", "lm_iterations_to_stop", "solver_stats"):
             assert k in d, (name, k)
         assert d["metric"].startswith("LM iterations/sec") and base["metric"].startswith("LM iterations/sec")
         assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
         assert workload in d["config"]["workload"] and "model" not in d["config"]
-        assert d["config"]["solver"] == "auto" and d["config"]["solver_resolved"] == solver == d["solver_stats"]["solver"]
+        assert d["config"]["solver"].startswith("library default") and d["config"]["solver_resolved"] == solver == d["solver_stats"]["solver"]
+        assert d["solver_stats"]["pcg_eta_loose"] == 0.0 and d["solver_stats"]["env_overrides"] == 0
         assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
-        assert d["rmse_delta_vs_direct_px"] < 1e-5 and d["lm_iterations_to_stop"] == d["direct"]["lm_iterations_to_stop"]
+        assert d["rmse_delta_vs_direct_px"] < 1e-6 and d["lm_iterations_to_stop"] == d["direct"]["lm_iterations_to_stop"]
+        assert max(d["pose_delta_vs_direct"].values()) < 1e-5                      # the default path's final poses as transforms against the direct solver's
         r = d["roofline"]
         assert r["bound"] in ("hbm", "fp64_valu", "fp64_mfma", "latency") and r["kernel"] in r["per_kernel"]
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] is not None and r["traffic"] > 0
-    d3 = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg3.json")))
+    d5 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg5.json")))["roofline"]
+    assert d5["kernel"] == "k_pcg" and d5["utilisation"]["frac"] > 10 * d5["frac"]            # k_pcg twice: its own traffic model (utilisation) and SURVEY 8d's algorithmic fraction
+    d3 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg3.json")))
     assert set(d3["amdahl"]["bound_at"]) == {"1", "2", "4", "8"} and d3["amdahl"]["bound_at"]["1"] == 1.0
     cb = d3["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+    # the driver's command (--gpus 1 --steps 20 --warmup 5): configs 4 and 5 ride in the same line
+    dd = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg3_driver_flags.json")))
+    assert dd["steps"] == 20 and dd["warmup"] == 5 and set(dd["other_workloads"]) == {"4", "5"}
+    for w, sol in (("4", "spcg"), ("5", "pcg")):
+        o = dd["other_workloads"][w]
+        for k in ("value", "ms_per_step", "solver_resolved", "cg_iterations_per_lm_step", "final_rmse_px", "rmse_delta_vs_direct_px", "pose_delta_vs_direct", "iteration_hbm", "roofline", "direct"):
+            assert k in o, (w, k)
+        assert o["solver_resolved"] == sol and o["rmse_delta_vs_direct_px"] < 1e-6 and max(o["pose_delta_vs_direct"].values()) < 1e-5
+        assert o["roofline"]["traffic"] and "fp64_valu" in o["roofline"] and 0 < o["iteration_hbm"]["frac"] < 1
     # the N > 1 line's extra workloads, as measured behind a single-rank communicator
-    sw = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg3_single_rank_rccl.json")))["scaling_workloads"]
-    assert sw["4"]["solver_resolved"] == "spcg" and sw["5"]["solver_resolved"] == "pcg" and sw["5"]["value"] > 900 and sw["4"]["amdahl"]["bound_at"]["8"] > 2.5
+    sw = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg3_single_rank_rccl.json")))["scaling_workloads"]
+    assert sw["4"]["solver_resolved"] == "spcg" and sw["5"]["solver_resolved"] == "pcg" and sw["5"]["value"] > 500 and sw["4"]["amdahl"]["bound_at"]["8"] > 1.5
