@@ -88,14 +88,14 @@ class CProblemDesc(C.Structure):
 
 class CSolverOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("solver", C.c_int32), ("deterministic", C.c_int32), ("pcg_max_it", C.c_int32),
-                ("pcg_eta", C.c_double), ("pcg_eta_loose", C.c_double), ("pcg_eta_switch", C.c_double)]
+                ("pcg_eta", C.c_double), ("pcg_eta_loose", C.c_double), ("pcg_eta_switch", C.c_double), ("pcg_abs_tol", C.c_double)]
 
 
 class CSolverStats(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("solver", C.c_int32), ("deterministic", C.c_int32), ("last_iterations", C.c_int32),
                 ("total_iterations", C.c_int64), ("solves", C.c_int64), ("fallbacks", C.c_int64), ("pcg_eta", C.c_double),
                 ("pcg_max_it", C.c_int32), ("env_overrides", C.c_int32), ("same_xcd_solves", C.c_int64), ("pcg_eta_loose", C.c_double),
-                ("pcg_eta_switch", C.c_double)]
+                ("pcg_eta_switch", C.c_double), ("pcg_abs_tol", C.c_double)]
 
 
 class CLmParams(C.Structure):
@@ -609,7 +609,7 @@ class Problem:
     """aar_problem: the bundle-adjustment problem resident on one GPU."""
 
     def __init__(self, ds, residual_mode=RES_F32, device=0, comm=None, optimize=None, with_huber=False, intrinsics=False,
-                 solver=None, deterministic=None, pcg_eta=None, pcg_max_it=None, pcg_eta_loose=None, pcg_eta_switch=None):
+                 solver=None, deterministic=None, pcg_eta=None, pcg_max_it=None, pcg_eta_loose=None, pcg_eta_switch=None, pcg_abs_tol=None):
         """intrinsics=True: Config::optimize_cam_intrinsics -- every vector ends with 9 per camera (x_with_intrinsics builds one)
         solver ("direct" | "spcg" | "pcg" | "auto"), deterministic, pcg_eta, pcg_max_it, pcg_eta_loose, pcg_eta_switch: aar_solver_options
         (None = the library's default: solver AUTO with its forcing sequence)"""
@@ -625,7 +625,7 @@ class Problem:
         d.device_id = device
         d.comm = comm.handle if comm is not None else None
         self.handle = C.c_void_p()
-        if all(v is None for v in (solver, deterministic, pcg_eta, pcg_max_it, pcg_eta_loose, pcg_eta_switch)):
+        if all(v is None for v in (solver, deterministic, pcg_eta, pcg_max_it, pcg_eta_loose, pcg_eta_switch, pcg_abs_tol)):
             _check(lib().aar_problem_create(C.byref(d), C.byref(self.handle)))
         else:
             so = CSolverOptions()
@@ -642,6 +642,8 @@ class Problem:
                 so.pcg_eta_loose = float(pcg_eta_loose)
             if pcg_eta_switch is not None:
                 so.pcg_eta_switch = float(pcg_eta_switch)
+            if pcg_abs_tol is not None:
+                so.pcg_abs_tol = float(pcg_abs_tol)
             _check(lib().aar_problem_create_ex(C.byref(d), C.byref(so), C.byref(self.handle)))
         self.full_len = lib().aar_problem_full_len(self.handle)
         self.num_vars = lib().aar_problem_num_vars(self.handle)
@@ -794,7 +796,7 @@ class Problem:
         _check(lib().aar_problem_get_solver_stats(self.handle, C.byref(st)))
         return dict(solver=SOLVER_NAMES[st.solver], deterministic=bool(st.deterministic), last_iterations=st.last_iterations,
                     total_iterations=st.total_iterations, solves=st.solves, fallbacks=st.fallbacks, pcg_eta=st.pcg_eta, pcg_max_it=st.pcg_max_it,
-                    same_xcd_solves=st.same_xcd_solves, pcg_eta_loose=st.pcg_eta_loose, pcg_eta_switch=st.pcg_eta_switch, env_overrides=st.env_overrides)
+                    same_xcd_solves=st.same_xcd_solves, pcg_eta_loose=st.pcg_eta_loose, pcg_eta_switch=st.pcg_eta_switch, pcg_abs_tol=st.pcg_abs_tol, env_overrides=st.env_overrides)
 
     def set_test_hook(self, hook, value):
         """aar_problem_set_test_hook (testing only): fault injection for the solvers' fall-back paths"""

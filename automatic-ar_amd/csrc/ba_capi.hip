@@ -1086,7 +1086,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
     if (const char *e = getenv("AAR_PCG_ETA")) if (so.pcg_eta == 0 && atof(e) > 0) { so.pcg_eta = atof(e); env_over |= AAR_ENV_PCG_ETA; }
     if (const char *e = getenv("AAR_PCG_MAX_IT")) if (so.pcg_max_it == 0 && atoi(e) > 0) { so.pcg_max_it = atoi(e); env_over |= AAR_ENV_PCG_MAX_IT; }
     if (so.solver < AAR_SOLVER_DIRECT || so.solver > AAR_SOLVER_AUTO) return set_error(AAR_ERR_INVALID, "aar_solver_options.solver %d is not one of AAR_SOLVER_*", so.solver);
-    if (so.pcg_eta < 0 || so.pcg_max_it < 0 || so.pcg_eta_loose < 0 || so.pcg_eta_switch < 0) return set_error(AAR_ERR_INVALID, "aar_solver_options: negative pcg_eta / pcg_eta_loose / pcg_eta_switch / pcg_max_it");
+    if (so.pcg_eta < 0 || so.pcg_max_it < 0 || so.pcg_eta_loose < 0 || so.pcg_eta_switch < 0 || so.pcg_abs_tol < 0) return set_error(AAR_ERR_INVALID, "aar_solver_options: negative pcg_eta / pcg_eta_loose / pcg_eta_switch / pcg_abs_tol / pcg_max_it");
     const int C = d->num_cams, M = d->num_markers, Fg = d->num_frames;
     const int64_t Ng = d->num_obs;
     if (C < 1 || M < 1 || Fg < 0 || Ng < 0) return set_error(AAR_ERR_INVALID, "aar_problem_create: bad sizes");
@@ -1259,6 +1259,9 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         else if (so.pcg_eta == 0 && (P.use_pcg || P.use_spcg)) P.pcg_eta_loose = P.use_pcg ? PCG_ETA_LOOSE_DEFAULT : SPCG_ETA_LOOSE_DEFAULT;   // (0: none)
         if (const char *e = getenv("AAR_PCG_ETA_LOOSE")) if (so.pcg_eta_loose == 0) P.pcg_eta_loose = atof(e);
         if (P.pcg_eta_loose <= P.pcg_eta) P.pcg_eta_loose = 0.0;   // (no sequence: one forcing term throughout)
+        P.pcg_abs_tol = P.use_pcg ? PCG_ABS_TOL_DEFAULT : SPCG_ABS_TOL_DEFAULT;
+        if (so.pcg_abs_tol > 0) P.pcg_abs_tol = so.pcg_abs_tol;
+        else if (const char *e = getenv("AAR_PCG_ABS_TOL")) P.pcg_abs_tol = atof(e);
         if (so.pcg_eta_switch > 0) P.pcg_eta_switch = so.pcg_eta_switch;
         else if (const char *e = getenv("AAR_PCG_ETA_SWITCH")) P.pcg_eta_switch = atof(e);
         P.pcg_eta_now = P.pcg_eta;
@@ -2137,6 +2140,7 @@ int aar_problem_get_solver_stats(aar_problem *pb, aar_solver_stats *out) {
     st.pcg_max_it = pb->P.use_spcg ? pb->P.spcg_max_it : pb->P.pcg_max_it;
     st.pcg_eta_loose = pb->P.pcg_eta_loose;
     st.pcg_eta_switch = pb->P.pcg_eta_switch;
+    st.pcg_abs_tol = pb->P.pcg_abs_tol;
     st.env_overrides = pb->env_overrides;
     st.fallbacks = pb->spcg_fallbacks;
     if (pb->P.use_pcg || pb->P.use_spcg) {

@@ -17,6 +17,7 @@ constexpr int SPCG_MAX_IT = 64, SPCG_BUFS = SPCG_MAX_IT + 2, SPCG_MAX_NT = 14;
 // Measured, uniform eta -> largest pose difference against the direct run (config 3, SPCG): 0.02 -> 2e-4, 3e-3 -> 2e-5, 1e-3 -> 1e-5, 3e-4 -> 2e-6, 1e-4 -> 6e-7;
 // (config 5, PCG): 0.1 -> 9e-5, 0.03 -> 2e-5, 0.01 -> 5e-6, 3e-3 -> 1e-6.  A loose-then-tight SEQUENCE buys nothing at equal cost: the early steps' errors along
 // weakly determined directions are never corrected by the later ones (round 4's 0.1 -> 0.02 sequence: 6e-4), so the default is ONE forcing term.
+constexpr double SPCG_ABS_TOL_DEFAULT = 2e-5, PCG_ABS_TOL_DEFAULT = 5e-5;   // (measured: free for SPCG at configs 3-4; PCG at config 5: 5e-5 +3 % CG iterations, 2e-5 +15 %)
 constexpr double SPCG_ETA_DEFAULT = 3e-4, SPCG_ETA_LOOSE_DEFAULT = 0.0, PCG_ETA_DEFAULT = 5e-3, PCG_ETA_LOOSE_DEFAULT = 0.0;
 inline int spcg_stride(int n_pad) { return 8 * (n_pad / 6); }   // doubles per hand-over buffer: one 64-byte record per entity
 
@@ -102,6 +103,10 @@ struct DeviceProblem {
     // accepted step took more than pcg_eta_switch of the error away) the inner solve stops at pcg_eta_loose, afterwards at pcg_eta -- the steps that decide
     // the stopping rule are solved as tightly as before (profiles/r04_pcg_eta_sweep.txt).  pcg_eta_now is what the next launch uses.
     double pcg_eta_loose = 0.0, pcg_eta_switch = 0.01, pcg_eta_now = 0.1;
+    // ... and an ABSOLUTE one beside the relative forcing term (both must hold): the error an inner solve leaves in the step, in the units of the pose vector (radians / metres).
+    // The relative term alone lets a solve stop while the step is still large in absolute terms -- far starts, a tiny initial damping (tau = 1e-6: poses 4e-3 off): there the
+    // absolute term keeps the CG going (or sends the try to the direct chain through the iteration cap).  Both solvers: r^T M^-1 r <= eps^2 mu (M = the block-Jacobi preconditioner).
+    double pcg_abs_tol = SPCG_ABS_TOL_DEFAULT;
     int pcg_n_items = 0;                  // work items of the entity-side passes (pcg_kernels.hip): ranges of one entity's incidences in pair_rec
     int32_t *pcg_it_ent = nullptr, *pcg_it_begin = nullptr, *pcg_it_end = nullptr, *pcg_ent_item_start = nullptr;
     double *pcg_ws = nullptr;             // items' shares [n_items][28] | t [6F]

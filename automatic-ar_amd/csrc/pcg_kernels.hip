@@ -33,6 +33,7 @@ struct PcgArgs {
     const int32_t *up_start, *up_ent;            // entity -> the other entities whose block of U can be non-zero (k_pcgf's operator; the others walk all of U)
     int A, F, n_pad;
     double mu, eta2;                             // damping; eta^2
+    double abs2;                                 // eps^2 mu: the ABSOLUTE stopping threshold on r^T M^-1 r, as in k_spcg (the bound |A^-1 r| <= |r| / mu on r^T r is 1000x too careful: measured)
     int max_it;
     // work space
     double *part;                                // [n_items][28] the items' shares (27 values in the set-up, 6 per iteration)
@@ -215,7 +216,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
 
     int it_cg = 0;
     double rr = bb;
-    while (it_cg < a.max_it && rr > a.eta2 * bb && bb > 0.0) {
+    while (it_cg < a.max_it && (rr > a.eta2 * bb || rz > a.abs2) && bb > 0.0) {
         // ---- frame pass: t_f = (V_f + mu I)^-1 (W_f^T p), one wavefront per frame ----
         for (int f = wg * (PCG_THREADS / 64) + wave; f < a.F; f += G * (PCG_THREADS / 64)) {
             const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
@@ -586,7 +587,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *_
 
     int it_cg = 0;
     double rr = bb;
-    while (it_cg < a.max_it && rr > a.eta2 * bb && bb > 0.0) {
+    while (it_cg < a.max_it && (rr > a.eta2 * bb || rz > a.abs2) && bb > 0.0) {
         double *ygc = yg + (size_t)(it_cg % 3) * a.n_pad, *ygn = yg + (size_t)((it_cg + 1) % 3) * a.n_pad;
         for (int i = wg * PCG_THREADS + tid; i < n; i += G * PCG_THREADS) st_agent(ygn + i, 0.0);
         pcgf_operator(a, p, yacc, red, wg, G);
@@ -851,7 +852,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter(const PcgDistArgs d) 
         itc += 1.0;
         __syncthreads();
     }
-    const bool done = !(itc < (double)a.max_it && rr > a.eta2 * bb && bb > 0.0);
+    const bool done = !(itc < (double)a.max_it && (rr > a.eta2 * bb || rz > a.abs2) && bb > 0.0);
     if (done || d.last) {
         if (wg == 0) {
             for (int i = tid; i < n; i += PCG_THREADS) a.x_out[i] = x[i];
@@ -1076,7 +1077,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
         itc += 1.0;
         __syncthreads();
     }
-    const bool done = !(itc < (double)a.max_it && rr > a.eta2 * bb && bb > 0.0);
+    const bool done = !(itc < (double)a.max_it && (rr > a.eta2 * bb || rz > a.abs2) && bb > 0.0);
     if (done || d.last) {
         if (wg == 0) {
             for (int i = tid; i < n; i += PCG_THREADS) a.x_out[i] = x[i];
@@ -1125,7 +1126,7 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.U = b.S; a.g0 = b.g0; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf;
     a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed; a.up_start = P.up_start; a.up_ent = P.up_ent;
     a.it_ent = P.pcg_it_ent; a.it_begin = P.pcg_it_begin; a.it_end = P.pcg_it_end; a.ent_item_start = P.pcg_ent_item_start; a.n_items = P.pcg_n_items;
-    a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.max_it = P.pcg_max_it;
+    a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.abs2 = P.pcg_abs_tol * P.pcg_abs_tol * mu; a.max_it = P.pcg_max_it;
     a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
     a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
@@ -1149,7 +1150,7 @@ static PcgDistArgs pcgd_args(const DeviceProblem &P, int which, double mu) {
     a.U = b.S; a.g0 = b.g0; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf;
     a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.pair_rec = P.pair_rec; a.ent_fixed = P.ent_fixed; a.up_start = P.up_start; a.up_ent = P.up_ent;
     a.it_ent = P.pcg_it_ent; a.it_begin = P.pcg_it_begin; a.it_end = P.pcg_it_end; a.ent_item_start = P.pcg_ent_item_start; a.n_items = P.pcg_n_items;
-    a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.max_it = P.pcg_max_it;
+    a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.abs2 = P.pcg_abs_tol * P.pcg_abs_tol * mu; a.max_it = P.pcg_max_it;
     a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
     a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;

@@ -60,6 +60,7 @@ struct SpcgArgs {
     const int32_t *ent_fixed;
     int n, n_pad;
     double mu, eta2;
+    double abs2_mu;                   // eps^2 mu: the ABSOLUTE stopping threshold on r^T M^-1 r (along a weakly determined direction M ~ mu, so |A^-1 r|^2 ~ r^T M^-1 r / mu <= eps^2)
     int max_it;
     double *ws;                       // [2][SPCG_BUFS][stride] hand-over records, one of 8 doubles (64 bytes) per entity: m [6] | share of (r,u) | share of (w,u)
     long long set_len;                // doubles per set
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             SP_STAMP(10 + 4 * it);
             if (it == 0) { SP_VAL(410, gam); SP_VAL(411, dlt); SP_VAL(412, m); SP_VAL(413, w); }
             if (dead) break;
-            if (gam <= a.eta2 * bb) { status = 1; break; }
+            if (gam <= a.eta2 * bb && gam <= a.abs2_mu) { status = 1; break; }
             if (it >= a.max_it) { status = 2; break; }
             const double nn = matvec();
             SP_STAMP(11 + 4 * it);
@@ -352,7 +353,7 @@ bool launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st, i
     const DeviceProblem::Blocks &b = P.blk[which];
     SpcgArgs a;
     a.S = b.S; a.rhs = b.rhs; a.g0 = b.g0; a.ent_fixed = P.ent_fixed; a.n = P.n; a.n_pad = P.n_pad;
-    a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.max_it = std::min(P.spcg_max_it, SPCG_MAX_IT);
+    a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.abs2_mu = P.pcg_abs_tol * P.pcg_abs_tol * mu; a.max_it = std::min(P.spcg_max_it, SPCG_MAX_IT);
     a.ws = P.spcg_ws; a.stride = spcg_stride(P.n_pad); a.set_len = (long long)SPCG_BUFS * a.stride; a.parity = P.spcg_parity;
     a.x_out = P.delta_s; a.iters = P.spcg_iters; a.flags = P.flags; a.test_drop = P.spcg_test_drop;
     a.spread = P.spcg_spread;

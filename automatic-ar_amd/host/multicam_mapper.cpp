@@ -284,6 +284,7 @@ int MultiCamMapper::ensure_problem() {
     so.pcg_max_it = solver_options_.pcg_max_it;
     so.pcg_eta_loose = solver_options_.pcg_eta_loose;
     so.pcg_eta_switch = solver_options_.pcg_eta_switch;
+    so.pcg_abs_tol = solver_options_.pcg_abs_tol;
     int rc = aar_problem_create_ex(&d, &so, &problem_);
     if (!rc && with_huber_) rc = aar_problem_set_huber_delta(problem_, hubberDelta);
     return rc;

@@ -370,6 +370,7 @@ class MultiCamMapper {
         int pcg_max_it = 0;               // iteration cap of an inner CG solve (0: the solver's default)
         double pcg_eta_loose = 0.0;       // forcing term of the early LM steps (0: default; <= pcg_eta: no sequence)
         double pcg_eta_switch = 0.0;      // "early" = the last accepted step took more than this share of the error away (0: default 0.01)
+        double pcg_abs_tol = 0.0;         // absolute tolerance of an inner solve in pose units, beside the relative one (0: default, SPCG 2e-5 / PCG 5e-5)
     };
     void set_solver_options(const SolverOptions &o);
     const SolverOptions &get_solver_options() const { return solver_options_; }

@@ -525,6 +525,7 @@ def main():
                     "through the frame blocks, no Schur complement, csrc/pcg_kernels.hip)")
     ap.add_argument("--pcg-eta", type=float, default=None, help="aar_solver_options.pcg_eta (forcing term of the inexact solvers; default: the library's)")
     ap.add_argument("--pcg-eta-loose", type=float, default=None, help="aar_solver_options.pcg_eta_loose (> pcg_eta: a forcing sequence, loose early / pcg_eta late; default: none)")
+    ap.add_argument("--pcg-abs-tol", type=float, default=None, help="aar_solver_options.pcg_abs_tol (absolute tolerance of an inner solve in pose units, beside the relative one)")
     ap.add_argument("--deterministic", action="store_true", help="aar_solver_options.deterministic: fixed-order sums instead of fp64 atomics (bit-identical runs)")
     ap.add_argument("--no-scaling-workloads", action="store_true", help="N > 1: skip the extra measurements of configs 4 and 5 (scaling_workloads)")
     ap.add_argument("--no-other-workloads", action="store_true", help="N = 1: skip the extra measurements of configs 4 and 5 (other_workloads)")
@@ -564,7 +565,7 @@ def main():
             dist.broadcast_object_list(uid, src=0)
         comm = aar.Comm(uid[0], world, rank, local_rank)
     problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics, solver=args.solver,
-                          deterministic=True if args.deterministic else None, pcg_eta=args.pcg_eta, pcg_eta_loose=args.pcg_eta_loose)
+                          deterministic=True if args.deterministic else None, pcg_eta=args.pcg_eta, pcg_eta_loose=args.pcg_eta_loose, pcg_abs_tol=args.pcg_abs_tol)
     # x_full of the default Config: the pose vector, then fx cx fy cy d0..d4 per camera (fill_io_vec_cam_intrinsics, :488-498)
     x0 = problem.x_with_intrinsics(ds.x_full) if args.intrinsics else ds.x_full
 
@@ -673,7 +674,7 @@ def main():
 
     # ---- N = 1: configs 4 and 5 on this GPU in the same line (the configurations with a meaningful roofline) ----
     others = None
-    if world == 1 and comm is None and not args.no_other_workloads and not args.intrinsics and args.solver is None and not args.deterministic and args.pcg_eta is None and args.pcg_eta_loose is None:
+    if world == 1 and comm is None and not args.no_other_workloads and not args.intrinsics and args.solver is None and not args.deterministic and args.pcg_eta is None and args.pcg_eta_loose is None and args.pcg_abs_tol is None:
         others = {}
         for w, (st_w, wu_w) in ((4, (90, 30)), (5, (45, 15))):
             if w != args.workload:

@@ -299,6 +299,10 @@ typedef struct aar_solver_options {
     double pcg_eta_loose;                     /* > pcg_eta: forcing term of the EARLY LM steps (a forcing sequence); 0 = none (default)            */
     double pcg_eta_switch;                    /* an LM step is "early" while the last accepted step took more than this share of the error
                                                  away; 0 = default (0.01)                                                              */
+    double pcg_abs_tol;                       /* ABSOLUTE tolerance of an inner solve beside the relative one (both must hold), in the units of the pose
+                                                 vector (radians / metres): what the inexact solve may leave out of the step along a weakly determined
+                                                 direction, measured in the preconditioner's norm (r^T M^-1 r <= tol^2 mu).  0 = default (SPCG 2e-5, PCG 5e-5); it only binds where the step is large while the damping is small (far
+                                                 starts, tau << 1): there the CG runs on, or hands the try to the direct chain at its iteration cap       */
 } aar_solver_options;
 void aar_solver_default_options(aar_solver_options *);   /* struct_size set, AUTO, not deterministic, default forcing sequence / cap */
 int aar_problem_create_ex(const aar_problem_desc *, const aar_solver_options *, aar_problem **out);
@@ -318,6 +322,7 @@ typedef struct aar_solver_stats {
     int64_t same_xcd_solves;                  /* SPCG: solves whose wavefronts all ran on one XCD (hand-overs through that XCD's L2: the fast case)   */
     double pcg_eta_loose;                     /* forcing term of the early LM steps (0: pcg_eta throughout)                            */
     double pcg_eta_switch;
+    double pcg_abs_tol;
 } aar_solver_stats;
 int aar_problem_get_solver_stats(aar_problem *, aar_solver_stats *out);
 /* TESTING ONLY: fault injection for the solvers' fall-back paths.  AAR_TEST_HOOK_SPCG_DROP: the CG wavefront of shared entity `value` never

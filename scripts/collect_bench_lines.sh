@@ -17,7 +17,7 @@ B --workload 5 --solver direct --steps 45 --warmup 15 --no-cpu-baseline > "$OUT/
 B --workload 5 --solver spcg --steps 45 --warmup 15 --no-cpu-baseline > "$OUT/bench_cfg5_spcg.json"
 B --workload 3 --solver pcg --no-cpu-baseline > "$OUT/bench_cfg3_pcg.json"
 B --workload 5 --solver pcg --steps 45 --warmup 15 --no-cpu-baseline > "$OUT/bench_cfg5_pcg.json"
-B --workload 3 --solver spcg --pcg-eta-loose 0.1 --pcg-eta 0.02 --no-cpu-baseline > "$OUT/bench_cfg3_round4_forcing_sequence.json"   # round 4's default forcing sequence, for comparison (opt-in now)
+B --workload 3 --solver spcg --pcg-eta-loose 0.1 --pcg-eta 0.02 --pcg-abs-tol 1 --no-cpu-baseline > "$OUT/bench_cfg3_round4_forcing_sequence.json"   # round 4's default forcing sequence, for comparison (opt-in now)
 B --workload 3 --intrinsics --no-cpu-baseline > "$OUT/bench_cfg3_intrinsics.json"
 B --workload 5 --intrinsics --steps 45 --warmup 15 --no-cpu-baseline > "$OUT/bench_cfg5_intrinsics.json"
 B --workload 3 --deterministic --no-cpu-baseline > "$OUT/bench_cfg3_deterministic.json"

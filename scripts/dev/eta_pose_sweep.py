@@ -59,7 +59,7 @@ def main():
                 continue
             for loose, tight in grid:
                 try:
-                    with aar.Problem(ds, solver=solver, pcg_eta=tight, pcg_eta_loose=loose if loose > 0 else tight) as p:
+                    with aar.Problem(ds, solver=solver, pcg_eta=tight, pcg_eta_loose=loose if loose > 0 else tight, pcg_abs_tol=float(os.environ.get("SWEEP_ABS_TOL", "1.0"))) as p:
                         x, rep = p.lm_solve(ds.x_full, params=prm, trace_cap=600)
                         rmse = p.reproj_stats(x)[0]
                         st = p.solver_stats()

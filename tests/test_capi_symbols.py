@@ -83,4 +83,4 @@ def test_default_solver_options_are_auto_with_one_forcing_term():
     so = aar.CSolverOptions()
     aar.lib().aar_solver_default_options(C.byref(so))
     assert so.struct_size == C.sizeof(aar.CSolverOptions) and so.solver == aar.SOLVER_AUTO and so.deterministic == 0
-    assert so.pcg_eta == 0.0 and so.pcg_eta_loose == 0.0 and so.pcg_eta_switch == 0.0 and so.pcg_max_it == 0
+    assert so.pcg_eta == 0.0 and so.pcg_eta_loose == 0.0 and so.pcg_eta_switch == 0.0 and so.pcg_abs_tol == 0.0 and so.pcg_max_it == 0

@@ -415,7 +415,7 @@ def test_solver_options_struct_is_forward_compatible_and_validated():
     aar.lib().aar_problem_desc_from_dataset(C.byref(cds), C.byref(d))
     so = aar.CSolverOptions()
     aar.lib().aar_solver_default_options(C.byref(so))
-    assert so.struct_size == C.sizeof(aar.CSolverOptions) and so.solver == aar.SOLVER_AUTO and so.deterministic == 0 and so.pcg_eta == 0.0 and so.pcg_eta_loose == 0.0
+    assert so.struct_size == C.sizeof(aar.CSolverOptions) and so.solver == aar.SOLVER_AUTO and so.deterministic == 0 and so.pcg_eta == 0.0 and so.pcg_eta_loose == 0.0 and so.pcg_abs_tol == 0.0
     h = C.c_void_p()
     so.solver, so.struct_size, so.deterministic, so.pcg_eta = aar.SOLVER_SPCG, 8, 1, 0.5      # a "short" caller: deterministic / eta lie beyond its struct
     assert aar.lib().aar_problem_create_ex(C.byref(d), C.byref(so), C.byref(h)) == 0
@@ -423,7 +423,7 @@ def test_solver_options_struct_is_forward_compatible_and_validated():
     assert aar.lib().aar_problem_get_solver_stats(h, C.byref(st)) == aar.AAR_ERR_INVALID      # the caller must say how large ITS struct is
     st.struct_size = C.sizeof(aar.CSolverStats)
     assert aar.lib().aar_problem_get_solver_stats(h, C.byref(st)) == 0
-    assert st.solver == aar.SOLVER_SPCG and st.deterministic == 0 and abs(st.pcg_eta - 3e-4) < 1e-18 and st.pcg_eta_loose == 0.0 and st.env_overrides == 0
+    assert st.solver == aar.SOLVER_SPCG and st.deterministic == 0 and abs(st.pcg_eta - 3e-4) < 1e-18 and st.pcg_eta_loose == 0.0 and st.env_overrides == 0 and st.pcg_abs_tol == 2e-5
     # a caller built against a SHORTER stats struct: nothing beyond its size is written
     buf = (C.c_uint8 * C.sizeof(aar.CSolverStats))(*([0xAB] * C.sizeof(aar.CSolverStats)))
     short = C.cast(buf, C.POINTER(aar.CSolverStats))
@@ -431,7 +431,7 @@ def test_solver_options_struct_is_forward_compatible_and_validated():
     assert aar.lib().aar_problem_get_solver_stats(h, short) == 0
     assert short.contents.solver == aar.SOLVER_SPCG and all(b == 0xAB for b in bytes(buf)[48:])
     aar.lib().aar_problem_destroy(h)
-    for bad in (dict(struct_size=0), dict(solver=7), dict(pcg_eta=-1.0), dict(pcg_max_it=-3), dict(pcg_eta_loose=-0.5), dict(pcg_eta_switch=-1.0)):
+    for bad in (dict(struct_size=0), dict(solver=7), dict(pcg_eta=-1.0), dict(pcg_max_it=-3), dict(pcg_eta_loose=-0.5), dict(pcg_eta_switch=-1.0), dict(pcg_abs_tol=-1e-6)):
         aar.lib().aar_solver_default_options(C.byref(so))
         for k, v in bad.items():
             setattr(so, k, v)
@@ -472,7 +472,8 @@ def test_forcing_sequence_is_an_option():
         xd, rd = p.lm_solve(ds.x_full)
         rmse_d = p.reproj_stats(xd)[0]
     out = {}
-    for name, kw in (("default", {}), ("sequence", dict(pcg_eta_loose=0.1, pcg_eta=0.02)), ("sequence_never", dict(pcg_eta_loose=0.1, pcg_eta=0.02, pcg_eta_switch=1e9))):
+    loose = dict(pcg_eta_loose=0.1, pcg_eta=0.02, pcg_abs_tol=1.0)      # (round 4's defaults; the absolute tolerance out of the way as well)
+    for name, kw in (("default", {}), ("sequence", loose), ("sequence_never", dict(loose, pcg_eta_switch=1e9))):
         with aar.Problem(ds, **kw) as p:
             st = p.solver_stats()
             assert st["solver"] == "spcg" and st["pcg_eta_loose"] == (0.0 if name == "default" else 0.1)
@@ -483,3 +484,26 @@ def test_forcing_sequence_is_an_option():
         assert abs(rmse - rmse_d) < 1e-5 and its == rd["iterations"] and fb == 0, (name, rmse, rmse_d, its)
     assert out["sequence"][2] < out["sequence_never"][2] < out["default"][2]
     assert out["default"][4] < POSE_BAR_OTHERS < out["sequence"][4]
+
+
+@pytest.mark.parametrize("scale,tau", [(3.0, 1.0), (1.0, 1e-6), (3.0, 1e-6)])
+def test_default_options_from_far_starts_and_tiny_initial_damping(scale, tau):
+    # The relative forcing term alone lets an inner solve stop while the step is still LARGE in absolute terms -- a start 3x further out, or tau = 1e-6 (a tiny initial
+    # damping: three Gauss-Newton-like steps through systems of condition ~1e9): what it leaves out lands in the final poses (measured without the absolute tolerance:
+    # 2e-5 at x3, 4e-3 .. 1e-2 at tau = 1e-6).  aar_solver_options.pcg_abs_tol (default 2e-5 / 5e-5, in pose units) is the second condition an inner solve has to meet:
+    # the CG runs on, or hands the try to the direct chain at its iteration cap.  Full-size config 3: same LM steps, RMSE within 1e-6 px, poses within 3e-5.
+    ds = aar.synth(3, init_scale=scale)
+    prm = aar.lm_default_params(tau=tau)
+    with aar.Problem(ds, solver="direct") as p:
+        x_d, rep_d = p.lm_solve(ds.x_full, params=prm)
+        rmse_d, _ = p.reproj_stats(x_d)
+    with aar.Problem(ds) as p:
+        assert p.solver_stats()["solver"] == "spcg" and p.solver_stats()["pcg_abs_tol"] == 2e-5
+        x, rep = p.lm_solve(ds.x_full, params=prm)
+        rmse, _ = p.reproj_stats(x)
+    assert rep["iterations"] == rep_d["iterations"] and abs(rmse - rmse_d) < 1e-6, (rep["iterations"], rep_d["iterations"], rmse, rmse_d)
+    assert max(pose_delta_max(ds, x, x_d)) < 3e-5, pose_delta_max(ds, x, x_d)
+    if tau < 1.0:      # ... and what the absolute tolerance is there for
+        with aar.Problem(ds, pcg_abs_tol=1.0) as p:
+            x_rel, _ = p.lm_solve(ds.x_full, params=prm)
+        assert max(pose_delta_max(ds, x_rel, x_d)) > 1e-4
