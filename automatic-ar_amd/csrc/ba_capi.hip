@@ -220,11 +220,16 @@ struct aar_problem {
     // fall-back, twice as many after each further one (a 505-step -with-huber run moves its damping both ways: CG gets another chance now and then);
     // aar_lm_init clears both
     int spcg_skip = 0, spcg_backoff = 0;
+    // CG iterations of the last SPCG solve of this LM run, as published with the step's scalars (-1: none yet).  Along an LM run the damping only falls and the systems only get
+    // harder: a solve that came within 20 % of the iteration cap is taken as the announcement that the next one will not fit -- that try goes to the direct chain at once,
+    // instead of through a failed CG attempt (64 .. 128 wasted iterations, the trial evaluation on a garbage step, a rebuild of the blocks)
+    int last_cg_its = -1;
     int64_t spcg_fallbacks = 0;
     double *h_pcg = nullptr;           // solver pcg with a communicator: pinned, mapped {done, iterations, -, sequence} the iteration launches publish
     unsigned long long pcg_seq = 0;
     int spec_chol_blk = -1;            // block set whose S a speculative factorisation has consumed (-1: none pending)
     double spec_chol_mu = -1;
+    bool spec_chol_by_cg = false;      // ... whether it was a CG solve (a speculative solve is only consumed by a try that takes the same solver)
     double spec_chol_eta = 0;          // ... and the forcing term it was solved to (inexact solvers: a speculative solve is only consumed by a try that wants the same)
     hipStream_t stream2 = nullptr;     // pass B of the trial point runs here, beside the speculative Schur complement
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -629,8 +634,11 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     DeviceProblem &P = pb->P;
     const int cur = pb->cur, tr = 1 - cur;
     bool chol_done = false;
+    const bool cg_near_cap = pb->last_cg_its >= 0 && 10 * pb->last_cg_its >= 8 * std::min(P.spcg_max_it, SPCG_MAX_IT);
+    const bool by_cg = P.use_spcg && !pb->force_direct && pb->spcg_skip == 0 && !cg_near_cap;
     if (pb->spec_chol_blk >= 0) {   // a factorisation was queued ahead of the host's decision (multi-GPU, see aar_problem::spec_chol)
-        if (pb->spec_chol_blk == cur && pb->spec_chol_mu == mu && pb->schur_mu == mu && pb->s_reduced && (!P.use_spcg || pb->spec_chol_eta == P.pcg_eta_now)) {
+        if (pb->spec_chol_blk == cur && pb->spec_chol_mu == mu && pb->schur_mu == mu && pb->s_reduced && pb->spec_chol_by_cg == by_cg &&
+            (!by_cg || pb->spec_chol_eta == P.pcg_eta_now)) {
             chol_done = true;       // the step was accepted with the predicted damping: this try's factorisation is already running
         } else {
             // rejected (the trial's block set is rebuilt from scratch) or accepted with another damping (s_reduced: the system is
@@ -730,7 +738,6 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     pb->s_reduced = false;      // the factorisation below consumes the system
     pb->trial_reduced = false;
     bool backsub_rode = false;
-    const bool by_cg = P.use_spcg && !pb->force_direct && pb->spcg_skip == 0;
     if (P.use_spcg && !pb->force_direct && pb->spcg_skip > 0) pb->spcg_skip--;   // CG on the explicit reduced system instead of the LDL^T chain (S stays as it is)
     if (!chol_done) {
         StageTimer t(pb, &pb->times.chol);
@@ -788,8 +795,11 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
         pb->trial_reduced = true;
         if (pb->spec_chol && !pb->stage_timers && !pb->profiling) {
             StageTimer t(pb, &pb->times.chol);
-            if (P.use_spcg && pb->spcg_skip == 0) launch_spcg(P, tr, mu * 0.33, pb->stream);
+            // (the solver the NEXT try is expected to take: this try's own CG count is not known yet, the previous one's is)
+            const bool spec_cg = P.use_spcg && pb->spcg_skip == 0 && !cg_near_cap;
+            if (spec_cg) launch_spcg(P, tr, mu * 0.33, pb->stream);
             else (void)launch_chol(P, tr, mu * 0.33, pb->stream);
+            pb->spec_chol_by_cg = spec_cg;
             pb->spec_chol_blk = tr;
             pb->spec_chol_mu = mu * 0.33;
             pb->spec_chol_eta = P.pcg_eta_now;   // (a forcing SEQUENCE may switch to the tight term for the next try: that try then solves again)
@@ -806,6 +816,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     }
     if ((rc = check_async("kernel launch"))) return rc;
     if ((rc = wait_result(pb))) return rc;
+    if (by_cg && pb->h_scal[7] >= 0.0) pb->last_cg_its = (int)pb->h_scal[7];
     if (pb->h_flags[0]) {
         (void)hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream);
         if (by_cg && (pb->h_flags[0] & (8 | 4))) {
@@ -1265,6 +1276,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         if (so.pcg_eta_switch > 0) P.pcg_eta_switch = so.pcg_eta_switch;
         else if (const char *e = getenv("AAR_PCG_ETA_SWITCH")) P.pcg_eta_switch = atof(e);
         P.pcg_eta_now = P.pcg_eta;
+        P.spcg_max_it = spcg_default_cap(P.nT);
         if (so.pcg_max_it > 0) { P.pcg_max_it = so.pcg_max_it; P.spcg_max_it = std::min(so.pcg_max_it, SPCG_MAX_IT); }
         if (P.use_pcg && !pcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_PCG keeps the CG vectors and the preconditioner of %d unknowns in LDS: too many shared entities", 6 * A);
         if (P.use_spcg && !spcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_SPCG keeps the reduced system in the registers of one wavefront per shared entity: %d unknowns are too many (limit %d, and at most %d entities)", 6 * A, 96 * SPCG_MAX_NT, cus);
@@ -1778,6 +1790,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     pb->schur_mu = -1;
     pb->s_reduced = pb->trial_reduced = false;
     pb->spcg_skip = pb->spcg_backoff = 0;   // (a one-off solve: the problem's own solver gets its chance whatever an earlier LM run ended with)
+    pb->last_cg_its = -1;
     pb->P.pcg_eta_now = pb->P.pcg_eta;      // (... and the forcing term itself, not the LM's forcing sequence)
     if ((rc = damped_try_fb(pb, mu, false))) return rc == TRY_NOT_POSITIVE_DEFINITE ? AAR_ERR_NUMERIC : rc;
     pb->lm_ready = false;
@@ -1802,6 +1815,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     pb->trial_points = 0;
     pb->launches = 0;
     pb->spcg_skip = pb->spcg_backoff = 0;
+    pb->last_cg_its = -1;
     if (pb->spec_chol_blk >= 0) {   // a factorisation queued ahead of the last step of the previous solve: its pivot flags mean nothing
         HIP_TRY(hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream));
         pb->spec_chol_blk = -1;

@@ -10,7 +10,9 @@ constexpr int CHOL_NB = 96;       // dense LDL^T tile (16 entity blocks of 6)
 constexpr int PASSB_CHUNK = 1024;  // upper limit of AAR_PASSB_CHUNK (observations of one (camera, marker) run handled by one wavefront; the default rule stops at 512)
 // CG on the explicit reduced system (spcg_kernels.hip): iteration cap (sizes the hand-over buffers: one per iteration plus the
 // start-up and the final one), largest system (tiles of 96 unknowns: the six rows of an entity live in one wavefront's registers)
-constexpr int SPCG_MAX_IT = 64, SPCG_BUFS = SPCG_MAX_IT + 2, SPCG_MAX_NT = 14;
+constexpr int SPCG_MAX_IT = 128, SPCG_BUFS = SPCG_MAX_IT + 2, SPCG_MAX_NT = 14;
+// default cap by system size: up to four tiles the direct chain (<= 120 us) is cheaper than a CG solve of more than ~64 iterations; larger systems' chains cost 200-500 us
+inline int spcg_default_cap(int nT) { return nT <= 4 ? 64 : SPCG_MAX_IT; }
 // Default forcing terms of the inexact solvers (include/aar.h: aar_solver_options.pcg_eta; DESIGN.md section 12, profiles/r05_eta_pose_sweep.txt).  Chosen for the
 // final POSES: with these the poses of a run agree with the direct solver's to ~2e-6 (rotation-matrix entries) / ~1e-6 m at configs 3-5 -- 100x closer than the
 // direct path is to the reference-faithful CPU run (analytic against central-difference Jacobian), 1000x closer than the reference's own last LM step moves them.
@@ -116,7 +118,7 @@ struct DeviceProblem {
     int32_t *up_start = nullptr, *up_ent = nullptr;   // [A + 1], [..]: entity -> the OTHER entities whose block of U can be non-zero (seen together in an observation); the CG operator skips the rest
     double *pcg_yg = nullptr;             // k_pcgf: y [3][n_pad] (rotating) | the set-up's sums [A][28]
     // solver spcg (spcg_kernels.hip): CG on the explicit Schur complement, one wavefront per shared entity
-    int use_spcg = 0, spcg_max_it = SPCG_MAX_IT;
+    int use_spcg = 0, spcg_max_it = 64;
     int spcg_spread = 8;                  // AAR_SPCG_SPREAD=1: every workgroup of the grid works (the wavefronts then sit on all XCDs and hand over through memory)
     int spcg_test_drop = -1;              // test hook (AAR_SPCG_TEST_DROP=entity): that entity's wavefront never shows up -> every hand-over times out -> flag 4 -> direct chain
     double *spcg_ws = nullptr;            // [2][SPCG_BUFS][spcg_stride(n_pad)] hand-over slots (sentinel-filled when idle)

@@ -61,6 +61,7 @@ struct ReduceArgs {   // the step's scalars: [sum r^2, sum |delta_f|^2, sum delt
     // md_U != nullptr (aar_lm_init): scal[4] = max over the free diagonal of J^T J as well (mu_0 = tau * max, libs/sparselevmarq.h:369-377):
     // k_maxdiag's sum in the same launch
     const double *md_U, *md_V; const int32_t *md_fixed; int md_n_pad, md_A, md_frames_fixed;
+    const int32_t *cg_iters;   // solver spcg: [0] = CG iterations of the step's solve -> scal[7], so that the host sees them with the step's scalars (nullptr: scal[7] = -1)
 };
 
 __device__ __forceinline__ void reduce_scalars_body(const ReduceArgs &r) {   // the first 256 threads of the workgroup, fixed summation order
@@ -126,6 +127,7 @@ __device__ __forceinline__ void reduce_scalars_body(const ReduceArgs &r) {   // 
         r.scal[2] = sum_dg + (r.fold_shared ? r.lin_part[2 * (size_t)r.F + 1] : 0.0);
         r.scal[3] = encode_flags(r.flags[0] | r.flags[1] | r.flags[2] | r.flags[3]);   // multi-GPU: joins the rank sum
         r.scal[5] = r.lin_part[2 * (size_t)r.F]; r.scal[6] = r.lin_part[2 * (size_t)r.F + 1];
+        r.scal[7] = r.cg_iters ? (double)r.cg_iters[0] : -1.0;
         if (r.publish_seq) publish_host(r.scal, r.flags, r.host, r.publish_seq);
     }
 }
@@ -1571,6 +1573,7 @@ static ReduceArgs reduce_args(const DeviceProblem &P, int n_err, bool fold_share
     r.err_part = P.err_part; r.n_err = n_err; r.lin_part = P.lin_part; r.F = P.F; r.fold_shared = fold_shared ? 1 : 0;
     r.scal = scal_out ? scal_out : P.scal; r.flags = P.flags; r.host = P.host_result; r.publish_seq = publish_seq;
     r.md_U = r.md_V = nullptr; r.md_fixed = nullptr; r.md_n_pad = r.md_A = r.md_frames_fixed = 0;
+    r.cg_iters = P.use_spcg ? P.spcg_iters : nullptr;
     return r;
 }
 

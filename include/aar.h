@@ -266,7 +266,7 @@ int aar_problem_create(const aar_problem_desc *, aar_problem **out);   /* = aar_
  *   AAR_SOLVER_DIRECT  per-frame elimination (Schur complement) + dense blocked LDL^T of the reduced system: the reference's step
  *   AAR_SOLVER_SPCG    the same Schur complement, then block-Jacobi-preconditioned CG on the EXPLICIT reduced system, one wavefront
  *                      per camera / marker (csrc/spcg_kernels.hip), stopped at a relative residual pcg_eta: an inexact LM step.  A solve
- *                      that needs more than pcg_max_it iterations (cap 64) or whose hand-over times out (device shared with another
+ *                      that needs more than pcg_max_it iterations or whose hand-over times out (device shared with another
  *                      process) is redone with the direct chain automatically.  Needs 6 (C + M [+ C]) <= 1344.
  *   AAR_SOLVER_PCG     no Schur complement at all: CG THROUGH the frame blocks (csrc/pcg_kernels.hip); with a communicator the frames'
  *                      blocks stay on their ranks and every CG iteration all-reduces 8 n bytes (nothing O(n^3) is replicated)
@@ -294,7 +294,8 @@ typedef struct aar_solver_options {
     uint32_t struct_size;                     /* sizeof(aar_solver_options) of the caller: fields beyond it keep their defaults      */
     int32_t solver;                           /* AAR_SOLVER_*                                                                        */
     int32_t deterministic;                    /* 0 | 1                                                                               */
-    int32_t pcg_max_it;                       /* iteration cap of an inner CG solve; 0 = default (PCG 200; SPCG 64, also its maximum)  */
+    int32_t pcg_max_it;                       /* iteration cap of an inner CG solve; 0 = default (PCG 200; SPCG 64 up to four tiles of unknowns,
+                                                 128 above -- 128 is also its maximum)                                                */
     double pcg_eta;                           /* forcing term of the inner solves; 0 = default (SPCG 3e-4, PCG 5e-3; aar_solver_stats.pcg_eta reports it)  */
     double pcg_eta_loose;                     /* > pcg_eta: forcing term of the EARLY LM steps (a forcing sequence); 0 = none (default)            */
     double pcg_eta_switch;                    /* an LM step is "early" while the last accepted step took more than this share of the error

@@ -179,8 +179,8 @@ def test_spcg_through_the_retry_far_start_and_huber_fixtures(name, huber):
 
 def test_spcg_iteration_cap_falls_back_to_the_direct_chain():
     # a cap of one iteration at a forcing term nobody reaches in one: the first try of every solve raises device flag 8 and is redone by the direct chain,
-    # which then keeps the next 8 tries (the damping only falls along accepted steps: the systems get harder), 16 after the next fall-back ... -- the run
-    # is the direct run (to the rounding of rebuilt blocks), and says how often it fell back
+    # which then keeps the rest of the LM run (the damping only falls along accepted steps: the systems get harder) -- the run is the direct run (to the
+    # rounding of rebuilt blocks), and says how often it fell back
     ds, g = load_golden("g1_cfg3_cut")
     with aar.Problem(ds, solver="direct") as p:
         x_d, rep_d = p.lm_solve(ds.x_full)
@@ -188,11 +188,13 @@ def test_spcg_iteration_cap_falls_back_to_the_direct_chain():
     with aar.Problem(ds, solver="spcg", pcg_eta=1e-12, pcg_max_it=1) as p:
         x, rep = p.lm_solve(ds.x_full)
         st = p.solver_stats()
-        assert st["fallbacks"] == 2 and st["solves"] == 2 and rep["trial_points"] == sum(t["tries"] for t in rep["trace"]) == 15      # tries 1 and 10
+        # (try 1 only: a solve that came within 20 % of its cap announces that the next systems -- the damping only falls -- will not fit either; the rest of the LM run
+        #  takes the direct chain without trying)
+        assert st["fallbacks"] == 1 and st["solves"] == 1 and rep["trial_points"] == sum(t["tries"] for t in rep["trace"]) == 15
         x2, rep2 = p.lm_solve(ds.x_full)
-        assert p.solver_stats()["fallbacks"] == 4 and p.solver_stats()["solves"] == 4          # every solve starts with its own solver again
+        assert p.solver_stats()["fallbacks"] == 2 and p.solver_stats()["solves"] == 2          # every solve starts with its own solver again
         d = p.eval_damped_step(ds.x_full, 1e4)
-        assert p.solver_stats()["fallbacks"] == 5
+        assert p.solver_stats()["fallbacks"] == 3
     assert rep["iterations"] == rep_d["iterations"]
     np.testing.assert_allclose([t["err"] for t in rep["trace"]], [t["err"] for t in rep_d["trace"]], rtol=1e-7)      # (the bar of the direct path's own traces: fp64 atomics)
     np.testing.assert_allclose(x, x_d, atol=1e-7)
