@@ -1107,11 +1107,19 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         return set_error(AAR_ERR_INVALID, "aar_problem_create: null array");
     if (Ng >= (1LL << 31) || (int64_t)C + M >= 32768) return set_error(AAR_ERR_UNSUPPORTED, "problem too large for 32-bit indexing");
     std::vector<int64_t> per_frame(Fg, 0);
-    for (int64_t o = 0; o < Ng; o++) {
-        const int f = d->obs_frame[o], c = d->obs_cam[o], m = d->obs_marker[o];
-        if (f < 0 || f >= Fg || c < 0 || c >= C || m < 0 || m >= M) return set_error(AAR_ERR_INVALID, "observation %lld has an index out of range", (long long)o);
-        if (o > 0 && f < d->obs_frame[o - 1]) return set_error(AAR_ERR_INVALID, "observations must be ordered by frame (reference residual order)");
-        per_frame[f]++;
+    // (entity, frame) incidences of the WHOLE data set, counted the same way on every rank: what AUTO's choice between the two CG solvers rests on must not
+    // depend on which frames a rank happens to own (ranks that chose differently would wait in different collectives forever)
+    int64_t global_slots = 0;
+    {
+        std::vector<int32_t> seen_c(C, -1), seen_m(M, -1);
+        for (int64_t o = 0; o < Ng; o++) {
+            const int f = d->obs_frame[o], c = d->obs_cam[o], m = d->obs_marker[o];
+            if (f < 0 || f >= Fg || c < 0 || c >= C || m < 0 || m >= M) return set_error(AAR_ERR_INVALID, "observation %lld has an index out of range", (long long)o);
+            if (o > 0 && f < d->obs_frame[o - 1]) return set_error(AAR_ERR_INVALID, "observations must be ordered by frame (reference residual order)");
+            per_frame[f]++;
+            if (seen_c[c] != f) { seen_c[c] = f; global_slots += d->optimize_cam_intrinsics ? 2 : 1; }
+            if (seen_m[m] != f) { seen_m[m] = f; global_slots += 1; }
+        }
     }
     int rc = ensure_device(d->device_id);
     if (rc) return rc;
@@ -1236,7 +1244,10 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         hipDeviceProp_t prop;
         const int cus = (hipGetDeviceProperties(&prop, pb->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;
         const bool pcg_ok = pcg_lds_bytes(A) <= 150 * 1024;
-        const bool spcg_ok = spcg_fits(P.nT) && P.n_pad / 6 <= cus;   // one wavefront per entity, every one of them resident
+        // one wavefront per entity, every one of them resident AT ONCE (they hand over to each other): asked of the runtime's occupancy calculator for this
+        // kernel's registers and LDS, as pcg_max_grid asks for the PCG grid.  (Another process on the device can still take the slots: k_spcg's time-out.)
+        const int spcg_per_cu = spcg_fits(P.nT) ? spcg_resident_per_cu(P.nT) : 0;
+        const bool spcg_ok = spcg_fits(P.nT) && P.n_pad / 6 <= std::max(1, spcg_per_cu) * cus;
         int solver = so.solver;
         if (solver == AAR_SOLVER_AUTO) {
             // Measured on MI355X at the default forcing terms (profiles/r05_auto_crossover.txt; scripts/dev/auto_crossover.py):
@@ -1246,9 +1257,10 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
             //  * PCG never forms the complement: its step costs (CG iterations) x (a pass over the frames' W blocks), SPCG's one Schur complement (work ~ slots x
             //    slots-per-frame) + CG iterations of ~1.7 us.  PCG overtakes on long sequences of frames that each see many entities: measured crossovers at
             //    ~100 k (entity, frame) incidences for 122 per frame (216 entities), ~230 k for 92 (160 entities), beyond 320 k for 64 (112 entities) -- fitted by
-            //    incidences x (incidences per frame - 55) >= 7e6.  (Per rank: a sharded problem's ranks see their own frames only.)
-            const double kf_avg = P.F > 0 ? (double)P.total_slots / (double)P.F : 0.0;
-            const bool pcg_pays = A >= 96 && pcg_ok && (double)P.total_slots * (kf_avg - 55.0) >= 7e6;
+            //    incidences x (incidences per frame - 55) >= 7e6.
+            // The rule is applied to a rank's SHARE of the whole data set (shards are balanced by observation count), from numbers every rank holds.
+            const double kf_avg = Fg > 0 ? (double)global_slots / (double)Fg : 0.0;
+            const bool pcg_pays = A >= 96 && pcg_ok && (double)global_slots / (double)world * (kf_avg - 55.0) >= 7e6;
             if (P.nT < 2) solver = AAR_SOLVER_DIRECT;
             else if (spcg_ok && !pcg_pays) solver = AAR_SOLVER_SPCG;
             else if (pcg_ok) solver = AAR_SOLVER_PCG;
@@ -1260,7 +1272,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         P.use_spcg = solver == AAR_SOLVER_SPCG ? 1 : 0;
         if (const char *t = getenv("AAR_SPCG_SPREAD")) P.spcg_spread = std::max(1, atoi(t));
         // (one XCD has an eighth of the CUs: more entities than that many wavefront slots would not all be resident there)
-        if (P.n_pad / 6 > 4 * (cus / 8)) P.spcg_spread = 1;
+        if (P.n_pad / 6 > std::min(4, std::max(1, spcg_per_cu)) * (cus / 8)) P.spcg_spread = 1;
         // Forcing term of the inexact solvers (include/aar.h; defaults and why: kernels.h).  The CG through the frame blocks measures |r| / |b|; the CG on the
         // explicit system measures in the preconditioner's norm (r^T M^-1 r, which its recurrences carry anyway).  pcg_eta_loose > pcg_eta: a forcing sequence (opt-in).
         P.pcg_eta = P.use_spcg ? SPCG_ETA_DEFAULT : PCG_ETA_DEFAULT;
@@ -1279,7 +1291,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         P.spcg_max_it = spcg_default_cap(P.nT);
         if (so.pcg_max_it > 0) { P.pcg_max_it = so.pcg_max_it; P.spcg_max_it = std::min(so.pcg_max_it, SPCG_MAX_IT); }
         if (P.use_pcg && !pcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_PCG keeps the CG vectors and the preconditioner of %d unknowns in LDS: too many shared entities", 6 * A);
-        if (P.use_spcg && !spcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_SPCG keeps the reduced system in the registers of one wavefront per shared entity: %d unknowns are too many (limit %d, and at most %d entities)", 6 * A, 96 * SPCG_MAX_NT, cus);
+        if (P.use_spcg && !spcg_ok && !local_rc) local_rc = set_error(AAR_ERR_UNSUPPORTED, "AAR_SOLVER_SPCG keeps the reduced system in the registers of one wavefront per shared entity: %d unknowns are too many (limit %d, and at most %d entities)", 6 * A, 96 * SPCG_MAX_NT, std::max(1, spcg_per_cu) * cus);
     }
     bool schur_mfma = A >= 96 && F > 0;
     if (const char *e = getenv("AAR_SCHUR_MFMA")) schur_mfma = atoi(e) != 0 && F > 0;

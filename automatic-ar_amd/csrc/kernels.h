@@ -229,6 +229,7 @@ size_t pcg_lds_bytes(int A);
 int pcg_max_grid(int A, int cus);   // largest co-resident grid of the persistent PCG kernels
 // solver spcg: delta_s by CG on the explicit reduced system S of block set `which` (the Schur complement for mu must have been taken; S is not modified)
 bool launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial = -1);   // trial >= 0: launch_backsub(which, trial) may ride (true: it did)
+int spcg_resident_per_cu(int nT);                          // occupancy query: wavefronts of k_spcg<nT> one CU holds (0: unknown)
 bool spcg_fits(int nT);                                    // the system's rows fit the wavefronts' registers
 size_t spcg_ws_doubles(int n_pad);
 void spcg_ws_reset(const DeviceProblem &P, hipStream_t st);   // every hand-over slot back to the sentinel (at creation, after a timed-out launch)

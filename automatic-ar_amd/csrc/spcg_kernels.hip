@@ -340,6 +340,20 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
 }
 
 bool spcg_fits(int nT) { return nT >= 1 && nT <= SPCG_MAX_NT; }
+// wavefronts (= workgroups) of k_spcg<nT> a CU can hold at once, as the runtime's occupancy calculator sees this kernel's registers and LDS (0: not known)
+int spcg_resident_per_cu(int nT) {
+    int nb = 0;
+    hipError_t rc = hipErrorInvalidValue;
+    switch (nT) {
+#define SPCG_CASE(t) case t: rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_spcg<t>, 64, 0); break;
+        SPCG_CASE(1) SPCG_CASE(2) SPCG_CASE(3) SPCG_CASE(4) SPCG_CASE(5) SPCG_CASE(6) SPCG_CASE(7) SPCG_CASE(8)
+        SPCG_CASE(9) SPCG_CASE(10) SPCG_CASE(11) SPCG_CASE(12) SPCG_CASE(13) SPCG_CASE(14)
+#undef SPCG_CASE
+        default: break;
+    }
+    if (rc != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return nb;
+}
 size_t spcg_ws_doubles(int n_pad) { return (size_t)2 * SPCG_BUFS * spcg_stride(n_pad); }
 void spcg_ws_reset(const DeviceProblem &P, hipStream_t st) {
     (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.spcg_ws), (int)0xFFF85EED, 2 * spcg_ws_doubles(P.n_pad), st);
