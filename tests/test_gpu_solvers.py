@@ -509,3 +509,38 @@ def test_default_options_from_far_starts_and_tiny_initial_damping(scale, tau):
         with aar.Problem(ds, pcg_abs_tol=1.0) as p:
             x_rel, _ = p.lm_solve(ds.x_full, params=prm)
         assert max(pose_delta_max(ds, x_rel, x_d)) > 1e-4
+
+
+def test_auto_resolves_to_the_same_solver_on_every_rank_of_a_lopsided_sharding():
+    # AUTO's choice between SPCG and PCG rests on (entity, frame) incidences.  Decided from a rank's OWN frames, the ranks of this data set would split --
+    # rank 0 owns frames that see ~120 entities each (incidences x (per frame - 55) >= 7e6: PCG), rank 1 mostly frames that see a dozen (SPCG) -- and wait in
+    # different collectives forever.  The rule is applied to the whole data set's numbers, the same on every rank: asserted right after creation, then solved
+    dense = 3000
+    ds = aar.synth(5, num_frames=7000)
+    keep = ~((ds.obs_frame >= dense) & ((ds.obs_marker >= 12) | (ds.obs_cam >= 4)))
+    for name in ("obs_frame", "obs_cam", "obs_marker", "obs_uv"):
+        setattr(ds, name, getattr(ds, name)[keep])
+    ds.num_obs = int(keep.sum())
+    begin = aar.plan_shards(np.bincount(ds.obs_frame, minlength=ds.num_frames), 2)
+    inc_c = np.unique(ds.obs_frame.astype(np.int64) * 4096 + ds.obs_cam) // 4096
+    inc_m = np.unique(ds.obs_frame.astype(np.int64) * 4096 + ds.obs_marker) // 4096
+    def own_rule(lo, hi):      # the rule of csrc/ba_capi.hip on the frames lo .. hi alone
+        slots = int(((inc_c >= lo) & (inc_c < hi)).sum() + ((inc_m >= lo) & (inc_m < hi)).sum())
+        return slots * (slots / (hi - lo) - 55.0) >= 7e6
+    assert own_rule(begin[0], begin[1]) and not own_rule(begin[1], begin[2])        # (decided per rank, the two would part)
+
+    def create(comm, rank):
+        with aar.Problem(ds, comm=comm) as q:
+            return q.solver_stats()["solver"]
+    out = _run_ranks(2, create)
+    assert out[0] == out[1] and out[0] in ("spcg", "pcg"), out
+    prm = lambda: aar.lm_default_params(max_iters=3)
+    with aar.Problem(ds, solver=out[0]) as p:
+        x, rep = p.lm_solve(ds.x_full, params=prm())
+    def solve(comm, rank):
+        with aar.Problem(ds, comm=comm) as q:
+            xs, reps = q.lm_solve(ds.x_full, params=prm())
+            return [t["err"] for t in reps["trace"]]
+    res = _run_ranks(2, solve)
+    assert res[0] == res[1]                                          # same trace on both ranks, bit for bit
+    np.testing.assert_allclose(res[0], [t["err"] for t in rep["trace"]], rtol=1e-6)
