@@ -9,8 +9,9 @@ for cfg, scale, tau in ((3, 1.0, 1.0), (3, 3.0, 1.0), (3, 8.0, 1.0), (3, 1.0, 1e
     ds = aar.synth(cfg, init_scale=scale)
     prm = aar.lm_default_params(tau=tau)
     out = {}
+    off = "--abs-tol-off" in sys.argv      # the relative forcing term alone (pcg_abs_tol = 1: never binding), as before the absolute tolerance existed
     for s in ("direct", None):
-        with aar.Problem(ds, solver=s) as p:
+        with aar.Problem(ds, solver=s, pcg_abs_tol=(1.0 if off and s is None else None)) as p:
             x, rep = p.lm_solve(ds.x_full, params=prm, trace_cap=600)
             st = p.solver_stats()
             out[s] = (x, rep, p.reproj_stats(x)[0], st)
