@@ -1604,6 +1604,11 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         AL(pcg_ws, (size_t)P.pcg_n_items * 28 + 6 * (size_t)F + 8); AL(pcg_counter, 8);
         AL(pcg_yg, (size_t)3 * P.n_pad + (size_t)28 * A + 8);
         if (const char *t = getenv("AAR_PCG_FUSED")) P.pcg_fused = atoi(t) != 0 ? 1 : 0;
+        {   // k_pcgf's operator reads an fp32 copy of W (half the bytes of its pass over the frames; written by the launch's own set-up): single-rank, non-deterministic runs
+            int w32 = 1;
+            if (const char *t = getenv("AAR_PCG_W32")) w32 = atoi(t) != 0 ? 1 : 0;
+            if (w32 && P.pcg_fused && !P.deterministic && !pb->comm) AL(pcg_wf, (size_t)P.total_slots * 36 + 4);
+        }
         hipDeviceProp_t prop;
         P.pcg_grid = (hipGetDeviceProperties(&prop, pb->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;   // one workgroup per CU: all resident
         // small problems: fewer workgroups make the two grid-wide hand-overs of an iteration cheaper than the passes get slower

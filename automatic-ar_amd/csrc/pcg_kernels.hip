@@ -24,6 +24,7 @@ namespace aar {
 struct PcgArgs {
     // blocks of the current point (pass A / pass B output; S holds U: the Schur complement kernels do not run in this mode)
     const double *U, *g0, *W, *Vinv, *hf;
+    float *Wf = nullptr;                         // k_pcgf: fp32 copy of W for the operator's passes (written by its set-up, read by the same lanes); nullptr: the operator reads W
     const int32_t *fslot_start, *fslot_ent;      // frame -> its W blocks / their entities
     const int32_t *it_ent, *it_begin, *it_end;   // work items of the entity-side passes: entity, range of its incidences in pair_rec
     const int32_t *ent_item_start;               // [A + 1] entity -> its items (1 .. PCG_MAX_ITEMS each)
@@ -77,8 +78,9 @@ __device__ __forceinline__ bool grid_hop(int32_t *counter, int &round, int G, in
 // sum of NV per-thread values over the 256 threads, fixed order; result in out[0..NV) on every thread.  lds: 4 * NV doubles
 constexpr int PCG_THREADS = 256;
 constexpr int PCG_NW = PCG_THREADS / 64;
+constexpr int PCGF32_THREADS = 512;   // k_pcgf<true>
 
-template <int NV>
+template <int NV, int TH = PCG_THREADS>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -96,7 +98,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *lds) {
     for (int i = 0; i < NV; i++) {
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < PCG_NW; w++) t += lds[w * NV + i];   // (the same order in every thread: the same bits)
+        for (int w = 0; w < TH / 64; w++) t += lds[w * NV + i];   // (the same order in every thread: the same bits)
         v[i] = t;
     }
 }
@@ -354,21 +356,27 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
 // yg: [3][n_pad] zero at entry; sg: [A][28] zero at entry (the launcher clears both)
 // ------------------------------------------------------------------------------------------------
 // every slot's share of W (V+mu)^-1 W^T (lower triangle, 21) and of W h_f (6) for the frames dealt to this workgroup, into sacc [A][27] (LDS, zeroed here)
+template <int TH = PCG_THREADS>
 __device__ __forceinline__ void pcgf_setup_slots(const PcgArgs &a, double *__restrict__ sacc, int wg, int G) {
-    constexpr int NW = PCG_THREADS / 64;
+    constexpr int NW = TH / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < 27 * a.A; i += PCG_THREADS) sacc[i] = 0.0;
+    for (int i = tid; i < 27 * a.A; i += TH) sacc[i] = 0.0;
     __syncthreads();
     for (int f = wg * NW + wave; f < a.F; f += G * NW) {
         const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
         const double *Vi = a.Vinv + (size_t)f * 36, *h = a.hf + (size_t)f * 6;
         for (int s = s0 + lane; s < s1; s += 64) {
             const int e = a.fslot_ent[s];
-            if (a.ent_fixed[e]) continue;
             const double *Wb = a.W + (size_t)s * 36;
             double w[36], yv[36];
 #pragma unroll
             for (int q = 0; q < 36; q++) w[q] = Wb[q];
+            if (a.Wf) {   // the operator's copy (the same lane reads it back in every iteration: pcgf_operator walks the frames exactly like this loop)
+                float4 *dstf = reinterpret_cast<float4 *>(a.Wf + (size_t)s * 36);
+#pragma unroll
+                for (int q = 0; q < 9; q++) dstf[q] = make_float4((float)w[4 * q], (float)w[4 * q + 1], (float)w[4 * q + 2], (float)w[4 * q + 3]);
+            }
+            if (a.ent_fixed[e]) continue;
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -401,10 +409,14 @@ __device__ __forceinline__ void pcgf_setup_slots(const PcgArgs &a, double *__res
 // this workgroup's share of  y = U p - sum_f W_f (V_f + mu I)^-1 W_f^T p  (no mu p term) into yacc [n] (LDS, zeroed here): ONE pass over the W blocks of
 // its frames -- c = W^T p, t = Vinv c, y -= W t, the first two rounds of a frame's slot list staying in registers across both uses -- and (U p)_e for the
 // entities dealt to it.  p: this workgroup's copy of the search direction (LDS)
+// W32: the frame pass reads the fp32 copy of W (a.Wf; half the bytes of the pass, which is HBM-bound at config 5) and widens on use: the right-hand side, the
+// preconditioner and the back-substitution keep fp64 W, and a rounding of 6e-8 in the operator is far below the forcing term -- final poses unchanged
+// (scripts/experiments/pcg_w_float.py; profiles/r05_attempts.txt section 5)
+template <bool W32, int TH = PCG_THREADS>
 __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__restrict__ p, double *__restrict__ yacc, double *__restrict__ red, int wg, int G) {
-    constexpr int NW = PCG_THREADS / 64;
+    constexpr int NW = TH / 64;
     const int n = 6 * a.A, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < n; i += PCG_THREADS) yacc[i] = 0.0;
+    for (int i = tid; i < n; i += TH) yacc[i] = 0.0;
     __syncthreads();
     // (U p) for the block rows dealt to this workgroup, FIRST (the wavefronts without blocks go straight to their frames): one thread per stored block
     // U_eb, b < e, of the blocks that exist (U is block-sparse: entities that share an observation -- camera x marker; at config 5, 16 of a marker's 216),
@@ -413,7 +425,7 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
     for (int e = wg; e < a.A; e += G) {
         if (a.ent_fixed[e]) continue;   // (uniform per workgroup)
         const int n0 = a.up_start[e], n1 = a.up_start[e + 1];
-        for (int q = n0 - 1 + tid; q < n1; q += PCG_THREADS) {
+        for (int q = n0 - 1 + tid; q < n1; q += TH) {
             if (q < n0) {   // the diagonal block (lower triangle stored)
                 double acc[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -452,37 +464,51 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
     for (int f = wg * NW + wave; f < a.F; f += G * NW) {
         const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
         const double *Vi = a.Vinv + (size_t)f * 36;
-        double2 w0[18], w1[18];
+        // a W block in registers: 18 double2 (W32: 9 float4), row-major -- wv(b, q) = entry q of the block, widened on use
+        typedef typename std::conditional<W32, float4, double2>::type wreg;
+        constexpr int NR = W32 ? 9 : 18;
+        struct Blk { wreg v[NR]; };
+        Blk w0, w1;
         int e0 = -1, e1 = -1;
         double c[6] = {0, 0, 0, 0, 0, 0};
-        auto gather_c = [&](const double2 (&wb)[18], int e) {
+        auto load = [&](Blk &b, int s) {
+            if constexpr (W32) {
+                const float4 *q = reinterpret_cast<const float4 *>(a.Wf + (size_t)s * 36);
+#pragma unroll
+                for (int u = 0; u < 9; u++) b.v[u] = q[u];
+            } else {
+                const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
+#pragma unroll
+                for (int u = 0; u < 18; u++) b.v[u] = q[u];
+            }
+        };
+        auto row = [&](const Blk &b, int i, double (&r)[6]) {   // row i of the block as doubles
+            if constexpr (W32) {
+                const float *fp = reinterpret_cast<const float *>(b.v);
+#pragma unroll
+                for (int j = 0; j < 6; j++) r[j] = (double)fp[6 * i + j];
+            } else {
+                r[0] = b.v[3 * i].x; r[1] = b.v[3 * i].y; r[2] = b.v[3 * i + 1].x; r[3] = b.v[3 * i + 1].y; r[4] = b.v[3 * i + 2].x; r[5] = b.v[3 * i + 2].y;
+            }
+        };
+        auto gather_c = [&](const Blk &b, int e) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const double pe = p[6 * e + i];
-                c[0] = fma(wb[3 * i].x, pe, c[0]); c[1] = fma(wb[3 * i].y, pe, c[1]); c[2] = fma(wb[3 * i + 1].x, pe, c[2]);
-                c[3] = fma(wb[3 * i + 1].y, pe, c[3]); c[4] = fma(wb[3 * i + 2].x, pe, c[4]); c[5] = fma(wb[3 * i + 2].y, pe, c[5]);
+                double r[6];
+                row(b, i, r);
+#pragma unroll
+                for (int j = 0; j < 6; j++) c[j] = fma(r[j], pe, c[j]);
             }
         };
-        if (s0 + lane < s1) {
-            e0 = a.fslot_ent[s0 + lane];
-            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)(s0 + lane) * 36);
-#pragma unroll
-            for (int u = 0; u < 18; u++) w0[u] = q[u];
-        }
-        if (s0 + lane + 64 < s1) {
-            e1 = a.fslot_ent[s0 + lane + 64];
-            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)(s0 + lane + 64) * 36);
-#pragma unroll
-            for (int u = 0; u < 18; u++) w1[u] = q[u];
-        }
+        if (s0 + lane < s1) { e0 = a.fslot_ent[s0 + lane]; load(w0, s0 + lane); }
+        if (s0 + lane + 64 < s1) { e1 = a.fslot_ent[s0 + lane + 64]; load(w1, s0 + lane + 64); }
         if (e0 >= 0) gather_c(w0, e0);
         if (e1 >= 0) gather_c(w1, e1);
         for (int s = s0 + lane + 128; s < s1; s += 64) {
             const int e = a.fslot_ent[s];
-            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
-            double2 wt[18];
-#pragma unroll
-            for (int u = 0; u < 18; u++) wt[u] = q[u];
+            Blk wt;
+            load(wt, s);
             gather_c(wt, e);
         }
 #pragma unroll
@@ -495,11 +521,13 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
             for (int j = 0; j < 6; j++) tv = fma(Vi[k * 6 + j], c[j], tv);
             t[k] = tv;
         }
-        auto scatter = [&](const double2 (&wb)[18], int e) {
+        auto scatter = [&](const Blk &b, int e) {
             if (a.ent_fixed[e]) return;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                const double v = wb[3 * i].x * t[0] + wb[3 * i].y * t[1] + wb[3 * i + 1].x * t[2] + wb[3 * i + 1].y * t[3] + wb[3 * i + 2].x * t[4] + wb[3 * i + 2].y * t[5];
+                double r[6];
+                row(b, i, r);
+                const double v = r[0] * t[0] + r[1] * t[1] + r[2] * t[2] + r[3] * t[3] + r[4] * t[4] + r[5] * t[5];
                 atomicAdd(yacc + 6 * e + i, -v);
             }
         };
@@ -507,17 +535,18 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
         if (e1 >= 0) scatter(w1, e1);
         for (int s = s0 + lane + 128; s < s1; s += 64) {
             const int e = a.fslot_ent[s];
-            const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
-            double2 wt[18];
-#pragma unroll
-            for (int u = 0; u < 18; u++) wt[u] = q[u];
+            Blk wt;
+            load(wt, s);
             scatter(wt, e);
         }
     }
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *__restrict__ yg, double *__restrict__ sg) {
+// (the fp32 operator needs 217 registers: two wavefronts per SIMD fit, and the frame pass is latency-bound -- 512 threads per workgroup there)
+template <bool W32>
+__global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(const PcgArgs a, double *__restrict__ yg, double *__restrict__ sg) {
+    constexpr int TH = W32 ? PCGF32_THREADS : PCG_THREADS;
     extern __shared__ __align__(16) double lds[];
     const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -528,8 +557,8 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *_
 
     // ---- set-up, first half: every slot's share of the diagonal blocks and of the right-hand side, by entity in LDS, then ONE atomic flush ----
     double *sacc = Mi;
-    pcgf_setup_slots(a, sacc, wg, G);
-    for (int i = tid; i < 27 * a.A; i += PCG_THREADS) {
+    pcgf_setup_slots<TH>(a, sacc, wg, G);
+    for (int i = tid; i < 27 * a.A; i += TH) {
         const double v = sacc[i];
         if (v != 0.0) atomicAdd(sg + (size_t)(i / 27) * 28 + (i % 27), v);
     }
@@ -537,7 +566,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *_
     // ---- set-up, second half, redundantly in every workgroup (one thread per entity): the diagonal block of S inverted straight into LDS,
     //      the right-hand side; x = 0, r = b.  (Every thread reads its sums into registers before the barrier below lets Mi overwrite sacc.) ----
     // (every thread reads the sums it needs past the L2, not from sacc: Mi may take sacc's place at once -- but only when all threads have flushed it)
-    for (int e = tid; e < a.A; e += PCG_THREADS) {
+    for (int e = tid; e < a.A; e += TH) {
         double out[36], be[6];
         if (a.ent_fixed[e]) {
 #pragma unroll
@@ -571,7 +600,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *_
     double rz = 0.0, bb = 0.0;
     {
         double sv[2] = {0.0, 0.0};
-        for (int i = tid; i < n; i += PCG_THREADS) {
+        for (int i = tid; i < n; i += TH) {
             const int e = i / 6, row = i - 6 * e;
             double z = 0.0;
 #pragma unroll
@@ -580,7 +609,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *_
             sv[0] += r[i] * z;
             sv[1] += r[i] * r[i];
         }
-        block_sum<2>(sv, red);
+        block_sum<2, TH>(sv, red);
         rz = sv[0]; bb = sv[1];
     }
     __syncthreads();
@@ -589,9 +618,9 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *_
     double rr = bb;
     while (it_cg < a.max_it && (rr > a.eta2 * bb || rz > a.abs2) && bb > 0.0) {
         double *ygc = yg + (size_t)(it_cg % 3) * a.n_pad, *ygn = yg + (size_t)((it_cg + 1) % 3) * a.n_pad;
-        for (int i = wg * PCG_THREADS + tid; i < n; i += G * PCG_THREADS) st_agent(ygn + i, 0.0);
-        pcgf_operator(a, p, yacc, red, wg, G);
-        for (int i = tid; i < n; i += PCG_THREADS) {
+        for (int i = wg * TH + tid; i < n; i += G * TH) st_agent(ygn + i, 0.0);
+        pcgf_operator<W32, TH>(a, p, yacc, red, wg, G);
+        for (int i = tid; i < n; i += TH) {
             const double v = yacc[i];
             if (v != 0.0) atomicAdd(ygc + i, v);
         }
@@ -602,19 +631,19 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *_
         {
             double sv[1] = {0.0};
             int ny = 0;
-            for (int i = tid; i < n; i += PCG_THREADS, ny++) {
+            for (int i = tid; i < n; i += TH, ny++) {
                 double yv = fma(a.mu, p[i], ld_agent(ygc + i));
                 if (a.ent_fixed[i / 6]) yv = p[i];
                 if (ny < 24) yl[ny] = yv;
                 sv[0] = fma(p[i], yv, sv[0]);
             }
-            block_sum<1>(sv, red);
+            block_sum<1, TH>(sv, red);
             pAp = sv[0];
         }
         const double alpha = rz / pAp;
         {
             int ny = 0;
-            for (int i = tid; i < n; i += PCG_THREADS, ny++) {
+            for (int i = tid; i < n; i += TH, ny++) {
                 x[i] = fma(alpha, p[i], x[i]);
                 r[i] = fma(-alpha, yl[ny < 24 ? ny : 23], r[i]);
             }
@@ -623,7 +652,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *_
         double s2[2] = {0.0, 0.0};
         double zloc[24];
         int nz = 0;
-        for (int i = tid; i < n; i += PCG_THREADS, nz++) {
+        for (int i = tid; i < n; i += TH, nz++) {
             const int e = i / 6, row = i - 6 * e;
             double z = 0.0;
 #pragma unroll
@@ -632,18 +661,18 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgf(const PcgArgs a, double *_
             s2[0] += r[i] * z;
             s2[1] += r[i] * r[i];
         }
-        block_sum<2>(s2, red);
+        block_sum<2, TH>(s2, red);
         const double beta = s2[0] / rz;
         rz = s2[0];
         rr = s2[1];
         nz = 0;
-        for (int i = tid; i < n; i += PCG_THREADS, nz++) p[i] = fma(beta, p[i], zloc[nz < 24 ? nz : 23]);
+        for (int i = tid; i < n; i += TH, nz++) p[i] = fma(beta, p[i], zloc[nz < 24 ? nz : 23]);
         __syncthreads();
         it_cg++;
     }
     if (wg == 0) {
-        for (int i = tid; i < n; i += PCG_THREADS) a.x_out[i] = x[i];
-        for (int i = n + tid; i < a.n_pad; i += PCG_THREADS) a.x_out[i] = 0.0;
+        for (int i = tid; i < n; i += TH) a.x_out[i] = x[i];
+        for (int i = n + tid; i < a.n_pad; i += TH) a.x_out[i] = 0.0;
         if (tid == 0) { a.iters_out[0] = it_cg; a.iters_out[1] += it_cg; a.iters_out[2] += 1; }
     }
 }
@@ -1088,7 +1117,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
         return;
     }
     for (int i = wg * PCG_THREADS + tid; i < n; i += G * PCG_THREADS) bf.y_zero[i] = 0.0;   // the buffer of the NEXT launch (last read two launches ago)
-    pcgf_operator(a, p, yacc, red, wg, G);
+    pcgf_operator<false>(a, p, yacc, red, wg, G);
     for (int i = tid; i < n; i += PCG_THREADS) {
         const double v = yacc[i];
         if (v != 0.0) atomicAdd(bf.y_wr + i, v);
@@ -1101,19 +1130,22 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
     publish(0.0, itc);
 }
 
-size_t pcg_lds_bytes(int A) { return ((size_t)10 * 6 * A + PCG_NW * 27 + 8) * sizeof(double); }   // x | r | p | Mi [6 n] | yacc [n] (k_pcgf) | red
+size_t pcg_lds_bytes(int A) { return ((size_t)10 * 6 * A + (PCGF32_THREADS / 64) * 27 + 8) * sizeof(double); }   // x | r | p | Mi [6 n] | yacc [n] (k_pcgf) | red
 
 // the largest grid of the persistent PCG kernels that is resident as a whole (their hand-overs wait for every workgroup): what the occupancy query
 // admits per CU for the kernel with the larger footprint, times the CUs
 int pcg_max_grid(int A, int cus) {
     const size_t lds = pcg_lds_bytes(A);
     static size_t g1 = 48 * 1024, g2 = 48 * 1024;
-    static size_t g3 = 48 * 1024;
+    static size_t g3 = 48 * 1024, g4 = 48 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, g1);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter), lds, g2);
-    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf), lds, g3);
-    int n1 = 0, n2 = 0, n3 = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, k_pcgf, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n3 = 1; }
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<false>), lds, g3);
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true>), lds, g4);
+    int n1 = 0, n2 = 0, n3 = 0, n4 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, k_pcgf<false>, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n3 = 1; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, k_pcgf<true>, PCGF32_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n4 = 1; }
+    n3 = std::min(n3, n4);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_pcg, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n1 = 1; }
     n1 = std::min(n1, n3);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_pcgd_iter, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n2 = 1; }
@@ -1131,12 +1163,21 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
     const size_t lds = pcg_lds_bytes(P.A);
-    static size_t granted = 48 * 1024, granted_f = 48 * 1024;
+    static size_t granted = 48 * 1024, granted_f = 48 * 1024, granted_f32 = 48 * 1024;
+    a.Wf = nullptr;
     HookScope _h(P, KID_PCG);
     if (P.pcg_fused && !P.deterministic) {   // one pass over W and one hand-over per iteration; its atomics take the sums in any order
         (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * P.n_pad + (size_t)28 * P.A) * sizeof(double), st);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf), lds, granted_f);
-        hipLaunchKernelGGL(k_pcgf, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * P.n_pad);
+        // the operator's passes read an fp32 copy of W (half the bytes; AAR_PCG_W32=0: fp64) -- while the forcing term is far above what that rounding can
+        // show (6e-8 relative in the operator): a caller who asks for residuals of 1e-5 and below gets the fp64 blocks
+        if (P.pcg_wf && P.pcg_eta_now >= PCG_W32_MIN_ETA) {
+            a.Wf = P.pcg_wf;
+            allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true>), lds, granted_f32);
+            hipLaunchKernelGGL(k_pcgf<true>, dim3(P.pcg_grid), dim3(PCGF32_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * P.n_pad);
+            return;
+        }
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<false>), lds, granted_f);
+        hipLaunchKernelGGL(k_pcgf<false>, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * P.n_pad);
         return;
     }
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, granted);
