@@ -1604,10 +1604,11 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         AL(pcg_ws, (size_t)P.pcg_n_items * 28 + 6 * (size_t)F + 8); AL(pcg_counter, 8);
         AL(pcg_yg, (size_t)3 * P.n_pad + (size_t)28 * A + 8);
         if (const char *t = getenv("AAR_PCG_FUSED")) P.pcg_fused = atoi(t) != 0 ? 1 : 0;
-        {   // k_pcgf's operator reads an fp32 copy of W (half the bytes of its pass over the frames; written by the launch's own set-up): single-rank, non-deterministic runs
+        {   // k_pcgf's operator reads an fp32 copy of W (half the bytes of its pass over the frames; written by pass A beside the fp64 blocks): single-rank, non-deterministic runs
             int w32 = 1;
             if (const char *t = getenv("AAR_PCG_W32")) w32 = atoi(t) != 0 ? 1 : 0;
-            if (w32 && P.pcg_fused && !P.deterministic && !pb->comm) AL(pcg_wf, (size_t)P.total_slots * 36 + 4);
+            if (w32 && P.pcg_fused && !P.deterministic && !pb->comm && P.pcg_eta >= PCG_W32_MIN_ETA)   // (a caller who asks for residuals below 1e-4 gets fp64 blocks throughout)
+                for (int w = 0; w < 2; w++) AL(blk[w].Wf, (size_t)P.total_slots * 36 + 4);
         }
         hipDeviceProp_t prop;
         P.pcg_grid = (hipGetDeviceProperties(&prop, pb->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;   // one workgroup per CU: all resident
@@ -1726,7 +1727,10 @@ int aar_eval_normal_equations(aar_problem *pb, const double *x_full, double *JtJ
     int rc = upload_z(pb, x_full, pb->cur);
     if (rc) return rc;
     if ((rc = zero_block_set(pb, pb->cur))) return rc;
-    if ((rc = eval_blocks(pb, pb->cur, -1.0, -1))) return rc;
+    P.want_w64 = 1;
+    rc = eval_blocks(pb, pb->cur, -1.0, -1);
+    P.want_w64 = 0;
+    if (rc) return rc;
     const int A = P.A, F = P.F, np = P.n_pad;
     const DeviceProblem::Blocks &bk = P.blk[pb->cur];
     std::vector<double> U0((size_t)np * np), g0(np), V((size_t)F * 36), gf((size_t)F * 6), W((size_t)P.total_slots * 36), ep(F);

@@ -37,6 +37,7 @@ __device__ __forceinline__ bool hop_wait(const int32_t *flag, int value) {   // 
 struct BacksubArgs {
     const int32_t *fslot_start, *fslot_ent;
     const double *W, *Vinv, *gf, *g0, *delta_s, *zc;
+    const float *Wf;            // PCG with the fp32 operator: pass A's fp32 copy of W (kernels.h, Blocks::Wf) instead of W -- what the solve itself has read; nullptr otherwise
     double *zt;
     int A, F, n_frame_blocks;
     double *lin_part, *ent_out;
@@ -94,9 +95,19 @@ __device__ __forceinline__ void backsub_body(const BacksubArgs &b, int blk, doub
     double2 w0[18];
     if (has) {
         a0 = b.fslot_ent[sl];
-        const double2 *wb = reinterpret_cast<const double2 *>(b.W + (size_t)sl * 36);
+        if (b.Wf) {
+            const float4 *wf = reinterpret_cast<const float4 *>(b.Wf + (size_t)s0 * 36) + lane;
+            const int kf = s1 - s0;
 #pragma unroll
-        for (int q = 0; q < 18; q++) w0[q] = wb[q];
+            for (int q = 0; q < 9; q++) {
+                const float4 v = wf[(size_t)q * kf];
+                w0[2 * q] = make_double2(v.x, v.y); w0[2 * q + 1] = make_double2(v.z, v.w);
+            }
+        } else {
+            const double2 *wb = reinterpret_cast<const double2 *>(b.W + (size_t)sl * 36);
+#pragma unroll
+            for (int q = 0; q < 18; q++) w0[q] = wb[q];
+        }
     }
     double g[6], vrow[6], zc6 = 0.0;
 #pragma unroll
@@ -117,13 +128,26 @@ __device__ __forceinline__ void backsub_body(const BacksubArgs &b, int blk, doub
     }
     for (int s = s0 + lane + 64; s < s1; s += 64) {
         const int a = b.fslot_ent[s];
-        const double2 *wb = reinterpret_cast<const double2 *>(b.W + (size_t)s * 36);
+        double2 wt[18];
+        if (b.Wf) {
+            const float4 *wf = reinterpret_cast<const float4 *>(b.Wf + (size_t)s0 * 36) + (s - s0);
+            const int kf = s1 - s0;
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                const float4 v = wf[(size_t)q * kf];
+                wt[2 * q] = make_double2(v.x, v.y); wt[2 * q + 1] = make_double2(v.z, v.w);
+            }
+        } else {
+            const double2 *wb = reinterpret_cast<const double2 *>(b.W + (size_t)s * 36);
+#pragma unroll
+            for (int q = 0; q < 18; q++) wt[q] = wb[q];
+        }
         double da[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) da[i] = dl(6 * a + i);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            const double2 x0 = wb[3 * i], x1 = wb[3 * i + 1], x2 = wb[3 * i + 2];
+            const double2 x0 = wt[3 * i], x1 = wt[3 * i + 1], x2 = wt[3 * i + 2];
             c[0] += x0.x * da[i]; c[1] += x0.y * da[i]; c[2] += x1.x * da[i];
             c[3] += x1.y * da[i]; c[4] += x2.x * da[i]; c[5] += x2.y * da[i];
         }

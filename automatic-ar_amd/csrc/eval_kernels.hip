@@ -143,6 +143,7 @@ struct PassAArgs {
     float huber;
     double h, mu_pred;
     double *V, *gf, *W, *Vinv, *hf, *err_part;
+    float *Wf;                    // fp32 copy of W for k_pcgf (kernels.h, Blocks::Wf); nullptr: not wanted
     double *zero0; int64_t zero0_n; double *zero1; int64_t zero1_n; double *zero2; int64_t zero2_n;
     int32_t *flags;
     // MFMA Schur path: the dense per-frame panels Wd / Yd = W (V_f + mu_pred I)^-1 leave from HERE (the W blocks are still in LDS),
@@ -163,7 +164,12 @@ template <int BLOCK>
 __device__ __forceinline__ void passA_epilogue(const PassAArgs &a, const double *Wl, const double *acc, double *scratch, const int f, const int s0, const int kf) {
     const int tid = threadIdx.x;
     // coalesced write-out
-    for (int i = tid; i < kf * 36; i += BLOCK) a.W[(size_t)s0 * 36 + i] = Wl[i + i / 36];
+    if (a.W) for (int i = tid; i < kf * 36; i += BLOCK) a.W[(size_t)s0 * 36 + i] = Wl[i + i / 36];
+    if (a.Wf)   // (element r of slot j -> piece r / 4 of slot j)
+        for (int i = tid; i < kf * 36; i += BLOCK) {
+            const int j = i / 36, r = i - 36 * j;
+            a.Wf[(size_t)s0 * 36 + ((size_t)(r >> 2) * kf + j) * 4 + (r & 3)] = (float)Wl[i + j];
+        }
     for (int t = tid; t < 36; t += BLOCK) a.V[(size_t)f * 36 + t] = acc[sym6(t / 6, t % 6)];
     for (int t = tid; t < 6; t += BLOCK) a.gf[(size_t)f * 6 + t] = acc[21 + t];
     if (tid == 0) a.err_part[f] = acc[27];
@@ -601,20 +607,28 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
         }
         if (INTR && e >= a.k_ent0) {   // an intrinsics entity's slot: W = M F (rows fx, cx, fy, cy; the entity's two idle rows are zero)
             const double *mk = Hl + ts * SL;
-            double2 *wp = reinterpret_cast<double2 *>(a.W + (size_t)(s0 + ts) * 36);
+            double wv[36];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                double m6[6], wr[3];
+                double m6[6];
 #pragma unroll
                 for (int j = 0; j < 6; j++) m6[j] = mk[i * 6 + j];
 #pragma unroll
-                for (int j = 0; j < 3; j++) wr[j] = m6[0] * ef.Jl[j] + m6[1] * ef.Jl[3 + j] + m6[2] * ef.Jl[6 + j];
-                wp[3 * i] = make_double2(wr[0], wr[1]);
-                wp[3 * i + 1] = make_double2(wr[2], m6[3]);
-                wp[3 * i + 2] = make_double2(m6[4], m6[5]);
+                for (int j = 0; j < 3; j++) wv[6 * i + j] = m6[0] * ef.Jl[j] + m6[1] * ef.Jl[3 + j] + m6[2] * ef.Jl[6 + j];
+                wv[6 * i + 3] = m6[3]; wv[6 * i + 4] = m6[4]; wv[6 * i + 5] = m6[5];
             }
 #pragma unroll
-            for (int q = 12; q < 18; q++) wp[q] = make_double2(0.0, 0.0);
+            for (int q = 24; q < 36; q++) wv[q] = 0.0;
+            if (a.W) {
+                double2 *wp = reinterpret_cast<double2 *>(a.W + (size_t)(s0 + ts) * 36);
+#pragma unroll
+                for (int q = 0; q < 18; q++) wp[q] = make_double2(wv[2 * q], wv[2 * q + 1]);
+            }
+            if (a.Wf) {
+                float4 *wf = reinterpret_cast<float4 *>(a.Wf + (size_t)s0 * 36) + ts;
+#pragma unroll
+                for (int q = 0; q < 9; q++) wf[(size_t)q * kf] = make_float4((float)wv[4 * q], (float)wv[4 * q + 1], (float)wv[4 * q + 2], (float)wv[4 * q + 3]);
+            }
             continue;
         }
         const bool cam = e < a.C;
@@ -643,14 +657,28 @@ __device__ __forceinline__ void passA_wrench_body(const PassAArgs &a, double *ld
             }
         }
         double2 *wp = reinterpret_cast<double2 *>(a.W + (size_t)(s0 + ts) * 36);
+        float4 *wf = a.Wf ? reinterpret_cast<float4 *>(a.Wf + (size_t)s0 * 36) + ts : nullptr;
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            double wr[3];
+        for (int i2 = 0; i2 < 3; i2++) {   // two rows = three float4 pieces of the fp32 copy
+            float w12[12];
 #pragma unroll
-            for (int j = 0; j < 3; j++) wr[j] = X[i][0] * ef.Jl[j] + X[i][1] * ef.Jl[3 + j] + X[i][2] * ef.Jl[6 + j];
-            wp[3 * i] = make_double2(wr[0], wr[1]);
-            wp[3 * i + 1] = make_double2(wr[2], X[i][3]);
-            wp[3 * i + 2] = make_double2(X[i][4], X[i][5]);
+            for (int ii = 0; ii < 2; ii++) {
+                const int i = 2 * i2 + ii;
+                double wr[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) wr[j] = X[i][0] * ef.Jl[j] + X[i][1] * ef.Jl[3 + j] + X[i][2] * ef.Jl[6 + j];
+                if (a.W) {
+                    wp[3 * i] = make_double2(wr[0], wr[1]);
+                    wp[3 * i + 1] = make_double2(wr[2], X[i][3]);
+                    wp[3 * i + 2] = make_double2(X[i][4], X[i][5]);
+                }
+                w12[6 * ii] = (float)wr[0]; w12[6 * ii + 1] = (float)wr[1]; w12[6 * ii + 2] = (float)wr[2];
+                w12[6 * ii + 3] = (float)X[i][3]; w12[6 * ii + 4] = (float)X[i][4]; w12[6 * ii + 5] = (float)X[i][5];
+            }
+            if (wf) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) wf[(size_t)(3 * i2 + q) * kf] = make_float4(w12[4 * q], w12[4 * q + 1], w12[4 * q + 2], w12[4 * q + 3]);
+            }
         }
     }
     PA_STAMP(7);
@@ -1238,7 +1266,8 @@ static PassAArgs passA_args(const DeviceProblem &P, int which, double mu_pred, i
     a.huber = P.huber;
     a.h = P.half_size; a.mu_pred = mu_pred;
     const DeviceProblem::Blocks &b = P.blk[which];
-    a.V = b.V; a.gf = b.gf; a.W = b.W; a.Vinv = b.Vinv; a.hf = b.hf; a.err_part = P.err_part;
+    a.V = b.V; a.gf = b.gf; a.W = b.W; a.Wf = b.Wf; a.Vinv = b.Vinv; a.hf = b.hf; a.err_part = P.err_part;
+    if (b.Wf && !P.want_w64) a.W = nullptr;   // PCG with the fp32 operator: nobody reads the fp64 blocks (175 MB per pass at config 5) unless the dense-output API asks
     a.zero0 = a.zero1 = a.zero2 = nullptr; a.zero0_n = a.zero1_n = a.zero2_n = 0;
     if (zero_blk >= 0) {
         const DeviceProblem::Blocks &zb = P.blk[zero_blk];

@@ -115,10 +115,10 @@ struct DeviceProblem {
     double *pcg_ws = nullptr;             // items' shares [n_items][28] | t [6F]
     int32_t *pcg_counter = nullptr;       // [0..1] grid-barrier counters (alternating), [2] iterations of the last solve, [3] running total
     mutable int pcg_parity = 0;
+    mutable int want_w64 = 0;             // aar_eval_normal_equations: pass A writes the fp64 W blocks even where the solver only reads the fp32 copy (Blocks::Wf)
     int pcg_fused = 1;                    // AAR_PCG_FUSED=0: k_pcg (two passes over W and two hand-overs per iteration) instead of k_pcgf
     int32_t *up_start = nullptr, *up_ent = nullptr;   // [A + 1], [..]: entity -> the OTHER entities whose block of U can be non-zero (seen together in an observation); the CG operator skips the rest
     double *pcg_yg = nullptr;             // k_pcgf: y [3][n_pad] (rotating) | the set-up's sums [A][28]
-    float *pcg_wf = nullptr;              // k_pcgf: fp32 copy of the current point's W blocks for the operator's passes (nullptr: AAR_PCG_W32=0, deterministic mode, sharded problems)
     // solver spcg (spcg_kernels.hip): CG on the explicit Schur complement, one wavefront per shared entity
     int use_spcg = 0, spcg_max_it = 64;
     int spcg_spread = 8;                  // AAR_SPCG_SPREAD=1: every workgroup of the grid works (the wavefronts then sit on all XCDs and hand over through memory)
@@ -154,6 +154,8 @@ struct DeviceProblem {
     struct Blocks {
         double *V = nullptr, *gf = nullptr;   // [F][36], [F][6]
         double *W = nullptr;                  // [total_slots][36]   W_af (rows: entity params, cols: frame params)
+        float *Wf = nullptr;                  // PCG (k_pcgf, fp32 operator): the same blocks in fp32, per frame piece-major -- float4 piece q (entries 4q .. 4q+3 of the
+                                              // row-major block) of the frame's slot j at float4 index (fslot_start[f] * 9 + q k_f + j) -- written by pass A beside W
         double *Vinv = nullptr, *hf = nullptr;// (V_f + mu I)^-1, (V_f + mu I)^-1 g_f
         double *S = nullptr;                  // [n_pad*n_pad] row-major lower triangle: shared blocks (pass B), then minus
                                               // the Schur terms, then (in place) its LDL^T factor

@@ -24,7 +24,8 @@ namespace aar {
 struct PcgArgs {
     // blocks of the current point (pass A / pass B output; S holds U: the Schur complement kernels do not run in this mode)
     const double *U, *g0, *W, *Vinv, *hf;
-    float *Wf = nullptr;                         // k_pcgf: fp32 copy of W for the operator's passes (written by its set-up, read by the same lanes); nullptr: the operator reads W
+    int dbg = 0;
+    float *Wf = nullptr;                         // k_pcgf: pass A's fp32 copy of W (kernels.h, Blocks::Wf) for the set-up and the operator's passes; nullptr: fp64 W
     const int32_t *fslot_start, *fslot_ent;      // frame -> its W blocks / their entities
     const int32_t *it_ent, *it_begin, *it_end;   // work items of the entity-side passes: entity, range of its incidences in pair_rec
     const int32_t *ent_item_start;               // [A + 1] entity -> its items (1 .. PCG_MAX_ITEMS each)
@@ -367,16 +368,21 @@ __device__ __forceinline__ void pcgf_setup_slots(const PcgArgs &a, double *__res
         const double *Vi = a.Vinv + (size_t)f * 36, *h = a.hf + (size_t)f * 6;
         for (int s = s0 + lane; s < s1; s += 64) {
             const int e = a.fslot_ent[s];
-            const double *Wb = a.W + (size_t)s * 36;
-            double w[36], yv[36];
-#pragma unroll
-            for (int q = 0; q < 36; q++) w[q] = Wb[q];
-            if (a.Wf) {   // the operator's copy (the same lane reads it back in every iteration: pcgf_operator walks the frames exactly like this loop)
-                float4 *dstf = reinterpret_cast<float4 *>(a.Wf + (size_t)s * 36);
-#pragma unroll
-                for (int q = 0; q < 9; q++) dstf[q] = make_float4((float)w[4 * q], (float)w[4 * q + 1], (float)w[4 * q + 2], (float)w[4 * q + 3]);
-            }
             if (a.ent_fixed[e]) continue;
+            double w[36], yv[36];
+            if (a.Wf) {   // pass A's fp32 copy (kernels.h, Blocks::Wf): half the bytes, consecutive lanes read consecutive pieces
+                const float4 *q4 = reinterpret_cast<const float4 *>(a.Wf + (size_t)s0 * 36) + (s - s0);
+                const int kf = s1 - s0;
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    const float4 v = q4[(size_t)q * kf];
+                    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+                }
+            } else {
+                const double *Wb = a.W + (size_t)s * 36;
+#pragma unroll
+                for (int q = 0; q < 36; q++) w[q] = Wb[q];
+            }
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -422,7 +428,7 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
     // U_eb, b < e, of the blocks that exist (U is block-sparse: entities that share an observation -- camera x marker; at config 5, 16 of a marker's 216),
     // read row-wise in 16-byte pieces, used twice -- y_e += U_eb p_b and y_b += U_eb^T p_e -- and added to the workgroup's y in LDS like the frames'
     // contributions: no reduction, no barrier.  (p of a gauge entity is zero and its y is overridden later.)
-    for (int e = wg; e < a.A; e += G) {
+    for (int e = wg; e < a.A && !(a.dbg & 1); e += G) {
         if (a.ent_fixed[e]) continue;   // (uniform per workgroup)
         const int n0 = a.up_start[e], n1 = a.up_start[e + 1];
         for (int q = n0 - 1 + tid; q < n1; q += TH) {
@@ -461,7 +467,7 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
             for (int j = 0; j < 6; j++) atomicAdd(yacc + 6 * b + j, yb[j]);
         }
     }
-    for (int f = wg * NW + wave; f < a.F; f += G * NW) {
+    for (int f = wg * NW + wave; f < a.F && !(a.dbg & 2); f += G * NW) {
         const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
         const double *Vi = a.Vinv + (size_t)f * 36;
         // a W block in registers: 18 double2 (W32: 9 float4), row-major -- wv(b, q) = entry q of the block, widened on use
@@ -473,9 +479,10 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
         double c[6] = {0, 0, 0, 0, 0, 0};
         auto load = [&](Blk &b, int s) {
             if constexpr (W32) {
-                const float4 *q = reinterpret_cast<const float4 *>(a.Wf + (size_t)s * 36);
+                const float4 *q = reinterpret_cast<const float4 *>(a.Wf + (size_t)s0 * 36) + (s - s0);
+                const int kf = s1 - s0;
 #pragma unroll
-                for (int u = 0; u < 9; u++) b.v[u] = q[u];
+                for (int u = 0; u < 9; u++) b.v[u] = q[(size_t)u * kf];
             } else {
                 const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
 #pragma unroll
@@ -620,7 +627,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
         double *ygc = yg + (size_t)(it_cg % 3) * a.n_pad, *ygn = yg + (size_t)((it_cg + 1) % 3) * a.n_pad;
         for (int i = wg * TH + tid; i < n; i += G * TH) st_agent(ygn + i, 0.0);
         pcgf_operator<W32, TH>(a, p, yacc, red, wg, G);
-        for (int i = tid; i < n; i += TH) {
+        for (int i = tid; i < n && !(a.dbg & 4); i += TH) {
             const double v = yacc[i];
             if (v != 0.0) atomicAdd(ygc + i, v);
         }
@@ -1165,13 +1172,14 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const size_t lds = pcg_lds_bytes(P.A);
     static size_t granted = 48 * 1024, granted_f = 48 * 1024, granted_f32 = 48 * 1024;
     a.Wf = nullptr;
+    { static const char *e = getenv("AAR_PCG_DBG"); a.dbg = e ? atoi(e) : 0; }
     HookScope _h(P, KID_PCG);
     if (P.pcg_fused && !P.deterministic) {   // one pass over W and one hand-over per iteration; its atomics take the sums in any order
         (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * P.n_pad + (size_t)28 * P.A) * sizeof(double), st);
         // the operator's passes read an fp32 copy of W (half the bytes; AAR_PCG_W32=0: fp64) -- while the forcing term is far above what that rounding can
         // show (6e-8 relative in the operator): a caller who asks for residuals of 1e-5 and below gets the fp64 blocks
-        if (P.pcg_wf && P.pcg_eta_now >= PCG_W32_MIN_ETA) {
-            a.Wf = P.pcg_wf;
+        if (b.Wf && P.pcg_eta_now >= PCG_W32_MIN_ETA) {
+            a.Wf = b.Wf;
             allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true>), lds, granted_f32);
             hipLaunchKernelGGL(k_pcgf<true>, dim3(P.pcg_grid), dim3(PCGF32_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * P.n_pad);
             return;

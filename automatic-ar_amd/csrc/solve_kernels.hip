@@ -1630,6 +1630,7 @@ BacksubArgs backsub_args(const DeviceProblem &P, int cur, int trial, int waves_p
     const DeviceProblem::Blocks &b = P.blk[cur];
     BacksubArgs a;
     a.fslot_start = P.fslot_start; a.fslot_ent = P.fslot_ent; a.W = b.W; a.Vinv = b.Vinv; a.gf = b.gf; a.g0 = b.g0;
+    a.Wf = P.use_pcg ? b.Wf : nullptr;   // (allocated only where the solve itself reads the fp32 blocks: ba_capi.hip)
     a.delta_s = P.delta_s; a.zc = P.z[cur]; a.zt = P.z[trial]; a.A = P.A; a.F = P.F;
     a.n_frame_blocks = (P.F + waves_per_block - 1) / waves_per_block;
     a.lin_part = P.lin_part; a.ent_out = P.ent[trial]; a.k_ent0 = P.intr ? P.C + P.M : P.A;

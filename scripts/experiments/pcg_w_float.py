@@ -17,6 +17,8 @@ def schur_pcg(U, W, V, bs, bf, mu, eta, abs_tol, wf32, max_it=2000):
     Vi = np.linalg.inv(V + mu * np.eye(6))
     Wb = W.reshape(ns, nf, 6)
     Wo = Wb.astype(np.float32).astype(np.float64) if wf32 else Wb          # what the operator reads
+    if wf32 == "all":                                                       # ... and the right-hand side, the preconditioner and the back-substitution too
+        Wb = Wo
     rhs = bs - np.einsum("sfi,fij,fj->s", Wb, Vi, bf.reshape(nf, 6))
     apply = lambda p: U @ p + mu * p - np.einsum("sfi,fi->s", Wo, np.einsum("fij,fj->fi", Vi, np.einsum("sfi,s->fi", Wo, p)))
     S_diag = np.zeros((ns // 6, 6, 6))
@@ -69,7 +71,7 @@ for cfg in ([int(a) for a in sys.argv[1:]] or [3, 5]):
     z0, rm0, st0, _ = lm(o, ds.x_full, ns, None)
     print("config %d (%d cams / %d markers / %d frames): exact LM %d steps, RMSE %.9f px  [%.0f s]" % (cfg, ds.num_cams, ds.num_markers, ds.num_frames, st0, rm0, time.time() - t0), flush=True)
     for eta in (5e-3, 1e-3):
-        for wf32 in (False, True):
+        for wf32 in (False, True, "all"):
             z, rm, st, its = lm(o, ds.x_full, ns, eta, wf32=wf32)
             print("   eta %-6g W in %s: %2d LM steps, CG %5.1f per solve, dRMSE %+.1e px, max |pose vector - exact run's| shared %.1e frames %.1e" % (
-                eta, "fp32" if wf32 else "fp64", st, np.mean(its), rm - rm0, np.abs(z - z0)[:ns].max(), np.abs(z - z0)[ns:].max()), flush=True)
+                eta, {False: "fp64", True: "fp32 (operator)", "all": "fp32 (everywhere)"}[wf32], st, np.mean(its), rm - rm0, np.abs(z - z0)[:ns].max(), np.abs(z - z0)[ns:].max()), flush=True)
