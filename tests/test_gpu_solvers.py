@@ -544,3 +544,34 @@ def test_auto_resolves_to_the_same_solver_on_every_rank_of_a_lopsided_sharding()
     res = _run_ranks(2, solve)
     assert res[0] == res[1]                                          # same trace on both ranks, bit for bit
     np.testing.assert_allclose(res[0], [t["err"] for t in rep["trace"]], rtol=1e-6)
+
+
+def test_pcg_with_fp32_blocks_ends_where_the_fp64_blocks_do(monkeypatch):
+    # PCG at the default forcing term reads W in fp32 (pass A writes a piece-major fp32 copy instead of the fp64 blocks; k_pcgf's set-up, its operator and the
+    # back-substitution read it): the final poses are those of the fp64 blocks (AAR_PCG_W32=0) to far below the bar, a forcing term below 1e-4 gets fp64 blocks by
+    # itself, and the dense-output API still sees fp64 W (config 5's shape on a 300-frame cut; full size: test_default_options_reach_the_direct_paths_poses...)
+    ds = aar.synth(5, num_frames=300)
+    with aar.Problem(ds, solver="direct") as p:
+        xd, repd = p.lm_solve(ds.x_full)
+        Hd, Bd, _ = p.eval_normal_equations(ds.x_full)
+    with aar.Problem(ds, solver="pcg") as p:
+        x32, rep32 = p.lm_solve(ds.x_full)
+        rm32, _ = p.reproj_stats(x32)
+        H, B, _ = p.eval_normal_equations(ds.x_full)               # (asks pass A for the fp64 blocks again)
+        assert np.abs(H - Hd).max() / np.abs(Hd).max() < 1e-12 and np.abs(B - Bd).max() / np.abs(Bd).max() < 1e-12
+        x32b, rep32b = p.lm_solve(ds.x_full)                        # ... and the solver is back on the fp32 copy afterwards
+        assert rep32b["iterations"] == rep32["iterations"] and max(pose_delta_max(ds, x32b, x32)) < 1e-6
+    monkeypatch.setenv("AAR_PCG_W32", "0")
+    with aar.Problem(ds, solver="pcg") as p:
+        x64, rep64 = p.lm_solve(ds.x_full)
+        rm64, _ = p.reproj_stats(x64)
+    monkeypatch.delenv("AAR_PCG_W32")
+    assert rep32["iterations"] == rep64["iterations"] == repd["iterations"]
+    assert abs(rm32 - rm64) < 1e-7
+    assert max(pose_delta_max(ds, x32, x64)) < 2e-6, pose_delta_max(ds, x32, x64)
+    assert max(pose_delta_max(ds, x32, xd)) < 3e-5
+    with aar.Problem(ds, solver="pcg", pcg_eta=1e-9, pcg_max_it=2000) as p:        # tight forcing term: fp64 blocks, the direct step to 1e-7
+        mu = 1e5
+        with aar.Problem(ds, solver="direct") as q:
+            d_ref = q.eval_damped_step(ds.x_full, mu)
+        assert _rel(p.eval_damped_step(ds.x_full, mu), d_ref) < 1e-7
