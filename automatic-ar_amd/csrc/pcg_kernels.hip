@@ -24,7 +24,6 @@ namespace aar {
 struct PcgArgs {
     // blocks of the current point (pass A / pass B output; S holds U: the Schur complement kernels do not run in this mode)
     const double *U, *g0, *W, *Vinv, *hf;
-    int dbg = 0;
     float *Wf = nullptr;                         // k_pcgf: pass A's fp32 copy of W (kernels.h, Blocks::Wf) for the set-up and the operator's passes; nullptr: fp64 W
     const int32_t *fslot_start, *fslot_ent;      // frame -> its W blocks / their entities
     const int32_t *it_ent, *it_begin, *it_end;   // work items of the entity-side passes: entity, range of its incidences in pair_rec
@@ -363,7 +362,8 @@ __device__ __forceinline__ void pcgf_setup_slots(const PcgArgs &a, double *__res
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 27 * a.A; i += TH) sacc[i] = 0.0;
     __syncthreads();
-    for (int f = wg * NW + wave; f < a.F; f += G * NW) {
+    const int f_lo = (int)((long long)wg * a.F / G), f_hi = (int)((long long)(wg + 1) * a.F / G);   // the workgroup's frames (see pcgf_operator)
+    for (int f = f_lo + wave; f < f_hi; f += NW) {
         const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
         const double *Vi = a.Vinv + (size_t)f * 36, *h = a.hf + (size_t)f * 6;
         for (int s = s0 + lane; s < s1; s += 64) {
@@ -428,10 +428,10 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
     // U_eb, b < e, of the blocks that exist (U is block-sparse: entities that share an observation -- camera x marker; at config 5, 16 of a marker's 216),
     // read row-wise in 16-byte pieces, used twice -- y_e += U_eb p_b and y_b += U_eb^T p_e -- and added to the workgroup's y in LDS like the frames'
     // contributions: no reduction, no barrier.  (p of a gauge entity is zero and its y is overridden later.)
-    for (int e = wg; e < a.A && !(a.dbg & 1); e += G) {
+    for (int e = wg; e < a.A; e += G) {
         if (a.ent_fixed[e]) continue;   // (uniform per workgroup)
         const int n0 = a.up_start[e], n1 = a.up_start[e + 1];
-        for (int q = n0 - 1 + tid; q < n1; q += TH) {
+        for (int q = n0 - 1 + (tid - (TH - 64)); q < n1 && tid >= TH - 64; q += 64) {   // (the LAST wavefront: the one with the fewest frames below)
             if (q < n0) {   // the diagonal block (lower triangle stored)
                 double acc[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -467,7 +467,11 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
             for (int j = 0; j < 6; j++) atomicAdd(yacc + 6 * b + j, yb[j]);
         }
     }
-    for (int f = wg * NW + wave; f < a.F && !(a.dbg & 2); f += G * NW) {
+    // Frames: a CONTIGUOUS range per workgroup (F / G of them, to one), dealt round-robin to its wavefronts -- every workgroup takes the same number of rounds
+    // (dealt wave-major over the whole grid, 5000 frames over 2048 wavefronts left 113 workgroups with three rounds and 143 with two), and when the count does
+    // not divide, the last wavefronts have one frame less: the last one also applies the workgroup's rows of U above, behind nobody's back
+    const int f_lo = (int)((long long)wg * a.F / G), f_hi = (int)((long long)(wg + 1) * a.F / G);
+    for (int f = f_lo + wave; f < f_hi; f += NW) {
         const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
         const double *Vi = a.Vinv + (size_t)f * 36;
         // a W block in registers: 18 double2 (W32: 9 float4), row-major -- wv(b, q) = entry q of the block, widened on use
@@ -627,7 +631,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
         double *ygc = yg + (size_t)(it_cg % 3) * a.n_pad, *ygn = yg + (size_t)((it_cg + 1) % 3) * a.n_pad;
         for (int i = wg * TH + tid; i < n; i += G * TH) st_agent(ygn + i, 0.0);
         pcgf_operator<W32, TH>(a, p, yacc, red, wg, G);
-        for (int i = tid; i < n && !(a.dbg & 4); i += TH) {
+        for (int i = tid; i < n; i += TH) {
             const double v = yacc[i];
             if (v != 0.0) atomicAdd(ygc + i, v);
         }
@@ -1172,7 +1176,6 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     const size_t lds = pcg_lds_bytes(P.A);
     static size_t granted = 48 * 1024, granted_f = 48 * 1024, granted_f32 = 48 * 1024;
     a.Wf = nullptr;
-    { static const char *e = getenv("AAR_PCG_DBG"); a.dbg = e ? atoi(e) : 0; }
     HookScope _h(P, KID_PCG);
     if (P.pcg_fused && !P.deterministic) {   // one pass over W and one hand-over per iteration; its atomics take the sums in any order
         (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * P.n_pad + (size_t)28 * P.A) * sizeof(double), st);
