@@ -431,7 +431,7 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
     for (int e = wg; e < a.A; e += G) {
         if (a.ent_fixed[e]) continue;   // (uniform per workgroup)
         const int n0 = a.up_start[e], n1 = a.up_start[e + 1];
-        for (int q = n0 - 1 + (tid - (TH - 64)); q < n1 && tid >= TH - 64; q += 64) {   // (the LAST wavefront: the one with the fewest frames below)
+        for (int q = n0 - 1 + tid; q < n1; q += TH) {
             if (q < n0) {   // the diagonal block (lower triangle stored)
                 double acc[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -468,8 +468,7 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
         }
     }
     // Frames: a CONTIGUOUS range per workgroup (F / G of them, to one), dealt round-robin to its wavefronts -- every workgroup takes the same number of rounds
-    // (dealt wave-major over the whole grid, 5000 frames over 2048 wavefronts left 113 workgroups with three rounds and 143 with two), and when the count does
-    // not divide, the last wavefronts have one frame less: the last one also applies the workgroup's rows of U above, behind nobody's back
+    // (dealt wave-major over the whole grid, 5000 frames over 2048 wavefronts left 113 workgroups with three rounds and 143 with two)
     const int f_lo = (int)((long long)wg * a.F / G), f_hi = (int)((long long)(wg + 1) * a.F / G);
     for (int f = f_lo + wave; f < f_hi; f += NW) {
         const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];

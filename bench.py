@@ -256,10 +256,13 @@ def kernel_profile(problem, ds, workload, x0, steps, params, world, intrinsics=F
             # launch is the reduced system once (8 (n^2/2 + n), 8d's "writes then reads the reduced system once").  `utilisation` is the kernel's own byte model instead:
             # one pass over the W blocks for the preconditioner, ONE per CG iteration (k_pcgf; two with k_pcg: deterministic mode, AAR_PCG_FUSED=0), 288 B per incidence
             passes = 2.0 if (deterministic or os.environ.get("AAR_PCG_FUSED") == "0") else 1.0
-            util_by = 288.0 * float(kf.sum()) / max(1, world) * (1.0 + passes * pcg_total / float(done))
+            # fp32 blocks (144 B per incidence) where the library keeps them: k_pcgf on one rank at a forcing term >= 1e-4 (csrc/ba_capi.hip, PCG_W32_MIN_ETA)
+            w32 = (passes == 1.0 and world == 1 and os.environ.get("AAR_FORCE_COMM") != "1" and os.environ.get("AAR_PCG_W32") != "0" and problem.solver_stats()["pcg_eta"] >= 1e-4)
+            blk_b = 144.0 if w32 else 288.0
+            util_by = blk_b * float(kf.sum()) / max(1, world) * (1.0 + passes * pcg_total / float(done))
             by = 8.0 * (n_pad * n_pad / 2 + n_pad)
             extra["utilisation"] = {"bytes_per_launch": util_by, "achieved": util_by / avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": util_by / avg_s / 1e9 / HBM_PEAK_GBPS,
-                                    "model": "288 B per (entity, frame) incidence per pass over W: the kernel's own traffic model (frame-owned blocks: overhead by SURVEY 8d, not algorithmic bytes)"}
+                                    "model": "%d B per (entity, frame) incidence per pass over W (%s blocks): the kernel's own traffic model (frame-owned blocks: overhead by SURVEY 8d, not algorithmic bytes)" % (int(blk_b), "fp32" if w32 else "fp64")}
         if k == "k_spcg":      # both triangles of the reduced system once into registers; a 6 x n product per wavefront per iteration (+ the one of the set-up)
             by = 8.0 * n_pad * n_pad
         if k == "k_passA" and merged:
