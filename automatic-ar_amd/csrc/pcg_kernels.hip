@@ -1178,9 +1178,9 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     HookScope _h(P, KID_PCG);
     if (P.pcg_fused && !P.deterministic) {   // one pass over W and one hand-over per iteration; its atomics take the sums in any order
         (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * P.n_pad + (size_t)28 * P.A) * sizeof(double), st);
-        // the operator's passes read an fp32 copy of W (half the bytes; AAR_PCG_W32=0: fp64) -- while the forcing term is far above what that rounding can
-        // show (6e-8 relative in the operator): a caller who asks for residuals of 1e-5 and below gets the fp64 blocks
-        if (b.Wf && P.pcg_eta_now >= PCG_W32_MIN_ETA) {
+        // fp32 blocks (kernels.h, Blocks::Wf): allocated -- and written by pass A INSTEAD of the fp64 blocks -- only where the forcing term is far above what
+        // that rounding can show (ba_capi.hip, PCG_W32_MIN_ETA; AAR_PCG_W32=0: never): the allocation is the one place that decides
+        if (b.Wf) {
             a.Wf = b.Wf;
             allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true>), lds, granted_f32);
             hipLaunchKernelGGL(k_pcgf<true>, dim3(P.pcg_grid), dim3(PCGF32_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * P.n_pad);
