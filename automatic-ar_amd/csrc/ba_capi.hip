@@ -1254,13 +1254,13 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
             //  * one tile of unknowns (up to 16 cameras + markers): the direct chain is a single 25-us launch -- about what 10 CG iterations cost;
             //  * CG on the EXPLICIT Schur complement (SPCG) beats both the LDL^T chain and the CG through the frame blocks wherever it fits (up to 224 shared
             //    entities), 48 .. 216 entities x 500 frames: 1.6x .. 1.4x the direct chain, 3.2x .. 1.1x PCG;
-            //  * PCG never forms the complement: its step costs (CG iterations) x (a pass over the frames' W blocks), SPCG's one Schur complement (work ~ slots x
-            //    slots-per-frame) + CG iterations of ~1.7 us.  PCG overtakes on long sequences of frames that each see many entities: measured crossovers at
-            //    ~100 k (entity, frame) incidences for 122 per frame (216 entities), ~230 k for 92 (160 entities), beyond 320 k for 64 (112 entities) -- fitted by
-            //    incidences x (incidences per frame - 55) >= 7e6.
+            //  * PCG never forms the complement: its step costs (CG iterations) x (a pass over the frames' W blocks -- fp32 since round 5), SPCG's one Schur complement
+            //    (work ~ slots x slots-per-frame) + CG iterations of ~1.7 us.  PCG overtakes on long sequences of frames that each see many entities: measured
+            //    crossovers at ~60 k (entity, frame) incidences for 122 per frame (216 entities), ~140 k for 92 (160 entities), ~200 k for 64 (112 entities) -- fitted
+            //    by  incidences x (incidences per frame - 40) >= 6e6.
             // The rule is applied to a rank's SHARE of the whole data set (shards are balanced by observation count), from numbers every rank holds.
             const double kf_avg = Fg > 0 ? (double)global_slots / (double)Fg : 0.0;
-            const bool pcg_pays = A >= 96 && pcg_ok && (double)global_slots / (double)world * (kf_avg - 55.0) >= 7e6;
+            const bool pcg_pays = A >= 96 && pcg_ok && (double)global_slots / (double)world * (kf_avg - 40.0) >= 6e6;
             if (P.nT < 2) solver = AAR_SOLVER_DIRECT;
             else if (spcg_ok && !pcg_pays) solver = AAR_SOLVER_SPCG;
             else if (pcg_ok) solver = AAR_SOLVER_PCG;
@@ -1604,10 +1604,10 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         AL(pcg_ws, (size_t)P.pcg_n_items * 28 + 6 * (size_t)F + 8); AL(pcg_counter, 8);
         AL(pcg_yg, (size_t)3 * P.n_pad + (size_t)28 * A + 8);
         if (const char *t = getenv("AAR_PCG_FUSED")) P.pcg_fused = atoi(t) != 0 ? 1 : 0;
-        {   // k_pcgf's operator reads an fp32 copy of W (half the bytes of its pass over the frames; written by pass A beside the fp64 blocks): single-rank, non-deterministic runs
+        {   // k_pcgf's operator reads an fp32 copy of W (half the bytes of its pass over the frames; written by pass A instead of the fp64 blocks): non-deterministic runs, one rank or many
             int w32 = 1;
             if (const char *t = getenv("AAR_PCG_W32")) w32 = atoi(t) != 0 ? 1 : 0;
-            if (w32 && P.pcg_fused && !P.deterministic && !pb->comm && P.pcg_eta >= PCG_W32_MIN_ETA)   // (a caller who asks for residuals below 1e-4 gets fp64 blocks throughout)
+            if (w32 && P.pcg_fused && !P.deterministic && P.pcg_eta >= PCG_W32_MIN_ETA)   // (a caller who asks for residuals below 1e-4 gets fp64 blocks throughout)
                 for (int w = 0; w < 2; w++) AL(blk[w].Wf, (size_t)P.total_slots * 36 + 4);
         }
         hipDeviceProp_t prop;

@@ -1010,6 +1010,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_setup_f(const PcgDistArgs 
 
 struct PcgDistBufs { const double *state_rd; double *state_wr; const double *y_rd; double *y_wr, *y_zero; };
 
+template <bool W32>   // (fp32 W blocks: kernels.h, Blocks::Wf)
 __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d, const PcgDistBufs bf) {
     extern __shared__ __align__(16) double lds[];
     const PcgArgs &a = d.a;
@@ -1127,7 +1128,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
         return;
     }
     for (int i = wg * PCG_THREADS + tid; i < n; i += G * PCG_THREADS) bf.y_zero[i] = 0.0;   // the buffer of the NEXT launch (last read two launches ago)
-    pcgf_operator<false>(a, p, yacc, red, wg, G);
+    pcgf_operator<W32>(a, p, yacc, red, wg, G);
     for (int i = tid; i < n; i += PCG_THREADS) {
         const double v = yacc[i];
         if (v != 0.0) atomicAdd(bf.y_wr + i, v);
@@ -1194,6 +1195,7 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     hipLaunchKernelGGL(k_pcg, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a);
 }
 
+static inline bool pcgd_fused(const DeviceProblem &P) { return P.pcg_fused && !P.deterministic; }
 static PcgDistArgs pcgd_args(const DeviceProblem &P, int which, double mu) {
     const DeviceProblem::Blocks &b = P.blk[which];
     PcgDistArgs d;
@@ -1205,6 +1207,7 @@ static PcgDistArgs pcgd_args(const DeviceProblem &P, int which, double mu) {
     a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
     a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
+    a.Wf = pcgd_fused(P) ? P.blk[which].Wf : nullptr;   // (allocated only where pass A writes it instead of the fp64 blocks)
     d.setup_local = P.pcgd_setup; d.minv = P.pcgd_minv; d.state = P.pcgd_state; d.y = P.pcgd_y;
     d.k = 0; d.last = 0; d.host = P.pcgd_host; d.publish_seq = 0;
     return d;
@@ -1213,7 +1216,6 @@ static PcgDistArgs pcgd_args(const DeviceProblem &P, int which, double mu) {
 // stride (doubles) of one of the three rotating y buffers / of one of the two state buffers of the fused sharded path
 static inline size_t pcgd_y_stride(const DeviceProblem &P) { return (size_t)6 * P.A + 8; }
 static inline size_t pcgd_state_stride(const DeviceProblem &P) { return (size_t)18 * P.A + 8; }
-static inline bool pcgd_fused(const DeviceProblem &P) { return P.pcg_fused && !P.deterministic; }
 // the buffer the host all-reduces after launch k
 double *pcgd_y_of_launch(const DeviceProblem &P, int k) { return pcgd_fused(P) ? P.pcgd_y + (size_t)(k % 3) * pcgd_y_stride(P) : P.pcgd_y; }
 
@@ -1243,8 +1245,14 @@ void launch_pcgd_iter(const DeviceProblem &P, int which, double mu, int k, bool 
         const size_t ys = pcgd_y_stride(P), ss = pcgd_state_stride(P);
         bf.state_rd = P.pcgd_state + (size_t)(k % 2) * ss; bf.state_wr = P.pcgd_state + (size_t)((k + 1) % 2) * ss;
         bf.y_rd = P.pcgd_y + (size_t)((k + 2) % 3) * ys; bf.y_wr = P.pcgd_y + (size_t)(k % 3) * ys; bf.y_zero = P.pcgd_y + (size_t)((k + 1) % 3) * ys;
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter_f), lds, granted_f);
-        hipLaunchKernelGGL(k_pcgd_iter_f, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, d, bf);
+        if (d.a.Wf) {
+            static size_t granted_f32 = 48 * 1024;
+            allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter_f<true>), lds, granted_f32);
+            hipLaunchKernelGGL(k_pcgd_iter_f<true>, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, d, bf);
+            return;
+        }
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter_f<false>), lds, granted_f);
+        hipLaunchKernelGGL(k_pcgd_iter_f<false>, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, d, bf);
         return;
     }
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter), lds, granted);

@@ -257,7 +257,7 @@ def kernel_profile(problem, ds, workload, x0, steps, params, world, intrinsics=F
             # one pass over the W blocks for the preconditioner, ONE per CG iteration (k_pcgf; two with k_pcg: deterministic mode, AAR_PCG_FUSED=0), 288 B per incidence
             passes = 2.0 if (deterministic or os.environ.get("AAR_PCG_FUSED") == "0") else 1.0
             # fp32 blocks (144 B per incidence) where the library keeps them: k_pcgf on one rank at a forcing term >= 1e-4 (csrc/ba_capi.hip, PCG_W32_MIN_ETA)
-            w32 = (passes == 1.0 and world == 1 and os.environ.get("AAR_FORCE_COMM") != "1" and os.environ.get("AAR_PCG_W32") != "0" and problem.solver_stats()["pcg_eta"] >= 1e-4)
+            w32 = (passes == 1.0 and os.environ.get("AAR_PCG_W32") != "0" and problem.solver_stats()["pcg_eta"] >= 1e-4)
             blk_b = 144.0 if w32 else 288.0
             util_by = blk_b * float(kf.sum()) / max(1, world) * (1.0 + passes * pcg_total / float(done))
             by = 8.0 * (n_pad * n_pad / 2 + n_pad)
