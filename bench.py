@@ -211,6 +211,10 @@ def kernel_profile(problem, ds, workload, x0, steps, params, world, intrinsics=F
     problem.set_kernel_profiling(True)
     # in up to eight chunks: a kernel's average is the MEDIAN of its per-chunk averages -- the boxes of this pool stall for tens of milliseconds once in a while
     # (seen: one 75-ms and one 400-ms bracket in 1000-step passes), and one such bracket would otherwise be some kernel's "average"
+    # A short timed region (the driver's --steps 20) would leave ONE chunk and no protection: the instrumented pass -- it is not the timed region -- then runs
+    # 120 steps (eight whole solves of the headline workload; `launches` and roofline["profiled_steps"] say so).  Config 5 keeps its 45 (three chunks).
+    if steps < 120 and workload != 5:
+        steps = 120
     n_chunks = max(1, min(8, steps // 15))
     done, prev, per_chunk = 0, {}, {}
     for c in range(n_chunks):
@@ -312,6 +316,7 @@ def kernel_profile(problem, ds, workload, x0, steps, params, world, intrinsics=F
                              # matrix: ~1 500 (pass A, slot images included) + ~1 700 (pass B) executed flops per observation
                              "executed_flops_per_observation": 3200, "executed_frac": 3200.0 * n_loc / tj / 1e12 / FP64_PEAK_TFLOPS}
     roofline["sum_kernel_us_per_step"] = sum(v["total_ms"] for v in kernels.values()) * 1e3 / float(done)     # all launches of the pass / its LM steps
+    roofline["profiled_steps"] = int(done)             # LM steps of the instrumented pass (>= 120 at configs 2-4 whatever --steps says): `kernels[*].launches` belong to these
     return kernels, roofline
 
 
