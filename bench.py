@@ -371,7 +371,36 @@ def other_workload(aar, w, device, steps, warmup):
         dR, dT = pose_delta_max(ds, x_fin, x_d)
         out.update(direct={"it_per_s": n_d / dt_d, "steps": n_d, "lm_iterations_to_stop": rep_d["iterations"], "final_rmse_px": rmse_d},
                    rmse_delta_vs_direct_px=abs(rmse - rmse_d), pose_delta_vs_direct={"rotation_matrix_entries": dR, "translation_m": dT})
+    if out["solver_resolved"] == "pcg":
+        out["block_storage"] = pcg_block_storage(aar, ds, device, steps, warmup, params, x_fin)
     return out
+
+
+def pcg_block_storage(aar, ds, device, steps, warmup, params, x_fin, intrinsics=False, solver=None):
+    """The PCG mode keeps the frame-entity coupling blocks W in fp32 (storage only: every product and sum is fp64; forcing terms >= 1e-4).  So that the
+    figure of this line can be judged: the SAME measurement with fp64 blocks (AAR_PCG_W32=0, read when a problem is created) and how far the two runs' final poses are apart."""
+    from pose_metrics import pose_delta_max
+    if os.environ.get("AAR_PCG_W32") == "0":
+        return {"W": "fp64 (AAR_PCG_W32=0)"}
+    os.environ["AAR_PCG_W32"] = "0"
+    try:
+        with aar.Problem(ds, residual_mode=aar.RES_F32, device=device, intrinsics=intrinsics, solver=solver) as p64:
+            x0 = p64.x_with_intrinsics(ds.x_full) if intrinsics else ds.x_full
+            p64.lm_solve(x0, params=params(), trace_cap=1)
+            n = min(steps, 30)
+            run_steps(p64, x0, min(warmup, 15), params)
+            aar.lib().aar_device_synchronize()
+            t0 = time.perf_counter()
+            run_steps(p64, x0, n, params)
+            aar.lib().aar_device_synchronize()
+            dt = time.perf_counter() - t0
+            x64, rep64 = p64.lm_solve(x0, params=params())
+    finally:
+        del os.environ["AAR_PCG_W32"]
+    dR, dT = pose_delta_max(ds, x_fin, x64)
+    return {"W": "fp32 storage, fp64 arithmetic (pass A writes the fp32 blocks; k_pcgf, the back-substitution read them)", "switch": "AAR_PCG_W32=0 keeps fp64 blocks",
+            "with_fp64_blocks": {"it_per_s": n / dt, "ms_per_step": 1e3 * dt / n, "steps": n, "lm_iterations_to_stop": rep64["iterations"]},
+            "pose_delta_fp32_vs_fp64_blocks": {"rotation_matrix_entries": dR, "translation_m": dT}}
 
 
 def scaling_workload(aar, w, world, rank, local_rank, comm, dist, steps, warmup):
@@ -688,6 +717,11 @@ def main():
             if w != args.workload:
                 others[str(w)] = other_workload(aar, w, local_rank, st_w, wu_w)
 
+    # ---- PCG keeps its W blocks in fp32: the same measurement with fp64 blocks beside it ----
+    block_storage = None
+    if solver == "pcg" and world == 1 and comm is None and not args.deterministic and (args.pcg_eta is None or args.pcg_eta >= 1e-4):
+        block_storage = pcg_block_storage(aar, ds, local_rank, args.steps, args.warmup, params, x_fin, intrinsics=args.intrinsics, solver=args.solver)
+
     # ---- N > 1 (or AAR_BENCH_SCALING=1 behind a single-rank communicator): the workloads BASELINE.json shards over 8 GPUs, in the same line ----
     scaling = None
     if (world > 1 or os.environ.get("AAR_BENCH_SCALING") == "1") and not args.no_scaling_workloads:
@@ -726,7 +760,7 @@ def main():
         "solver_stats": problem.solver_stats(),
         # the direct solver on the same problem (the reference's step to rounding): what the inexact default is judged against
         "direct_it_per_s": direct["it_per_s"] if direct else None, "direct": direct,
-        "rmse_delta_vs_direct_px": abs(rmse - direct["final_rmse_px"]) if direct else None, "pose_delta_vs_direct": pose_delta,
+        "rmse_delta_vs_direct_px": abs(rmse - direct["final_rmse_px"]) if direct else None, "pose_delta_vs_direct": pose_delta, "block_storage": block_storage,
         # N = 1: configs 4 and 5 on the same GPU through the same default path (other_workload above)
         "other_workloads": others,
         # multi-GPU bookkeeping: ranks RCCL itself reports for the communicator, observations per rank (frame-range shards

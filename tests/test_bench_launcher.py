@@ -117,6 +117,11 @@ def test_committed_bench_lines_keep_the_contract():
             assert k in o, (w, k)
         assert o["solver_resolved"] == sol and o["rmse_delta_vs_direct_px"] < 1e-6 and max(o["pose_delta_vs_direct"].values()) < 1e-5
         assert o["roofline"]["traffic"] and "fp64_valu" in o["roofline"] and 0 < o["iteration_hbm"]["frac"] < 1
+    # config 5 runs PCG with fp32 W blocks (storage only): the line carries the same measurement with fp64 blocks and the distance between the two runs' final poses
+    bs = dd["other_workloads"]["5"]["block_storage"]
+    assert bs["W"].startswith("fp32 storage") and bs["with_fp64_blocks"]["lm_iterations_to_stop"] == dd["other_workloads"]["5"]["lm_iterations_to_stop"]
+    assert 0 < bs["with_fp64_blocks"]["it_per_s"] < dd["other_workloads"]["5"]["value"] and max(bs["pose_delta_fp32_vs_fp64_blocks"].values()) < 1e-7
+    assert dd["block_storage"] is None and "block_storage" not in dd["other_workloads"]["4"]          # (SPCG: fp64 throughout)
     # the N > 1 line's extra workloads, as measured behind a single-rank communicator
     sw = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg3_single_rank_rccl.json")))["scaling_workloads"]
     assert sw["4"]["solver_resolved"] == "spcg" and sw["5"]["solver_resolved"] == "pcg" and sw["5"]["value"] > 500 and sw["4"]["amdahl"]["bound_at"]["8"] > 1.5
