@@ -1227,7 +1227,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         auto env_int = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
         env_int("AAR_FUSED_PANEL", P.tune.fused_panel); env_int("AAR_BS_RIDES", P.tune.bs_rides); env_int("AAR_BACKSUB_RIDES", P.tune.backsub_rides);
         env_int("AAR_LDL_LOOKAHEAD", P.tune.lookahead); env_int("AAR_PASSA_VARIANT", P.tune.passA_variant); env_int("AAR_PACK_SYSTEM", P.tune.pack_system);
-        env_int("AAR_INIT_HEADSTART", P.tune.init_headstart); env_int("AAR_PASSB_LEAN", P.tune.passB_lean); env_int("AAR_PASSA_WRENCH", P.tune.passA_wrench); env_int("AAR_PASSB_WRENCH_MERGED", P.tune.passB_wrench_merged); env_int("AAR_SPCG_BACKSUB_RIDES", P.tune.spcg_backsub_rides);
+        env_int("AAR_INIT_HEADSTART", P.tune.init_headstart); env_int("AAR_PASSB_LEAN", P.tune.passB_lean); env_int("AAR_PASSA_WRENCH", P.tune.passA_wrench); env_int("AAR_PASSB_WRENCH_MERGED", P.tune.passB_wrench_merged); env_int("AAR_SPCG_BACKSUB_RIDES", P.tune.spcg_backsub_rides); env_int("AAR_PASSAB_OCC2", P.tune.passAB_occ2);
     }
     // the frame-block kernel keeps a frame's slots in LDS: sized by the form that is actually launched (wrench form: 21 + 4 doubles per slot; row form: 62)
     const size_t ldsA = P.tune.passA_wrench ? passA_wrench_lds_bytes(P.max_kf, L.oi)
@@ -1243,6 +1243,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
     {   // which solver (aar_solver_options; AUTO: DESIGN.md section 12)
         hipDeviceProp_t prop;
         const int cus = (hipGetDeviceProperties(&prop, pb->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;
+        P.n_cus = cus;
         const bool pcg_ok = pcg_lds_bytes(A) <= 150 * 1024;
         // one wavefront per entity, every one of them resident AT ONCE (they hand over to each other): asked of the runtime's occupancy calculator for this
         // kernel's registers and LDS, as pcg_max_grid asks for the PCG grid.  (Another process on the device can still take the slots: k_spcg's time-out.)

@@ -1173,6 +1173,14 @@ __global__ void __launch_bounds__(BLOCK) k_passAB(const PassAArgs a, const PassB
     } else if (WRB) passB_wrench_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
     else passB_body(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
 }
+// the same capped at 256 registers (two wavefronts per SIMD; pass B's corner loop not unrolled): long sequences, whose frame workgroups would otherwise take
+// more than one round of the chip's wavefront slots (AAR_PASSAB_OCC2; profiles/r05_attempts.txt section 6)
+template <int BLOCK, int CPL>
+__global__ void __launch_bounds__(BLOCK, 2) k_passAB_o2(const PassAArgs a, const PassBArgs b) {
+    extern __shared__ double lds[];
+    if ((int)blockIdx.x < a.F) passA_wrench_body<BLOCK, CPL>(a, lds, (int)blockIdx.x, a.F);
+    else passB_body<false, true>(b, lds, ((int)blockIdx.x - a.F) * (BLOCK / 64));
+}
 // the same with camera intrinsics optimised: pass A with the W_kf blocks, pass B, and pass B's intrinsics blocks (three launches before)
 template <int BLOCK, int CPL, bool WR>
 __global__ void __launch_bounds__(BLOCK) k_passAB_intr(const PassAArgs a, const PassBArgs b, int nb) {
@@ -1320,6 +1328,13 @@ static void launch_passA_t(const DeviceProblem &P, const PassAArgs &a, const Pas
             allow_dynamic_lds(reinterpret_cast<const void *>(k_passA_intr<B, CPL, false>), lds, granted_i);
             hipLaunchKernelGGL((k_passA_intr<B, CPL, false>), dim3(P.F), dim3(B), lds, st, a);
         }
+    } else if (pbargs && P.tune.passA_wrench && !P.tune.passB_wrench_merged &&
+               (P.tune.passAB_occ2 >= 0 ? P.tune.passAB_occ2 != 0 : P.F + (P.n_chunks + B / 64 - 1) / (B / 64) > P.n_cus * 4 / (B / 64))) {
+        // more workgroups than the chip holds at one wavefront per SIMD (388 registers): at two the frames of a long sequence run in one round instead of two
+        // (config 4, 2000 frames: 36.3 -> 32.6 us; config 3's 500 frames fit anyway and keep the unrolled pass B)
+        static size_t granted_o2 = 48 * 1024;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB_o2<B, CPL>), lds, granted_o2);
+        hipLaunchKernelGGL((k_passAB_o2<B, CPL>), dim3(P.F + (P.n_chunks + B / 64 - 1) / (B / 64)), dim3(B), lds, st, a, *pbargs);
     } else if (pbargs && P.tune.passA_wrench && !P.tune.passB_wrench_merged) {   // (the default: pass A in wrench form, pass B's chunks in row form)
         static size_t granted_abr = 48 * 1024;
         allow_dynamic_lds(reinterpret_cast<const void *>(k_passAB<B, CPL, true, false>), lds, granted_abr);

@@ -115,6 +115,7 @@ struct DeviceProblem {
     double *pcg_ws = nullptr;             // items' shares [n_items][28] | t [6F]
     int32_t *pcg_counter = nullptr;       // [0..1] grid-barrier counters (alternating), [2] iterations of the last solve, [3] running total
     mutable int pcg_parity = 0;
+    int n_cus = 256;                      // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     mutable int want_w64 = 0;             // aar_eval_normal_equations: pass A writes the fp64 W blocks even where the solver only reads the fp32 copy (Blocks::Wf)
     int pcg_fused = 1;                    // AAR_PCG_FUSED=0: k_pcg (two passes over W and two hand-overs per iteration) instead of k_pcgf
     int32_t *up_start = nullptr, *up_ent = nullptr;   // [A + 1], [..]: entity -> the OTHER entities whose block of U can be non-zero (seen together in an observation); the CG operator skips the rest
@@ -139,6 +140,7 @@ struct DeviceProblem {
         int backsub_rides = 0;     // AAR_BACKSUB_RIDES=1: the frame back-substitution rides in the last tile's launch
         int lookahead = 1;         // AAR_LDL_LOOKAHEAD=0: tall block columns launch k_ldl_update
         int passA_variant = 0;     // AAR_PASSA_VARIANT: 641 / 642 / 644 / 1281 / 1282 / 1284 / 2564 force a pass A workgroup shape (threads, corners per lane)
+        int passAB_occ2 = -1;       // AAR_PASSAB_OCC2=0 / 1: the merged observation passes capped at 256 registers (two wavefronts per SIMD); -1: when their workgroups exceed one round of the chip's slots
         int spcg_backsub_rides = 0; // AAR_SPCG_BACKSUB_RIDES=1 (experiment, slower: profiles/r04_attempts.txt): the frame back-substitution rides in k_spcg's launch on the XCDs the CG leaves idle
         int passA_wrench = 1;      // AAR_PASSA_WRENCH=0: pass A in its row form (three Jacobian blocks per row, 100 accumulators per lane) -- the A/B reference of the wrench form
         int passB_wrench_merged = 0;   // AAR_PASSB_WRENCH_MERGED=1: pass B in wrench form also inside the merged launch of small problems (there a lane has one observation and the
