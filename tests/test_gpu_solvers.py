@@ -66,9 +66,10 @@ POSE_BAR_CAMS, POSE_BAR_OTHERS = 1e-5, 1e-5
 POSE_BAR_FAITHFUL = 3e-4
 
 
-def _assert_poses_close(ds, x, x_direct, what):
+def _assert_poses_close(ds, x, x_direct, what, cams_bar=None):
     d = pose_delta(ds, x, x_direct)
-    assert max(d["cams"]) < POSE_BAR_CAMS, (what, d)
+    cr, ct = cams_bar if cams_bar is not None else (POSE_BAR_CAMS, POSE_BAR_CAMS)
+    assert d["cams"][0] < cr and d["cams"][1] < ct, (what, d)
     assert max(d["markers"]) < POSE_BAR_OTHERS and max(d["frames"]) < POSE_BAR_OTHERS, (what, d)
     return d
 
@@ -91,7 +92,9 @@ def test_default_options_reach_the_direct_paths_poses_at_full_size(cfg):
     assert rep["iterations"] == rep_d["iterations"], (rep["iterations"], rep_d["iterations"])
     assert abs(rmse - rmse_d) < 1e-6, (rmse, rmse_d)
     assert st["total_iterations"] > 0 and st["fallbacks"] <= 1
-    _assert_poses_close(ds, x, x_d, "config %d" % cfg)
+    # cameras: 1e-6 at configs 3 and 4 (measured 5e-8 / 3e-7 and 2e-7 / 4e-7); at config 5 the cameras' ROTATIONS are within 1e-6 too (3e-7), their translations
+    # 4.7e-6 m (16 cameras around a 200-marker scene: the rig's scale is its weakest direction; forced SPCG ends 4.5e-6 away there as well): 1e-5 stated
+    _assert_poses_close(ds, x, x_d, "config %d" % cfg, cams_bar=(1e-6, 1e-5 if cfg == 5 else 1e-6))
 
 
 @pytest.mark.parametrize("name", ["g1_cfg2", "g1_cfg2_far", "g1_cfg2_retry", "g1_cfg2_huber", "g1_cfg2_huber_retry", "g1_cfg2_intr", "g1_cfg3_cut"])
