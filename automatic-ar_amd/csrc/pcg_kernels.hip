@@ -39,6 +39,7 @@ struct PcgArgs {
     // work space
     double *part;                                // [n_items][28] the items' shares (27 values in the set-up, 6 per iteration)
     double *t;                                   // [6 F]
+    int32_t *hop = nullptr;                      // k_pcgf: [2][PCG_NY][16] spread barrier counters (grid_hop_spread)
     int32_t *counter;                            // [2]  grid barrier counters: this launch uses counter[parity] (zero at entry) and clears the other
     int parity;
     double *x_out;                               // [6 A (.. n_pad)] delta_s
@@ -46,6 +47,16 @@ struct PcgArgs {
     int32_t *flags;
 };
 
+#ifdef AAR_PCG_STAMPS   // diagnostic build (scripts/dev/pcg_stamps.sh): s_memtime stamps of three workgroups of k_pcgf, per CG iteration
+__device__ unsigned long long g_pcg_st[3][32][16];
+__device__ __forceinline__ void pcg_stamp(int wg, int G, int it, int slot) {
+    const int sel = wg == 0 ? 0 : (wg == G / 2 ? 1 : (wg == G - 1 ? 2 : -1));
+    if (sel >= 0 && it < 32 && (threadIdx.x & 63) == 0) g_pcg_st[sel][it][slot] = __builtin_amdgcn_s_memtime();
+}
+#define PCG_STAMP(it, slot) do { __builtin_amdgcn_sched_barrier(0); pcg_stamp(wg, G, (it), (slot)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PCG_STAMP(it, slot) do { } while (0)
+#endif
 __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -73,6 +84,34 @@ __device__ __forceinline__ bool grid_hop(int32_t *counter, int &round, int G, in
     }
     __syncthreads();
     return hop_dead == 0;
+}
+
+// The same for k_pcgf with the arrivals SPREAD over PCG_NY counters (one per 64 bytes): 256 agent-scope increments of ONE address serialise at the memory
+// side (~60 ns each: the 15 us a hop used to cost at config 5); 16 per counter do not.  The first wavefront polls: lane k reads counter k, the sum decides.
+__device__ __forceinline__ bool grid_hop_spread(int32_t *cnt, int &round, int G, int32_t *flags, int wg) {
+    __shared__ int hop_dead_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    round++;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_fetch_add(cnt + (wg % PCG_NY) * 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = round * G;
+        long spins = 0;
+        int dead = 0;
+        for (;;) {
+            int v = lane < PCG_NY ? __hip_atomic_load(cnt + lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+            for (int off = 1; off < PCG_NY; off <<= 1) v += __shfl_xor(v, off);
+            if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 0x3ff) == 0 && (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) { dead = 1; break; }
+            if (spins > (1L << 26)) { if (lane == 0) atomicOr(flags, 4); dead = 1; break; }
+        }
+        if (lane == 0) hop_dead_s = dead;
+    }
+    __syncthreads();
+    return hop_dead_s == 0;
 }
 
 // sum of NV per-thread values over the 256 threads, fixed order; result in out[0..NV) on every thread.  lds: 4 * NV doubles
@@ -419,11 +458,12 @@ __device__ __forceinline__ void pcgf_setup_slots(const PcgArgs &a, double *__res
 // preconditioner and the back-substitution keep fp64 W, and a rounding of 6e-8 in the operator is far below the forcing term -- final poses unchanged
 // (scripts/experiments/pcg_w_float.py; profiles/r05_attempts.txt section 5)
 template <bool W32, int TH = PCG_THREADS>
-__device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__restrict__ p, double *__restrict__ yacc, double *__restrict__ red, int wg, int G) {
+__device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__restrict__ p, double *__restrict__ yacc, double *__restrict__ red, int wg, int G, int st_it = 0) {
     constexpr int NW = TH / 64;
     const int n = 6 * a.A, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < n; i += TH) yacc[i] = 0.0;
     __syncthreads();
+    if (wave == 0) PCG_STAMP(st_it, 1);
     // (U p) for the block rows dealt to this workgroup, FIRST (the wavefronts without blocks go straight to their frames): one thread per stored block
     // U_eb, b < e, of the blocks that exist (U is block-sparse: entities that share an observation -- camera x marker; at config 5, 16 of a marker's 216),
     // read row-wise in 16-byte pieces, used twice -- y_e += U_eb p_b and y_b += U_eb^T p_e -- and added to the workgroup's y in LDS like the frames'
@@ -467,6 +507,7 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
             for (int j = 0; j < 6; j++) atomicAdd(yacc + 6 * b + j, yb[j]);
         }
     }
+    if (wave == 0) PCG_STAMP(st_it, 2);
     // Frames: a CONTIGUOUS range per workgroup (F / G of them, to one), dealt round-robin to its wavefronts -- every workgroup takes the same number of rounds
     // (dealt wave-major over the whole grid, 5000 frames over 2048 wavefronts left 113 workgroups with three rounds and 143 with two)
     const int f_lo = (int)((long long)wg * a.F / G), f_hi = (int)((long long)(wg + 1) * a.F / G);
@@ -550,7 +591,9 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
             scatter(wt, e);
         }
     }
+    PCG_STAMP(st_it, 3 + (wave < 8 ? wave : 7));
     __syncthreads();
+    if (wave == 0) PCG_STAMP(st_it, 11);
 }
 
 // (the fp32 operator needs 217 registers: two wavefronts per SIMD fit, and the frame pass is latency-bound -- 512 threads per workgroup there)
@@ -561,18 +604,18 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *x = lds, *r = lds + n, *p = r + n, *Mi = p + n, *yacc = Mi + 6 * n, *red = yacc + n;
-    int32_t *counter = a.counter + a.parity;
+    int32_t *counter = a.hop + a.parity * PCG_NY * 16;   // (PCG_NY counters: grid_hop_spread)
     int round = 0;
-    if (wg == 0 && tid == 0) __hip_atomic_store(a.counter + (1 - a.parity), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    if (wg == 0 && tid < PCG_NY) __hip_atomic_store(a.hop + (1 - a.parity) * PCG_NY * 16 + tid * 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
 
     // ---- set-up, first half: every slot's share of the diagonal blocks and of the right-hand side, by entity in LDS, then ONE atomic flush ----
     double *sacc = Mi;
     pcgf_setup_slots<TH>(a, sacc, wg, G);
     for (int i = tid; i < 27 * a.A; i += TH) {
         const double v = sacc[i];
-        if (v != 0.0) atomicAdd(sg + (size_t)(i / 27) * 28 + (i % 27), v);
+        if (v != 0.0) atomicAdd(sg + (size_t)(i / 27) * 28 + (i % 27), v);   // (once per solve: not spread over partial tables -- every workgroup would read PCG_NY x 27 A values back: measured +78 us)
     }
-    if (!grid_hop(counter, round, G, a.flags)) return;
+    if (!grid_hop_spread(counter, round, G, a.flags, wg)) return;
     // ---- set-up, second half, redundantly in every workgroup (one thread per entity): the diagonal block of S inverted straight into LDS,
     //      the right-hand side; x = 0, r = b.  (Every thread reads its sums into registers before the barrier below lets Mi overwrite sacc.) ----
     // (every thread reads the sums it needs past the L2, not from sacc: Mi may take sacc's place at once -- but only when all threads have flushed it)
@@ -627,14 +670,18 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     int it_cg = 0;
     double rr = bb;
     while (it_cg < a.max_it && (rr > a.eta2 * bb || rz > a.abs2) && bb > 0.0) {
-        double *ygc = yg + (size_t)(it_cg % 3) * a.n_pad, *ygn = yg + (size_t)((it_cg + 1) % 3) * a.n_pad;
-        for (int i = wg * TH + tid; i < n; i += G * TH) st_agent(ygn + i, 0.0);
-        pcgf_operator<W32, TH>(a, p, yacc, red, wg, G);
+        // y of this iteration: PCG_NY partial vectors (workgroup wg adds into vector wg % PCG_NY: 16 instead of 256 atomics per address), summed by every reader
+        double *ygc = yg + (size_t)(it_cg % 3) * PCG_NY * a.n_pad, *ygn = yg + (size_t)((it_cg + 1) % 3) * PCG_NY * a.n_pad;
+        for (int i = wg * TH + tid; i < PCG_NY * a.n_pad; i += G * TH) st_agent(ygn + i, 0.0);
+        if (wave == 0) PCG_STAMP(it_cg, 0);
+        pcgf_operator<W32, TH>(a, p, yacc, red, wg, G, it_cg);
         for (int i = tid; i < n; i += TH) {
             const double v = yacc[i];
-            if (v != 0.0) atomicAdd(ygc + i, v);
+            if (v != 0.0) atomicAdd(ygc + (size_t)(wg % PCG_NY) * a.n_pad + i, v);
         }
-        if (!grid_hop(counter, round, G, a.flags)) return;
+        if (wave == 0) PCG_STAMP(it_cg, 12);
+        if (!grid_hop_spread(counter, round, G, a.flags, wg)) return;
+        if (wave == 0) PCG_STAMP(it_cg, 13);
         // ---- vector updates, redundantly in every workgroup (same numbers, same order: same decisions) ----
         double yl[24];
         double pAp = 0.0;
@@ -642,7 +689,13 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
             double sv[1] = {0.0};
             int ny = 0;
             for (int i = tid; i < n; i += TH, ny++) {
-                double yv = fma(a.mu, p[i], ld_agent(ygc + i));
+                double ys[PCG_NY];
+#pragma unroll
+                for (int k = 0; k < PCG_NY; k++) ys[k] = ld_agent(ygc + (size_t)k * a.n_pad + i);   // (all in flight together; added in a fixed order)
+                double ysum = 0.0;
+#pragma unroll
+                for (int k = 0; k < PCG_NY; k++) ysum += ys[k];
+                double yv = fma(a.mu, p[i], ysum);
                 if (a.ent_fixed[i / 6]) yv = p[i];
                 if (ny < 24) yl[ny] = yv;
                 sv[0] = fma(p[i], yv, sv[0]);
@@ -678,6 +731,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
         nz = 0;
         for (int i = tid; i < n; i += TH, nz++) p[i] = fma(beta, p[i], zloc[nz < 24 ? nz : 23]);
         __syncthreads();
+        if (wave == 0) PCG_STAMP(it_cg, 14);
         it_cg++;
     }
     if (wg == 0) {
@@ -1171,24 +1225,24 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.it_ent = P.pcg_it_ent; a.it_begin = P.pcg_it_begin; a.it_end = P.pcg_it_end; a.ent_item_start = P.pcg_ent_item_start; a.n_items = P.pcg_n_items;
     a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.abs2 = P.pcg_abs_tol * P.pcg_abs_tol * mu; a.max_it = P.pcg_max_it;
     a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
-    a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
+    a.counter = P.pcg_counter; a.hop = P.pcg_hop; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
     const size_t lds = pcg_lds_bytes(P.A);
     static size_t granted = 48 * 1024, granted_f = 48 * 1024, granted_f32 = 48 * 1024;
     a.Wf = nullptr;
     HookScope _h(P, KID_PCG);
     if (P.pcg_fused && !P.deterministic) {   // one pass over W and one hand-over per iteration; its atomics take the sums in any order
-        (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * P.n_pad + (size_t)28 * P.A) * sizeof(double), st);
+        (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * PCG_NY * P.n_pad + (size_t)28 * P.A) * sizeof(double), st);
         // fp32 blocks (kernels.h, Blocks::Wf): allocated -- and written by pass A INSTEAD of the fp64 blocks -- only where the forcing term is far above what
         // that rounding can show (ba_capi.hip, PCG_W32_MIN_ETA; AAR_PCG_W32=0: never): the allocation is the one place that decides
         if (b.Wf) {
             a.Wf = b.Wf;
             allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true>), lds, granted_f32);
-            hipLaunchKernelGGL(k_pcgf<true>, dim3(P.pcg_grid), dim3(PCGF32_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * P.n_pad);
+            hipLaunchKernelGGL(k_pcgf<true>, dim3(P.pcg_grid), dim3(PCGF32_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NY * P.n_pad);
             return;
         }
         allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<false>), lds, granted_f);
-        hipLaunchKernelGGL(k_pcgf<false>, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * P.n_pad);
+        hipLaunchKernelGGL(k_pcgf<false>, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NY * P.n_pad);
         return;
     }
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, granted);
@@ -1260,3 +1314,9 @@ void launch_pcgd_iter(const DeviceProblem &P, int which, double mu, int k, bool 
 }
 
 }  // namespace aar
+
+#ifdef AAR_PCG_STAMPS
+extern "C" int aar_debug_pcg_stamps(unsigned long long *out) {   // [3][32][16]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(aar::g_pcg_st), sizeof(unsigned long long) * 3 * 32 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
