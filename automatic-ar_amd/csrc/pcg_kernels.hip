@@ -39,7 +39,7 @@ struct PcgArgs {
     // work space
     double *part;                                // [n_items][28] the items' shares (27 values in the set-up, 6 per iteration)
     double *t;                                   // [6 F]
-    int32_t *hop = nullptr;                      // k_pcgf: [2][PCG_NY][16] spread barrier counters (grid_hop_spread)
+    int32_t *hop = nullptr;                      // k_pcgf: [2][PCG_HOP_WORDS] barrier words by launch parity (grid_hop_tree)
     int32_t *counter;                            // [2]  grid barrier counters: this launch uses counter[parity] (zero at entry) and clears the other
     int parity;
     double *x_out;                               // [6 A (.. n_pad)] delta_s
@@ -86,29 +86,29 @@ __device__ __forceinline__ bool grid_hop(int32_t *counter, int &round, int G, in
     return hop_dead == 0;
 }
 
-// The same for k_pcgf with the arrivals SPREAD over PCG_NY counters (one per 64 bytes): 256 agent-scope increments of ONE address serialise at the memory
-// side (~60 ns each: the 15 us a hop used to cost at config 5); 16 per counter do not.  The first wavefront polls: lane k reads counter k, the sum decides.
-__device__ __forceinline__ bool grid_hop_spread(int32_t *cnt, int &round, int G, int32_t *flags, int wg) {
+// The same for k_pcgf as a two-level tree, so that no address sees more than PCG_NY agent-scope operations per hop (256 increments of ONE address serialise at
+// the memory side, ~60 ns each: the 15 us a hop used to cost at config 5; 256 pollers of one address are no better): workgroup wg arrives at counter wg % PCG_NY;
+// the last arrival of a group arrives at the second level; the last arrival there raises every group's own flag, which is all a group's workgroups poll.
+// cnt: [PCG_NY] first level | [1] second level | [PCG_NY] flags, one per 64 bytes; all monotonic over the hops of a launch (zero at entry).
+__device__ __forceinline__ bool grid_hop_tree(int32_t *cnt, int &round, int G, int32_t *flags, int wg) {
     __shared__ int hop_dead_s;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     round++;
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        if (lane == 0) __hip_atomic_fetch_add(cnt + (wg % PCG_NY) * 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int target = round * G;
+    if (threadIdx.x == 0) {
+        const int g = wg % PCG_NY, n_groups = G < PCG_NY ? G : PCG_NY, members = (G - g + PCG_NY - 1) / PCG_NY;
+        int32_t *l1 = cnt + g * 16, *l2 = cnt + PCG_NY * 16, *go = cnt + (PCG_NY + 1) * 16;
+        if (__hip_atomic_fetch_add(l1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == round * members)
+            if (__hip_atomic_fetch_add(l2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == round * n_groups)
+                for (int k = 0; k < n_groups; k++) __hip_atomic_store(go + k * 16, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         long spins = 0;
         int dead = 0;
-        for (;;) {
-            int v = lane < PCG_NY ? __hip_atomic_load(cnt + lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-#pragma unroll
-            for (int off = 1; off < PCG_NY; off <<= 1) v += __shfl_xor(v, off);
-            if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+        while (__hip_atomic_load(go + g * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 0x3ff) == 0 && (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) { dead = 1; break; }
-            if (spins > (1L << 26)) { if (lane == 0) atomicOr(flags, 4); dead = 1; break; }
+            if (spins > (1L << 26)) { atomicOr(flags, 4); dead = 1; break; }
         }
-        if (lane == 0) hop_dead_s = dead;
+        hop_dead_s = dead;
     }
     __syncthreads();
     return hop_dead_s == 0;
@@ -604,9 +604,9 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *x = lds, *r = lds + n, *p = r + n, *Mi = p + n, *yacc = Mi + 6 * n, *red = yacc + n;
-    int32_t *counter = a.hop + a.parity * PCG_NY * 16;   // (PCG_NY counters: grid_hop_spread)
+    int32_t *counter = a.hop + a.parity * PCG_HOP_WORDS;   // (grid_hop_tree)
     int round = 0;
-    if (wg == 0 && tid < PCG_NY) __hip_atomic_store(a.hop + (1 - a.parity) * PCG_NY * 16 + tid * 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    if (wg == 0 && tid < 2 * PCG_NY + 1) __hip_atomic_store(a.hop + (1 - a.parity) * PCG_HOP_WORDS + tid * 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
 
     // ---- set-up, first half: every slot's share of the diagonal blocks and of the right-hand side, by entity in LDS, then ONE atomic flush ----
     double *sacc = Mi;
@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
         const double v = sacc[i];
         if (v != 0.0) atomicAdd(sg + (size_t)(i / 27) * 28 + (i % 27), v);   // (once per solve: not spread over partial tables -- every workgroup would read PCG_NY x 27 A values back: measured +78 us)
     }
-    if (!grid_hop_spread(counter, round, G, a.flags, wg)) return;
+    if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
     // ---- set-up, second half, redundantly in every workgroup (one thread per entity): the diagonal block of S inverted straight into LDS,
     //      the right-hand side; x = 0, r = b.  (Every thread reads its sums into registers before the barrier below lets Mi overwrite sacc.) ----
     // (every thread reads the sums it needs past the L2, not from sacc: Mi may take sacc's place at once -- but only when all threads have flushed it)
@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
             if (v != 0.0) atomicAdd(ygc + (size_t)(wg % PCG_NY) * a.n_pad + i, v);
         }
         if (wave == 0) PCG_STAMP(it_cg, 12);
-        if (!grid_hop_spread(counter, round, G, a.flags, wg)) return;
+        if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
         if (wave == 0) PCG_STAMP(it_cg, 13);
         // ---- vector updates, redundantly in every workgroup (same numbers, same order: same decisions) ----
         double yl[24];
