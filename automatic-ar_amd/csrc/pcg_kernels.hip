@@ -65,28 +65,7 @@ __device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomi
 // workgroup LEAVES the kernel at its next hop instead of spinning through the remaining ones (up to two per CG iteration): the launch ends within
 // one time-out, the host reports AAR_ERR_NUMERIC ("chain timed out").  Co-residency itself is not assumed blindly: the grid is clamped to what the
 // occupancy query admits (pcg_max_grid).
-__device__ __forceinline__ bool grid_hop(int32_t *counter, int &round, int G, int32_t *flags) {
-    __shared__ int hop_dead;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have been acknowledged
-    __syncthreads();
-    round++;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int target = round * G;
-        long spins = 0;
-        int dead = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 0x3ff) == 0 && (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) { dead = 1; break; }   // another workgroup gave up: its arrivals will never come
-            if (spins > (1L << 26)) { atomicOr(flags, 4); dead = 1; break; }   // never a hung device
-        }
-        hop_dead = dead;
-    }
-    __syncthreads();
-    return hop_dead == 0;
-}
-
-// The same for k_pcgf as a two-level tree, so that no address sees more than PCG_NY agent-scope operations per hop (256 increments of ONE address serialise at
+// The arrivals form a two-level tree, so that no address sees more than PCG_NY agent-scope operations per hop (256 increments of ONE address serialise at
 // the memory side, ~60 ns each: the 15 us a hop used to cost at config 5; 256 pollers of one address are no better): workgroup wg arrives at counter wg % PCG_NY;
 // the last arrival of a group arrives at the second level; the last arrival there raises every group's own flag, which is all a group's workgroups poll.
 // cnt: [PCG_NY] first level | [1] second level | [PCG_NY] flags, one per 64 bytes; all monotonic over the hops of a launch (zero at entry).
@@ -154,9 +133,9 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
     const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *x = lds, *r = lds + n, *p = r + n, *Mi = p + n, *red = Mi + 6 * n;
-    int32_t *counter = a.counter + a.parity;
+    int32_t *counter = a.hop + a.parity * PCG_HOP_WORDS;   // (grid_hop_tree)
     int round = 0;
-    if (wg == 0 && tid == 0) __hip_atomic_store(a.counter + (1 - a.parity), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    if (wg == 0 && tid < 2 * PCG_NY + 1) __hip_atomic_store(a.hop + (1 - a.parity) * PCG_HOP_WORDS + tid * 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
 
     // ---- set-up, first half: every item's share of sum_f W (V+mu)^-1 W^T (lower triangle, 21) and of sum_f W h_f (6) ----
     for (int it = wg; it < a.n_items; it += G) {
@@ -199,7 +178,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
             for (int i = 0; i < 27; i++) st_agent(a.part + (size_t)it * 28 + i, acc[i]);
         }
     }
-    if (!grid_hop(counter, round, G, a.flags)) return;
+    if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
     // ---- set-up, second half, redundantly in every workgroup (one thread per entity): the items' shares in item order, the diagonal
     //      block of S inverted straight into LDS, the right-hand side; x = 0, r = b ----
     for (int e = tid; e < a.A; e += PCG_THREADS) {
@@ -284,7 +263,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
                 st_agent(a.t + (size_t)f * 6 + lane, tv);
             }
         }
-        if (!grid_hop(counter, round, G, a.flags)) return;
+        if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
         // ---- entity pass, by item: its share of -sum_f W_ef t_f; the entity's first item also carries (U p)_e ----
         for (int it = wg; it < a.n_items; it += G) {
             const int e = a.it_ent[it];
@@ -318,7 +297,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
             block_sum<6>(acc, red);
             if (tid < 6) st_agent(a.part + (size_t)it * 28 + tid, acc[tid]);
         }
-        if (!grid_hop(counter, round, G, a.flags)) return;
+        if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
         // ---- vector updates, redundantly in every workgroup (same numbers, same order: same decisions) ----
         // y = S p: the items' shares of every entry, ALL requested before the first is used (an agent-scope load is ~1 us: one round
         // trip, not one per item), added in item order; + mu p; identity rows for gauge entities
@@ -810,11 +789,11 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_setup(const PcgDistArgs d)
     __shared__ double red[PCG_NW * 27];
     const PcgArgs &a = d.a;
     const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
-    int32_t *counter = a.counter + a.parity;
+    int32_t *counter = a.hop + a.parity * PCG_HOP_WORDS;   // (grid_hop_tree)
     int round = 0;
-    if (wg == 0 && tid == 0) __hip_atomic_store(a.counter + (1 - a.parity), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wg == 0 && tid < 2 * PCG_NY + 1) __hip_atomic_store(a.hop + (1 - a.parity) * PCG_HOP_WORDS + tid * 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pcgd_items_setup(a, red, wg, G, tid);
-    if (!grid_hop(counter, round, G, a.flags)) return;
+    if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
     for (int e = wg * PCG_THREADS + tid; e < a.A; e += G * PCG_THREADS) {
         double acc[27];
 #pragma unroll
@@ -843,9 +822,9 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter(const PcgDistArgs d) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *x = lds, *r = lds + n, *p = r + n, *Mi = p + n, *red = Mi + 6 * n;
     double *gx = d.state, *gr = gx + n, *gp = gr + n, *gs = gp + n;
-    int32_t *counter = a.counter + a.parity;
+    int32_t *counter = a.hop + a.parity * PCG_HOP_WORDS;   // (grid_hop_tree)
     int round = 0;
-    if (wg == 0 && tid == 0) __hip_atomic_store(a.counter + (1 - a.parity), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wg == 0 && tid < 2 * PCG_NY + 1) __hip_atomic_store(a.hop + (1 - a.parity) * PCG_HOP_WORDS + tid * 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     auto publish = [&](double done_v, double it_v) {
         if (d.publish_seq && wg == 0 && tid == 0) {
             d.host[0] = done_v; d.host[1] = it_v;
@@ -981,7 +960,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter(const PcgDistArgs d) 
             st_agent(a.t + (size_t)f * 6 + lane, tv);
         }
     }
-    if (!grid_hop(counter, round, G, a.flags)) { publish(1.0, itc); return; }   // (the host stops queueing; device flag 4 says why)
+    if (!grid_hop_tree(counter, round, G, a.flags, wg)) { publish(1.0, itc); return; }   // (the host stops queueing; device flag 4 says why)
     // ---- entity pass over this rank's incidences, by item; the entity's first item also carries (U_rank p)_e ----
     for (int it = wg; it < a.n_items; it += G) {
         const int e = a.it_ent[it];
@@ -1015,7 +994,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter(const PcgDistArgs d) 
         block_sum<6>(acc, red);
         if (tid < 6) st_agent(a.part + (size_t)it * 28 + tid, acc[tid]);
     }
-    if (!grid_hop(counter, round, G, a.flags)) { publish(1.0, itc); return; }
+    if (!grid_hop_tree(counter, round, G, a.flags, wg)) { publish(1.0, itc); return; }
     // ---- this rank's partial y (the items' shares in item order), the CG state back to memory ----
     for (int i = wg * PCG_THREADS + tid; i < n; i += G * PCG_THREADS) {
         const int e = i / 6, row = i - 6 * e;
@@ -1259,7 +1238,7 @@ static PcgDistArgs pcgd_args(const DeviceProblem &P, int which, double mu) {
     a.it_ent = P.pcg_it_ent; a.it_begin = P.pcg_it_begin; a.it_end = P.pcg_it_end; a.ent_item_start = P.pcg_ent_item_start; a.n_items = P.pcg_n_items;
     a.A = P.A; a.F = P.F; a.n_pad = P.n_pad; a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.abs2 = P.pcg_abs_tol * P.pcg_abs_tol * mu; a.max_it = P.pcg_max_it;
     a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
-    a.counter = P.pcg_counter; a.parity = P.pcg_parity & 1; P.pcg_parity++;
+    a.counter = P.pcg_counter; a.hop = P.pcg_hop; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
     a.Wf = pcgd_fused(P) ? P.blk[which].Wf : nullptr;   // (allocated only where pass A writes it instead of the fp64 blocks)
     d.setup_local = P.pcgd_setup; d.minv = P.pcgd_minv; d.state = P.pcgd_state; d.y = P.pcgd_y;
