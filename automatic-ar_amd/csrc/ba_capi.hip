@@ -1603,7 +1603,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
     if (P.deterministic) { AL(sp_part, (size_t)sp_total); AL(pb_part, (size_t)P.n_chunks * P.pb_stride); }
     if (P.use_pcg) {
         AL(pcg_ws, (size_t)P.pcg_n_items * 28 + 6 * (size_t)F + 8); AL(pcg_counter, 8);
-        AL(pcg_yg, (size_t)3 * PCG_NY * P.n_pad + (size_t)28 * A + 8); AL(pcg_hop, 2 * PCG_HOP_WORDS);
+        AL(pcg_yg, (size_t)3 * PCG_NYV * P.n_pad + (size_t)28 * A + 8); AL(pcg_hop, 2 * PCG_HOP_WORDS);
         if (const char *t = getenv("AAR_PCG_FUSED")) P.pcg_fused = atoi(t) != 0 ? 1 : 0;
         {   // k_pcgf's operator reads an fp32 copy of W (half the bytes of its pass over the frames; written by pass A instead of the fp64 blocks): non-deterministic runs, one rank or many
             int w32 = 1;

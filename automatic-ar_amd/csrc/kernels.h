@@ -19,7 +19,8 @@ inline int spcg_default_cap(int nT) { return nT <= 4 ? 64 : SPCG_MAX_IT; }
 // Measured, uniform eta -> largest pose difference against the direct run (config 3, SPCG): 0.02 -> 2e-4, 3e-3 -> 2e-5, 1e-3 -> 1e-5, 3e-4 -> 2e-6, 1e-4 -> 6e-7;
 // (config 5, PCG): 0.1 -> 9e-5, 0.03 -> 2e-5, 0.01 -> 5e-6, 3e-3 -> 1e-6.  A loose-then-tight SEQUENCE buys nothing at equal cost: the early steps' errors along
 // weakly determined directions are never corrected by the later ones (round 4's 0.1 -> 0.02 sequence: 6e-4), so the default is ONE forcing term.
-constexpr int PCG_NY = 16;   // k_pcgf: partial y vectors / barrier counters the workgroups spread their atomics over (256 workgroups on ONE address serialise at ~60 ns each: 15 us)
+constexpr int PCG_NY = 16;   // width of the PCG kernels' barrier tree (pcg_kernels.hip, grid_hop_tree): 256 workgroups on ONE address serialise at ~60 ns each: 15 us per hop
+constexpr int PCG_NYV = 2;   // k_pcgf: partial y vectors (workgroup wg adds into vector wg % PCG_NYV; every reader adds them up)
 constexpr int PCG_HOP_WORDS = (2 * PCG_NY + 1) * 16;   // k_pcgf's barrier tree: PCG_NY first-level counters, one second-level counter, PCG_NY flags (64 bytes apart)
 constexpr double PCG_W32_MIN_ETA = 1e-4;   // k_pcgf reads the fp32 copy of W only at forcing terms from here up (pcg_kernels.hip, launch_pcg)
 constexpr double SPCG_ABS_TOL_DEFAULT = 2e-5, PCG_ABS_TOL_DEFAULT = 5e-5;   // (measured: free for SPCG at configs 3-4; PCG at config 5: 5e-5 +3 % CG iterations, 2e-5 +15 %)
@@ -121,7 +122,7 @@ struct DeviceProblem {
     mutable int want_w64 = 0;             // aar_eval_normal_equations: pass A writes the fp64 W blocks even where the solver only reads the fp32 copy (Blocks::Wf)
     int pcg_fused = 1;                    // AAR_PCG_FUSED=0: k_pcg (two passes over W and two hand-overs per iteration) instead of k_pcgf
     int32_t *up_start = nullptr, *up_ent = nullptr;   // [A + 1], [..]: entity -> the OTHER entities whose block of U can be non-zero (seen together in an observation); the CG operator skips the rest
-    double *pcg_yg = nullptr;             // k_pcgf: y [3][PCG_NY][n_pad] (rotating; PCG_NY partial vectors) | the set-up's sums [A][28]
+    double *pcg_yg = nullptr;             // k_pcgf: y [3][PCG_NYV][n_pad] (rotating; PCG_NYV partial vectors) | the set-up's sums [A][28]
     int32_t *pcg_hop = nullptr;           // k_pcgf: [2][PCG_HOP_WORDS] barrier tree (pcg_kernels.hip, grid_hop_tree), by launch parity
     // solver spcg (spcg_kernels.hip): CG on the explicit Schur complement, one wavefront per shared entity
     int use_spcg = 0, spcg_max_it = 64;

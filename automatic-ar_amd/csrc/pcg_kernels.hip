@@ -649,14 +649,15 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     int it_cg = 0;
     double rr = bb;
     while (it_cg < a.max_it && (rr > a.eta2 * bb || rz > a.abs2) && bb > 0.0) {
-        // y of this iteration: PCG_NY partial vectors (workgroup wg adds into vector wg % PCG_NY: 16 instead of 256 atomics per address), summed by every reader
-        double *ygc = yg + (size_t)(it_cg % 3) * PCG_NY * a.n_pad, *ygn = yg + (size_t)((it_cg + 1) % 3) * PCG_NY * a.n_pad;
-        for (int i = wg * TH + tid; i < PCG_NY * a.n_pad; i += G * TH) st_agent(ygn + i, 0.0);
+        // y of this iteration: PCG_NYV partial vectors (workgroup wg adds into vector wg % PCG_NYV), summed by every reader.  Measured at config 5, k_pcg us per
+        // solve: 1 vector 458, 2: 436, 4: 449, 8: 452, 16: 474 -- the flush's atomics are not what a hop waited for (that was the barrier's one counter)
+        double *ygc = yg + (size_t)(it_cg % 3) * PCG_NYV * a.n_pad, *ygn = yg + (size_t)((it_cg + 1) % 3) * PCG_NYV * a.n_pad;
+        for (int i = wg * TH + tid; i < PCG_NYV * a.n_pad; i += G * TH) st_agent(ygn + i, 0.0);
         if (wave == 0) PCG_STAMP(it_cg, 0);
         pcgf_operator<W32, TH>(a, p, yacc, red, wg, G, it_cg);
         for (int i = tid; i < n; i += TH) {
             const double v = yacc[i];
-            if (v != 0.0) atomicAdd(ygc + (size_t)(wg % PCG_NY) * a.n_pad + i, v);
+            if (v != 0.0) atomicAdd(ygc + (size_t)(wg % PCG_NYV) * a.n_pad + i, v);
         }
         if (wave == 0) PCG_STAMP(it_cg, 12);
         if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
@@ -668,12 +669,12 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
             double sv[1] = {0.0};
             int ny = 0;
             for (int i = tid; i < n; i += TH, ny++) {
-                double ys[PCG_NY];
+                double ys[PCG_NYV];
 #pragma unroll
-                for (int k = 0; k < PCG_NY; k++) ys[k] = ld_agent(ygc + (size_t)k * a.n_pad + i);   // (all in flight together; added in a fixed order)
+                for (int k = 0; k < PCG_NYV; k++) ys[k] = ld_agent(ygc + (size_t)k * a.n_pad + i);   // (all in flight together; added in a fixed order)
                 double ysum = 0.0;
 #pragma unroll
-                for (int k = 0; k < PCG_NY; k++) ysum += ys[k];
+                for (int k = 0; k < PCG_NYV; k++) ysum += ys[k];
                 double yv = fma(a.mu, p[i], ysum);
                 if (a.ent_fixed[i / 6]) yv = p[i];
                 if (ny < 24) yl[ny] = yv;
@@ -1211,17 +1212,17 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.Wf = nullptr;
     HookScope _h(P, KID_PCG);
     if (P.pcg_fused && !P.deterministic) {   // one pass over W and one hand-over per iteration; its atomics take the sums in any order
-        (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * PCG_NY * P.n_pad + (size_t)28 * P.A) * sizeof(double), st);
+        (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * PCG_NYV * P.n_pad + (size_t)28 * P.A) * sizeof(double), st);
         // fp32 blocks (kernels.h, Blocks::Wf): allocated -- and written by pass A INSTEAD of the fp64 blocks -- only where the forcing term is far above what
         // that rounding can show (ba_capi.hip, PCG_W32_MIN_ETA; AAR_PCG_W32=0: never): the allocation is the one place that decides
         if (b.Wf) {
             a.Wf = b.Wf;
             allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true>), lds, granted_f32);
-            hipLaunchKernelGGL(k_pcgf<true>, dim3(P.pcg_grid), dim3(PCGF32_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NY * P.n_pad);
+            hipLaunchKernelGGL(k_pcgf<true>, dim3(P.pcg_grid), dim3(PCGF32_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NYV * P.n_pad);
             return;
         }
         allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<false>), lds, granted_f);
-        hipLaunchKernelGGL(k_pcgf<false>, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NY * P.n_pad);
+        hipLaunchKernelGGL(k_pcgf<false>, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NYV * P.n_pad);
         return;
     }
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, granted);
