@@ -589,12 +589,16 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
 
     // ---- set-up, first half: every slot's share of the diagonal blocks and of the right-hand side, by entity in LDS, then ONE atomic flush ----
     double *sacc = Mi;
+    if (wave == 0) PCG_STAMP(31, 0);
     pcgf_setup_slots<TH>(a, sacc, wg, G);
+    if (wave == 0) PCG_STAMP(31, 1);
     for (int i = tid; i < 27 * a.A; i += TH) {
         const double v = sacc[i];
         if (v != 0.0) atomicAdd(sg + (size_t)(i / 27) * 28 + (i % 27), v);   // (once per solve: not spread over partial tables -- every workgroup would read PCG_NY x 27 A values back: measured +78 us)
     }
+    if (wave == 0) PCG_STAMP(31, 2);
     if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
+    if (wave == 0) PCG_STAMP(31, 3);
     // ---- set-up, second half, redundantly in every workgroup (one thread per entity): the diagonal block of S inverted straight into LDS,
     //      the right-hand side; x = 0, r = b.  (Every thread reads its sums into registers before the barrier below lets Mi overwrite sacc.) ----
     // (every thread reads the sums it needs past the L2, not from sacc: Mi may take sacc's place at once -- but only when all threads have flushed it)
@@ -628,6 +632,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     }
     __syncthreads();
 
+    if (wave == 0) PCG_STAMP(31, 4);
     // ---- z = Minv r, p = z ----
     double rz = 0.0, bb = 0.0;
     {
@@ -646,6 +651,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     }
     __syncthreads();
 
+    if (wave == 0) PCG_STAMP(31, 5);
     int it_cg = 0;
     double rr = bb;
     while (it_cg < a.max_it && (rr > a.eta2 * bb || rz > a.abs2) && bb > 0.0) {

@@ -25,4 +25,6 @@ with aar.Problem(ds, solver="pcg") as p:
             t0 = st[sel, it, 0]
             rows.append([(st[sel, it, k] - t0) * tick * 1e-3 for k in range(1, 15)] + [(st[sel, it + 1, 0] - t0) * tick * 1e-3 if it + 1 < its else np.nan])
         r = np.nanmean(np.array(rows), axis=0)
+        su = [(st[sel, 31, k] - st[sel, 31, 0]) * tick * 1e-3 for k in range(1, 6)] + [(st[sel, 0, 0] - st[sel, 31, 0]) * tick * 1e-3]
+        print(label, "SET-UP:", " ".join("%s %.1f" % (n, v) for n, v in zip(["slots pass", "flush issued", "hop", "inverses", "z p init", "first iteration top"], su)))
         print(label, " ".join("%s %.1f" % (n, v) for n, v in zip(names[1:] + ["next top"], r)))
