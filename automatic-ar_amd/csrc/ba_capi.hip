@@ -1257,11 +1257,11 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
             //    entities), 48 .. 216 entities x 500 frames: 1.6x .. 1.4x the direct chain, 3.2x .. 1.1x PCG;
             //  * PCG never forms the complement: its step costs (CG iterations) x (a pass over the frames' W blocks -- fp32 since round 5), SPCG's one Schur complement
             //    (work ~ slots x slots-per-frame) + CG iterations of ~1.7 us.  PCG overtakes on long sequences of frames that each see many entities: measured
-            //    crossovers at ~60 k (entity, frame) incidences for 122 per frame (216 entities), ~140 k for 92 (160 entities), ~200 k for 64 (112 entities) -- fitted
-            //    by  incidences x (incidences per frame - 40) >= 6e6.
+            //    crossovers (PCG with fp32 blocks and the barrier tree) at ~45 k (entity, frame) incidences for 122 per frame (216 entities), ~85 k for 92 (160
+            //    entities), ~95 k for 64 (112 entities) -- fitted by  incidences x (incidences per frame - 30) >= 4e6.
             // The rule is applied to a rank's SHARE of the whole data set (shards are balanced by observation count), from numbers every rank holds.
             const double kf_avg = Fg > 0 ? (double)global_slots / (double)Fg : 0.0;
-            const bool pcg_pays = A >= 96 && pcg_ok && (double)global_slots / (double)world * (kf_avg - 40.0) >= 6e6;
+            const bool pcg_pays = A >= 96 && pcg_ok && (double)global_slots / (double)world * (kf_avg - 30.0) >= 4e6;
             if (P.nT < 2) solver = AAR_SOLVER_DIRECT;
             else if (spcg_ok && !pcg_pays) solver = AAR_SOLVER_SPCG;
             else if (pcg_ok) solver = AAR_SOLVER_PCG;

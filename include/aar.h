@@ -275,7 +275,7 @@ int aar_problem_create(const aar_problem_desc *, aar_problem **out);   /* = aar_
  *   AAR_SOLVER_AUTO    THE DEFAULT (a NULL options pointer, aar_solver_default_options): the fastest of the three for the problem's size as measured on
  *                      MI355X (profiles/r05_auto_crossover.txt): one tile of unknowns (up to 16 cameras + markers) DIRECT; SPCG wherever
  *                      it fits (up to 224 cameras + markers), except on long sequences whose frames each see many entities, where PCG -- which never
- *                      forms the Schur complement -- overtakes it (from 96 entities on: (entity, frame) incidences x (incidences per frame - 40) >= 6e6, e.g.
+ *                      forms the Schur complement -- overtakes it (from 96 entities on: (entity, frame) incidences x (incidences per frame - 30) >= 4e6, e.g.
  *                      BASELINE.json's 16-camera / 200-marker / 5000-frame configuration); PCG also where SPCG does not fit.
  * Inexact solvers stop an inner solve at a relative residual pcg_eta (PCG: |r| <= eta |b|; SPCG: sqrt(r^T M^-1 r) <= eta sqrt(b^T M^-1 b), M = the
  * block-Jacobi preconditioner).  The LM trajectory is then not the reference's step for step, and -- the reference's stopping rule being loose (its own

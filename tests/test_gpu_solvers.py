@@ -516,7 +516,7 @@ def test_default_options_from_far_starts_and_tiny_initial_damping(scale, tau):
 
 def test_auto_resolves_to_the_same_solver_on_every_rank_of_a_lopsided_sharding():
     # AUTO's choice between SPCG and PCG rests on (entity, frame) incidences.  Decided from a rank's OWN frames, the ranks of this data set would split --
-    # rank 0 owns frames that see ~120 entities each (incidences x (per frame - 40) >= 6e6: PCG), rank 1 mostly frames that see a dozen (SPCG) -- and wait in
+    # rank 0 owns frames that see ~120 entities each (incidences x (per frame - 30) >= 4e6: PCG), rank 1 mostly frames that see a dozen (SPCG) -- and wait in
     # different collectives forever.  The rule is applied to the whole data set's numbers, the same on every rank: asserted right after creation, then solved
     dense = 3000
     ds = aar.synth(5, num_frames=7000)
@@ -529,7 +529,7 @@ def test_auto_resolves_to_the_same_solver_on_every_rank_of_a_lopsided_sharding()
     inc_m = np.unique(ds.obs_frame.astype(np.int64) * 4096 + ds.obs_marker) // 4096
     def own_rule(lo, hi):      # the rule of csrc/ba_capi.hip on the frames lo .. hi alone
         slots = int(((inc_c >= lo) & (inc_c < hi)).sum() + ((inc_m >= lo) & (inc_m < hi)).sum())
-        return slots * (slots / (hi - lo) - 40.0) >= 6e6
+        return slots * (slots / (hi - lo) - 30.0) >= 4e6
     assert own_rule(begin[0], begin[1]) and not own_rule(begin[1], begin[2])        # (decided per rank, the two would part)
 
     def create(comm, rank):
