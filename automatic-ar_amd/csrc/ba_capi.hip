@@ -636,6 +636,9 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     bool chol_done = false;
     const bool cg_near_cap = pb->last_cg_its >= 0 && 10 * pb->last_cg_its >= 8 * std::min(P.spcg_max_it, SPCG_MAX_IT);
     const bool by_cg = P.use_spcg && !pb->force_direct && pb->spcg_skip == 0 && !cg_near_cap;
+    // the coarse space of the CG (k_spcg_pre + the roots' wavefronts) costs ~8 us per solve and saves iterations only once block-Jacobi needs many: it joins when a
+    // solve of this run has taken spcg_coarse_from iterations and stays (the damping only falls from there on)
+    if (!P.spcg_coarse_on && spcg_coarse_now(P) && (P.spcg_coarse_from <= 0 || pb->last_cg_its >= P.spcg_coarse_from)) P.spcg_coarse_on = 1;
     if (pb->spec_chol_blk >= 0) {   // a factorisation was queued ahead of the host's decision (multi-GPU, see aar_problem::spec_chol)
         if (pb->spec_chol_blk == cur && pb->spec_chol_mu == mu && pb->schur_mu == mu && pb->s_reduced && pb->spec_chol_by_cg == by_cg &&
             (!by_cg || pb->spec_chol_eta == P.pcg_eta_now)) {
@@ -1169,6 +1172,10 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
     P.n = 6 * P.A;
     P.nT = (P.n + CHOL_NB - 1) / CHOL_NB;
     P.n_pad = P.nT * CHOL_NB;
+    // solver spcg, coarse space (spcg_kernels.hip, k_spcg_pre): a group with free entities lends its root's slot to the group's rigid-motion unknowns
+    P.spcg_root_c = (L.oc && C > 1) ? L.rc : -1;
+    P.spcg_root_m = (L.om && M > 1) ? C + L.rm : -1;
+    P.spcg_n_free = (L.oc ? C - 1 : 0) + (L.om ? M - 1 : 0) + (L.oi ? C : 0);
     P.res_f32 = d->residual_mode == AAR_RES_F64 ? 0 : 1;
     pb->with_huber = d->with_huber != 0;
     P.huber = pb->with_huber ? pb->hubber_delta : -1.f;
@@ -1247,7 +1254,9 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         const bool pcg_ok = pcg_lds_bytes(A) <= 150 * 1024;
         // one wavefront per entity, every one of them resident AT ONCE (they hand over to each other): asked of the runtime's occupancy calculator for this
         // kernel's registers and LDS, as pcg_max_grid asks for the PCG grid.  (Another process on the device can still take the slots: k_spcg's time-out.)
-        const int spcg_per_cu = spcg_fits(P.nT) ? spcg_resident_per_cu(P.nT) : 0;
+        if (const char *t = getenv("AAR_SPCG_COARSE")) P.spcg_coarse = atoi(t) != 0;
+        if (const char *t = getenv("AAR_SPCG_COARSE_FROM")) P.spcg_coarse_from = atoi(t);
+        const int spcg_per_cu = spcg_fits(P.nT) ? spcg_resident_per_cu(P.nT, spcg_coarse_now(P)) : 0;
         const bool spcg_ok = spcg_fits(P.nT) && P.n_pad / 6 <= std::max(1, spcg_per_cu) * cus;
         int solver = so.solver;
         if (solver == AAR_SOLVER_AUTO) {
@@ -1634,6 +1643,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
     }
     if (P.use_spcg) {
         AL(spcg_ws, spcg_ws_doubles(P.n_pad)); AL(spcg_iters, 8); AL(spcg_done, 2);
+        if (spcg_coarse_now(P)) AL(spcg_pre, spcg_pre_doubles(P.n_pad));   // (zeroed: the restriction rows' columns of fixed entities stay zero)
         spcg_ws_reset(P, pb->stream);
     }
     if (P.n_smwork) { AL(Wd, (size_t)F * P.Ad * 36); AL(Yd, (size_t)F * P.Ad * 36); }   // zeroed here, once: absent pairs are never written
@@ -1813,6 +1823,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     pb->s_reduced = pb->trial_reduced = false;
     pb->spcg_skip = pb->spcg_backoff = 0;   // (a one-off solve: the problem's own solver gets its chance whatever an earlier LM run ended with)
     pb->last_cg_its = -1;
+    pb->P.spcg_coarse_on = 0;
     pb->P.pcg_eta_now = pb->P.pcg_eta;      // (... and the forcing term itself, not the LM's forcing sequence)
     if ((rc = damped_try_fb(pb, mu, false))) return rc == TRY_NOT_POSITIVE_DEFINITE ? AAR_ERR_NUMERIC : rc;
     pb->lm_ready = false;
@@ -1838,6 +1849,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     pb->launches = 0;
     pb->spcg_skip = pb->spcg_backoff = 0;
     pb->last_cg_its = -1;
+    P.spcg_coarse_on = 0;
     if (pb->spec_chol_blk >= 0) {   // a factorisation queued ahead of the last step of the previous solve: its pivot flags mean nothing
         HIP_TRY(hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream));
         pb->spec_chol_blk = -1;

@@ -27,6 +27,7 @@ constexpr double SPCG_ABS_TOL_DEFAULT = 2e-5, PCG_ABS_TOL_DEFAULT = 5e-5;   // (
 constexpr double SPCG_ETA_DEFAULT = 3e-4, SPCG_ETA_LOOSE_DEFAULT = 0.0, PCG_ETA_DEFAULT = 5e-3, PCG_ETA_LOOSE_DEFAULT = 0.0;
 inline int spcg_stride(int n_pad) { return 8 * (n_pad / 6); }   // doubles per hand-over buffer: one 64-byte record per entity
 
+
 #ifndef SPCG_PRE
 #define SPCG_PRE 0   // s_sleep units (64 cycles) between a wavefront's publish and its first poll of a hand-over (measured: 0 is best, profiles/r04_spcg_probe.txt)
 #endif
@@ -127,6 +128,12 @@ struct DeviceProblem {
     // solver spcg (spcg_kernels.hip): CG on the explicit Schur complement, one wavefront per shared entity
     int use_spcg = 0, spcg_max_it = 64;
     int spcg_spread = 8;                  // AAR_SPCG_SPREAD=1: every workgroup of the grid works (the wavefronts then sit on all XCDs and hand over through memory)
+    int spcg_coarse = 1;                  // AAR_SPCG_COARSE=0: block-Jacobi only (the A/B reference of the two-level preconditioner)
+    int spcg_coarse_from = 12;            // AAR_SPCG_COARSE_FROM: the coarse space joins once a solve of the LM run has taken this many CG iterations (0: from the first solve)
+    mutable int spcg_coarse_on = 0;       // the next k_spcg launch carries the coarse space (damped_try decides; sticky within an LM run)
+    double *spcg_pre = nullptr;           // workspace of k_spcg_pre (spcg_pre_doubles): augmented rows | right-hand side | inverse blocks | Z | (A Z)^T | shares | counter
+    mutable int spcg_pre_epoch = 0;       // launches of k_spcg_pre (its arrival counter is monotonic)
+    int spcg_root_c = -1, spcg_root_m = -1, spcg_n_free = 0;   // the fixed entity of each group whose slot carries the group's rigid-motion unknowns (-1: none); free entities
     int spcg_test_drop = -1;              // test hook (AAR_SPCG_TEST_DROP=entity): that entity's wavefront never shows up -> every hand-over times out -> flag 4 -> direct chain
     double *spcg_ws = nullptr;            // [2][SPCG_BUFS][spcg_stride(n_pad)] hand-over slots (sentinel-filled when idle)
     int32_t *spcg_iters = nullptr;        // [0] iterations of the last solve, [1] running total, [2] solves, [3] solves that hit the cap (flag 8)
@@ -239,9 +246,11 @@ size_t pcg_lds_bytes(int A);
 int pcg_max_grid(int A, int cus);   // largest co-resident grid of the persistent PCG kernels
 // solver spcg: delta_s by CG on the explicit reduced system S of block set `which` (the Schur complement for mu must have been taken; S is not modified)
 bool launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial = -1);   // trial >= 0: launch_backsub(which, trial) may ride (true: it did)
-int spcg_resident_per_cu(int nT);                          // occupancy query: wavefronts of k_spcg<nT> one CU holds (0: unknown)
+int spcg_resident_per_cu(int nT, bool coarse);             // occupancy query: wavefronts of k_spcg<nT> one CU holds (0: unknown)
+inline bool spcg_coarse_now(const DeviceProblem &P) { return P.spcg_coarse && (P.spcg_root_c >= 0 || P.spcg_root_m >= 0); }   // this problem's k_spcg can carry the coarse space
 bool spcg_fits(int nT);                                    // the system's rows fit the wavefronts' registers
 size_t spcg_ws_doubles(int n_pad);
+size_t spcg_pre_doubles(int n_pad);
 void spcg_ws_reset(const DeviceProblem &P, hipStream_t st);   // every hand-over slot back to the sentinel (at creation, after a timed-out launch)
 // the same with a communicator: set-up share -> [all-reduce] -> launches k = 0, 1, .. with an all-reduce of pcgd_y between two of them
 void launch_pcgd_setup(const DeviceProblem &P, int which, double mu, hipStream_t st);

@@ -76,11 +76,17 @@ struct SpcgArgs {
     int32_t *done;                    // [0] arrivals (monotonic over launches), [1] flag = done_epoch once all n_ent_total CG workgroups of this launch have left
     int done_epoch;
     int test_drop;                    // test hook (AAR_SPCG_TEST_DROP): the wavefront of this entity leaves without a word, as if it had never been scheduled
+    // CO kernels (two-level preconditioner through the AUGMENTED system, see k_spcg_pre): everything a wavefront keeps comes assembled from k_spcg_pre --
+    // rows of the augmented matrix [n_pad][n_pad] (damping in, columns of fixed entities zero, the groups' roots turned into the coarse unknowns), right-hand side
+    // [n_pad], inverse diagonal blocks [n_ent][36], Z_e [n_ent][36]
+    const double *pre_rows, *pre_minv, *pre_z, *pre_azt, *pre_share;
+    int root_c, root_m;               // the fixed entity whose slot carries the cameras' / markers' rigid-motion unknowns (-1: that group has none)
+    int C, M;
 };
 
 typedef unsigned int sp_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT>
+template <int NT, bool CO>
 __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     // NL: 16-byte pieces of a buffer per lane (a buffer = 16 NT records of 64 bytes = 64 NT pieces); piece c = lane + 64 k belongs to record
     // c / 4 and holds its words 2 (lane % 4), 2 (lane % 4) + 1: lanes with lane % 4 < 3 gather entries of m, lanes with lane % 4 == 3 the two shares
@@ -108,16 +114,22 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
         }
     };
     const int n_free_ent = a.n / 6;   // entities beyond are padding: identity rows
-    auto fixed = [&](int ent) -> bool { return ent >= n_free_ent || a.ent_fixed[ent < n_free_ent ? ent : 0] != 0; };
+    // (CO: a group's root carries the group's coarse unknowns -- its wavefront works, its record is read like any other)
+    auto fixed = [&](int ent) -> bool { return ent >= n_free_ent || (a.ent_fixed[ent < n_free_ent ? ent : 0] != 0 && !(CO && (ent == a.root_c || ent == a.root_m))); };
+    double *set = a.ws + (size_t)a.parity * a.set_len, *other = a.ws + (size_t)(1 - a.parity) * a.set_len;
+    const int nprev_raw = a.iters[0];
+    {   // the record this wavefront owns in the other set's buffers, for the launch after this one (the previous launch dirtied iters[0] + 2 of them): 8 buffers per store.
+        // Wavefronts of fixed entities do it too: a root's record is written by the launches that carry the coarse space and must read as idle to the others
+        const int nprev = min(nprev_raw + 2, SPCG_BUFS);
+        for (int bq = lane >> 3; bq < nprev; bq += 8) sp_st(other + (size_t)bq * a.stride + 8 * e + (lane & 7), __longlong_as_double((long long)SPCG_EMPTY));
+    }
     if (fixed(e)) {   // gauge / switched-off / padding entity: identity rows, zero right-hand side; nobody waits for this wavefront
         if (lane < 6) sp_st(a.x_out + 6 * e + lane, 0.0);
         leave();
         return;
     }
     if (e == a.test_drop) return;
-    double *set = a.ws + (size_t)a.parity * a.set_len, *other = a.ws + (size_t)(1 - a.parity) * a.set_len;
     // ---- every load of the set-up is issued before the first is used: one memory latency, not one per stage ----
-    const int nprev_raw = a.iters[0];
     int e0 = -1, n_act = 0;    // the first free entity (its wavefront reports), the number of free entities
 #pragma unroll
     for (int k = 0; k < NEB; k++) {
@@ -134,37 +146,55 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     const bool ra = i < 6;
     const int row = 6 * e + (ra ? i : 0);
     double A2[2 * NK];
-    unsigned long long cfx[(NK + 63) / 64] = {};   // bit k: column pair k belongs to a gauge / padding entity
-#pragma unroll
-    for (int k = 0; k < NK; k++) {
-        const int c0 = 16 * k + 2 * g, c1 = c0 + 1;
-        A2[2 * k] = a.S[(c0 <= row) ? (size_t)row * a.n_pad + c0 : (size_t)c0 * a.n_pad + row];
-        A2[2 * k + 1] = a.S[(c1 <= row) ? (size_t)row * a.n_pad + c1 : (size_t)c1 * a.n_pad + row];
-        if (fixed(c0 / 6)) cfx[k >> 6] |= 1ull << (k & 63);
-    }
     double blk[6][6];
+    double r, mi[6], zo[6];
+    const bool pseudo = CO && (e == a.root_c || e == a.root_m);   // this wavefront's six unknowns are its group's rigid motion
+    const int my_root = e < a.C ? a.root_c : (e < a.C + a.M ? a.root_m : -1);   // where this entity's group keeps its coarse unknowns
+    if (CO) {
+        // regular rows: assembled by k_spcg_pre (damping in, columns of fixed entities zero, (A Z)(row, .) in the roots' columns); a root's rows -- the coarse
+        // unknowns' -- are rows of (A Z)^T (zero in the roots' own columns: E is kept apart, below)
+        const double *rp = pseudo ? a.pre_azt + (size_t)((e == a.root_c ? 0 : 6) + (ra ? i : 0)) * a.n_pad : a.pre_rows + (size_t)row * a.n_pad;
 #pragma unroll
-    for (int p = 0; p < 6; p++)
+        for (int k = 0; k < NK; k++) {
+            const double2 t = reinterpret_cast<const double2 *>(rp)[8 * k + g];
+            A2[2 * k] = ra ? t.x : 0.0; A2[2 * k + 1] = ra ? t.y : 0.0;
+        }
 #pragma unroll
-        for (int q = 0; q <= p; q++) blk[p][q] = a.S[(size_t)(6 * e + p) * a.n_pad + 6 * e + q];
-    double r = a.rhs[row] + a.g0[row];
+        for (int k = 0; k < 3; k++) {
+            const double2 t = reinterpret_cast<const double2 *>(a.pre_minv + 36 * e + 6 * (ra ? i : 0))[k];
+            mi[2 * k] = (ra && !pseudo) ? t.x : 0.0; mi[2 * k + 1] = (ra && !pseudo) ? t.y : 0.0;
+            const double2 z2 = reinterpret_cast<const double2 *>(a.pre_z + 36 * e + 6 * (ra ? i : 0))[k];
+            const bool zon = ra && !pseudo && my_root >= 0;
+            zo[2 * k] = zon ? z2.x : 0.0; zo[2 * k + 1] = zon ? z2.y : 0.0;
+        }
+        r = (ra && !pseudo) ? a.rhs[row] + a.g0[row] : 0.0;
+    } else {
+        unsigned long long cfx[(NK + 63) / 64] = {};   // bit k: column pair k belongs to a gauge / padding entity
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int c0 = 16 * k + 2 * g, c1 = c0 + 1;
+            A2[2 * k] = a.S[(c0 <= row) ? (size_t)row * a.n_pad + c0 : (size_t)c0 * a.n_pad + row];
+            A2[2 * k + 1] = a.S[(c1 <= row) ? (size_t)row * a.n_pad + c1 : (size_t)c1 * a.n_pad + row];
+            if (fixed(c0 / 6)) cfx[k >> 6] |= 1ull << (k & 63);
+        }
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int q = 0; q <= p; q++) blk[p][q] = a.S[(size_t)(6 * e + p) * a.n_pad + 6 * e + q];
+        r = a.rhs[row] + a.g0[row];
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int c0 = 16 * k + 2 * g;
+            const bool off = !ra || ((cfx[k >> 6] >> (k & 63)) & 1);
+            A2[2 * k] = off ? 0.0 : A2[2 * k] + (c0 == row ? a.mu : 0.0);
+            A2[2 * k + 1] = off ? 0.0 : A2[2 * k + 1] + (c0 + 1 == row ? a.mu : 0.0);
+        }
+        if (!ra) r = 0.0;
+    }
     SP_STAMP(0);
-    {   // the record this wavefront owns in the other set's buffers, for the launch after this one (the previous launch dirtied iters[0] + 2 of them): 8 buffers per store
-        const int nprev = min(nprev_raw + 2, SPCG_BUFS);
-        for (int bq = lane >> 3; bq < nprev; bq += 8) sp_st(other + (size_t)bq * a.stride + 8 * e + (lane & 7), __longlong_as_double((long long)SPCG_EMPTY));
-    }
-#pragma unroll
-    for (int k = 0; k < NK; k++) {
-        const int c0 = 16 * k + 2 * g;
-        const bool off = !ra || ((cfx[k >> 6] >> (k & 63)) & 1);
-        A2[2 * k] = off ? 0.0 : A2[2 * k] + (c0 == row ? a.mu : 0.0);
-        A2[2 * k + 1] = off ? 0.0 : A2[2 * k + 1] + (c0 + 1 == row ? a.mu : 0.0);
-    }
-    if (!ra) r = 0.0;
     SP_STAMP(1);
-    // ---- the preconditioner: inverse of the damped diagonal block, every lane the whole block (same instruction stream), keeps its row ----
-    double mi[6];
-    {
+    // ---- the preconditioner: inverse of the damped diagonal block, every lane the whole block (same instruction stream), keeps its row (CO: k_spcg_pre did it) ----
+    if (!CO) {
         double inv[36];
 #pragma unroll
         for (int p = 0; p < 6; p++) {
@@ -180,6 +210,58 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             for (int p = 0; p < 6; p++) v = (i == p) ? inv[p * 6 + k] : v;
             mi[k] = v;
         }
+    }
+    // CO, a root's wavefront: row i of E (the coarse unknowns against each other) and entry i of Z^T b are sums of the shares k_spcg_pre's workgroups left, taken in
+    // entity order; the preconditioner's block is the inverse of E's diagonal block
+    double ec[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) ec[q] = 0.0;
+    if (CO && pseudo) {
+        const int Gq = e == a.root_c ? 0 : 1, elo = Gq ? a.C : 0, ehi = Gq ? a.C + a.M : a.C;
+        // lane (class = lane % 8, slots 10 (lane / 8) .. + 9): the entities q = class mod 8 of the group, 40 entities per round with every load in flight at once
+        // (a fixed entity's slots are zero from the allocation on); then the eight classes are added: a fixed order
+        const int ecl = lane & 7, sg = lane >> 3;
+        double acc[10];
+#pragma unroll
+        for (int t = 0; t < 10; t++) acc[t] = 0.0;
+        for (int q0 = elo; q0 < ehi; q0 += 40) {
+            double2 v[5][5];
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++) {
+                const int q = q0 + 8 * kk + ecl;
+#pragma unroll
+                for (int t = 0; t < 5; t++) v[kk][t] = q < ehi ? reinterpret_cast<const double2 *>(a.pre_share + 80 * q + 10 * sg)[t] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++)
+#pragma unroll
+                for (int t = 0; t < 5; t++) { acc[2 * t] += v[kk][t].x; acc[2 * t + 1] += v[kk][t].y; }
+        }
+#pragma unroll
+        for (int t = 0; t < 10; t++) acc[t] = sum8(acc[t]);
+        if (ecl == 0) {
+#pragma unroll
+            for (int t = 0; t < 5; t++) reinterpret_cast<double2 *>(mv + 10 * sg)[t] = make_double2(acc[2 * t], acc[2 * t + 1]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        double eb[6][6], inv[36];
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int q = 0; q <= p; q++) { const double v = mv[12 * p + 6 * Gq + q]; eb[p][q] = v; eb[q][p] = v; }
+        if (!spd6_inverse(eb, inv) && lane == 0) atomicOr(a.flags, 2);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            double v = 0.0;
+#pragma unroll
+            for (int p = 0; p < 6; p++) v = (i == p) ? inv[p * 6 + k] : v;
+            mi[k] = v;
+        }
+        // (the shares of a group's entities are that group's ROWS of E, all twelve columns: the coupling block too)
+#pragma unroll
+        for (int b = 0; b < 12; b++) ec[b] = ra ? mv[12 * i + b] : 0.0;
+        r = ra ? mv[72 + i] : 0.0;
+        __builtin_amdgcn_wave_barrier();
     }
     auto prec = [&](double w) -> double {   // (M^-1 w)_i from the six entries of w in this wavefront
         double s = 0.0;
@@ -234,6 +316,7 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             if (++spins > (1L << 19)) { dead = true; break; }   // ~1 s: a wavefront of the grid is not running (device shared / oversubscribed)
             __builtin_amdgcn_s_sleep(1);
         }
+        SP_STAMP(300 + b);
         const int w2 = lane & 3;
         double sg = 0.0, sd = 0.0;
 #pragma unroll
@@ -259,6 +342,13 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             s0 = fma(A2[2 * k], t.x, s0);
             s1 = fma(A2[2 * k + 1], t.y, s1);
         }
+        if (CO && pseudo && g == 0) {   // the coarse unknowns against each other: E times the roots' entries of the vector
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                s0 = fma(ec[b], a.root_c >= 0 ? mv[6 * max(a.root_c, 0) + b] : 0.0, s0);
+                s1 = fma(ec[6 + b], a.root_m >= 0 ? mv[6 * max(a.root_m, 0) + b] : 0.0, s1);
+            }
+        }
         const double s = sum8(s0 + s1);
         __builtin_amdgcn_wave_barrier();   // (mv is overwritten by the next gather: program order is enough)
         return s;
@@ -281,8 +371,15 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     }
     SP_VAL(400, bb); SP_VAL(401, d1); SP_VAL(402, u); SP_VAL(403, r); SP_VAL(404, mv[0]); SP_VAL(405, mv[6]); SP_VAL(406, mv[7]);
     int it = 0, status = 0;   // status: 1 converged, 2 cap, 3 non-positive curvature
+    // CO: every wavefront carries its group's coarse unknowns along (row i: entry i) -- the same recurrences on the root's entries of the gathered vectors with the
+    // same alpha, beta -- so that x = x' + Z_e c needs no hand-over of its own at the end
+    double uc = 0.0, qc = 0.0, pc = 0.0, xc = 0.0;
+    const int rslot = (CO && my_root >= 0 && ra) ? 6 * my_root + i : 0;
+    const bool track = CO && my_root >= 0 && ra && !pseudo;
+    if (track) uc = mv[rslot];
     if (!dead) {
         w = matvec();
+        SP_STAMP(6);
         double inv_g = 0.0, inv_a = 0.0;   // 1 / gamma and 1 / alpha of the previous iteration
         if (!(bb > 0.0)) status = 1;   // b = 0: x = 0
         while (!status) {
@@ -297,6 +394,7 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             if (dead) break;
             if (gam <= a.eta2 * bb && gam <= a.abs2_mu) { status = 1; break; }
             if (it >= a.max_it) { status = 2; break; }
+            const double mc = track ? mv[rslot] : 0.0;
             const double nn = matvec();
             SP_STAMP(11 + 4 * it);
             const double beta = gam * inv_g;                   // (0 in the first iteration)
@@ -320,10 +418,16 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
             r = fma(-alpha, s, r);
             u = fma(-alpha, q, u);
             w = fma(-alpha, z, w);
+            if (CO) { qc = fma(beta, qc, mc); pc = fma(beta, pc, uc); xc = fma(alpha, pc, xc); uc = fma(-alpha, qc, uc); }
             it++;
         }
     }
     SP_STAMP(5);
+    if (CO) {   // x = x' + Z_e c; the root's own entries of delta_s are zero
+#pragma unroll
+        for (int q = 0; q < 6; q++) x = fma(zo[q], rl(xc, 8 * q), x);
+        if (pseudo) x = 0.0;
+    }
     if (ra && g == 0) sp_st(a.x_out + row, x);
     leave();
     if (lane == 0) {
@@ -339,13 +443,184 @@ __global__ void __launch_bounds__(64) k_spcg(const SpcgArgs a) {
     }
 }
 
+// ---- k_spcg_pre: the two-level preconditioner of k_spcg<.., true>, as an AUGMENTED system; one workgroup per shared entity, launched right before k_spcg ----
+//
+// The <= 8 eigenvalues of the block-Jacobi-preconditioned reduced system that fall below 0.1 at late LM steps (the rest of the spectrum sits in [0.1, 1.8]) belong
+// to the near-gauge modes of T = T_c^-1 T_f T_m: ALL non-root cameras moved by one rigid motion G (T_c <- G T_c: every frame absorbs it, T_f <- G T_f, only the root
+// camera's observations resist) and ALL non-root markers moved by one (T_m <- G T_m, T_f <- T_f G^-1).  In the Rodrigues parameters entity j's rows of those modes
+// are Z_j = [[J_l(w_j)^-1, 0], [-[t_j]x, I]] (columns: rotation, translation of G), in the six columns of its group (scripts/experiments/spcg_coarse.py: they span the
+// weak eigenvectors to 0.99 in the preconditioner's norm; with them the CG needs 12 instead of 21 iterations per LM step at the pose-grade forcing term, 18 instead
+// of 57 at the last step).  The additive two-level preconditioner D^-1 + Z blockdiag(E_cc, E_mm)^-1 Z^T, E = Z^T A Z, is block-Jacobi on the augmented system
+//      [ A      A Z ] [x']   [ b     ]
+//      [ Z^T A  E   ] [c ] = [ Z^T b ],      x = x' + Z c        (positive semi-definite, consistent: CG does not mind)
+// and the augmented system needs NO new machinery in k_spcg: the twelve coarse unknowns take the places of the two ROOT entities -- whose rows and columns of the
+// reduced system are idle (identity) and whose hand-over records nobody reads.  k_spcg then runs exactly as before on 6 (C + M) unknowns, two more of its wavefronts
+// working; the coarse coefficients travel in the hand-over that exists, at no cost per iteration.  This kernel assembles what the wavefronts keep: the rows of the
+// augmented matrix with the damping in and the columns of fixed entities zero, the inverse diagonal blocks, the right-hand side and Z_j; the workgroup that finishes
+// last adds up E and Z^T b and writes the roots' rows.
+struct SpcgPreArgs {
+    const double *S, *rhs, *g0;
+    const double *ent;                // entity rows {R, t, J_l} of the pose S was built at
+    const int32_t *ent_fixed;
+    int n, n_pad, n_ent, C, M, root_c, root_m;
+    double mu;
+    double *rows, *minv, *z;          // what k_spcg's regular wavefronts read: their rows of the augmented matrix [n_pad][n_pad], inverse diagonal blocks [n_ent][36], Z_j [n_ent][36]
+    double *azt;                      // [12][n_pad] (A Z)^T
+    double *share;                    // [n_ent][80]: Z_j^T (A Z)_j (6 x 12) | Z_j^T b_j (6) | idle
+    int32_t *flags;
+};
+
+__device__ __forceinline__ void coarse_block(const double *__restrict__ row, bool on, double *__restrict__ Z) {   // Z_j from {t, J_l} = row[9..20]
+    const double *t = row + 9, *J = row + 12;
+    const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+    const double det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+    const double id = on ? 1.0 / det : 0.0, o1 = on ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < 36; q++) Z[q] = 0.0;
+    Z[0] = c00 * id; Z[1] = (J[2] * J[7] - J[1] * J[8]) * id; Z[2] = (J[1] * J[5] - J[2] * J[4]) * id;
+    Z[6] = c01 * id; Z[7] = (J[0] * J[8] - J[2] * J[6]) * id; Z[8] = (J[2] * J[3] - J[0] * J[5]) * id;
+    Z[12] = c02 * id; Z[13] = (J[1] * J[6] - J[0] * J[7]) * id; Z[14] = (J[0] * J[4] - J[1] * J[3]) * id;
+    Z[19] = o1 * t[2]; Z[20] = -o1 * t[1];
+    Z[24] = -o1 * t[2]; Z[26] = o1 * t[0];
+    Z[30] = o1 * t[1]; Z[31] = -o1 * t[0];
+    Z[21] = o1; Z[28] = o1; Z[35] = o1;
+}
+
+__global__ void __launch_bounds__(256) k_spcg_pre(const SpcgPreArgs a) {
+    extern __shared__ __align__(16) double sh[];
+    const int tid = threadIdx.x, j = blockIdx.x;
+    const int n_free_ent = a.n / 6, npose = a.C + a.M;
+    if (j >= n_free_ent || a.ent_fixed[j]) return;
+    double *zl = sh;                                  // [n_ent][36]
+    double *al = zl + 36 * a.n_ent;                   // [6][n_pad]: rows 6j .. 6j+5 of A = S + mu I, the columns of fixed / padding entities zero
+    double *az = al + 6 * a.n_pad;                    // [3][72] partial sums, then [72] (A Z)_j
+    double *bj = az + 216;                            // [6] b_j
+    int32_t *fx = reinterpret_cast<int32_t *>(bj + 8);   // [n_ent] 1: fixed / padding entity
+    for (int q = tid; q < a.n_ent; q += 256) fx[q] = (q >= n_free_ent || a.ent_fixed[q < n_free_ent ? q : 0] != 0) ? 1 : 0;
+    double er[12];   // {t, J_l} of entity tid (the loads travel with those of S below)
+    {
+        const bool pose = tid < npose && tid < a.n_ent;
+#pragma unroll
+        for (int q = 0; q < 12; q++) er[q] = pose ? a.ent[(size_t)tid * ENT_STRIDE + 9 + q] : 0.0;
+    }
+    // rows of S: every load in flight before the first is used (the transposed half is one line per element)
+    {
+        const int total = 6 * a.n_pad;
+#pragma unroll 1
+        for (int q0 = tid; q0 < total; q0 += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int q = q0 + 256 * k;
+                if (q < total) {
+                    const int i = q / a.n_pad, col = q - i * a.n_pad, row = 6 * j + i;
+                    v[k] = a.S[(col <= row) ? (size_t)row * a.n_pad + col : (size_t)col * a.n_pad + row];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int q = q0 + 256 * k;
+                if (q < total) {
+                    const int i = q / a.n_pad, col = q - i * a.n_pad, row = 6 * j + i;
+                    al[q] = v[k] + (col == row ? a.mu : 0.0);
+                }
+            }
+        }
+    }
+    for (int q = tid; q < a.n_ent; q += 256) {
+        double Z[36], row[21];
+        const bool pose = q < npose;
+#pragma unroll
+        for (int k = 0; k < 12; k++) row[9 + k] = q == tid ? er[k] : (pose ? a.ent[(size_t)q * ENT_STRIDE + 9 + k] : 0.0);
+        coarse_block(row, pose && !(q >= n_free_ent || a.ent_fixed[q < n_free_ent ? q : 0] != 0), Z);
+#pragma unroll
+        for (int k = 0; k < 18; k++) reinterpret_cast<double2 *>(zl + 36 * q)[k] = make_double2(Z[2 * k], Z[2 * k + 1]);
+    }
+    if (tid < 6) bj[tid] = a.rhs[6 * j + tid] + a.g0[6 * j + tid];
+    __syncthreads();
+    for (int q = tid; q < 6 * a.n_pad; q += 256) { const int col = q % a.n_pad; if (fx[col / 6]) al[q] = 0.0; }   // the columns of fixed / padding entities
+    __syncthreads();
+    const bool pose = j < npose;
+    if (tid >= 224) {   // half a wavefront's worth of idle lanes; one of them inverts the diagonal block while the others form (A Z)_j
+        if (tid == 224) {
+            double blk[6][6], inv[36];
+#pragma unroll
+            for (int p = 0; p < 6; p++)
+#pragma unroll
+                for (int q = 0; q < 6; q++) blk[p][q] = al[p * a.n_pad + 6 * j + q];
+            if (!spd6_inverse(blk, inv)) atomicOr(a.flags, 2);
+#pragma unroll
+            for (int q = 0; q < 36; q++) a.minv[36 * j + q] = inv[q];
+        }
+    } else if (tid < 216) {   // (A Z)(i, c) over a third of the group's entities each
+        const int o = tid % 72, part = tid / 72, i = o / 12, c = o % 12;
+        const int elo = c < 6 ? 0 : a.C, ehi = c < 6 ? a.C : npose, per = (ehi - elo + 2) / 3;
+        const int lo = 6 * min(elo + part * per, ehi), hi = 6 * min(elo + (part + 1) * per, ehi);
+        double acc = 0.0;
+#pragma unroll 6
+        for (int col = lo; col < hi; col++) acc = fma(al[i * a.n_pad + col], zl[6 * col + (c % 6)], acc);
+        az[72 * part + o] = acc;
+    }
+    __syncthreads();
+    if (tid < 72) {
+        const int i = tid / 12, c = tid % 12;
+        const double v = (az[tid] + az[72 + tid]) + az[144 + tid];
+        az[tid] = v;
+        a.azt[(size_t)c * a.n_pad + 6 * j + i] = v;
+        const int root = c < 6 ? a.root_c : a.root_m;       // the coarse unknowns' columns of this entity's rows: where the root's (zero) columns were
+        if (root >= 0) al[i * a.n_pad + 6 * root + (c % 6)] = v;
+    }
+    __syncthreads();
+    for (int q = tid; q < 3 * a.n_pad; q += 256) reinterpret_cast<double2 *>(a.rows + (size_t)6 * j * a.n_pad)[q] = reinterpret_cast<const double2 *>(al)[q];
+    const double *Zj = zl + 36 * j;
+    if (tid < 36) a.z[36 * j + tid] = Zj[tid];
+    if (pose && tid >= 64 && tid < 64 + 78) {   // shares of E (rows: this entity's group) and of Z^T b
+        const int o = tid - 64;
+        double v = 0.0;
+        if (o < 72) {
+            const int c = o / 12, b = o % 12;
+#pragma unroll
+            for (int i = 0; i < 6; i++) v = fma(Zj[6 * i + c], az[12 * i + b], v);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) v = fma(Zj[6 * i + (o - 72)], bj[i], v);
+        }
+        a.share[80 * j + o] = v;
+    }
+}
+
+size_t spcg_pre_lds_bytes(int n_pad) { return sizeof(double) * ((size_t)36 * (n_pad / 6) + (size_t)6 * n_pad + 224) + sizeof(int32_t) * (n_pad / 6 + 2); }
+// doubles of k_spcg_pre's workspace: rows of the augmented matrix | minv | Z | (A Z)^T | shares
+size_t spcg_pre_doubles(int n_pad) { const size_t ne = n_pad / 6; return (size_t)n_pad * n_pad + 36 * ne + 36 * ne + (size_t)12 * n_pad + 80 * ne + 8; }
+
+static void launch_spcg_pre(const DeviceProblem &P, int which, double mu, hipStream_t st, SpcgArgs &k) {
+    const size_t ne = P.n_pad / 6;
+    SpcgPreArgs a;
+    a.S = P.blk[which].S; a.rhs = P.blk[which].rhs; a.g0 = P.blk[which].g0; a.ent = P.ent[which]; a.ent_fixed = P.ent_fixed;
+    a.n = P.n; a.n_pad = P.n_pad; a.n_ent = (int)ne; a.C = P.C; a.M = P.M; a.mu = mu;
+    a.root_c = P.spcg_root_c; a.root_m = P.spcg_root_m;
+    double *w = P.spcg_pre;
+    a.rows = w; w += (size_t)P.n_pad * P.n_pad;
+    a.minv = w; w += 36 * ne;
+    a.z = w; w += 36 * ne;
+    a.azt = w; w += (size_t)12 * P.n_pad;
+    a.share = w; w += 80 * ne;
+    a.flags = P.flags;
+    k.pre_rows = a.rows; k.pre_minv = a.minv; k.pre_z = a.z; k.pre_azt = a.azt; k.pre_share = a.share; k.root_c = a.root_c; k.root_m = a.root_m;
+    static size_t granted = 0;
+    const size_t lds = spcg_pre_lds_bytes(P.n_pad);
+    allow_dynamic_lds(reinterpret_cast<const void *>(k_spcg_pre), lds, granted);
+    hipLaunchKernelGGL(k_spcg_pre, dim3((unsigned)ne), dim3(256), lds, st, a);
+}
+
 bool spcg_fits(int nT) { return nT >= 1 && nT <= SPCG_MAX_NT; }
 // wavefronts (= workgroups) of k_spcg<nT> a CU can hold at once, as the runtime's occupancy calculator sees this kernel's registers and LDS (0: not known)
-int spcg_resident_per_cu(int nT) {
+int spcg_resident_per_cu(int nT, bool coarse) {
     int nb = 0;
     hipError_t rc = hipErrorInvalidValue;
     switch (nT) {
-#define SPCG_CASE(t) case t: rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_spcg<t>, 64, 0); break;
+#define SPCG_CASE(t) case t: { int nc = 1 << 30; if (coarse) rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, k_spcg<t, true>, 64, 0); \
+                               if (!coarse || rc == hipSuccess) rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_spcg<t, false>, 64, 0); nb = std::min(nb, nc); } break;
         SPCG_CASE(1) SPCG_CASE(2) SPCG_CASE(3) SPCG_CASE(4) SPCG_CASE(5) SPCG_CASE(6) SPCG_CASE(7) SPCG_CASE(8)
         SPCG_CASE(9) SPCG_CASE(10) SPCG_CASE(11) SPCG_CASE(12) SPCG_CASE(13) SPCG_CASE(14)
 #undef SPCG_CASE
@@ -370,6 +645,9 @@ bool launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st, i
     a.mu = mu; a.eta2 = P.pcg_eta_now * P.pcg_eta_now; a.abs2_mu = P.pcg_abs_tol * P.pcg_abs_tol * mu; a.max_it = std::min(P.spcg_max_it, SPCG_MAX_IT);
     a.ws = P.spcg_ws; a.stride = spcg_stride(P.n_pad); a.set_len = (long long)SPCG_BUFS * a.stride; a.parity = P.spcg_parity;
     a.x_out = P.delta_s; a.iters = P.spcg_iters; a.flags = P.flags; a.test_drop = P.spcg_test_drop;
+    a.pre_rows = a.pre_minv = a.pre_z = a.pre_azt = a.pre_share = nullptr; a.root_c = a.root_m = -1; a.C = P.C; a.M = P.M;
+    const bool coarse = spcg_coarse_now(P) && P.spcg_coarse_on;   // this solve carries the coarse space: k_spcg_pre assembles the augmented system first
+    if (coarse) launch_spcg_pre(P, which, mu, st, a);
     a.spread = P.spcg_spread;
     P.spcg_parity ^= 1;
     const int n_ent = P.n_pad / 6;
@@ -389,7 +667,8 @@ bool launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st, i
     }
     HookScope _h(P, KID_SPCG);
     switch (P.nT) {
-#define SPCG_CASE(t) case t: hipLaunchKernelGGL(k_spcg<t>, dim3(grid), dim3(64), 0, st, a); break;
+#define SPCG_CASE(t) case t: if (coarse) hipLaunchKernelGGL((k_spcg<t, true>), dim3(grid), dim3(64), 0, st, a); \
+                             else hipLaunchKernelGGL((k_spcg<t, false>), dim3(grid), dim3(64), 0, st, a); break;
         SPCG_CASE(1) SPCG_CASE(2) SPCG_CASE(3) SPCG_CASE(4) SPCG_CASE(5) SPCG_CASE(6) SPCG_CASE(7) SPCG_CASE(8)
         SPCG_CASE(9) SPCG_CASE(10) SPCG_CASE(11) SPCG_CASE(12) SPCG_CASE(13) SPCG_CASE(14)
 #undef SPCG_CASE

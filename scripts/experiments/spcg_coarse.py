@@ -1,0 +1,139 @@
+"""Experiment (CPU, numpy; the oracle is test infrastructure, nothing here is product code): a COARSE SPACE for the CG on the explicit reduced system
+S + mu I (csrc/spcg_kernels.hip).  Round 5 measured 21 CG iterations per LM step at the pose-grade forcing term with block-Jacobi, 57 at the last step.
+The preconditioned spectrum shows why: <= 8 eigenvalues of M^-1 (S + mu I) fall below 0.1 while the rest sit in [0.1, 1.8], and those eigenvectors are
+(to 0.99 in the M-norm) the NEAR-GAUGE modes of T = T_c^-1 T_f T_m: all non-root cameras moved by one rigid motion G (T_c <- G T_c, absorbed by every frame
+T_f <- G T_f and resisted only by the root camera's observations), and all non-root markers moved by one rigid motion (T_m <- G T_m, T_f <- T_f G^-1,
+resisted only by the root marker's).  In the Rodrigues parametrisation entity e's rows of those modes are Z_e = [[J_l(w_e)^-1, 0], [-[t_e]x, I]].
+Two-level additive preconditioner  M^-1 = blockdiag(S_ee)^-1 + Z (Z^T A Z)^-1 Z^T  with Z = 6 camera + 6 marker columns ("cm"; "cmCM" adds the
+right-multiplied modes T <- T G), inside the pipelined recurrences of the kernel (one reduction per iteration), same stopping rule
+(r^T M^-1 r <= eta^2 b^T M^-1 b  and  <= eps^2 mu), along an INEXACT LM run; reported: CG iterations per LM step, final RMSE and largest pose-vector
+distance to the exact run.
+    python scripts/experiments/spcg_coarse.py [config] [frames]
+"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "automatic-ar_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "scripts", "experiments")]
+import aar, oracle_lib as ol
+import pcg_reduced_system as E
+from scipy.spatial.transform import Rotation as Rot
+
+
+def skew(v): return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+def Jl(w):
+    th = np.linalg.norm(w); K = skew(w)
+    if th < 1e-9: return np.eye(3) + 0.5 * K
+    return np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+
+
+APPROX = False   # d omega = w instead of J_l^-1 w (small-rotation form of the modes)
+
+
+def coarse(z, ns, nc, which):
+    out = []
+    for grp in which:
+        Z = np.zeros((ns, 6))
+        for e in range(ns // 6):
+            if (6 * e < nc) != (grp in "cC"): continue
+            w, t = z[6 * e:6 * e + 3], z[6 * e + 3:6 * e + 6]
+            B = np.zeros((6, 6))
+            if grp in "cm":   # T <- exp(xi) T
+                B[:3, :3] = np.eye(3) if APPROX else np.linalg.inv(Jl(w)); B[3:, :3] = -skew(t); B[3:, 3:] = np.eye(3)
+            else:             # T <- T exp(xi)
+                R = Rot.from_rotvec(w).as_matrix(); B[:3, :3] = np.linalg.inv(Jl(w)) @ R; B[3:, 3:] = R
+            Z[6 * e:6 * e + 6] = B
+        out.append(Z)
+    return np.concatenate(out, axis=1) if out else None
+
+
+STALE = {}
+
+
+def pipelined(S, b, mu, eta, eps, Z, max_it=400, blockdiag=False, stale=False):
+    ns = S.shape[0]
+    Mi = np.linalg.inv(np.stack([S[6 * a: 6 * a + 6, 6 * a: 6 * a + 6] for a in range(ns // 6)]))
+    bj = lambda r: np.einsum("aij,aj->ai", Mi, r.reshape(-1, 6)).reshape(-1)
+    if Z is not None:
+        AZ = S @ Z; Em = Z.T @ AZ
+        if stale == 1:   # E of the previous solve (undamped part) + mu Z^T Z; the current one is left for the next solve
+            fresh = Em - mu * (Z.T @ Z)
+            Em = STALE.get("E", fresh) + mu * (Z.T @ Z)
+            STALE["E"] = fresh
+        elif stale == 2:   # E of the previous solve as it was, its damping included
+            fresh = Em.copy()
+            Em = STALE.get("E", fresh)
+            STALE["E"] = fresh
+        elif stale == 3:   # E of the solve before the previous one
+            fresh = Em.copy()
+            Em = STALE.get("E2", STALE.get("E", fresh))
+            STALE["E2"] = STALE.get("E", fresh); STALE["E"] = fresh
+        if blockdiag:
+            for a in range(0, Em.shape[0], 6): Em[a:a + 6, :a] = 0; Em[a:a + 6, a + 6:] = 0
+        Ei = np.linalg.inv(Em)
+        prec = lambda r: bj(r) + Z @ (Ei @ (Z.T @ r))
+    else:
+        prec = bj
+    x = np.zeros(ns); r = b.copy(); u = prec(r); w = S @ u; bb = r @ u
+    z = q = s = p = np.zeros(ns); g_old = a_old = 0.0; it = 0
+    while True:
+        m = prec(w); gam, dlt = r @ u, w @ u
+        if (gam <= eta * eta * bb and gam <= eps * eps * mu) or it >= max_it: break
+        n = S @ m
+        beta = gam / g_old if it else 0.0
+        alpha = gam / (dlt - beta * gam / a_old) if it else gam / dlt
+        z = n + beta * z; q = m + beta * q; s = w + beta * s; p = u + beta * p
+        x = x + alpha * p; r = r - alpha * s; u = u - alpha * q; w = w - alpha * z
+        g_old, a_old = gam, alpha; it += 1
+    return x, it
+
+
+def lm(o, x0, ns, nc, mode, eta=3e-4, eps=2e-5, thresh=0, max_steps=60, blockdiag=False, stale=False, approx=False):
+    global APPROX
+    APPROX = approx
+    STALE.clear()
+    x = x0.copy(); z = o.extract_z(x)
+    H, B = o.normal_equations(x, z=z, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+    err = float(np.sum(o.residuals(x, z=z, res_mode=ol.RES_F32) ** 2))
+    mu, v, prev = H.diagonal().max(), 2.0, err
+    its, rows = [], 8.0 * o.N
+    last = 1000
+    for step in range(max_steps):
+        accepted = False
+        for _ in range(6):
+            U, W, V, bs, bf = E.split(H, B, ns); nf = V.shape[0]
+            Vi = np.linalg.inv(V + mu * np.eye(6)); Wb = W.reshape(ns, nf, 6)
+            S = U + mu * np.eye(ns) - np.einsum("sfi,fij,tfj->st", Wb, Vi, Wb)
+            rhs = bs - np.einsum("sfi,fij,fj->s", Wb, Vi, bf.reshape(nf, 6))
+            if mode is None:
+                xs = np.linalg.solve(S, rhs)
+            else:
+                Z = coarse(z, ns, nc, mode) if (mode and last >= thresh) else None
+                xs, it = pipelined(S, rhs, mu, eta, eps, Z, blockdiag=blockdiag, stale=stale); its.append(it); last = it if Z is None else max(it, thresh)
+            df = np.einsum("fij,fj->fi", Vi, bf.reshape(-1, 6) - np.einsum("sfi,s->fi", Wb, xs)).reshape(-1)
+            d = np.concatenate([xs, df]); zt = z + d
+            et = float(np.sum(o.residuals(x, z=zt, res_mode=ol.RES_F32) ** 2))
+            L = 0.5 * d @ (mu * d - B); gain = (et - prev) / L
+            if gain > 0 and et - prev < 0:
+                mu *= max(0.33, 1 - (2 * gain - 1) ** 3); v = 2.0; z, err, accepted = zt, et, True
+                break
+            mu *= v; v *= 5
+        if accepted:
+            H, B = o.normal_equations(x, z=z, jac_mode=ol.JAC_ANALYTIC, res_mode=ol.RES_F32)
+        stop = abs(prev - err) / rows <= 1e-4 or not accepted or err > prev
+        prev = err
+        if stop: break
+    return np.sqrt(err / (4.0 * o.N)), step + 1, its, z
+
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+ds = aar.synth(cfg) if len(sys.argv) <= 2 else aar.synth(cfg, num_frames=int(sys.argv[2]))
+o = ol.Oracle(ds); nc = 6 * (ds.num_cams - 1); ns = nc + 6 * (ds.num_markers - 1)
+rm0, st0, _, z0 = lm(o, ds.x_full, ns, nc, None)
+print("config %d (%d frames, n = %d): exact LM %d steps, RMSE %.9f px" % (cfg, ds.num_frames, ns, st0, rm0), flush=True)
+for name, mode, kw in (("block-Jacobi", "", {}), ("+ cm", "cm", {}), ("+ cm, E block-diagonal", "cm", dict(blockdiag=True)), ("+ cm, E block-diagonal, from the previous solve", "cm", dict(blockdiag=True, stale=1)), ("+ cm, E block-diagonal, previous solve's incl. its mu", "cm", dict(blockdiag=True, stale=2)),
+                       ("+ cm, E block-diagonal, of two solves ago", "cm", dict(blockdiag=True, stale=3))):
+    rm, st, its, z = lm(o, ds.x_full, ns, nc, mode, **kw)
+    print("  %-20s LM steps %2d  CG its total %4d  per step %-60s |RMSE - exact| %.1e px  max |z - z_exact| shared %.1e frames %.1e" %
+          (name, st, sum(its), " ".join(map(str, its)), abs(rm - rm0), np.abs(z - z0)[:ns].max(), np.abs(z - z0)[ns:].max()), flush=True)
