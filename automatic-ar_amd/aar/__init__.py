@@ -612,7 +612,8 @@ class Problem:
                  solver=None, deterministic=None, pcg_eta=None, pcg_max_it=None, pcg_eta_loose=None, pcg_eta_switch=None, pcg_abs_tol=None):
         """intrinsics=True: Config::optimize_cam_intrinsics -- every vector ends with 9 per camera (x_with_intrinsics builds one)
         solver ("direct" | "spcg" | "pcg" | "auto"), deterministic, pcg_eta, pcg_max_it, pcg_eta_loose, pcg_eta_switch: aar_solver_options
-        (None = the library's default: solver AUTO with its forcing sequence)"""
+        (None = the library's default: solver AUTO -- direct for one tile of unknowns, SPCG wherever it fits, PCG for many entities per frame x many frames -- with
+        one pose-grade forcing term and an absolute tolerance; a forcing SEQUENCE only when pcg_eta_loose is given)"""
         self.ds = ds
         self._cds = ds.as_c()
         d = CProblemDesc()

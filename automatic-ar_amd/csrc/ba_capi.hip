@@ -224,6 +224,7 @@ struct aar_problem {
     // harder: a solve that came within 20 % of the iteration cap is taken as the announcement that the next one will not fit -- that try goes to the direct chain at once,
     // instead of through a failed CG attempt (64 .. 128 wasted iterations, the trial evaluation on a garbage step, a rebuild of the blocks)
     int last_cg_its = -1;
+    int near_cap_tries = 0;            // tries the announcement above has sent to the direct chain: after 8 of them it is forgotten and the CG gets its chance again
     int64_t spcg_fallbacks = 0;
     double *h_pcg = nullptr;           // solver pcg with a communicator: pinned, mapped {done, iterations, -, sequence} the iteration launches publish
     unsigned long long pcg_seq = 0;
@@ -820,6 +821,10 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
     if ((rc = check_async("kernel launch"))) return rc;
     if ((rc = wait_result(pb))) return rc;
     if (by_cg && pb->h_scal[7] >= 0.0) pb->last_cg_its = (int)pb->h_scal[7];
+    // every rank must take the same decisions from last_cg_its, and the flags ARE joined over the ranks: a solve that gave up anywhere counts as one at the cap everywhere
+    // (a time-out records SPCG_BUFS on the rank it happened on only)
+    if (by_cg && (pb->h_flags[0] & (8 | 4))) pb->last_cg_its = std::min(P.spcg_max_it, SPCG_MAX_IT);
+    if (cg_near_cap && P.use_spcg && !pb->force_direct && pb->spcg_skip == 0 && ++pb->near_cap_tries >= 8) { pb->last_cg_its = -1; pb->near_cap_tries = 0; }   // (the latch decays)
     if (pb->h_flags[0]) {
         (void)hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream);
         if (by_cg && (pb->h_flags[0] & (8 | 4))) {
@@ -1823,6 +1828,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     pb->s_reduced = pb->trial_reduced = false;
     pb->spcg_skip = pb->spcg_backoff = 0;   // (a one-off solve: the problem's own solver gets its chance whatever an earlier LM run ended with)
     pb->last_cg_its = -1;
+    pb->near_cap_tries = 0;
     pb->P.spcg_coarse_on = 0;
     pb->P.pcg_eta_now = pb->P.pcg_eta;      // (... and the forcing term itself, not the LM's forcing sequence)
     if ((rc = damped_try_fb(pb, mu, false))) return rc == TRY_NOT_POSITIVE_DEFINITE ? AAR_ERR_NUMERIC : rc;
@@ -1849,6 +1855,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     pb->launches = 0;
     pb->spcg_skip = pb->spcg_backoff = 0;
     pb->last_cg_its = -1;
+    pb->near_cap_tries = 0;
     P.spcg_coarse_on = 0;
     if (pb->spec_chol_blk >= 0) {   // a factorisation queued ahead of the last step of the previous solve: its pivot flags mean nothing
         HIP_TRY(hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream));

@@ -11,21 +11,35 @@ namespace {
 constexpr size_t STAGE_BYTES = (size_t)8 << 20;   // two halves of 4 MiB: the DMA of one chunk overlaps the memcpy of the next
 
 // One staging buffer per host thread (the in-process rank groups of the tests drive one problem per thread; a mutex-guarded shared buffer
-// would serialise their copies for nothing).  Freed when the thread ends -- unless the process is already tearing the runtime down.
+// would serialise their copies for nothing), freed when the thread ends.  The buffer is portable page-locked memory (any device may DMA
+// through it); the two events belong to ONE device -- an event may only be recorded on a stream of the device it was created on -- so they
+// are made again when the thread's current device is another one than last time (a thread that drives problems on devices 0 and 1 in turn).
 struct Stage {
     char *buf = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    int dev = -1;
+    bool gone = false;   // the thread's destructors have run (a process-exit handler still copying: see d2h)
+    void drop_events() {
+        for (int i = 0; i < 2; i++) { if (ev[i]) (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
+        dev = -1;
+    }
     ~Stage() {
-        if (ev[0]) (void)hipEventDestroy(ev[0]);
-        if (ev[1]) (void)hipEventDestroy(ev[1]);
+        drop_events();
         if (buf) (void)hipHostFree(buf);
+        buf = nullptr;
+        gone = true;
     }
     hipError_t ensure() {
-        if (buf) return hipSuccess;
-        hipError_t e = hipHostMalloc((void **)&buf, STAGE_BYTES, hipHostMallocDefault);
-        if (e != hipSuccess) { buf = nullptr; return e; }
-        for (int i = 0; i < 2; i++)
-            if ((e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)) != hipSuccess) return e;
+        hipError_t e;
+        int cur = 0;
+        if ((e = hipGetDevice(&cur)) != hipSuccess) return e;
+        if (!buf && (e = hipHostMalloc((void **)&buf, STAGE_BYTES, hipHostMallocPortable)) != hipSuccess) { buf = nullptr; return e; }
+        if (dev != cur || !ev[0] || !ev[1]) {
+            drop_events();
+            for (int i = 0; i < 2; i++)
+                if ((e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)) != hipSuccess) { ev[i] = nullptr; drop_events(); return e; }
+            dev = cur;
+        }
         return hipSuccess;
     }
 };
@@ -60,6 +74,15 @@ int h2d(void *dst, const void *src, size_t bytes, hipStream_t st, const char **w
 
 int d2h(void *dst, const void *src, size_t bytes, hipStream_t st, const char **what) {
     if (bytes == 0) return 0;
+    if (t_stage.gone) {   // after the thread's destructors (an atexit handler of a diagnostic build): a page-locked landing zone of its own, no staging state
+        void *tmp = nullptr;
+        hipError_t e2 = hipHostMalloc(&tmp, bytes, hipHostMallocPortable);
+        if (e2 != hipSuccess) return fail(e2, "hipHostMalloc(exit-time copy)", what);
+        e2 = hipMemcpy(tmp, src, bytes, hipMemcpyDeviceToHost);
+        if (e2 == hipSuccess) memcpy(dst, tmp, bytes);
+        (void)hipHostFree(tmp);
+        return e2 == hipSuccess ? 0 : fail(e2, "hipMemcpy(exit-time copy)", what);
+    }
     hipError_t e = t_stage.ensure();
     if (e != hipSuccess) return fail(e, "hipHostMalloc(staging)", what);
     const size_t half = STAGE_BYTES / 2;

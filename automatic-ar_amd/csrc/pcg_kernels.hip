@@ -433,9 +433,12 @@ __device__ __forceinline__ void pcgf_setup_slots(const PcgArgs &a, double *__res
 // this workgroup's share of  y = U p - sum_f W_f (V_f + mu I)^-1 W_f^T p  (no mu p term) into yacc [n] (LDS, zeroed here): ONE pass over the W blocks of
 // its frames -- c = W^T p, t = Vinv c, y -= W t, the first two rounds of a frame's slot list staying in registers across both uses -- and (U p)_e for the
 // entities dealt to it.  p: this workgroup's copy of the search direction (LDS)
-// W32: the frame pass reads the fp32 copy of W (a.Wf; half the bytes of the pass, which is HBM-bound at config 5) and widens on use: the right-hand side, the
-// preconditioner and the back-substitution keep fp64 W, and a rounding of 6e-8 in the operator is far below the forcing term -- final poses unchanged
-// (scripts/experiments/pcg_w_float.py; profiles/r05_attempts.txt section 5)
+// W32: the frame pass reads the fp32 copy of W (a.Wf; half the bytes of the pass, which is HBM-bound at config 5) and widens on use.  Where that copy exists
+// NOTHING reads fp64 blocks any more: pass A writes Wf INSTEAD of W (a.W is then stale -- never written -- unless aar_eval_normal_equations asked for it through
+// want_w64), and the set-up pass (right-hand side, preconditioner) and the back-substitution read Wf too; a rounding of 6e-8 is far below the forcing terms
+// this storage is allowed at (PCG_W32_MIN_ETA) -- final poses unchanged (scripts/experiments/pcg_w_float.py; profiles/r05_attempts.txt section 5).  The kernels
+// that read a.W unconditionally (k_pcg, k_pcgd_setup / k_pcgd_iter, the Schur kernels) must therefore never run on a block set that has Wf: launch_pcg and
+// launch_pcgd_* refuse (flag 2 -> AAR_ERR_NUMERIC) instead of reading stale blocks
 template <bool W32, int TH = PCG_THREADS>
 __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__restrict__ p, double *__restrict__ yacc, double *__restrict__ red, int wg, int G, int st_it = 0) {
     constexpr int NW = TH / 64;
@@ -1231,6 +1234,7 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
         hipLaunchKernelGGL(k_pcgf<false>, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NYV * P.n_pad);
         return;
     }
+    if (b.Wf) { (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.flags), 2, 1, st); return; }   // (k_pcg reads the fp64 blocks, which a block set with Wf does not keep: see pcgf_operator)
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcg), lds, granted);
     hipLaunchKernelGGL(k_pcg, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a);
 }
@@ -1271,6 +1275,7 @@ void launch_pcgd_setup(const DeviceProblem &P, int which, double mu, hipStream_t
         hipLaunchKernelGGL(k_pcgd_setup_f, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, d);
         return;
     }
+    if (P.blk[which].Wf) { (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.flags), 2, 1, st); return; }   // (reads the fp64 blocks: never on a block set that keeps Wf instead)
     hipLaunchKernelGGL(k_pcgd_setup, dim3(P.pcg_grid), dim3(PCG_THREADS), 0, st, d);
 }
 
@@ -1296,6 +1301,7 @@ void launch_pcgd_iter(const DeviceProblem &P, int which, double mu, int k, bool 
         return;
     }
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_iter), lds, granted);
+    if (P.blk[which].Wf) { (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.flags), 2, 1, st); return; }
     hipLaunchKernelGGL(k_pcgd_iter, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, d);
 }
 

@@ -20,12 +20,32 @@ namespace aar {
 
 class MultiCamMapper;
 
-// Stand-in for Eigen::SparseMatrix<T> in the signature of a Jacobian function (libs/sparselevmarq.h:63): the Jacobian of the
-// accelerated path never exists as a host matrix -- its blocks are accumulated into J^T J on the device -- so the type only
-// keeps reference-shaped code compiling.
+// Stand-in for Eigen::SparseMatrix<T> in the signature of a Jacobian function (libs/sparselevmarq.h:63).  The Jacobian of the
+// accelerated path never exists as a host matrix -- its blocks are accumulated into J^T J on the device -- so for
+// MultiCamMapper's own functions the type only keeps reference-shaped code compiling.  A caller's OWN Jacobian function (the
+// host loop of detail::HostLevMarq) fills it entry by entry: coordinate form, duplicates are added up, as Eigen's
+// setFromTriplets does.
+template <typename T>
+struct Triplet {   // Eigen::Triplet's interface
+    Triplet() {}
+    Triplet(int64_t r, int64_t c, T v) : r_(r), c_(c), v_(v) {}
+    int64_t row() const { return r_; }
+    int64_t col() const { return c_; }
+    T value() const { return v_; }
+    int64_t r_ = 0, c_ = 0;
+    T v_ = 0;
+};
 template <typename T>
 struct SparseJacobian {
     int64_t rows = 0, cols = 0;
+    std::vector<int64_t> row, col;
+    std::vector<T> val;
+    void resize(int64_t r, int64_t c) { rows = r; cols = c; setZero(); }
+    void setZero() { row.clear(); col.clear(); val.clear(); }
+    T &insert(int64_t r, int64_t c) { row.push_back(r); col.push_back(c); val.push_back(T(0)); return val.back(); }
+    template <class It>
+    void setFromTriplets(It begin, It end) { setZero(); for (It t = begin; t != end; ++t) insert(t->row(), t->col()) = t->value(); }
+    int64_t nonZeros() const { return (int64_t)val.size(); }
 };
 
 namespace detail {
@@ -45,6 +65,29 @@ struct EvalProbe {
     EvalId id;
 };
 EvalProbe &eval_probe();   // one per thread
+// The LM loop of libs/sparselevmarq.h for evaluation functions that live on the host (host_levmarq.cpp): what SparseLevMarq<double> runs when its callables are
+// not MultiCamMapper's own.  Dense normal equations, LDL^T without pivoting; same init / step / solve rules, exits and quirks as the reference.
+class HostLevMarq {
+   public:
+    typedef std::vector<double> eVector;
+    typedef std::function<void(const eVector &, eVector &)> F;
+    typedef std::function<void(const eVector &, SparseJacobian<double> &)> FJ;
+    struct Prm {
+        int maxIters = 100;
+        double minError = 1e-5, min_step_error_diff = 0, min_average_step_error_diff = 0.001, tau = 1, der_epsilon = 1e-3;
+        bool verbose = false;
+    };
+    void init(const eVector &z, const F &f);                                     // libs/sparselevmarq.h:238-249
+    bool step(const F &f, const FJ &fJ, const Prm &prm);                         // :349-430
+    double solve(eVector &z, const F &f, const FJ &fJ, const Prm &prm, const std::function<void(const eVector &)> &step_cb,
+                 const std::function<bool(const eVector &)> &stop_fn);            // :440-472
+    static void central_differences(const eVector &z, SparseJacobian<double> &J, const F &f, double der_epsilon);   // :193-214
+    eVector curr_z, x;            // current point; the residual vector of the LAST evaluation (the reference's x64)
+    double currErr = 0, prevErr = 0, mu = -1, v = 2, last_gain = 0;
+    int last_tries = 0, iterations = 0, exit_code = 0;   // exit_code: the reference's mustExit (1 minError, 2 small step / rejected, 3 error grew; 0: maxIters or a stop function)
+    bool active = false;          // init() has run on the host path
+    SparseJacobian<double> J;
+};
 // the mapper's device problem (created on demand) and its full parameter vector for the current Config; throws on failure
 aar_problem *bind_problem(MultiCamMapper *owner, std::vector<double> &x_full);
 aar_problem *current_problem(const MultiCamMapper *owner);   // what the mapper holds right now (nullptr after a Config change)
@@ -54,9 +97,11 @@ double solve_tracking(MultiCamMapper *owner, std::vector<double> &z);
 
 // ucoslam::SparseLevMarq<T> (libs/sparselevmarq.h:26-141) over the C ABI: Params with the reference's field names, setParams,
 // solve / init / step with the reference's signatures (:80,88,95-96,118), getCurrentSolution, setStepCallBackFunc, setStopFunction.
-// The evaluation functions must be aar::MultiCamMapper's own (see detail::EvalProbe): error_function + jacobian_function run as
-// the HIP kernels of that mapper's device problem, error_function_tracking as aar_track; any other callable -> std::logic_error.
-// solve(z, f) -- "automatic Jacobian" in the reference, central differences -- uses the same analytic device Jacobian.
+// Evaluation functions that are aar::MultiCamMapper's own (see detail::EvalProbe) run on the GPU: error_function + jacobian_function as
+// the HIP kernels of that mapper's device problem, error_function_tracking as aar_track; there solve(z, f) -- "automatic Jacobian" in the
+// reference, central differences -- uses the same analytic device Jacobian.  Any OTHER callable is a host function: the solver then is the
+// reference's general sparse LM on the host (detail::HostLevMarq, host_levmarq.cpp: same rules, exits and quirks; central differences for
+// solve(z, f)), as SURVEY.md section 8b keeps it for API compatibility.  The probe costs a host function one extra evaluation per solve / init.
 // z is the reference's parameter vector for the problem's Config (mats2eVec order).
 template <typename T>
 class SparseLevMarq {
@@ -79,7 +124,7 @@ class SparseLevMarq {
         T min_step_error_diff = 0;
         T min_average_step_error_diff = 0.001;
         T tau = 1;
-        T der_epsilon = 1e-3;  // unused: the Jacobian is analytic here
+        T der_epsilon = 1e-3;  // the host loop's central differences (the device Jacobian is analytic)
         bool cal_dev_parallel = true;
         bool use_omp = true;
         bool verbose = false;
@@ -105,22 +150,29 @@ class SparseLevMarq {
     void setParams(const Params &p) { _params = p; }
 
     T solve(eVector &z, F_z_x f_z_x, F_z_J f_J) {   // :80, :440-472
-        bind_eval(z, f_z_x, &f_J);
+        if (bind_eval(z, f_z_x, &f_J) == detail::EVAL_NONE) return host_.solve(z, f_z_x, f_J, host_prm(), step_cb_, stop_fn_);
         return solve(z);
     }
     T solve(eVector &z, F_z_x f_z_x) {   // :118, :474-477
-        if (bind_eval(z, f_z_x, nullptr) == detail::EVAL_ERROR_FUNCTION_TRACKING) return detail::solve_tracking(owner_, z);
+        const int kind = bind_eval(z, f_z_x, nullptr);
+        if (kind == detail::EVAL_NONE) return host_.solve(z, f_z_x, numeric_jacobian(f_z_x), host_prm(), step_cb_, stop_fn_);
+        if (kind == detail::EVAL_ERROR_FUNCTION_TRACKING) return detail::solve_tracking(owner_, z);
         return solve(z);
     }
     void init(eVector &z, F_z_x f_z_x) {   // :88, :238-249
-        if (bind_eval(z, f_z_x, nullptr) != detail::EVAL_ERROR_FUNCTION) throw std::logic_error("SparseLevMarq::init: the step-by-step mode runs MultiCamMapper::error_function only");
+        const int kind = bind_eval(z, f_z_x, nullptr);
+        if (kind == detail::EVAL_NONE) { host_.init(z, f_z_x); return; }
+        if (kind != detail::EVAL_ERROR_FUNCTION) throw std::logic_error("SparseLevMarq::init: the step-by-step mode runs MultiCamMapper::error_function or a host function");
+        host_.active = false;
         init(z);
     }
     bool step(F_z_x f_z_x, F_z_J f_J) {   // :95, :349-430
+        if (host_.active) return host_.step(f_z_x, f_J, host_prm());   // (the functions init() was given: a host loop cannot tell, the reference does not check either)
         check_eval(f_z_x, &f_J);
         return step();
     }
     bool step(F_z_x f_z_x) {   // :96, :250-256
+        if (host_.active) return host_.step(f_z_x, numeric_jacobian(f_z_x), host_prm());
         check_eval(f_z_x, nullptr);
         return step();
     }
@@ -150,6 +202,7 @@ class SparseLevMarq {
         return it.accepted != 0;
     }
     T getCurrentSolution(eVector &z) {   // :432-437
+        if (host_.active) { z = host_.curr_z; return host_.currErr; }
         need();
         double err = 0;
         if (aar_lm_get_solution(problem_, x_.data(), &err)) fail();
@@ -162,8 +215,9 @@ class SparseLevMarq {
     void setStopFunction(std::function<bool(const eVector &)> stop_function) { stop_fn_ = stop_function; }
 
     Params _params;
-    aar_lm_report report;     // of the last solve()
-    aar_lm_iter last_iter;    // of the last step()
+    aar_lm_report report;     // of the last solve() on the device path
+    aar_lm_iter last_iter;    // of the last step() on the device path
+    const detail::HostLevMarq &host_state() const { return host_; }   // of the host path: mu, errors, iterations, the reference's exit code
 
    private:
     void need() const { if (!problem_) throw std::runtime_error("SparseLevMarq: no problem attached"); }
@@ -178,24 +232,24 @@ class SparseLevMarq {
         Out out;
         try { fn(z, out); } catch (...) { p.active = false; throw; }
         p.active = false;
-        if (p.id.kind == detail::EVAL_NONE)
-            throw std::logic_error("SparseLevMarq: the evaluation function is not aar::MultiCamMapper's error_function / jacobian_function / "
-                                   "error_function_tracking; this solver runs those on the GPU and has no CPU loop for host callbacks");
-        return p.id;
+        return p.id;   // kind EVAL_NONE: nobody answered -- a host function
     }
     static detail::EvalId identify_pair(const eVector &z, const F_z_x &f, const F_z_J *J) {
         const detail::EvalId idf = identify<F_z_x, eVector>(f, z);
         if (idf.kind == detail::EVAL_JACOBIAN_FUNCTION) throw std::logic_error("SparseLevMarq: a Jacobian function was passed as the error function");
         if (J) {
             const detail::EvalId idj = identify<F_z_J, SparseJacobian<T>>(*J, z);
+            if (idf.kind == detail::EVAL_NONE && idj.kind == detail::EVAL_NONE) return idf;   // both on the host
             if (idj.kind != detail::EVAL_JACOBIAN_FUNCTION || idj.owner != idf.owner || idf.kind != detail::EVAL_ERROR_FUNCTION)
-                throw std::logic_error("SparseLevMarq: error and Jacobian function must be error_function and jacobian_function of the same MultiCamMapper");
+                throw std::logic_error("SparseLevMarq: error and Jacobian function must be error_function and jacobian_function of the same MultiCamMapper, or both host functions");
         }
         return idf;
     }
     // identify the pair and attach to their mapper's device problem; returns the kind of f
     int bind_eval(const eVector &z, const F_z_x &f, const F_z_J *J) {
         const detail::EvalId id = identify_pair(z, f, J);
+        host_.active = false;
+        if (id.kind == detail::EVAL_NONE) return id.kind;
         owner_ = id.owner;
         if (id.kind == detail::EVAL_ERROR_FUNCTION) problem_ = detail::bind_problem(owner_, x_);
         return id.kind;
@@ -209,6 +263,16 @@ class SparseLevMarq {
             problem_ = nullptr;
             throw std::runtime_error("SparseLevMarq::step: the mapper's device problem has changed since init()");
         }
+    }
+    detail::HostLevMarq::Prm host_prm() const {
+        detail::HostLevMarq::Prm p;
+        p.maxIters = _params.maxIters; p.minError = _params.minError; p.min_step_error_diff = _params.min_step_error_diff;
+        p.min_average_step_error_diff = _params.min_average_step_error_diff; p.tau = _params.tau; p.der_epsilon = _params.der_epsilon; p.verbose = _params.verbose;
+        return p;
+    }
+    F_z_J numeric_jacobian(const F_z_x &f) const {   // libs/sparselevmarq.h:222-228: calcDerivates bound to f
+        const double eps = _params.der_epsilon;
+        return [f, eps](const eVector &z, SparseJacobian<T> &J) { detail::HostLevMarq::central_differences(z, J, f, eps); };
     }
     aar_lm_params c_params() const {
         aar_lm_params p;
@@ -236,6 +300,7 @@ class SparseLevMarq {
         if (aar_lm_set_stop_function(problem_, stop_fn_ ? &stop_tramp : nullptr, this)) fail();
     }
     aar_problem *problem_ = nullptr;
+    detail::HostLevMarq host_;          // the host loop and its state (evaluation functions that are not the mapper's)
     MultiCamMapper *owner_ = nullptr;   // whose evaluation functions the last solve / init named
     std::vector<double> x_;
     eVector zbuf_;
@@ -359,9 +424,10 @@ class MultiCamMapper {
     int residual_mode = AAR_RES_F32;
     // How the damped normal equations are solved (aar_solver_options, include/aar.h) -- the counterpart of configuring the reference's solver object
     // through SparseLevMarq::Params (libs/sparselevmarq.h:30-50), and kept beside them.  AUTO (the default) picks by size: the direct chain for one tile of
-    // unknowns, CG on the explicit reduced system (SPCG) below 96 cameras + markers, CG through the frame blocks (PCG) from there -- inexact LM with a forcing
-    // sequence (loose early, tight for the late steps the final poses are made of); DIRECT is the reference's Eigen::SimplicialLDLT step to rounding, for
-    // callers who want the reference's every step.  Takes effect when the device problem is (re)built: set it before solve() / track();
+    // unknowns (<= 16 cameras + markers); CG on the explicit reduced system (SPCG, two-level preconditioned: block-Jacobi + the groups' rigid-motion modes)
+    // wherever it fits (<= 224 cameras + markers); CG through the frame blocks (PCG) from 96 entities on when incidences x (incidences per frame - 30) >= 4e6,
+    // and where SPCG does not fit -- inexact LM with ONE pose-grade forcing term (SPCG 3e-4, PCG 5e-3) and an absolute tolerance beside it; DIRECT is the
+    // reference's Eigen::SimplicialLDLT step to rounding, for callers who want the reference's every step.  Takes effect when the device problem is (re)built: set it before solve() / track();
     // set_solver_options() drops a problem that exists already.
     struct SolverOptions {
         int solver = AAR_SOLVER_AUTO;     // AAR_SOLVER_AUTO | _DIRECT | _SPCG | _PCG

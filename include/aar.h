@@ -310,7 +310,9 @@ typedef struct aar_solver_options {
 void aar_solver_default_options(aar_solver_options *);   /* struct_size set, AUTO, not deterministic, default forcing sequence / cap */
 int aar_problem_create_ex(const aar_problem_desc *, const aar_solver_options *, aar_problem **out);
 /* what the problem runs with (AUTO resolved), and what its inner solver has done so far.  The CALLER sets struct_size = sizeof(aar_solver_stats)
- * before the call; the library fills at most that many bytes (a caller built against an older, shorter struct keeps working). */
+ * before the call; the library fills at most that many bytes, so fields appended LATER do not break a caller built against this layout.
+ * ABI note: struct_size itself arrived in round 5, as the FIRST member -- an incompatible change against the round-4 struct (which began with `solver` and
+ * carried a `reserved` word): a binary built against round 4 must be rebuilt.  From here on the struct only grows at its end. */
 enum { AAR_ENV_SOLVER = 1, AAR_ENV_DETERMINISTIC = 2, AAR_ENV_PCG_ETA = 4, AAR_ENV_PCG_MAX_IT = 8 };
 typedef struct aar_solver_stats {
     uint32_t struct_size;                     /* in: sizeof(aar_solver_stats) of the caller                                            */

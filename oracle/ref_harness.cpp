@@ -162,4 +162,52 @@ int ref_damped_solve(int64_t n_rows, int64_t P, int64_t nnz, const int32_t *rows
 /* The reference's own numeric differentiation helper, SparseLevMarq::calcDerivates (libs/sparselevmarq.h:199-220)
  * is exercised by track(), which is out of scope; not exported. */
 
+
+/* ---- the real solver on the toy problems of tests/tools/toy_problems.h: what the host-callback path of aar::SparseLevMarq (automatic-ar_amd/host/host_levmarq.cpp)
+ * is compared with.  mode 0: solve(z, f, J) with problem 0's analytic Jacobian; 1: solve(z, f) -- the solver's own central differences; 2: mode 0 or 1 (by problem)
+ * under a stop function that says yes at its stop_after-th call; 3: init + `steps` calls of step(f, J) / step(f).  The trace holds, per step: currErr, mu, and (mode
+ * 3) whether the step was accepted.  Returns the final error; z_out the final vector. */
+}
+#include "../tests/tools/toy_problems.h"
+extern "C" {
+double ref_lm_toy(int problem, int mode, int max_iters, double min_error, double min_step, double min_avg, double tau, double der_eps, int stop_after, int steps,
+                  double *trace_err, double *trace_mu, int32_t *trace_acc, int32_t trace_cap, int32_t *n_trace, double *z_out) {
+    omp_set_num_threads(1);
+    const int n = toy::num_unknowns(problem), m = toy::num_residuals(problem, n);
+    Solver solver;
+    Solver::Params prms(max_iters, min_error, min_step, min_avg, tau, der_eps);
+    prms.min_average_step_error_diff = min_avg;   // (the constructor stores min_step in both fields, libs/sparselevmarq.h:32-39)
+    prms.verbose = false;
+    prms.use_omp = false;
+    prms.cal_dev_parallel = false;
+    solver.setParams(prms);
+    solver.v = 2;
+    auto f = [&](const eVector &z, eVector &err) { err.resize(m); toy::residuals(problem, z.data(), n, err.data()); };
+    auto fJ = [&](const eVector &z, Eigen::SparseMatrix<double> &J) {
+        std::vector<Eigen::Triplet<double>> t;
+        toy::jacobian0(z.data(), n, [&](int r, int c, double v) { t.push_back(Eigen::Triplet<double>(r, c, v)); });
+        J.resize(m, n);
+        J.setFromTriplets(t.begin(), t.end());
+    };
+    eVector z(n);
+    toy::start(problem, z.data());
+    int32_t nt = 0;
+    auto record = [&](int acc) { if (nt < trace_cap) { trace_err[nt] = solver.currErr; trace_mu[nt] = solver.mu; trace_acc[nt] = acc; } nt++; };
+    const bool analytic = problem == 0 && mode != 1;
+    double err = 0;
+    if (mode == 3) {
+        solver.prevErr = std::numeric_limits<double>::max();
+        solver.init(z, f);
+        for (int k = 0; k < steps; k++) { const bool acc = analytic ? solver.step(f, fJ) : solver.step(f); record(acc ? 1 : 0); }
+        err = solver.getCurrentSolution(z);
+    } else {
+        int calls = 0;
+        solver.setStepCallBackFunc([&](const eVector &) { record(-1); });
+        if (mode == 2) solver.setStopFunction([&](const eVector &) { return ++calls >= stop_after; });
+        err = analytic ? solver.solve(z, f, fJ) : solver.solve(z, f);
+    }
+    *n_trace = nt;
+    for (int i = 0; i < n; i++) z_out[i] = z[i];
+    return err;
+}
 }  // extern "C"

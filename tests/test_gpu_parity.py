@@ -1006,9 +1006,11 @@ def test_reference_shaped_solver_calls_compile_and_run_against_the_mirror(tmp_pa
     assert sum(l.startswith("Curr Error=") and "dumping factor=" in l for l in run.stderr.splitlines()) == 2
     vals = dict(t.split("=") for t in stage[0].split())
     assert float(vals["J"]) > 0 and float(vals["chol"]) > 0 and float(vals["Jt*J"]) > 0
-    # host callbacks are refused (no CPU loop), mismatched owners too; the Jacobian function is not callable by hand; a solver
-    # whose device problem was destroyed by a Config change says so instead of using freed memory
-    assert kv["host_callback"] == "logic_error" and int(kv["host_callback_calls"]) == 1      # (called once: the probe)
+    # a caller's own evaluation function runs on the host loop of the same solver object (tests/test_host_levmarq.py holds that loop against the reference's
+    # solver); a host function mixed with a mapper function is refused, mismatched owners too; the Jacobian function is not callable by hand; a solver whose
+    # device problem was destroyed by a Config change says so instead of using freed memory
+    assert kv["host_callback"] == "solved" and int(kv["host_callback_calls"]) > 10 and float(kv["host_callback_err"]) < 1e-12
+    assert np.allclose([float(t) for t in kv["host_callback_z"].split()], [1.0, -0.5], atol=1e-6) and kv["mixed_host_device"] == "logic_error"
     assert kv["mixed_owners"] == "logic_error" and kv["direct_jacobian"] == "logic_error" and kv["stale_step"] == "runtime_error"
     # track() in the reference's shape: every frame refined, z = the frame poses
     assert int(kv["track_frames"]) == ds.num_frames and int(kv["track_zlen"]) == 6 * ds.num_frames and float(kv["track_max_err"]) < 100.0
@@ -1239,3 +1241,17 @@ def test_observation_passes_wrench_form_equals_row_form(shape, monkeypatch):
     with Problem(ds, deterministic=True, solver="direct", **kw) as p:
         H, B, ss = p.eval_normal_equations(x_eval)
     assert np.array_equal(H, out["1", True][0]) and np.array_equal(B, out["1", True][1]) and ss == out["1", True][2]
+
+
+@pytest.mark.gpu
+def test_one_thread_drives_problems_on_two_devices():
+    """the page-locked staging of csrc/hostcopy.hip keeps two events per host thread; an event belongs to ONE device, so a thread that uploads to
+    device 0 and then to device 1 must get events of device 1 (skipped on a one-GPU box: the pool's boxes have one)."""
+    if aar.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ds = aar.synth(2)
+    with aar.Problem(ds, device=0) as p0, aar.Problem(ds, device=1) as p1:
+        x0, r0 = p0.lm_solve(ds.x_full)
+        x1, r1 = p1.lm_solve(ds.x_full)
+        x0b, _ = p0.lm_solve(ds.x_full)
+    assert r0["iterations"] == r1["iterations"] and np.allclose(x0, x1, atol=1e-9) and np.allclose(x0, x0b, atol=1e-9)

@@ -81,15 +81,25 @@ int main(int argc, char **argv) {
         p.maxIters = b.solver_params.maxIters;
         solver.setParams(p);
 
-        // ---- (4) a host callback is refused, with std::logic_error, before anything runs
+        // ---- (4) a host callback runs on the host loop (libs/sparselevmarq.h semantics, host_levmarq.cpp): the same solver object, a caller's own residuals
         int host_calls = 0;
         try {
-            z = z0;
-            solver.solve(z, [&](const ucoslam::SparseLevMarq<double>::eVector &, ucoslam::SparseLevMarq<double>::eVector &x) { host_calls++; x.assign(8, 0.0); });
-            printf("host_callback = accepted\n");
+            ucoslam::SparseLevMarq<double>::eVector zh = {3.0, -2.0};   // r = (z0 - 1, 2 (z1 + 0.5), z0 z1 + 0.5): minimum at (1, -0.5)
+            ucoslam::SparseLevMarq<double>::Params ph(50, 1e-20, 0, 1e-14, 1e-3);
+            ph.min_average_step_error_diff = 1e-14;
+            solver.setParams(ph);
+            const double eh = solver.solve(zh, [&](const ucoslam::SparseLevMarq<double>::eVector &zz, ucoslam::SparseLevMarq<double>::eVector &x) {
+                host_calls++; x.assign(3, 0.0); x[0] = zz[0] - 1; x[1] = 2 * (zz[1] + 0.5); x[2] = zz[0] * zz[1] + 0.5; });
+            printf("host_callback = solved\nhost_callback_calls = %d\nhost_callback_err = %.3e\nhost_callback_z = %.9f %.9f\n", host_calls, eh, zh[0], zh[1]);
+            solver.setParams(p);
         } catch (const std::logic_error &e) {
             printf("host_callback = logic_error\nhost_callback_calls = %d\n", host_calls);
         }
+        try {   // a host error function with the mapper's Jacobian function: refused
+            z = z0;
+            solver.solve(z, [&](const ucoslam::SparseLevMarq<double>::eVector &, ucoslam::SparseLevMarq<double>::eVector &x) { x.assign(8, 0.0); }, J);
+            printf("mixed_host_device = accepted\n");
+        } catch (const std::logic_error &) { printf("mixed_host_device = logic_error\n"); }
         try {   // error function of one mapper with the Jacobian of another
             solver.solve(z, bind(&MultiCamMapper::error_function, &a, placeholders::_1, placeholders::_2), J);
             printf("mixed_owners = accepted\n");
