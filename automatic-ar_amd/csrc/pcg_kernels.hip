@@ -1,20 +1,20 @@
-// OPT-IN solver of the damped normal equations (AAR_SOLVER=pcg; the default stays the direct solve of solve_kernels.hip, whose step is
-// the reference's Eigen::SimplicialLDLT step to rounding, libs/sparselevmarq.h:394-400).
+// Solver "pcg" (aar_solver_options.solver = AAR_SOLVER_PCG; what AAR_SOLVER_AUTO picks for many entities per frame x many frames -- config 5 -- and where the
+// explicit reduced system does not fit k_spcg): the damped reduced camera / marker system of one LM try,
+//     S x = b,   S = U + mu I - sum_f W_f (V_f + mu I)^-1 W_f^T          (libs/sparselevmarq.h:384-400 after block elimination of the frames)
+// solved by block-Jacobi-preconditioned conjugate gradients THROUGH the frame blocks -- S is never formed, nothing is factored:
+//     y = S p  =  (U + mu I) p - sum_f W_f t_f,    t_f = (V_f + mu I)^-1 (W_f^T p).
+// Inexact LM: an inner solve stops when BOTH |r| <= eta |b| (one forcing term, default 5e-3: kernels.h PCG_ETA_DEFAULT -- chosen for the final POSES, which then
+// agree with the direct solver's to ~4e-6; a loose-then-tight sequence is an option, not the default) AND r^T M^-1 r <= eps^2 mu (absolute tolerance, default 5e-5)
+// hold; the LM gain test judges the inexact step as it judges an exact one.  It is the one formulation of this solve in which nothing O(n^3) is left: the frame sum
+// shards by frame and an iteration exchanges 8 n bytes (k_pcgd_* below: the same solver with the frames sharded over ranks).
 //
-// Inexact LM: the reduced camera / marker system  S x = b,  S = U + mu I - sum_f W_f (V_f + mu I)^-1 W_f^T,  is solved by
-// block-Jacobi-preconditioned conjugate gradients THROUGH the frame blocks -- S is never formed, nothing is factored:
-//     y = S p  =  (U + mu I) p - sum_f W_f t_f,    t_f = (V_f + mu I)^-1 (W_f^T p)
-// i.e. two passes over the W blocks per iteration and n-vectors.  Stopped at |r| <= eta |b| (eta = 0.1 by default: a forcing term, as in
-// inexact Newton methods): the LM trajectory is then NOT the reference's step for step, only its fixed point is -- measured final RMSE
-// within 1e-6 px of the direct path (north star bar: 1e-4 px), same number of LM steps (profiles/r03_pcg_experiment.txt, r03_pcg_bench.txt).
-// Why it exists: it is the one formulation of this solve in which nothing O(n^3) is left -- the frame sum shards by
-// frame, an iteration exchanges 8 n bytes (k_pcgd_* below: the same solver with the frames sharded over ranks).
-//
-// ONE persistent launch per solve: G workgroups (one per CU), each keeps its own copy of the CG vectors x, r, p in LDS and updates them
-// redundantly (n is a few hundred to a few thousand), so an iteration needs only two grid-wide hand-overs -- t (6 F doubles) after the
-// frame pass, the work items' shares of y after the entity pass -- done with agent-scope atomic stores / loads and a counter, no
-// cache-maintenance fences (1.1 us per hop, scripts/probe/hop_probe.hip).  The convergence test is taken by every workgroup from the
-// same numbers in the same order: all leave in the same iteration.
+// k_pcgf (the default form; k_pcg = two passes over W and two hand-overs per iteration, kept for deterministic mode): ONE persistent launch per solve, one workgroup
+// per CU over a contiguous range of frames; every workgroup keeps its own copy of the CG vectors in LDS and updates them redundantly, so an iteration is ONE pass
+// over its frames' W blocks (c = W^T p, t = V^-1 c, y -= W t with the blocks in registers across both uses) + one atomic flush of its y into two partial vectors +
+// ONE grid-wide hand-over through a two-level barrier tree (grid_hop_tree: 16 first-level counters, one second-level counter, 16 flags -- no address sees more than
+// 16 agent-scope operations; one counter for 256 workgroups cost 16 us per hop).  Where the forcing term is >= PCG_W32_MIN_ETA the W blocks are STORED in fp32 (pass A
+// writes that copy instead of the fp64 blocks; every product and sum stays fp64; see pcgf_operator).  The convergence test is taken by every workgroup from the same
+// numbers in the same order: all leave in the same iteration.
 #include "geom.hpp"
 #include "kernels.h"
 #include "wave.hpp"

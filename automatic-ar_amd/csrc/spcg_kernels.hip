@@ -1,10 +1,15 @@
-// Solver "spcg" (aar_solver_options.solver = AAR_SOLVER_SPCG, and what AAR_SOLVER_AUTO picks for reduced systems that fit):
-// the damped reduced system  (S + mu I) x = b  of one LM try (libs/sparselevmarq.h:384-400 after block elimination of the frames)
-// solved by block-Jacobi-preconditioned conjugate gradients on the EXPLICIT Schur complement S that k_schur / k_schur_mfma have
-// already left in HBM -- instead of the dense LDL^T chain of solve_kernels.hip (48 serial 6x6 pivot steps per 96-wide tile, 70 % of a
-// step at 8 cameras / 40 markers).  Inexact LM: stopped at |r| <= eta |b| (eta = 0.1), the LM gain test judges the step as it
-// judges an exact one; a solve that does not get there within the iteration cap raises device flag 8 and the host redoes that try
-// with the direct chain (S is never modified here).
+// Solver "spcg" (aar_solver_options.solver = AAR_SOLVER_SPCG, and what AAR_SOLVER_AUTO picks for reduced systems that fit: up to 224 cameras + markers):
+// the damped reduced system  (S + mu I) x = b  of one LM try (libs/sparselevmarq.h:384-400 after block elimination of the frames) solved by preconditioned
+// conjugate gradients on the EXPLICIT Schur complement S that k_schur / k_schur_mfma have already left in HBM -- instead of the dense LDL^T chain of
+// solve_kernels.hip (48 serial 6x6 pivot steps per 96-wide tile).  Inexact LM: an inner solve stops when BOTH r^T M^-1 r <= eta^2 b^T M^-1 b (ONE forcing term,
+// default 3e-4: kernels.h SPCG_ETA_DEFAULT -- chosen for the final POSES, which then agree with the direct solver's to ~1e-6) AND r^T M^-1 r <= eps^2 mu (absolute
+// tolerance, default 2e-5) hold; the LM gain test judges the step as it judges an exact one.  A solve that does not get there within the iteration cap (64 up to
+// four tiles, 128 above) or meets non-positive curvature raises device flag 8 and the host redoes that try with the direct chain (S is never modified here); a solve
+// whose predecessor came within 20 % of the cap goes there at once.
+//
+// Preconditioner.  Block-Jacobi (the 6x6 diagonal blocks) while that converges in a dozen iterations -- the early LM steps; once a solve of the run has needed
+// spcg_coarse_from (12) iterations the COARSE SPACE of the groups' rigid motions joins (k_spcg_pre below: two-level additive preconditioner as block-Jacobi on an
+// augmented system whose twelve extra unknowns sit in the two root entities' idle slots): 18 instead of 57 iterations at the last LM step of config 3.
 //
 // Mapping.  ONE WAVEFRONT PER SHARED ENTITY (camera / marker), each its own workgroup on its own CU: wavefront e keeps the six rows
 // 6e .. 6e+5 of S + mu I in REGISTERS (lane = (row i = lane / 8, column group g = lane % 8): columns {16k + 2g, 16k + 2g + 1},
@@ -21,7 +26,9 @@
 // still read as the sentinel.  One buffer per iteration (no slot is ever reused inside a launch), two buffer sets alternating between
 // launches: a launch clears, at its start, the slots it owns in the OTHER set (the kernel boundary orders that against the next
 // launch).  Against hop_publish / hop_wait (payload, s_waitcnt, flag | poll flag, load payload) this saves a memory round trip on
-// each side.
+// each side.  Measured (scripts/probe/spcg_probe.hip, cycle stamps): an iteration is ~3 300 shader cycles -- publish 300, the poll's round trip 960 (260 per
+// 16-byte load instruction: the number of records matters, not their placement), the sums over the gathered shares 720, the matrix-vector product 750, scalars
+// and recurrences 560 -- and every piece of straight-line set-up code costs about one cycle per byte of instructions (the instruction cache is cold at every launch).
 #include "geom.hpp"
 #include "kernels.h"
 #include "backsub.hpp"

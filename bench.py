@@ -36,6 +36,22 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 FP64_PEAK_TFLOPS = 78.6      # vector fp64
 
 
+class stdout_to_stderr:
+    """RCCL greets every new communicator with a version banner on the process's STDOUT (file descriptor 1, from inside librccl): the bench line must stay the only
+    thing there, so the descriptor points at stderr while a communicator is made."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def run_steps(problem, x0, steps, params_factory):
     """Exactly `steps` LM iterations as repeated solve() calls from x0.  Returns (iterations, trial_points, last x, last report)."""
     done, trials, x, rep = 0, 0, None, None
@@ -289,6 +305,10 @@ def kernel_profile(problem, ds, workload, x0, steps, params, world, intrinsics=F
             r["traffic"] = traffic_tab["k_schur_mfma"] + fill * traffic_tab.get("k_schur_fill", 0.0)      # (fill launches per mfma launch: ~0.07, the steps whose damping was not the predicted one)
         if k == "k_pcg" and r["traffic"] is None:                                            # the launcher's kernels: k_pcgf on one GPU, k_pcgd_* with ranks
             r["traffic"] = traffic_tab.get("k_pcgf", traffic_tab.get("k_pcgd_iter_f"))
+        # `traffic` doubles FETCH_SIZE (the guide's gfx950 rule, stated for wide coalesced read streams: it may overstate a gather kernel); the uncorrected sum beside it
+        rk = "k_passAB" if (k == "k_passA" and merged) else ("k_pcgf" if (k == "k_pcg" and "raw_k_pcgf" in traffic_tab) else k)
+        raw = traffic_tab.get("raw_" + rk)
+        r["traffic_uncorrected"] = (raw["FETCH_SIZE_KB"] + raw["WRITE_SIZE_KB"]) * 1024.0 if isinstance(raw, dict) and r["traffic"] is not None else None
         # the contract's fields, priced against the roofline that applies to this kernel: `bound` says which -- "hbm" (GB/s),
         # "fp64_valu" / "fp64_mfma" (TFLOP/s against the 78.6 TFLOP/s fp64 peak of the vector / matrix pipes), or "latency": a
         # single-workgroup dependent chain, for which a throughput fraction says nothing -- its useful flops over its duration
@@ -307,7 +327,7 @@ def kernel_profile(problem, ds, workload, x0, steps, params, world, intrinsics=F
     roofline["traffic_source"] = traffic_note
     roofline["kernel_source_sha1"] = src_hash
     roofline["observation_pass"] = roof("k_passA")     # the streaming scan the north star prices against HBM
-    roofline["per_kernel"] = {k: {f: v for f, v in roof(k).items() if f in ("bound", "achieved", "peak", "unit", "frac", "avg_us", "avg_us_rocprofv3", "traffic", "utilisation")}
+    roofline["per_kernel"] = {k: {f: v for f, v in roof(k).items() if f in ("bound", "achieved", "peak", "unit", "frac", "avg_us", "avg_us_rocprofv3", "traffic", "traffic_uncorrected", "utilisation")}
                               for k in kernels if k in KERNEL_BOUND}
     tj = (kernels["k_passA"]["avg_us"] + (kernels["k_passB"]["avg_us"] if "k_passB" in kernels else 0.0)) * 1e-6
     roofline["fp64_valu"] = {"kernels": "k_passA+k_passB" if not merged else "k_passA (passes A and B in one launch)", "achieved": 4800.0 * n_loc / tj / 1e12,
@@ -316,6 +336,8 @@ def kernel_profile(problem, ds, workload, x0, steps, params, world, intrinsics=F
                              # matrix: ~1 500 (pass A, slot images included) + ~1 700 (pass B) executed flops per observation
                              "executed_flops_per_observation": 3200, "executed_frac": 3200.0 * n_loc / tj / 1e12 / FP64_PEAK_TFLOPS}
     roofline["sum_kernel_us_per_step"] = sum(v["total_ms"] for v in kernels.values()) * 1e3 / float(done)     # all launches of the pass / its LM steps
+    roofline["sum_kernel_us_per_step_note"] = ("HIP-event brackets around every launch: each adds ~2-3 us to what rocprofv3 reports for the kernel itself, so this sum EXCEEDS "
+                                               "ms_per_step of the un-instrumented run; k_spcg's bracket includes k_spcg_pre where the solve carries the coarse space")
     roofline["profiled_steps"] = int(done)             # LM steps of the instrumented pass (>= 120 at configs 2-4 whatever --steps says): `kernels[*].launches` belong to these
     return kernels, roofline
 
@@ -373,6 +395,63 @@ def other_workload(aar, w, device, steps, warmup):
                    rmse_delta_vs_direct_px=abs(rmse - rmse_d), pose_delta_vs_direct={"rotation_matrix_entries": dR, "translation_m": dT})
     if out["solver_resolved"] == "pcg":
         out["block_storage"] = pcg_block_storage(aar, ds, device, steps, warmup, params, x_fin)
+    out["amdahl"] = single_rank_comm_leg(aar, ds, device, steps, warmup, params, out["value"])
+    return out
+
+
+def single_rank_comm_leg(aar, ds, device, steps, warmup, params, one_gpu_it_per_s):
+    """What a SCALE run of this workload can be held against: the same problem behind a SINGLE-RANK RCCL communicator on this GPU -- the
+    code path of N > 1 (fused all-reduce of S | rhs | g0 | scalars per damped solve, or of 8 n bytes per CG iteration with PCG; replicated solve; speculative next
+    solve) with nothing to shard -- timed, its collectives counted, and a stage-timed pass split into replicated / sharded / collective microseconds per LM step.
+    predicted_upper_bound_it_per_s[n] = 1e6 / (replicated + sharded / n + collective): perfect sharding, the collective at its single-rank cost (a real ring over
+    n GPUs costs more), no skew.  PCG: the damped solve itself shards (its frame passes), one kernel launch + one all-reduce per CG iteration: the split then counts
+    the solve as sharded and reports launches and all-reduces per LM step."""
+    try:
+        with stdout_to_stderr():
+            comm = aar.Comm(aar.Comm.make_id(), 1, 0, device)
+    except Exception as e:   # no RCCL on this box: say so, keep the line
+        return {"error": "single-rank RCCL communicator: %s" % e}
+    out = {"source": "the workload behind a single-rank RCCL communicator on this GPU (the N > 1 code path, nothing to shard)"}
+    with aar.Problem(ds, residual_mode=aar.RES_F32, device=device, comm=comm, solver="auto") as pc:
+        for _ in range(2):
+            pc.lm_solve(ds.x_full, params=params(), trace_cap=1)
+        n_t = max(15, min(steps, 60))
+        run_steps(pc, ds.x_full, min(warmup, 15), params)
+        c0 = comm.stats()
+        aar.lib().aar_device_synchronize()
+        t0 = time.perf_counter()
+        done, _, _, _ = run_steps(pc, ds.x_full, n_t, params)
+        aar.lib().aar_device_synchronize()
+        dt = time.perf_counter() - t0
+        c1 = comm.stats()
+        st = pc.solver_stats()
+        pc.set_stage_timers(True)
+        acc, done_am = {}, 0
+        while done_am < n_t:
+            _, rep_am = pc.lm_solve(ds.x_full, params=params(max_iters=n_t - done_am), trace_cap=1)
+            for kk, vv in pc.stage_times().items():
+                acc[kk] = acc.get(kk, 0.0) + vv
+            done_am += rep_am["iterations"]
+        pc.set_stage_timers(False)
+    us = lambda k: 1e6 * acc.get(k, 0.0) / max(1, done_am)
+    pcg = st["solver"] == "pcg"
+    rep = us("control") + (0.0 if pcg else us("chol"))
+    shard = us("jacobian_normal_eq") + us("schur") + us("backsub") + us("unpack") + us("residual") + (us("chol") if pcg else 0.0)
+    coll = us("allreduce")
+    # the stage-timed pass serialises host and device: scale its split to the step time measured without timers
+    t_step = 1e6 * dt / done
+    k = t_step / max(1e-9, rep + shard + coll)
+    rep, shard, coll = rep * k, shard * k, coll * k
+    out.update(solver_resolved=st["solver"], it_per_s_single_rank_rccl=done / dt, us_per_step_single_rank_rccl=t_step, it_per_s_without_communicator=one_gpu_it_per_s,
+               communicator_overhead_us_per_step=t_step - 1e6 / one_gpu_it_per_s,
+               allreduce_calls_per_lm_step=(c1["allreduce_calls"] - c0["allreduce_calls"]) / float(done),
+               allreduce_bytes_per_lm_step=(c1["allreduce_bytes"] - c0["allreduce_bytes"]) / float(done),
+               cg_iterations_per_lm_step=st["total_iterations"] / max(1, st["solves"]) if st["solver"] != "direct" else None,
+               replicated_us=rep, sharded_us_one_gpu=shard, collective_us=coll,
+               split_note="stage-timer shares of an instrumented pass, scaled to the un-instrumented step time; PCG: the solve counts as sharded, one launch + one all-reduce per CG iteration" if pcg
+               else "stage-timer shares of an instrumented pass, scaled to the un-instrumented step time; the reduced-system solve is replicated",
+               bound_at={str(n): (rep + shard + coll) / (rep + shard / n + coll) for n in (1, 2, 4, 8)},
+               predicted_upper_bound_it_per_s={str(n): 1e6 / (rep + shard / n + coll) for n in (2, 4, 8)})
     return out
 
 
@@ -600,7 +679,8 @@ def main():
         uid = [aar.Comm.make_id() if rank == 0 else None]
         if dist is not None:
             dist.broadcast_object_list(uid, src=0)
-        comm = aar.Comm(uid[0], world, rank, local_rank)
+        with stdout_to_stderr():
+            comm = aar.Comm(uid[0], world, rank, local_rank)
     problem = aar.Problem(ds, residual_mode=aar.RES_F32, device=local_rank, comm=comm, intrinsics=args.intrinsics, solver=args.solver,
                           deterministic=True if args.deterministic else None, pcg_eta=args.pcg_eta, pcg_eta_loose=args.pcg_eta_loose, pcg_abs_tol=args.pcg_abs_tol)
     # x_full of the default Config: the pose vector, then fx cx fy cy d0..d4 per camera (fill_io_vec_cam_intrinsics, :488-498)

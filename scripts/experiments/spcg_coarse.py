@@ -127,13 +127,15 @@ def lm(o, x0, ns, nc, mode, eta=3e-4, eps=2e-5, thresh=0, max_steps=60, blockdia
     return np.sqrt(err / (4.0 * o.N)), step + 1, its, z
 
 
-cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-ds = aar.synth(cfg) if len(sys.argv) <= 2 else aar.synth(cfg, num_frames=int(sys.argv[2]))
-o = ol.Oracle(ds); nc = 6 * (ds.num_cams - 1); ns = nc + 6 * (ds.num_markers - 1)
-rm0, st0, _, z0 = lm(o, ds.x_full, ns, nc, None)
-print("config %d (%d frames, n = %d): exact LM %d steps, RMSE %.9f px" % (cfg, ds.num_frames, ns, st0, rm0), flush=True)
-for name, mode, kw in (("block-Jacobi", "", {}), ("+ cm", "cm", {}), ("+ cm, E block-diagonal", "cm", dict(blockdiag=True)), ("+ cm, E block-diagonal, from the previous solve", "cm", dict(blockdiag=True, stale=1)), ("+ cm, E block-diagonal, previous solve's incl. its mu", "cm", dict(blockdiag=True, stale=2)),
-                       ("+ cm, E block-diagonal, of two solves ago", "cm", dict(blockdiag=True, stale=3))):
-    rm, st, its, z = lm(o, ds.x_full, ns, nc, mode, **kw)
-    print("  %-20s LM steps %2d  CG its total %4d  per step %-60s |RMSE - exact| %.1e px  max |z - z_exact| shared %.1e frames %.1e" %
-          (name, st, sum(its), " ".join(map(str, its)), abs(rm - rm0), np.abs(z - z0)[:ns].max(), np.abs(z - z0)[ns:].max()), flush=True)
+if __name__ == "__main__":
+    cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    ds = aar.synth(cfg) if len(sys.argv) <= 2 else aar.synth(cfg, num_frames=int(sys.argv[2]))
+    o = ol.Oracle(ds); nc = 6 * (ds.num_cams - 1); ns = nc + 6 * (ds.num_markers - 1)
+    rm0, st0, _, z0 = lm(o, ds.x_full, ns, nc, None)
+    print("config %d (%d frames, n = %d): exact LM %d steps, RMSE %.9f px" % (cfg, ds.num_frames, ns, st0, rm0), flush=True)
+    for name, mode, kw in (("block-Jacobi", "", {}), ("+ cm", "cm", {}), ("+ cm, E block-diagonal", "cm", dict(blockdiag=True)), ("+ cm, E block-diagonal, from the previous solve", "cm", dict(blockdiag=True, stale=1)), ("+ cm, E block-diagonal, previous solve's incl. its mu", "cm", dict(blockdiag=True, stale=2)),
+                           ("+ cm, E block-diagonal, of two solves ago", "cm", dict(blockdiag=True, stale=3))):
+        rm, st, its, z = lm(o, ds.x_full, ns, nc, mode, **kw)
+        print("  %-20s LM steps %2d  CG its total %4d  per step %-60s |RMSE - exact| %.1e px  max |z - z_exact| shared %.1e frames %.1e" %
+              (name, st, sum(its), " ".join(map(str, its)), abs(rm - rm0), np.abs(z - z0)[:ns].max(), np.abs(z - z0)[ns:].max()), flush=True)
+

@@ -48,7 +48,7 @@ def main():
         fk, n = f[k]
         wk = w.get(k, (0.0, 0))[0]
         entry[k] = (2.0 * fk + wk) * 1024.0
-        entry["raw_" + k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "launches": n}
+        entry["raw_" + k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "launches": n, "bytes_uncorrected": (fk + wk) * 1024.0}
         rows.append((k, n, fk, wk, entry[k]))
     if stats:
         entry["_rocprofv3_avg_us"] = {}

@@ -61,9 +61,16 @@ def test_spcg_damped_step_is_the_direct_step_at_a_tight_forcing_term(name, kw):
 # 1.5e-4 / 6e-5 m away from the reference-faithful CPU run (analytic against central-difference float Jacobian), and the reference's own last LM step -- after
 # which its stopping rule fires -- still moves the poses by 3e-3 / 1e-4 m.
 POSE_BAR_CAMS, POSE_BAR_OTHERS = 1e-5, 1e-5
-# ... and against the reference-faithful CPU run's final vector (fixtures): the direct path's own distance from it is 1.5e-4 / 6e-5 (analytic against
-# central-difference float Jacobian, unchanged since round 1); the solver must not add to that
+# ... and against the reference-faithful CPU run's final vector: the direct path's own distance from it (analytic against the reference's float-quantised
+# central-difference Jacobian) is what the solver must not add to.  WHO carries that distance (profiles/r06_pose_delta_by_entity.txt, scripts/dev/
+# pose_delta_by_entity.py): at config 3, full size, the cameras (1 560 .. 1 620 observations each) are within 2.6e-7 / 5.3e-7 m, the frames within 4.5e-6 / 1.5e-7,
+# the markers within 1.6e-5 / 2.0e-6 -- the largest two markers are seen 84 and 96 times, the 20 markers seen 400 times and more stay below 1.0e-5.  On the
+# 390-observation fixture g1_cfg2 the cameras (83 .. 112 observations) are at 1.5e-5 / 3.1e-5 and the worst entities are FRAMES with one marker in view
+# (78 of 100 frames have 0 .. 4 observations: 4.4e-5).  The blanket bar below only remains for the two tau = 1e-6 fixtures, whose rejected tries depend on the last
+# bits of a step (two direct runs part by as much); everything else gets the bars by entity kind.
 POSE_BAR_FAITHFUL = 3e-4
+POSE_BAR_FAITHFUL_FIXTURES = 1e-4                  # fixtures without rejected tries (measured <= 6.1e-5: g1_cfg2_far's markers)
+POSE_BAR_FAITHFUL_CFG3 = {"cams": (2e-6, 2e-6), "markers": (5e-5, 1e-5), "frames": (2e-5, 2e-6)}   # config 3 at full size: (rotation-matrix entries, metres)
 
 
 def _assert_poses_close(ds, x, x_direct, what, cams_bar=None):
@@ -126,7 +133,7 @@ def test_spcg_reaches_the_direct_paths_poses_on_every_fixture(name):
     if not huber and not intr:      # (the -with-huber fixtures' faithful run weights by another residual than the fp64 statistics: their poses are compared with the direct run only)
         f = pose_delta_max(ds, x, g["faithful_x"])
         f_d = pose_delta_max(ds, x_d, g["faithful_x"])
-        assert max(f) < POSE_BAR_FAITHFUL and max(f) < max(f_d) + 3e-5, (f, f_d)
+        assert max(f) < (POSE_BAR_FAITHFUL if "retry" in name else POSE_BAR_FAITHFUL_FIXTURES) and max(f) < max(f_d) + 3e-5, (f, f_d)
 
 
 def test_auto_at_full_size_config3_against_compiled_reference_and_direct_path():
@@ -151,6 +158,11 @@ def test_auto_at_full_size_config3_against_compiled_reference_and_direct_path():
     # poses against the REAL reference solver's run (central-difference float Jacobian): the default path is where the direct path is
     f, f_d = pose_delta_max(ds, x, x_ref), pose_delta_max(ds, x_d, x_ref)
     assert max(f) < POSE_BAR_FAITHFUL and max(f) < max(f_d) + 3e-5, (f, f_d)
+    # ... by entity kind (the cameras carry almost none of it; the markers seen fewest carry the most)
+    for xx in (x, x_d):
+        by = pose_delta(ds, xx, x_ref)
+        for kind, (br, bt) in POSE_BAR_FAITHFUL_CFG3.items():
+            assert by[kind][0] < br and by[kind][1] < bt, (kind, by)
     assert rep["iterations"] == rep_d["iterations"] and abs(rep["iterations"] - rep_ref["iterations"]) <= 1
     assert all(t["tries"] == 1 and t["accepted"] == 1 for t in rep["trace"])
     assert st["fallbacks"] == 0 and 0 < st["total_iterations"] <= 64 * st["solves"]
