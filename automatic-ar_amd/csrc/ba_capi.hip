@@ -1261,6 +1261,9 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         // kernel's registers and LDS, as pcg_max_grid asks for the PCG grid.  (Another process on the device can still take the slots: k_spcg's time-out.)
         if (const char *t = getenv("AAR_SPCG_COARSE")) P.spcg_coarse = atoi(t) != 0;
         if (const char *t = getenv("AAR_SPCG_COARSE_FROM")) P.spcg_coarse_from = atoi(t);
+        if (const char *t = getenv("AAR_PCG_COARSE")) P.pcg_coarse = atoi(t) != 0;
+        if (const char *t = getenv("AAR_PCG_COARSE_FROM")) P.pcg_coarse_from = atoi(t);
+        if (pcg_lds_bytes(A, true) > 150 * 1024) P.pcg_coarse = 0;   // (the coarse space's tables do not fit beside the vectors of this many entities: block-Jacobi only)
         const int spcg_per_cu = spcg_fits(P.nT) ? spcg_resident_per_cu(P.nT, spcg_coarse_now(P)) : 0;
         const bool spcg_ok = spcg_fits(P.nT) && P.n_pad / 6 <= std::max(1, spcg_per_cu) * cus;
         int solver = so.solver;
@@ -1617,7 +1620,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
     if (P.deterministic) { AL(sp_part, (size_t)sp_total); AL(pb_part, (size_t)P.n_chunks * P.pb_stride); }
     if (P.use_pcg) {
         AL(pcg_ws, (size_t)P.pcg_n_items * 28 + 6 * (size_t)F + 8); AL(pcg_counter, 8);
-        AL(pcg_yg, (size_t)3 * PCG_NYV * P.n_pad + (size_t)28 * A + 8); AL(pcg_hop, 2 * PCG_HOP_WORDS);
+        AL(pcg_yg, (size_t)3 * PCG_NYV * P.n_pad + (size_t)28 * A + 160 + 8); AL(pcg_hop, 2 * PCG_HOP_WORDS);   // (+ 160: the coarse operator's accumulator)
         if (const char *t = getenv("AAR_PCG_FUSED")) P.pcg_fused = atoi(t) != 0 ? 1 : 0;
         {   // k_pcgf's operator reads an fp32 copy of W (half the bytes of its pass over the frames; written by pass A instead of the fp64 blocks): non-deterministic runs, one rank or many
             int w32 = 1;
@@ -1830,6 +1833,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     pb->last_cg_its = -1;
     pb->near_cap_tries = 0;
     pb->P.spcg_coarse_on = 0;
+    if (pb->P.use_pcg && pb->P.pcg_counter) HIP_TRY(hipMemsetAsync(pb->P.pcg_counter + 2, 0, sizeof(int32_t), pb->stream));   // (k_pcgf's coarse space joins by the previous solve's count)
     pb->P.pcg_eta_now = pb->P.pcg_eta;      // (... and the forcing term itself, not the LM's forcing sequence)
     if ((rc = damped_try_fb(pb, mu, false))) return rc == TRY_NOT_POSITIVE_DEFINITE ? AAR_ERR_NUMERIC : rc;
     pb->lm_ready = false;
@@ -1857,6 +1861,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     pb->last_cg_its = -1;
     pb->near_cap_tries = 0;
     P.spcg_coarse_on = 0;
+    if (P.use_pcg && P.pcg_counter) HIP_TRY(hipMemsetAsync(P.pcg_counter + 2, 0, sizeof(int32_t), pb->stream));   // (k_pcgf's coarse space joins by the previous solve's count)
     if (pb->spec_chol_blk >= 0) {   // a factorisation queued ahead of the last step of the previous solve: its pivot flags mean nothing
         HIP_TRY(hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream));
         pb->spec_chol_blk = -1;

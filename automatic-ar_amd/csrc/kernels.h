@@ -122,6 +122,7 @@ struct DeviceProblem {
     int n_cus = 256;                      // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     mutable int want_w64 = 0;             // aar_eval_normal_equations: pass A writes the fp64 W blocks even where the solver only reads the fp32 copy (Blocks::Wf)
     int pcg_fused = 1;                    // AAR_PCG_FUSED=0: k_pcg (two passes over W and two hand-overs per iteration) instead of k_pcgf
+    int pcg_coarse = 1, pcg_coarse_from = 8;   // AAR_PCG_COARSE=0 / AAR_PCG_COARSE_FROM: k_pcgf's coarse space (the groups' rigid-motion modes) joins when the previous solve of the LM run took this many iterations
     int32_t *up_start = nullptr, *up_ent = nullptr;   // [A + 1], [..]: entity -> the OTHER entities whose block of U can be non-zero (seen together in an observation); the CG operator skips the rest
     double *pcg_yg = nullptr;             // k_pcgf: y [3][PCG_NYV][n_pad] (rotating; PCG_NYV partial vectors) | the set-up's sums [A][28]
     int32_t *pcg_hop = nullptr;           // k_pcgf: [2][PCG_HOP_WORDS] barrier tree (pcg_kernels.hip, grid_hop_tree), by launch parity
@@ -242,7 +243,7 @@ bool launch_schur(const DeviceProblem &P, int which, double sign, hipStream_t st
 bool launch_chol(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial = -1);
 void launch_backsub(const DeviceProblem &P, int cur, int trial, hipStream_t st);   // z[trial] = z[cur] + delta, lin_part
 void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st);     // AAR_SOLVER=pcg: delta_s by PCG through the frame blocks (needs Vinv, hf for mu)
-size_t pcg_lds_bytes(int A);
+size_t pcg_lds_bytes(int A, bool coarse = false);   // coarse: with the tables of k_pcgf's coarse space
 int pcg_max_grid(int A, int cus);   // largest co-resident grid of the persistent PCG kernels
 // solver spcg: delta_s by CG on the explicit reduced system S of block set `which` (the Schur complement for mu must have been taken; S is not modified)
 bool launch_spcg(const DeviceProblem &P, int which, double mu, hipStream_t st, int trial = -1);   // trial >= 0: launch_backsub(which, trial) may ride (true: it did)

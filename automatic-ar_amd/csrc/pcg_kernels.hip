@@ -45,6 +45,12 @@ struct PcgArgs {
     double *x_out;                               // [6 A (.. n_pad)] delta_s
     int32_t *iters_out;                          // [2] iterations of this solve, running total
     int32_t *flags;
+    // k_pcgf, coarse space (the rigid-motion modes of the two groups, as in spcg_kernels.hip: k_spcg_pre -- here as the plain additive two-level preconditioner
+    // M^-1 = blockdiag(S_ee)^-1 + Z blockdiag(E_cc, E_mm)^-1 Z^T, the vectors being replicated in every workgroup anyway): entity rows of the pose, group sizes,
+    // the accumulator of E = Z^T S Z [144] (zero at entry), and from how many iterations of the previous solve on it joins (< 0: never)
+    const double *ent = nullptr;
+    int C = 0, M = 0, coarse_from = -1;
+    double *eg = nullptr;
 };
 
 #ifdef AAR_PCG_STAMPS   // diagnostic build (scripts/dev/pcg_stamps.sh): s_memtime stamps of three workgroups of k_pcgf, per CG iteration
@@ -374,6 +380,169 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcg(const PcgArgs a) {
 // yg: [3][n_pad] zero at entry; sg: [A][28] zero at entry (the launcher clears both)
 // ------------------------------------------------------------------------------------------------
 // every slot's share of W (V+mu)^-1 W^T (lower triangle, 21) and of W h_f (6) for the frames dealt to this workgroup, into sacc [A][27] (LDS, zeroed here)
+// ---- coarse space of k_pcgf ----
+// zd: per entity Jinv (9, row-major) | t (3): Z_e = [[J_l^-1, 0], [-[t]x, I]] (rows: the entity's six parameters; columns: rotation, translation of the group's rigid
+// motion); an entity without modes (fixed, or not a pose) has an all-zero record -- the diagonal of a J_l^-1 is never all zero (its trace is at least 1)
+__device__ __forceinline__ bool pcgf_on(const double *__restrict__ zd_e) { return zd_e[0] != 0.0 || zd_e[4] != 0.0 || zd_e[8] != 0.0; }
+__device__ __forceinline__ void pcgf_zrow(const double *__restrict__ zd_e, int row, double (&zr)[6]) {
+    if (row < 3) {
+        zr[0] = zd_e[3 * row]; zr[1] = zd_e[3 * row + 1]; zr[2] = zd_e[3 * row + 2]; zr[3] = 0.0; zr[4] = 0.0; zr[5] = 0.0;
+    } else {
+        const double t0 = zd_e[9], t1 = zd_e[10], t2 = zd_e[11];
+        zr[0] = row == 3 ? 0.0 : (row == 4 ? -t2 : t1);
+        zr[1] = row == 3 ? t2 : (row == 4 ? 0.0 : -t0);
+        zr[2] = row == 3 ? -t1 : (row == 4 ? t0 : 0.0);
+        const double on = pcgf_on(zd_e) ? 1.0 : 0.0;
+        zr[3] = row == 3 ? on : 0.0; zr[4] = row == 4 ? on : 0.0; zr[5] = row == 5 ? on : 0.0;
+    }
+}
+__device__ __forceinline__ void pcgf_zfull(const double *__restrict__ zd_e, double (&Z)[36]) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double zr[6];
+        pcgf_zrow(zd_e, i, zr);
+#pragma unroll
+        for (int c = 0; c < 6; c++) Z[6 * i + c] = zr[c];
+    }
+}
+__device__ __forceinline__ bool pcgf_modes(const PcgArgs &a, int e) { return e < a.C + a.M && a.ent_fixed[e] == 0; }
+
+// E = Z^T S Z, this workgroup's share into Ews [144] (LDS, zeroed here; row-major 12 x 12: cameras' modes 0..5, markers' 6..11):
+//   frames:  - sum_f P_f^T (V_f + mu I)^-1 P_f,   P_f = W_f^T Z = sum over the frame's slots of W_ef^T Z_e  (6 x 12: one more use of the blocks the set-up reads),
+//   U:       + Z^T (U + mu I) Z over the stored blocks of the entities dealt to this workgroup.
+// wl: per-wavefront scratch [TH / 64][144]
+template <int TH>
+__device__ __forceinline__ void pcgf_setup_coarse(const PcgArgs &a, const double *__restrict__ zd, double *__restrict__ Ews, double *__restrict__ wl, int wg, int G) {
+    constexpr int NW = TH / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 144; i += TH) Ews[i] = 0.0;
+    __syncthreads();
+    double *Pl = wl + 144 * wave, *Ql = Pl + 72;
+    double eacc[3] = {0.0, 0.0, 0.0};
+    const int f_lo = (int)((long long)wg * a.F / G), f_hi = (int)((long long)(wg + 1) * a.F / G);
+    for (int f = f_lo + wave; f < f_hi; f += NW) {
+        const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
+        const double *Vi = a.Vinv + (size_t)f * 36;
+        // ONE pass over the frame's slots (entity-ascending: the cameras' come first and, being at most 64, all fall into the first round).  A lane forms the 36
+        // entries of T = W_ef^T Z_e of its slot one by one: the cameras' are summed over the wavefront at once (first round only), the markers' accumulate in
+        // 36 registers over the rounds and are summed at the end -- never two sets of accumulators alive
+        double Tm[36];
+#pragma unroll
+        for (int q = 0; q < 36; q++) Tm[q] = 0.0;
+        if (s0 == s1 && lane < 36) Pl[lane] = 0.0;   // (a frame without slots: no first round to write the cameras' sums)
+        for (int s = s0 + lane, rnd = 0; s - lane < s1; s += 64, rnd++) {
+            const bool in = s < s1;
+            const int e = in ? a.fslot_ent[s] : 0;
+            const double *z = zd + 12 * e;
+            const bool on = in && pcgf_on(z), cam = on && e < a.C, mk = on && e >= a.C;
+            double w[36];
+#pragma unroll
+            for (int q = 0; q < 36; q++) w[q] = 0.0;
+            if (on) {
+                if (a.Wf) {
+                    const float4 *q4 = reinterpret_cast<const float4 *>(a.Wf + (size_t)s0 * 36) + (s - s0);
+                    const int kf = s1 - s0;
+#pragma unroll
+                    for (int q = 0; q < 9; q++) {
+                        const float4 v = q4[(size_t)q * kf];
+                        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+                    }
+                } else {
+                    const double *Wb = a.W + (size_t)s * 36;
+#pragma unroll
+                    for (int q = 0; q < 36; q++) w[q] = Wb[q];
+                }
+            }
+            const double t0 = z[9], t1 = z[10], t2 = z[11];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {   // T(k, a) = sum_i W(i, k) Z_e(i, a)
+                const double w0 = w[k], w1 = w[6 + k], w2 = w[12 + k], w3 = w[18 + k], w4 = w[24 + k], w5 = w[30 + k];
+                double tq[6];
+                tq[0] = w0 * z[0] + w1 * z[3] + w2 * z[6] + (w5 * t1 - w4 * t2);
+                tq[1] = w0 * z[1] + w1 * z[4] + w2 * z[7] + (w3 * t2 - w5 * t0);
+                tq[2] = w0 * z[2] + w1 * z[5] + w2 * z[8] + (w4 * t0 - w3 * t1);
+                tq[3] = w3; tq[4] = w4; tq[5] = w5;
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    if (rnd == 0) {   // (wave-uniform)
+                        const double v = wave_sum_dpp(cam ? tq[c] : 0.0);
+                        if (lane == 0) Pl[6 * k + c] = v;
+                    }
+                    Tm[6 * k + c] += mk ? tq[c] : 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 36; q++) {
+            const double v = wave_sum_dpp(Tm[q]);
+            if (lane == 0) Pl[36 + q] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int o = lane; o < 72; o += 64) {   // Q(k, b12) = sum_j Vinv(k, j) P(j, b12)
+            const int grp = o / 36, k = (o % 36) / 6, b = o % 6;
+            double v = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) v = fma(Vi[6 * k + j], Pl[36 * grp + 6 * j + b], v);
+            Ql[o] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int o = lane + 64 * u;
+            if (o < 144) {
+                const int a12 = o / 12, b12 = o % 12;
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) v = fma(Pl[36 * (a12 / 6) + 6 * k + a12 % 6], Ql[36 * (b12 / 6) + 6 * k + b12 % 6], v);
+                eacc[u] -= v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int u = 0; u < 3; u++) { const int o = lane + 64 * u; if (o < 144 && eacc[u] != 0.0) atomicAdd(Ews + o, eacc[u]); }
+    // Z^T (U + mu I) Z: the block rows dealt to this workgroup (as in pcgf_operator), one thread per stored block
+    for (int e = wg; e < a.A; e += G) {
+        if (!pcgf_on(zd + 12 * e)) continue;   // (uniform per workgroup)
+        const int n0 = a.up_start[e], n1 = a.up_start[e + 1], ge = e >= a.C ? 6 : 0;
+        double Ze[36];
+        pcgf_zfull(zd + 12 * e, Ze);
+        for (int q = n0 - 1 + tid; q < n1; q += TH) {
+            const int b = q < n0 ? e : a.up_ent[q];
+            if (b > e || (q >= n0 && b == e) || !pcgf_on(zd + 12 * b)) continue;
+            double Zb[36], X[36];
+            pcgf_zfull(zd + 12 * b, Zb);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {   // X = U_eb Z_b  (the diagonal block: lower triangle stored, mu on its diagonal)
+                double u[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++)
+                    u[j] = b == e ? ((j <= i ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] : a.U[(size_t)(6 * e + j) * a.n_pad + 6 * e + i]) + (i == j ? a.mu : 0.0))
+                                  : a.U[(size_t)(6 * e + i) * a.n_pad + 6 * b + j];
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) v = fma(u[j], Zb[6 * j + c], v);
+                    X[6 * i + c] = v;
+                }
+            }
+            const int gb = b >= a.C ? 6 : 0;
+#pragma unroll
+            for (int aa = 0; aa < 6; aa++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) {   // R = Z_e^T X
+                    double v = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) v = fma(Ze[6 * i + aa], X[6 * i + c], v);
+                    atomicAdd(Ews + 12 * (ge + aa) + gb + c, v);
+                    if (b != e) atomicAdd(Ews + 12 * (gb + c) + ge + aa, v);
+                }
+        }
+    }
+    __syncthreads();
+}
+
 template <int TH = PCG_THREADS>
 __device__ __forceinline__ void pcgf_setup_slots(const PcgArgs &a, double *__restrict__ sacc, int wg, int G) {
     constexpr int NW = TH / 64;
@@ -586,9 +755,33 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *x = lds, *r = lds + n, *p = r + n, *Mi = p + n, *yacc = Mi + 6 * n, *red = yacc + n;
+    // coarse space (pcg_lds_bytes): zd [12 A] | Ews [144] | einv [72] | per-wavefront scratch [TH / 64][144]
+    double *zd = red + (PCGF32_THREADS / 64) * 27 + 8, *Ews = zd + 12 * a.A, *einv = Ews + 144, *wl = einv + 72;
+    // it joins when the previous solve needed many iterations (every workgroup reads the same count, before anybody can overwrite it: that happens behind the last hop)
+    const bool co = a.coarse_from >= 0 && a.ent != nullptr && a.iters_out[0] >= a.coarse_from;
     int32_t *counter = a.hop + a.parity * PCG_HOP_WORDS;   // (grid_hop_tree)
     int round = 0;
     if (wg == 0 && tid < 2 * PCG_NY + 1) __hip_atomic_store(a.hop + (1 - a.parity) * PCG_HOP_WORDS + tid * 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    if (co) {
+        for (int e = tid; e < a.A; e += TH) {
+            double z12[12];
+#pragma unroll
+            for (int q = 0; q < 12; q++) z12[q] = 0.0;
+            if (pcgf_modes(a, e)) {
+                const double *row = a.ent + (size_t)e * ENT_STRIDE;
+                const double *J = row + 12;
+                const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+                const double id = 1.0 / (J[0] * c00 + J[1] * c01 + J[2] * c02);
+                z12[0] = c00 * id; z12[1] = (J[2] * J[7] - J[1] * J[8]) * id; z12[2] = (J[1] * J[5] - J[2] * J[4]) * id;
+                z12[3] = c01 * id; z12[4] = (J[0] * J[8] - J[2] * J[6]) * id; z12[5] = (J[2] * J[3] - J[0] * J[5]) * id;
+                z12[6] = c02 * id; z12[7] = (J[1] * J[6] - J[0] * J[7]) * id; z12[8] = (J[0] * J[4] - J[1] * J[3]) * id;
+                z12[9] = row[9]; z12[10] = row[10]; z12[11] = row[11];
+            }
+#pragma unroll
+            for (int q = 0; q < 12; q++) zd[12 * e + q] = z12[q];
+        }
+        __syncthreads();
+    }
 
     // ---- set-up, first half: every slot's share of the diagonal blocks and of the right-hand side, by entity in LDS, then ONE atomic flush ----
     double *sacc = Mi;
@@ -599,9 +792,74 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
         const double v = sacc[i];
         if (v != 0.0) atomicAdd(sg + (size_t)(i / 27) * 28 + (i % 27), v);   // (once per solve: not spread over partial tables -- every workgroup would read PCG_NY x 27 A values back: measured +78 us)
     }
+    if (co) {   // this workgroup's share of the coarse operator E = Z^T S Z, flushed with the rest
+        pcgf_setup_coarse<TH>(a, zd, Ews, wl, wg, G);
+        for (int i = tid; i < 144; i += TH) { const double v = Ews[i]; if (v != 0.0) atomicAdd(a.eg + i, v); }
+    }
     if (wave == 0) PCG_STAMP(31, 2);
     if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
     if (wave == 0) PCG_STAMP(31, 3);
+    if (co && tid < 2) {   // E_cc, E_mm (lower triangles of the sums) inverted; a group without modes, or a block that is not positive definite in floating point: no modes
+        double eb[6][6], inv[36];
+        bool have = false;
+#pragma unroll
+        for (int pp = 0; pp < 6; pp++)
+#pragma unroll
+            for (int q = 0; q <= pp; q++) {
+                const double v = ld_agent(a.eg + 12 * (6 * tid + pp) + 6 * tid + q);
+                eb[pp][q] = v; eb[q][pp] = v;
+                have = have || v != 0.0;
+            }
+        if (!have) {
+#pragma unroll
+            for (int pp = 0; pp < 6; pp++) eb[pp][pp] = 1.0;
+        }
+        if (!spd6_inverse(eb, inv)) have = false;
+#pragma unroll
+        for (int q = 0; q < 36; q++) einv[36 * tid + q] = have ? inv[q] : 0.0;
+    }
+    // z = M^-1 r: block-Jacobi plus the coarse part Z c, c = blockdiag(E_cc, E_mm)^-1 Z^T r.  Wavefront a < 6 forms entries a of Z_c^T r and Z_m^T r (its lanes
+    // stride over the entities: column a of Z_e against the entity's six entries of r), ONE sum over the wavefront each; twelve threads then apply the inverse
+    // blocks; everybody reads c (12) back
+    double *cvec = wl;   // [12] s, [12] c (the per-wavefront scratch of the set-up is free by now)
+    auto coarse_coef = [&](const double *__restrict__ rv, double (&cs)[12]) {
+        __syncthreads();   // (cvec may still be read from the previous call; rv is complete)
+        for (int ca = wave; ca < 6; ca += TH / 64) {   // (wave-uniform; k_pcgf<false> has four wavefronts)
+            double sc = 0.0, sm = 0.0;
+            for (int e = lane; e < a.C + a.M; e += 64) {
+                const double *z = zd + 12 * e;
+                double v;
+                if (ca < 3) {   // column ca of [[Jinv], [-[t]x]]
+                    const double t0 = z[9], t1 = z[10], t2 = z[11];
+                    const double n0 = ca == 0 ? 0.0 : (ca == 1 ? t2 : -t1), n1 = ca == 0 ? -t2 : (ca == 1 ? 0.0 : t0), n2 = ca == 0 ? t1 : (ca == 1 ? -t0 : 0.0);
+                    v = z[ca] * rv[6 * e] + z[3 + ca] * rv[6 * e + 1] + z[6 + ca] * rv[6 * e + 2] + (n0 * rv[6 * e + 3] + n1 * rv[6 * e + 4] + n2 * rv[6 * e + 5]);
+                } else {
+                    v = pcgf_on(z) ? rv[6 * e + ca] : 0.0;
+                }
+                if (e < a.C) sc += v; else sm += v;
+            }
+            sc = wave_sum_dpp(sc); sm = wave_sum_dpp(sm);
+            if (lane == 0) { cvec[ca] = sc; cvec[6 + ca] = sm; }
+        }
+        __syncthreads();
+        if (tid < 12) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) v = fma(einv[36 * (tid / 6) + 6 * (tid % 6) + k], cvec[6 * (tid / 6) + k], v);
+            cvec[12 + tid] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 12; q++) cs[q] = cvec[12 + q];
+    };
+    auto coarse_add = [&](int e, int row, const double (&cs)[12]) -> double {   // (Z c)_i
+        double zr[6];
+        pcgf_zrow(zd + 12 * e, row, zr);
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) v = fma(zr[q], e < a.C ? cs[q] : cs[6 + q], v);
+        return v;
+    };
     // ---- set-up, second half, redundantly in every workgroup (one thread per entity): the diagonal block of S inverted straight into LDS,
     //      the right-hand side; x = 0, r = b.  (Every thread reads its sums into registers before the barrier below lets Mi overwrite sacc.) ----
     // (every thread reads the sums it needs past the L2, not from sacc: Mi may take sacc's place at once -- but only when all threads have flushed it)
@@ -638,6 +896,8 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     if (wave == 0) PCG_STAMP(31, 4);
     // ---- z = Minv r, p = z ----
     double rz = 0.0, bb = 0.0;
+    double cs[12];
+    if (co) coarse_coef(r, cs);
     {
         double sv[2] = {0.0, 0.0};
         for (int i = tid; i < n; i += TH) {
@@ -645,6 +905,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
             double z = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            if (co) z += coarse_add(e, row, cs);
             p[i] = z;
             sv[0] += r[i] * z;
             sv[1] += r[i] * r[i];
@@ -701,6 +962,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
             }
         }
         __syncthreads();
+        if (co) coarse_coef(r, cs);
         double s2[2] = {0.0, 0.0};
         double zloc[24];
         int nz = 0;
@@ -709,6 +971,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
             double z = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            if (co) z += coarse_add(e, row, cs);
             if (nz < 24) zloc[nz] = z;
             s2[0] += r[i] * z;
             s2[1] += r[i] * r[i];
@@ -1184,7 +1447,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
     publish(0.0, itc);
 }
 
-size_t pcg_lds_bytes(int A) { return ((size_t)10 * 6 * A + (PCGF32_THREADS / 64) * 27 + 8) * sizeof(double); }   // x | r | p | Mi [6 n] | yacc [n] (k_pcgf) | red
+size_t pcg_lds_bytes(int A, bool coarse) { return ((size_t)10 * 6 * A + (PCGF32_THREADS / 64) * 27 + 8 + (coarse ? (size_t)12 * A + 144 + 72 + (PCGF32_THREADS / 64) * 144 : 0)) * sizeof(double); }   // x | r | p | Mi [6 n] | yacc [n] (k_pcgf) | red | coarse space: zd [12 A] | Ews | einv | scratch
 
 // the largest grid of the persistent PCG kernels that is resident as a whole (their hand-overs wait for every workgroup): what the occupancy query
 // admits per CU for the kernel with the larger footprint, times the CUs
@@ -1216,12 +1479,14 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.part = P.pcg_ws; a.t = a.part + (size_t)P.pcg_n_items * 28;
     a.counter = P.pcg_counter; a.hop = P.pcg_hop; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
-    const size_t lds = pcg_lds_bytes(P.A);
+    const size_t lds = pcg_lds_bytes(P.A, P.pcg_coarse != 0);
     static size_t granted = 48 * 1024, granted_f = 48 * 1024, granted_f32 = 48 * 1024;
     a.Wf = nullptr;
     HookScope _h(P, KID_PCG);
     if (P.pcg_fused && !P.deterministic) {   // one pass over W and one hand-over per iteration; its atomics take the sums in any order
-        (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * PCG_NYV * P.n_pad + (size_t)28 * P.A) * sizeof(double), st);
+        (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * PCG_NYV * P.n_pad + (size_t)28 * P.A + 160) * sizeof(double), st);
+        a.ent = P.ent[which]; a.C = P.C; a.M = P.M; a.coarse_from = (P.pcg_coarse && P.C <= 64) ? P.pcg_coarse_from : -1;
+        a.eg = P.pcg_yg + (size_t)3 * PCG_NYV * P.n_pad + (size_t)28 * P.A;
         // fp32 blocks (kernels.h, Blocks::Wf): allocated -- and written by pass A INSTEAD of the fp64 blocks -- only where the forcing term is far above what
         // that rounding can show (ba_capi.hip, PCG_W32_MIN_ETA; AAR_PCG_W32=0: never): the allocation is the one place that decides
         if (b.Wf) {
