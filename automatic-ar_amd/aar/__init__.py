@@ -36,7 +36,7 @@ SYMBOLS = [
     "aar_solution_read_ex", "aar_cam_configs_read_ex", "aar_set_stage_timers", "aar_problem_pcg_iterations",
     "aar_solver_default_options", "aar_problem_create_ex", "aar_problem_get_solver_stats", "aar_problem_set_test_hook",
 ]
-NUM_KERNELS = 16
+NUM_KERNELS = 17
 SOLVER_DIRECT, SOLVER_PCG, SOLVER_SPCG, SOLVER_AUTO = 0, 1, 2, 3
 TEST_HOOK_SPCG_DROP = 1
 ENV_SOLVER, ENV_DETERMINISTIC, ENV_PCG_ETA, ENV_PCG_MAX_IT = 1, 2, 4, 8

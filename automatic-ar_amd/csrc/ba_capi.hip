@@ -2173,7 +2173,7 @@ int aar_get_kernel_times(aar_problem *pb, double seconds[AAR_NUM_KERNELS], int64
 const char *aar_kernel_name(int kid) {
     static const char *names[KID_COUNT] = {"k_unpack", "k_residual", "k_passA", "k_passB", "k_maxdiag", "k_frame_inv", "k_schur",
                                            "k_ldl_diag", "k_ldl_trsm", "k_ldl_update", "k_ldl_backsolve", "k_backsub",
-                                           "k_reduce_scalars", "k_ldl_panel", "k_pcg", "k_spcg"};
+                                           "k_reduce_scalars", "k_ldl_panel", "k_pcg", "k_spcg", "k_spcg_pre"};
     return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
 }
 

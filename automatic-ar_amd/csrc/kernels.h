@@ -34,7 +34,7 @@ inline int spcg_stride(int n_pad) { return 8 * (n_pad / 6); }   // doubles per h
 
 // Kernel ids for the optional per-launch timing hooks (aar_get_kernel_times)
 enum KernelId { KID_UNPACK = 0, KID_RESIDUAL, KID_PASSA, KID_PASSB, KID_MAXDIAG, KID_FRAME_INV, KID_SCHUR, KID_LDL_DIAG,
-                KID_LDL_TRSM, KID_LDL_UPDATE, KID_LDL_BACKSOLVE, KID_BACKSUB, KID_REDUCE, KID_LDL_PANEL, KID_PCG, KID_SPCG, KID_COUNT };
+                KID_LDL_TRSM, KID_LDL_UPDATE, KID_LDL_BACKSOLVE, KID_BACKSUB, KID_REDUCE, KID_LDL_PANEL, KID_PCG, KID_SPCG, KID_SPCG_PRE, KID_COUNT };
 
 struct LaunchHook {  // called around every kernel launch when profiling is on
     void (*pre)(void *ctx, int kid) = nullptr;

@@ -617,6 +617,7 @@ static void launch_spcg_pre(const DeviceProblem &P, int which, double mu, hipStr
     static size_t granted = 0;
     const size_t lds = spcg_pre_lds_bytes(P.n_pad);
     allow_dynamic_lds(reinterpret_cast<const void *>(k_spcg_pre), lds, granted);
+    HookScope _h(P, KID_SPCG_PRE);
     hipLaunchKernelGGL(k_spcg_pre, dim3((unsigned)ne), dim3(256), lds, st, a);
 }
 

@@ -89,6 +89,7 @@ KERNEL_BOUND = {
     "k_backsub": "hbm", "k_frame_inv": "hbm", "k_unpack": "hbm",
     "k_pcg": "hbm",                    # --solver pcg: an iteration is two passes over the W blocks (288 B per (entity, frame) incidence)
     "k_spcg": "latency",               # --solver spcg: one wavefront per entity, an iteration is one hand-over between them (~1.3 us) + a 6 x n matrix-vector product
+    "k_spcg_pre": "latency",           # ... its coarse space: one workgroup per entity assembles the augmented rows (one memory round trip + 12 x n products + the stores)
 }
 
 
@@ -125,6 +126,7 @@ def algorithmic_flops(kernel, N, n_pad, sum_kf2, merged_passes):
         "k_ldl_update": avg(upd),
         "k_ldl_panel": avg([m * NB * NB * NB + (m * NB) ** 2 * NB for m in fused]),
         "k_ldl_backsolve": 2.0 * n_pad * n_pad / 2.0,
+        "k_spcg_pre": 2.0 * n_pad * n_pad * 12.0,   # (A Z): every row against the twelve coarse columns
     }
     return tab.get(kernel, 0.0)
 
@@ -149,6 +151,7 @@ def algorithmic_bytes(kernel, N, A, F, n_pad):
         "k_ldl_panel": avg([2 * tile * m + tile + 2 * tile * m * (m + 1) / 2 for m in fused]),   # both of the above in one launch
         "k_ldl_backsolve": 8 * (n_pad * n_pad // 2 + 2 * n_pad),
         "k_frame_inv": 8 * 48 * F * 2, "k_backsub": 8 * P * 2, "k_reduce_scalars": 8 * 3 * F, "k_maxdiag": 8 * (n_pad + 6 * F),
+        "k_spcg": 8 * n_pad * n_pad, "k_spcg_pre": 2 * 8 * n_pad * n_pad,          # the reduced system once / read once and its augmented rows written once
     }
     return table.get(kernel, 0)
 
@@ -337,7 +340,7 @@ def kernel_profile(problem, ds, workload, x0, steps, params, world, intrinsics=F
                              "executed_flops_per_observation": 3200, "executed_frac": 3200.0 * n_loc / tj / 1e12 / FP64_PEAK_TFLOPS}
     roofline["sum_kernel_us_per_step"] = sum(v["total_ms"] for v in kernels.values()) * 1e3 / float(done)     # all launches of the pass / its LM steps
     roofline["sum_kernel_us_per_step_note"] = ("HIP-event brackets around every launch: each adds ~2-3 us to what rocprofv3 reports for the kernel itself, so this sum EXCEEDS "
-                                               "ms_per_step of the un-instrumented run; k_spcg's bracket includes k_spcg_pre where the solve carries the coarse space")
+                                               "ms_per_step of the un-instrumented run")
     roofline["profiled_steps"] = int(done)             # LM steps of the instrumented pass (>= 120 at configs 2-4 whatever --steps says): `kernels[*].launches` belong to these
     return kernels, roofline
 

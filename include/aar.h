@@ -435,7 +435,7 @@ int aar_problem_pcg_iterations(aar_problem *, int32_t out[2]);
 /* Per-kernel device time: when profiling is on, every kernel launch of this problem is bracketed by two HIP
  * events on the library's own stream (the stream the kernels run on) and the elapsed times are accumulated
  * per kernel.  bench.py's roofline figures come from here.  Switching profiling on resets the accumulators. */
-#define AAR_NUM_KERNELS 16
+#define AAR_NUM_KERNELS 17
 int aar_set_kernel_profiling(aar_problem *, int on);
 int aar_get_kernel_times(aar_problem *, double seconds[AAR_NUM_KERNELS], int64_t launches[AAR_NUM_KERNELS]);
 const char *aar_kernel_name(int kernel_id);
