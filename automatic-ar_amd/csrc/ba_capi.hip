@@ -665,7 +665,7 @@ int damped_try(aar_problem *pb, double mu, bool evaluate_trial) {
             // frames sharded over ranks: the set-up shares and every iteration's partial y are all-reduced between launches; every
             // fourth launch publishes {done, iterations} so that the host stops queueing (all ranks read the same: same control flow)
             { StageTimer t(pb, &pb->times.chol); launch_pcgd_setup(P, cur, mu, pb->stream); }
-            { StageTimer t(pb, &pb->times.allreduce); int rc = allreduce(pb, P.pcgd_setup, (size_t)P.A * 28, NCCL_SUM); if (rc) return rc; }
+            { StageTimer t(pb, &pb->times.allreduce); int rc = allreduce(pb, P.pcgd_setup, (size_t)P.A * 28 + ((P.pcg_fused && !P.deterministic && P.pcg_coarse) ? 144 : 0), NCCL_SUM); if (rc) return rc; }   // (+ the coarse operator's shares)
             pb->launches += 1;
             for (int k = 0;; k++) {
                 const bool last = k >= P.pcg_max_it + 1;
@@ -1160,6 +1160,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
 
     // ---- shard by frame range ----
     const int world = pb->comm ? pb->comm->world : 1, rank = pb->comm ? pb->comm->rank : 0;
+    pb->P.pcg_rank0 = rank == 0 ? 1 : 0;
     std::vector<int32_t> begin(world + 1, 0);
     if ((rc = aar_plan_shards(Fg, per_frame.data(), world, begin.data()))) return fail(rc);
     pb->f_begin = begin[rank];
@@ -1635,7 +1636,8 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         const int64_t want = std::max<int64_t>(32, ((int64_t)F + 3) / 4);
         P.pcg_grid = (int)std::min<int64_t>(P.pcg_grid, want);
         if (pb->comm) {
-            AL(pcgd_setup, (size_t)A * 28); AL(pcgd_minv, (size_t)A * 36); AL(pcgd_state, 2 * (18 * (size_t)A + 8)); AL(pcgd_y, 3 * (6 * (size_t)A + 8));
+            AL(pcgd_setup, (size_t)A * 28 + 152); AL(pcgd_minv, (size_t)A * 36 + 72 + (size_t)12 * A + 8);   // (+ the coarse operator's shares; + its inverse blocks and the table of Z)
+            AL(pcgd_state, 2 * (18 * (size_t)A + 8)); AL(pcgd_y, 3 * (6 * (size_t)A + 8));
             if (hipHostMalloc((void **)&pb->h_pcg, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
                 return fail(set_error(AAR_ERR_HIP, "hipHostMalloc failed"));
             memset(pb->h_pcg, 0, 8 * sizeof(double));

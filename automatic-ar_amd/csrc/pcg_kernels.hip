@@ -406,13 +406,102 @@ __device__ __forceinline__ void pcgf_zfull(const double *__restrict__ zd_e, doub
     }
 }
 __device__ __forceinline__ bool pcgf_modes(const PcgArgs &a, int e) { return e < a.C + a.M && a.ent_fixed[e] == 0; }
+// the table from the entity rows {R, t, J_l} (one thread per entity; the caller synchronises)
+template <int TH>
+__device__ __forceinline__ void pcgf_build_zd(const PcgArgs &a, double *__restrict__ zd) {
+    for (int e = threadIdx.x; e < a.A; e += TH) {
+        double z12[12];
+#pragma unroll
+        for (int q = 0; q < 12; q++) z12[q] = 0.0;
+        if (pcgf_modes(a, e)) {
+            const double *row = a.ent + (size_t)e * ENT_STRIDE;
+            const double *J = row + 12;
+            const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+            const double id = 1.0 / (J[0] * c00 + J[1] * c01 + J[2] * c02);
+            z12[0] = c00 * id; z12[1] = (J[2] * J[7] - J[1] * J[8]) * id; z12[2] = (J[1] * J[5] - J[2] * J[4]) * id;
+            z12[3] = c01 * id; z12[4] = (J[0] * J[8] - J[2] * J[6]) * id; z12[5] = (J[2] * J[3] - J[0] * J[5]) * id;
+            z12[6] = c02 * id; z12[7] = (J[1] * J[6] - J[0] * J[7]) * id; z12[8] = (J[0] * J[4] - J[1] * J[3]) * id;
+            z12[9] = row[9]; z12[10] = row[10]; z12[11] = row[11];
+        }
+#pragma unroll
+        for (int q = 0; q < 12; q++) zd[12 * e + q] = z12[q];
+    }
+}
+// c = blockdiag(E_cc, E_mm)^-1 Z^T rv into cs (every thread): wavefront ca < 6 forms entries ca of Z_c^T rv and Z_m^T rv (its lanes stride over the entities: column ca
+// of Z_e against the entity's six entries of rv), ONE sum over the wavefront each; twelve threads apply the inverse blocks; everybody reads c back.  cvec: 24 doubles
+template <int TH>
+__device__ __forceinline__ void pcgf_coarse_coef(const PcgArgs &a, const double *__restrict__ zd, const double *__restrict__ einv, double *__restrict__ cvec,
+                                                 const double *__restrict__ rv, double (&cs)[12]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __syncthreads();   // (cvec may still be read from the previous call; rv is complete)
+    for (int ca = wave; ca < 6; ca += TH / 64) {   // (wave-uniform)
+        double sc = 0.0, sm = 0.0;
+        for (int e = lane; e < a.C + a.M; e += 64) {
+            const double *z = zd + 12 * e;
+            double v;
+            if (ca < 3) {   // column ca of [[Jinv], [-[t]x]]
+                const double t0 = z[9], t1 = z[10], t2 = z[11];
+                const double n0 = ca == 0 ? 0.0 : (ca == 1 ? t2 : -t1), n1 = ca == 0 ? -t2 : (ca == 1 ? 0.0 : t0), n2 = ca == 0 ? t1 : (ca == 1 ? -t0 : 0.0);
+                v = z[ca] * rv[6 * e] + z[3 + ca] * rv[6 * e + 1] + z[6 + ca] * rv[6 * e + 2] + (n0 * rv[6 * e + 3] + n1 * rv[6 * e + 4] + n2 * rv[6 * e + 5]);
+            } else {
+                v = pcgf_on(z) ? rv[6 * e + ca] : 0.0;
+            }
+            if (e < a.C) sc += v; else sm += v;
+        }
+        sc = wave_sum_dpp(sc); sm = wave_sum_dpp(sm);
+        if (lane == 0) { cvec[ca] = sc; cvec[6 + ca] = sm; }
+    }
+    __syncthreads();
+    if (tid < 12) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) v = fma(einv[36 * (tid / 6) + 6 * (tid % 6) + k], cvec[6 * (tid / 6) + k], v);
+        cvec[12 + tid] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 12; q++) cs[q] = cvec[12 + q];
+}
+__device__ __forceinline__ double pcgf_coarse_add(const PcgArgs &a, const double *__restrict__ zd, int e, int row, const double (&cs)[12]) {   // (Z c)_i
+    double zr[6];
+    pcgf_zrow(zd + 12 * e, row, zr);
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) v = fma(zr[q], e < a.C ? cs[q] : cs[6 + q], v);
+    return v;
+}
+// the two inverse blocks of E (lower triangles of the sums at Eg, 12 x 12 row-major) by threads 0 and 1 into einv [72]; a group without modes, or a block that is not
+// positive definite in floating point: no modes (zeros)
+__device__ __forceinline__ void pcgf_invert_E(const double *Eg, double *__restrict__ einv, bool agent_loads) {
+    const int tid = threadIdx.x;
+    if (tid >= 2) return;
+    double eb[6][6], inv[36];
+    bool have = false;
+#pragma unroll
+    for (int pp = 0; pp < 6; pp++)
+#pragma unroll
+        for (int q = 0; q <= pp; q++) {
+            const double *src = Eg + 12 * (6 * tid + pp) + 6 * tid + q;
+            const double v = agent_loads ? ld_agent(src) : *src;
+            eb[pp][q] = v; eb[q][pp] = v;
+            have = have || v != 0.0;
+        }
+    if (!have) {
+#pragma unroll
+        for (int pp = 0; pp < 6; pp++) eb[pp][pp] = 1.0;
+    }
+    if (!spd6_inverse(eb, inv)) have = false;
+#pragma unroll
+    for (int q = 0; q < 36; q++) einv[36 * tid + q] = have ? inv[q] : 0.0;
+}
 
 // E = Z^T S Z, this workgroup's share into Ews [144] (LDS, zeroed here; row-major 12 x 12: cameras' modes 0..5, markers' 6..11):
 //   frames:  - sum_f P_f^T (V_f + mu I)^-1 P_f,   P_f = W_f^T Z = sum over the frame's slots of W_ef^T Z_e  (6 x 12: one more use of the blocks the set-up reads),
 //   U:       + Z^T (U + mu I) Z over the stored blocks of the entities dealt to this workgroup.
 // wl: per-wavefront scratch [TH / 64][144]
+// add_mu: the damping's Z^T (mu I) Z is added here (one rank; with ranks every rank holds a PARTIAL U: only rank 0 adds it)
 template <int TH>
-__device__ __forceinline__ void pcgf_setup_coarse(const PcgArgs &a, const double *__restrict__ zd, double *__restrict__ Ews, double *__restrict__ wl, int wg, int G) {
+__device__ __forceinline__ void pcgf_setup_coarse(const PcgArgs &a, const double *__restrict__ zd, double *__restrict__ Ews, double *__restrict__ wl, int wg, int G, bool add_mu = true) {
     constexpr int NW = TH / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 144; i += TH) Ews[i] = 0.0;
@@ -517,7 +606,7 @@ __device__ __forceinline__ void pcgf_setup_coarse(const PcgArgs &a, const double
                 double u[6];
 #pragma unroll
                 for (int j = 0; j < 6; j++)
-                    u[j] = b == e ? ((j <= i ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] : a.U[(size_t)(6 * e + j) * a.n_pad + 6 * e + i]) + (i == j ? a.mu : 0.0))
+                    u[j] = b == e ? ((j <= i ? a.U[(size_t)(6 * e + i) * a.n_pad + 6 * e + j] : a.U[(size_t)(6 * e + j) * a.n_pad + 6 * e + i]) + ((i == j && add_mu) ? a.mu : 0.0))
                                   : a.U[(size_t)(6 * e + i) * a.n_pad + 6 * b + j];
 #pragma unroll
                 for (int c = 0; c < 6; c++) {
@@ -763,23 +852,7 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     int round = 0;
     if (wg == 0 && tid < 2 * PCG_NY + 1) __hip_atomic_store(a.hop + (1 - a.parity) * PCG_HOP_WORDS + tid * 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
     if (co) {
-        for (int e = tid; e < a.A; e += TH) {
-            double z12[12];
-#pragma unroll
-            for (int q = 0; q < 12; q++) z12[q] = 0.0;
-            if (pcgf_modes(a, e)) {
-                const double *row = a.ent + (size_t)e * ENT_STRIDE;
-                const double *J = row + 12;
-                const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
-                const double id = 1.0 / (J[0] * c00 + J[1] * c01 + J[2] * c02);
-                z12[0] = c00 * id; z12[1] = (J[2] * J[7] - J[1] * J[8]) * id; z12[2] = (J[1] * J[5] - J[2] * J[4]) * id;
-                z12[3] = c01 * id; z12[4] = (J[0] * J[8] - J[2] * J[6]) * id; z12[5] = (J[2] * J[3] - J[0] * J[5]) * id;
-                z12[6] = c02 * id; z12[7] = (J[1] * J[6] - J[0] * J[7]) * id; z12[8] = (J[0] * J[4] - J[1] * J[3]) * id;
-                z12[9] = row[9]; z12[10] = row[10]; z12[11] = row[11];
-            }
-#pragma unroll
-            for (int q = 0; q < 12; q++) zd[12 * e + q] = z12[q];
-        }
+        pcgf_build_zd<TH>(a, zd);
         __syncthreads();
     }
 
@@ -799,67 +872,11 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     if (wave == 0) PCG_STAMP(31, 2);
     if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
     if (wave == 0) PCG_STAMP(31, 3);
-    if (co && tid < 2) {   // E_cc, E_mm (lower triangles of the sums) inverted; a group without modes, or a block that is not positive definite in floating point: no modes
-        double eb[6][6], inv[36];
-        bool have = false;
-#pragma unroll
-        for (int pp = 0; pp < 6; pp++)
-#pragma unroll
-            for (int q = 0; q <= pp; q++) {
-                const double v = ld_agent(a.eg + 12 * (6 * tid + pp) + 6 * tid + q);
-                eb[pp][q] = v; eb[q][pp] = v;
-                have = have || v != 0.0;
-            }
-        if (!have) {
-#pragma unroll
-            for (int pp = 0; pp < 6; pp++) eb[pp][pp] = 1.0;
-        }
-        if (!spd6_inverse(eb, inv)) have = false;
-#pragma unroll
-        for (int q = 0; q < 36; q++) einv[36 * tid + q] = have ? inv[q] : 0.0;
-    }
-    // z = M^-1 r: block-Jacobi plus the coarse part Z c, c = blockdiag(E_cc, E_mm)^-1 Z^T r.  Wavefront a < 6 forms entries a of Z_c^T r and Z_m^T r (its lanes
-    // stride over the entities: column a of Z_e against the entity's six entries of r), ONE sum over the wavefront each; twelve threads then apply the inverse
-    // blocks; everybody reads c (12) back
-    double *cvec = wl;   // [12] s, [12] c (the per-wavefront scratch of the set-up is free by now)
-    auto coarse_coef = [&](const double *__restrict__ rv, double (&cs)[12]) {
-        __syncthreads();   // (cvec may still be read from the previous call; rv is complete)
-        for (int ca = wave; ca < 6; ca += TH / 64) {   // (wave-uniform; k_pcgf<false> has four wavefronts)
-            double sc = 0.0, sm = 0.0;
-            for (int e = lane; e < a.C + a.M; e += 64) {
-                const double *z = zd + 12 * e;
-                double v;
-                if (ca < 3) {   // column ca of [[Jinv], [-[t]x]]
-                    const double t0 = z[9], t1 = z[10], t2 = z[11];
-                    const double n0 = ca == 0 ? 0.0 : (ca == 1 ? t2 : -t1), n1 = ca == 0 ? -t2 : (ca == 1 ? 0.0 : t0), n2 = ca == 0 ? t1 : (ca == 1 ? -t0 : 0.0);
-                    v = z[ca] * rv[6 * e] + z[3 + ca] * rv[6 * e + 1] + z[6 + ca] * rv[6 * e + 2] + (n0 * rv[6 * e + 3] + n1 * rv[6 * e + 4] + n2 * rv[6 * e + 5]);
-                } else {
-                    v = pcgf_on(z) ? rv[6 * e + ca] : 0.0;
-                }
-                if (e < a.C) sc += v; else sm += v;
-            }
-            sc = wave_sum_dpp(sc); sm = wave_sum_dpp(sm);
-            if (lane == 0) { cvec[ca] = sc; cvec[6 + ca] = sm; }
-        }
-        __syncthreads();
-        if (tid < 12) {
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) v = fma(einv[36 * (tid / 6) + 6 * (tid % 6) + k], cvec[6 * (tid / 6) + k], v);
-            cvec[12 + tid] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 12; q++) cs[q] = cvec[12 + q];
-    };
-    auto coarse_add = [&](int e, int row, const double (&cs)[12]) -> double {   // (Z c)_i
-        double zr[6];
-        pcgf_zrow(zd + 12 * e, row, zr);
-        double v = 0.0;
-#pragma unroll
-        for (int q = 0; q < 6; q++) v = fma(zr[q], e < a.C ? cs[q] : cs[6 + q], v);
-        return v;
-    };
+    if (co) pcgf_invert_E(a.eg, einv, true);
+    // z = M^-1 r: block-Jacobi plus the coarse part Z c, c = blockdiag(E_cc, E_mm)^-1 Z^T r (pcgf_coarse_coef / pcgf_coarse_add)
+    double *cvec = wl;   // (the per-wavefront scratch of the set-up is free by now)
+    auto coarse_coef = [&](const double *__restrict__ rv, double (&cs)[12]) { pcgf_coarse_coef<TH>(a, zd, einv, cvec, rv, cs); };
+    auto coarse_add = [&](int e, int row, const double (&cs)[12]) -> double { return pcgf_coarse_add(a, zd, e, row, cs); };
     // ---- set-up, second half, redundantly in every workgroup (one thread per entity): the diagonal block of S inverted straight into LDS,
     //      the right-hand side; x = 0, r = b.  (Every thread reads its sums into registers before the barrier below lets Mi overwrite sacc.) ----
     // (every thread reads the sums it needs past the L2, not from sacc: Mi may take sacc's place at once -- but only when all threads have flushed it)
@@ -1013,6 +1030,9 @@ struct PcgDistArgs {
     int k, last;              // launch number (0: builds the preconditioner and r = b); last: budget exhausted, write delta_s and leave
     double *host;             // mapped host record {done, iterations, -, sequence}; written when publish_seq != 0
     unsigned long long publish_seq;
+    // coarse space (fused kernels): this rank's share of E = Z^T S Z rides behind setup_local ([A][28] | [144]: ONE all-reduce); behind minv: E^-1 blocks [72] | the
+    // table zd [12 A] (launch 0 writes them for the later launches).  add_mu: this rank adds the damping's Z^T (mu I) Z (rank 0 only: every rank's U is partial)
+    int add_mu = 1;
 };
 
 __device__ __forceinline__ void pcgd_items_setup(const PcgArgs &a, double *red, int wg, int G, int tid) {
@@ -1303,6 +1323,13 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_setup_f(const PcgDistArgs 
         const double v = lds[i];
         if (v != 0.0) atomicAdd(d.setup_local + (size_t)(i / 27) * 28 + (i % 27), -v);
     }
+    if (a.coarse_from >= 0 && a.ent != nullptr && a.iters_out[0] >= a.coarse_from) {   // this rank's share of the coarse operator (pcgf_setup_coarse), into the same all-reduce
+        double *zd = lds + 27 * a.A, *Ews = zd + 12 * a.A, *wl = Ews + 144;
+        pcgf_build_zd<PCG_THREADS>(a, zd);
+        __syncthreads();
+        pcgf_setup_coarse<PCG_THREADS>(a, zd, Ews, wl, wg, G, d.add_mu != 0);
+        for (int i = tid; i < 144; i += PCG_THREADS) { const double v = Ews[i]; if (v != 0.0) atomicAdd(d.setup_local + (size_t)28 * a.A + i, v); }
+    }
     for (int e = wg * PCG_THREADS + tid; e < a.A; e += G * PCG_THREADS) {   // this rank's U_ee and g0_e (partial sums over its observations)
         if (a.ent_fixed[e]) continue;
 #pragma unroll
@@ -1322,6 +1349,10 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
     const PcgArgs &a = d.a;
     const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
     double *x = lds, *r = lds + n, *p = r + n, *Mi = p + n, *yacc = Mi + 6 * n, *red = yacc + n;
+    double *zd = red + (PCGF32_THREADS / 64) * 27 + 8, *einv = zd + 12 * a.A + 144, *cvec = einv + 72;   // (the layout of k_pcgf: pcg_lds_bytes)
+    const bool co = a.coarse_from >= 0 && a.ent != nullptr && a.iters_out[0] >= a.coarse_from;   // (the same on every rank: a count the ranks agree on; a solve's launches all see the previous solve's)
+    double *g_einv = d.minv + (size_t)36 * a.A, *g_zd = g_einv + 72;
+    double cs[12];
     const double *gx = bf.state_rd, *gr = gx + n, *gp = gr + n, *gs = gp + n;
     double *hx = bf.state_wr, *hr = hx + n, *hp = hr + n, *hs = hp + n;
     auto publish = [&](double done_v, double it_v) {
@@ -1358,13 +1389,23 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
 #pragma unroll
             for (int i = 0; i < 6; i++) { r[6 * e + i] = be[i]; x[6 * e + i] = 0.0; }
         }
+        if (co) {   // the table and the inverse blocks of the all-reduced E; kept for the later launches of this solve
+            pcgf_build_zd<PCG_THREADS>(a, zd);
+            pcgf_invert_E(d.setup_local + (size_t)28 * a.A, einv, false);
+        }
         __syncthreads();
+        if (co && wg == 0) {
+            for (int i = tid; i < 12 * a.A; i += PCG_THREADS) g_zd[i] = zd[i];
+            if (tid < 72) g_einv[tid] = einv[tid];
+        }
+        if (co) pcgf_coarse_coef<PCG_THREADS>(a, zd, einv, cvec, r, cs);
         double sv[2] = {0.0, 0.0};
         for (int i = tid; i < n; i += PCG_THREADS) {
             const int e = i / 6, row = i - 6 * e;
             double z = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            if (co) z += pcgf_coarse_add(a, zd, e, row, cs);
             p[i] = z;
             sv[0] += r[i] * z;
             sv[1] += r[i] * r[i];
@@ -1379,6 +1420,10 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
             return;
         }
         for (int i = tid; i < 6 * n; i += PCG_THREADS) Mi[i] = d.minv[i];
+        if (co) {
+            for (int i = tid; i < 12 * a.A; i += PCG_THREADS) zd[i] = g_zd[i];
+            if (tid < 72) einv[tid] = g_einv[tid];
+        }
         for (int i = tid; i < n; i += PCG_THREADS) { x[i] = gx[i]; r[i] = gr[i]; p[i] = gp[i]; }
         rz = gs[0]; bb = gs[1]; itc = gs[3];
         __syncthreads();
@@ -1402,6 +1447,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
             }
         }
         __syncthreads();
+        if (co) pcgf_coarse_coef<PCG_THREADS>(a, zd, einv, cvec, r, cs);
         double s2[2] = {0.0, 0.0};
         double zloc[24];
         int nz = 0;
@@ -1410,6 +1456,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
             double z = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; k++) z = fma(Mi[e * 36 + row * 6 + k], r[6 * e + k], z);
+            if (co) z += pcgf_coarse_add(a, zd, e, row, cs);
             if (nz < 24) zloc[nz] = z;
             s2[0] += r[i] * z;
             s2[1] += r[i] * r[i];
@@ -1517,6 +1564,8 @@ static PcgDistArgs pcgd_args(const DeviceProblem &P, int which, double mu) {
     a.counter = P.pcg_counter; a.hop = P.pcg_hop; a.parity = P.pcg_parity & 1; P.pcg_parity++;
     a.x_out = P.delta_s; a.iters_out = P.pcg_counter + 2; a.flags = P.flags;
     a.Wf = pcgd_fused(P) ? P.blk[which].Wf : nullptr;   // (allocated only where pass A writes it instead of the fp64 blocks)
+    if (pcgd_fused(P)) { a.ent = P.ent[which]; a.C = P.C; a.M = P.M; a.coarse_from = (P.pcg_coarse && P.C <= 64) ? P.pcg_coarse_from : -1; }
+    d.add_mu = P.pcg_rank0 ? 1 : 0;
     d.setup_local = P.pcgd_setup; d.minv = P.pcgd_minv; d.state = P.pcgd_state; d.y = P.pcgd_y;
     d.k = 0; d.last = 0; d.host = P.pcgd_host; d.publish_seq = 0;
     return d;
@@ -1532,9 +1581,9 @@ void launch_pcgd_setup(const DeviceProblem &P, int which, double mu, hipStream_t
     const PcgDistArgs d = pcgd_args(P, which, mu);
     HookScope _h(P, KID_PCG);
     if (pcgd_fused(P)) {
-        (void)hipMemsetAsync(P.pcgd_setup, 0, (size_t)28 * P.A * sizeof(double), st);
+        (void)hipMemsetAsync(P.pcgd_setup, 0, ((size_t)28 * P.A + 144) * sizeof(double), st);
         (void)hipMemsetAsync(P.pcgd_y, 0, 3 * pcgd_y_stride(P) * sizeof(double), st);
-        const size_t lds = (size_t)27 * P.A * sizeof(double);
+        const size_t lds = ((size_t)27 * P.A + (P.pcg_coarse ? (size_t)12 * P.A + 144 + (PCG_THREADS / 64) * 144 : 0)) * sizeof(double);
         static size_t granted = 48 * 1024;
         allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgd_setup_f), lds, granted);
         hipLaunchKernelGGL(k_pcgd_setup_f, dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, d);
@@ -1547,7 +1596,7 @@ void launch_pcgd_setup(const DeviceProblem &P, int which, double mu, hipStream_t
 void launch_pcgd_iter(const DeviceProblem &P, int which, double mu, int k, bool last, unsigned long long publish_seq, hipStream_t st) {
     PcgDistArgs d = pcgd_args(P, which, mu);
     d.k = k; d.last = last ? 1 : 0; d.publish_seq = publish_seq;
-    const size_t lds = pcg_lds_bytes(P.A);
+    const size_t lds = pcg_lds_bytes(P.A, pcgd_fused(P) && P.pcg_coarse != 0);
     static size_t granted = 48 * 1024, granted_f = 48 * 1024;
     HookScope _h(P, KID_PCG);
     if (pcgd_fused(P)) {
