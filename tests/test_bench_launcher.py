@@ -82,11 +82,11 @@ def test_amdahl_object_and_kernel_models():
 
 
 def test_committed_bench_lines_keep_the_contract():
-    # profiles/r05_bench_cfg{3,5}.json and r05_bench_cfg3_driver_flags.json are bench.py's own lines from the GPU box (scripts/collect_profiles.sh, then scripts/collect_bench_lines.sh
+    # profiles/r06_bench_cfg{3,5}.json and r06_bench_cfg3_driver_flags.json are bench.py's own lines from the GPU box (scripts/collect_profiles.sh, then scripts/collect_bench_lines.sh
     # once the PMC fold exists): the fields the driver and the judge read must be there, with the metric of BASELINE.json, the roofline of the dominant kernel with its PMC traffic, the CPU
     # baseline beside it, what the library's DEFAULT options resolved to, and the direct solver's figures -- error AND poses -- on the same problem
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    for name, workload, solver in (("r05_bench_cfg3.json", "8-cam/40-marker/500-frame", "spcg"), ("r05_bench_cfg5.json", "16-cam/200-marker/5000-frame", "pcg")):
+    for name, workload, solver in (("r06_bench_cfg3.json", "8-cam/40-marker/500-frame", "spcg"), ("r06_bench_cfg5.json", "16-cam/200-marker/5000-frame", "pcg")):
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
                   "roofline", "cpu_baseline", "amdahl", "final_rmse_px", "direct_it_per_s", "rmse_delta_vs_direct_px", "pose_delta_vs_direct", "lm_iterations_to_stop", "solver_stats"):
@@ -102,14 +102,14 @@ def test_committed_bench_lines_keep_the_contract():
         r = d["roofline"]
         assert r["bound"] in ("hbm", "fp64_valu", "fp64_mfma", "latency") and r["kernel"] in r["per_kernel"]
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] is not None and r["traffic"] > 0
-    d5 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg5.json")))["roofline"]
+    d5 = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_cfg5.json")))["roofline"]
     assert d5["kernel"] == "k_pcg" and d5["utilisation"]["frac"] > 10 * d5["frac"]            # k_pcg twice: its own traffic model (utilisation) and SURVEY 8d's algorithmic fraction
-    d3 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg3.json")))
+    d3 = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_cfg3.json")))
     assert set(d3["amdahl"]["bound_at"]) == {"1", "2", "4", "8"} and d3["amdahl"]["bound_at"]["1"] == 1.0
     cb = d3["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
     # the driver's command (--gpus 1 --steps 20 --warmup 5): configs 4 and 5 ride in the same line
-    dd = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg3_driver_flags.json")))
+    dd = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_cfg3_driver_flags.json")))
     assert dd["steps"] == 20 and dd["warmup"] == 5 and set(dd["other_workloads"]) == {"4", "5"}
     for w, sol in (("4", "spcg"), ("5", "pcg")):
         o = dd["other_workloads"][w]
@@ -117,11 +117,20 @@ def test_committed_bench_lines_keep_the_contract():
             assert k in o, (w, k)
         assert o["solver_resolved"] == sol and o["rmse_delta_vs_direct_px"] < 1e-6 and max(o["pose_delta_vs_direct"].values()) < 1e-5
         assert o["roofline"]["traffic"] and "fp64_valu" in o["roofline"] and 0 < o["iteration_hbm"]["frac"] < 1
+        assert o["roofline"]["traffic_uncorrected"] and o["roofline"]["traffic_uncorrected"] <= o["roofline"]["traffic"]      # (raw FETCH + WRITE beside the doubled-FETCH figure)
+        # what a SCALE run can be held against: the workload behind a single-rank RCCL communicator, split and extrapolated
+        am = o["amdahl"]
+        for k in ("it_per_s_single_rank_rccl", "communicator_overhead_us_per_step", "allreduce_calls_per_lm_step", "allreduce_bytes_per_lm_step", "replicated_us", "sharded_us_one_gpu",
+                  "collective_us", "bound_at", "predicted_upper_bound_it_per_s"):
+            assert k in am, (w, k)
+        assert am["solver_resolved"] == sol and set(am["bound_at"]) == {"1", "2", "4", "8"} and am["bound_at"]["1"] == 1.0 and set(am["predicted_upper_bound_it_per_s"]) == {"2", "4", "8"}
+        assert 0 < am["it_per_s_single_rank_rccl"] <= 1.02 * o["value"] and am["predicted_upper_bound_it_per_s"]["8"] > am["it_per_s_single_rank_rccl"]
+        assert am["allreduce_calls_per_lm_step"] >= (1.0 if sol == "spcg" else o["cg_iterations_per_lm_step"])
     # config 5 runs PCG with fp32 W blocks (storage only): the line carries the same measurement with fp64 blocks and the distance between the two runs' final poses
     bs = dd["other_workloads"]["5"]["block_storage"]
     assert bs["W"].startswith("fp32 storage") and bs["with_fp64_blocks"]["lm_iterations_to_stop"] == dd["other_workloads"]["5"]["lm_iterations_to_stop"]
     assert 0 < bs["with_fp64_blocks"]["it_per_s"] < dd["other_workloads"]["5"]["value"] and max(bs["pose_delta_fp32_vs_fp64_blocks"].values()) < 1e-7
     assert dd["block_storage"] is None and "block_storage" not in dd["other_workloads"]["4"]          # (SPCG: fp64 throughout)
     # the N > 1 line's extra workloads, as measured behind a single-rank communicator
-    sw = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg3_single_rank_rccl.json")))["scaling_workloads"]
+    sw = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_cfg3_single_rank_rccl.json")))["scaling_workloads"]
     assert sw["4"]["solver_resolved"] == "spcg" and sw["5"]["solver_resolved"] == "pcg" and sw["5"]["value"] > 500 and sw["4"]["amdahl"]["bound_at"]["8"] > 1.5
