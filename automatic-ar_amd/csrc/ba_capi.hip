@@ -1264,6 +1264,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         if (const char *t = getenv("AAR_SPCG_COARSE_FROM")) P.spcg_coarse_from = atoi(t);
         if (const char *t = getenv("AAR_PCG_COARSE")) P.pcg_coarse = atoi(t) != 0;
         if (const char *t = getenv("AAR_PCG_COARSE_FROM")) P.pcg_coarse_from = atoi(t);
+        if (const char *t = getenv("AAR_PCG_E_EVERY")) P.pcg_e_every = std::max(1, atoi(t));
         if (pcg_lds_bytes(A, true) > 150 * 1024) P.pcg_coarse = 0;   // (the coarse space's tables do not fit beside the vectors of this many entities: block-Jacobi only)
         const int spcg_per_cu = spcg_fits(P.nT) ? spcg_resident_per_cu(P.nT, spcg_coarse_now(P)) : 0;
         const bool spcg_ok = spcg_fits(P.nT) && P.n_pad / 6 <= std::max(1, spcg_per_cu) * cus;
@@ -1835,6 +1836,7 @@ int aar_eval_damped_step(aar_problem *pb, const double *x_full, double mu, doubl
     pb->last_cg_its = -1;
     pb->near_cap_tries = 0;
     pb->P.spcg_coarse_on = 0;
+    pb->P.pcg_e_age = 0;
     if (pb->P.use_pcg && pb->P.pcg_counter) HIP_TRY(hipMemsetAsync(pb->P.pcg_counter + 2, 0, sizeof(int32_t), pb->stream));   // (k_pcgf's coarse space joins by the previous solve's count)
     pb->P.pcg_eta_now = pb->P.pcg_eta;      // (... and the forcing term itself, not the LM's forcing sequence)
     if ((rc = damped_try_fb(pb, mu, false))) return rc == TRY_NOT_POSITIVE_DEFINITE ? AAR_ERR_NUMERIC : rc;
@@ -1863,6 +1865,7 @@ int aar_lm_init(aar_problem *pb, const double *x_full, const aar_lm_params *prm)
     pb->last_cg_its = -1;
     pb->near_cap_tries = 0;
     P.spcg_coarse_on = 0;
+    P.pcg_e_age = 0;
     if (P.use_pcg && P.pcg_counter) HIP_TRY(hipMemsetAsync(P.pcg_counter + 2, 0, sizeof(int32_t), pb->stream));   // (k_pcgf's coarse space joins by the previous solve's count)
     if (pb->spec_chol_blk >= 0) {   // a factorisation queued ahead of the last step of the previous solve: its pivot flags mean nothing
         HIP_TRY(hipMemsetAsync(P.flags, 0, 4 * sizeof(int32_t), pb->stream));

@@ -47,9 +47,11 @@ struct PcgArgs {
     int32_t *flags;
     // k_pcgf, coarse space (the rigid-motion modes of the two groups, as in spcg_kernels.hip: k_spcg_pre -- here as the plain additive two-level preconditioner
     // M^-1 = blockdiag(S_ee)^-1 + Z blockdiag(E_cc, E_mm)^-1 Z^T, the vectors being replicated in every workgroup anyway): entity rows of the pose, group sizes,
-    // the accumulator of E = Z^T S Z [144] (zero at entry), and from how many iterations of the previous solve on it joins (< 0: never)
+    // the accumulator of E = Z^T S Z [144] | [144] = 1 once it holds a complete sum, and from how many iterations of the previous solve on it joins (< 0: never).
+    // e_refresh = 0: the sums of an EARLIER solve of the LM run are used as they are (the launcher then leaves them alone; a preconditioner only has to be
+    // symmetric positive definite and fixed during a solve -- Z of today with E of some steps ago is both); without a complete sum the kernel forms it anyway
     const double *ent = nullptr;
-    int C = 0, M = 0, coarse_from = -1;
+    int C = 0, M = 0, coarse_from = -1, e_refresh = 1;
     double *eg = nullptr;
 };
 
@@ -472,7 +474,8 @@ __device__ __forceinline__ double pcgf_coarse_add(const PcgArgs &a, const double
 }
 // the two inverse blocks of E (lower triangles of the sums at Eg, 12 x 12 row-major) by threads 0 and 1 into einv [72]; a group without modes, or a block that is not
 // positive definite in floating point: no modes (zeros)
-__device__ __forceinline__ void pcgf_invert_E(const double *Eg, double *__restrict__ einv, bool agent_loads) {
+// Gl != nullptr: the sums at Eg were formed WITHOUT the damping's Z^T (mu I) Z, which is added here as mu * Gl (Gl = Z^T Z of today's Z, 12 x 12 row-major in LDS)
+__device__ __forceinline__ void pcgf_invert_E(const double *Eg, double *__restrict__ einv, bool agent_loads, const double *__restrict__ Gl = nullptr, double mu = 0.0) {
     const int tid = threadIdx.x;
     if (tid >= 2) return;
     double eb[6][6], inv[36];
@@ -482,7 +485,8 @@ __device__ __forceinline__ void pcgf_invert_E(const double *Eg, double *__restri
 #pragma unroll
         for (int q = 0; q <= pp; q++) {
             const double *src = Eg + 12 * (6 * tid + pp) + 6 * tid + q;
-            const double v = agent_loads ? ld_agent(src) : *src;
+            double v = agent_loads ? ld_agent(src) : *src;
+            if (Gl && v != 0.0) v = fma(mu, Gl[12 * (6 * tid + pp) + 6 * tid + q], v);
             eb[pp][q] = v; eb[q][pp] = v;
             have = have || v != 0.0;
         }
@@ -865,14 +869,37 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
         const double v = sacc[i];
         if (v != 0.0) atomicAdd(sg + (size_t)(i / 27) * 28 + (i % 27), v);   // (once per solve: not spread over partial tables -- every workgroup would read PCG_NY x 27 A values back: measured +78 us)
     }
-    if (co) {   // this workgroup's share of the coarse operator E = Z^T S Z, flushed with the rest
-        pcgf_setup_coarse<TH>(a, zd, Ews, wl, wg, G);
+    const bool e_new = co && (a.e_refresh != 0 || ld_agent(a.eg + 144) == 0.0);   // (uniform over the grid: the mark is only ever written behind the hop below)
+    if (e_new) {   // this workgroup's share of the coarse operator E = Z^T S Z, flushed with the rest
+        pcgf_setup_coarse<TH>(a, zd, Ews, wl, wg, G, false);   // (without the damping's part: that is added at today's mu below, so that kept sums do not carry an old one)
         for (int i = tid; i < 144; i += TH) { const double v = Ews[i]; if (v != 0.0) atomicAdd(a.eg + i, v); }
     }
     if (wave == 0) PCG_STAMP(31, 2);
     if (!grid_hop_tree(counter, round, G, a.flags, wg)) return;
     if (wave == 0) PCG_STAMP(31, 3);
-    if (co) pcgf_invert_E(a.eg, einv, true);
+    if (co) {   // E = (kept or new) Z^T S Z + mu Z^T Z, the second term from today's Z (every workgroup for itself: a few hundred LDS additions)
+        __syncthreads();
+        for (int i = tid; i < 144; i += TH) Ews[i] = 0.0;
+        __syncthreads();
+        for (int e = tid; e < a.A; e += TH) {
+            if (!pcgf_on(zd + 12 * e)) continue;
+            double Ze[36];
+            pcgf_zfull(zd + 12 * e, Ze);
+            const int ge = e >= a.C ? 6 : 0;
+#pragma unroll
+            for (int aa = 0; aa < 6; aa++)
+#pragma unroll
+                for (int c = 0; c <= aa; c++) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) v = fma(Ze[6 * i + aa], Ze[6 * i + c], v);
+                    atomicAdd(Ews + 12 * (ge + aa) + ge + c, v);
+                }
+        }
+        __syncthreads();
+        pcgf_invert_E(a.eg, einv, true, Ews, a.mu);
+    }
+    if (e_new && wg == 0 && tid == 0) __hip_atomic_store(a.eg + 144, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // z = M^-1 r: block-Jacobi plus the coarse part Z c, c = blockdiag(E_cc, E_mm)^-1 Z^T r (pcgf_coarse_coef / pcgf_coarse_add)
     double *cvec = wl;   // (the per-wavefront scratch of the set-up is free by now)
     auto coarse_coef = [&](const double *__restrict__ rv, double (&cs)[12]) { pcgf_coarse_coef<TH>(a, zd, einv, cvec, rv, cs); };
@@ -1531,7 +1558,11 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
     a.Wf = nullptr;
     HookScope _h(P, KID_PCG);
     if (P.pcg_fused && !P.deterministic) {   // one pass over W and one hand-over per iteration; its atomics take the sums in any order
-        (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * PCG_NYV * P.n_pad + (size_t)28 * P.A + 160) * sizeof(double), st);
+        // the coarse operator's sums are formed every pcg_e_every-th solve of an LM run (and by the first one that needs them: the kernel looks at their mark)
+        const bool e_refresh = P.pcg_e_every <= 1 || P.pcg_e_age <= 0 || P.pcg_e_age >= P.pcg_e_every;
+        P.pcg_e_age = e_refresh ? 1 : P.pcg_e_age + 1;
+        a.e_refresh = e_refresh ? 1 : 0;
+        (void)hipMemsetAsync(P.pcg_yg, 0, ((size_t)3 * PCG_NYV * P.n_pad + (size_t)28 * P.A + (e_refresh ? 160 : 0)) * sizeof(double), st);
         a.ent = P.ent[which]; a.C = P.C; a.M = P.M; a.coarse_from = (P.pcg_coarse && P.C <= 64) ? P.pcg_coarse_from : -1;
         a.eg = P.pcg_yg + (size_t)3 * PCG_NYV * P.n_pad + (size_t)28 * P.A;
         // fp32 blocks (kernels.h, Blocks::Wf): allocated -- and written by pass A INSTEAD of the fp64 blocks -- only where the forcing term is far above what

@@ -592,6 +592,28 @@ def test_pcg_with_fp32_blocks_ends_where_the_fp64_blocks_do(monkeypatch):
         assert _rel(p.eval_damped_step(ds.x_full, mu), d_ref) < 1e-7
 
 
+def test_pcg_keeping_the_coarse_operator_between_solves_ends_where_forming_it_every_solve_does(monkeypatch):
+    # k_pcgf forms Z^T S Z of its coarse space every third solve of an LM run and keeps it in between (AAR_PCG_E_EVERY; the damping's mu Z^T Z is always today's):
+    # a preconditioner only has to be symmetric positive definite and fixed during a solve, so the solves end at the same forcing term -- the poses of the run
+    # agree with forming it every solve far below the bar, at a few more CG iterations (config 5's shape on a 300-frame cut; the coarse space joins from
+    # 8 iterations of the previous solve on, so the first LM steps never use it)
+    ds = aar.synth(5, num_frames=300)
+    out = {}
+    for every in ("1", "3", "6"):
+        monkeypatch.setenv("AAR_PCG_E_EVERY", every)
+        with aar.Problem(ds, solver="pcg") as p:
+            x, rep = p.lm_solve(ds.x_full)
+            out[every] = (x, rep, p.solver_stats())
+    monkeypatch.delenv("AAR_PCG_E_EVERY")
+    x1, rep1, st1 = out["1"]
+    assert st1["total_iterations"] > 4 * rep1["iterations"]         # (the problem is one where the coarse space is at work at all)
+    for every in ("3", "6"):
+        x, rep, st = out[every]
+        assert rep["iterations"] == rep1["iterations"]
+        assert max(pose_delta_max(ds, x, x1)) < 1e-5, (every, pose_delta_max(ds, x, x1))
+        assert st["total_iterations"] < 1.5 * st1["total_iterations"], (every, st["total_iterations"], st1["total_iterations"])
+
+
 @pytest.mark.parametrize("name", ["g1_cfg2", "g1_cfg2_far", "g1_cfg2_retry", "g1_cfg2_huber", "g1_cfg2_huber_retry", "g1_cfg2_intr", "g1_cfg3_cut"])
 def test_pcg_with_its_fp32_blocks_reaches_the_direct_paths_poses_on_every_fixture(name):
     # PCG FORCED (AUTO never picks it at these sizes) at its default forcing term -- fp32 W blocks, k_pcgf -- on every LM fixture.  Its default term (5e-3 on |r| / |b|)
