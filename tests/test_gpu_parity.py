@@ -1124,9 +1124,15 @@ def test_pcg_solver_mode_against_the_direct_path():
     # launches); same LM steps, the same solution and (almost) the same CG iteration counts as on one GPU
     # (round 6: both the one-GPU kernel and the sharded kernels carry the coarse space -- AAR_PCG_COARSE -- by the same rule: the comparison below is between two
     #  two-level preconditioned runs; block-Jacobi alone must need clearly more iterations for the same run)
-    with Problem(ds, solver="pcg") as p:
-        x_1, rep_1 = p.lm_solve(ds.x_full)
-        its_1 = p.pcg_iterations()[1]
+    # (the one-GPU kernel keeps its coarse operator for three solves -- AAR_PCG_E_EVERY, tests/test_gpu_solvers.py -- the sharded ones form it every solve, its shares
+    #  riding in the set-up's all-reduce anyway: the iteration counts are compared like for like)
+    os.environ["AAR_PCG_E_EVERY"] = "1"
+    try:
+        with Problem(ds, solver="pcg") as p:
+            x_1, rep_1 = p.lm_solve(ds.x_full)
+            its_1 = p.pcg_iterations()[1]
+    finally:
+        del os.environ["AAR_PCG_E_EVERY"]
     os.environ["AAR_PCG_COARSE"] = "0"
     try:
         with Problem(ds, solver="pcg") as p:
