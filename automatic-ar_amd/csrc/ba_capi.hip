@@ -1265,6 +1265,7 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         if (const char *t = getenv("AAR_PCG_COARSE")) P.pcg_coarse = atoi(t) != 0;
         if (const char *t = getenv("AAR_PCG_COARSE_FROM")) P.pcg_coarse_from = atoi(t);
         if (const char *t = getenv("AAR_PCG_E_EVERY")) P.pcg_e_every = std::max(1, atoi(t));
+        if (const char *t = getenv("AAR_PCG_RESIDENT")) P.pcg_resident = atoi(t) != 0;
         if (pcg_lds_bytes(A, true) > 150 * 1024) P.pcg_coarse = 0;   // (the coarse space's tables do not fit beside the vectors of this many entities: block-Jacobi only)
         const int spcg_per_cu = spcg_fits(P.nT) ? spcg_resident_per_cu(P.nT, spcg_coarse_now(P)) : 0;
         const bool spcg_ok = spcg_fits(P.nT) && P.n_pad / 6 <= std::max(1, spcg_per_cu) * cus;

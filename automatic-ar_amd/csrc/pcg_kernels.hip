@@ -701,8 +701,55 @@ __device__ __forceinline__ void pcgf_setup_slots(const PcgArgs &a, double *__res
 // this storage is allowed at (PCG_W32_MIN_ETA) -- final poses unchanged (scripts/experiments/pcg_w_float.py; profiles/r05_attempts.txt section 5).  The kernels
 // that read a.W unconditionally (k_pcg, k_pcgd_setup / k_pcgd_iter, the Schur kernels) must therefore never run on a block set that has Wf: launch_pcg and
 // launch_pcgd_* refuse (flag 2 -> AAR_ERR_NUMERIC) instead of reading stale blocks
-template <bool W32, int TH = PCG_THREADS>
-__device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__restrict__ p, double *__restrict__ yacc, double *__restrict__ red, int wg, int G, int st_it = 0) {
+// a W block in registers: 18 double2 (W32: 9 float4), row-major, widened on use
+template <bool W32>
+struct PcgBlk { typename std::conditional<W32, float4, double2>::type v[W32 ? 9 : 18]; };
+template <bool W32>
+__device__ __forceinline__ void pcgf_load_blk(const PcgArgs &a, PcgBlk<W32> &b, int s0, int s1, int s) {
+    if constexpr (W32) {
+        const float4 *q = reinterpret_cast<const float4 *>(a.Wf + (size_t)s0 * 36) + (s - s0);
+        const int kf = s1 - s0;
+#pragma unroll
+        for (int u = 0; u < 9; u++) b.v[u] = q[(size_t)u * kf];
+    } else {
+        const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
+#pragma unroll
+        for (int u = 0; u < 18; u++) b.v[u] = q[u];
+    }
+}
+// RESIDENT BLOCKS (fp32 storage only).  A workgroup's frames are the same in every CG iteration, and so is their deal to its wavefronts, so blocks can stay in registers
+// for the whole damped solve instead of being streamed once per iteration: RES = 1: the first round of a wavefront's first frame (9 float4 = 36 registers per lane:
+// a fifth of a wavefront's 4.9 rounds at config 5); 2: + its second round; 3: + the first round of the second frame (61 %).  They are loaded after the set-up passes
+// (pcgf_load_resident), so the kernel's peak is the larger of the two phases, not their sum -- and still only RES = 1 fits: the CG loop holds ~220 registers of the
+// 256 a wavefront has at two per SIMD (hoisted addresses, the two streamed blocks of the generic frames), 2 / 3 spill 63 / 162 registers and LOSE
+// (profiles/r06_attempts.txt section 5; config 5: k_pcg 309 -> 296 us with one block, 336 / 387 with two / three).  Only RES = 0 and 1 are instantiated.
+// eres: the blocks' entities (-1: no such slot).
+template <bool W32, int TH, int RES>
+__device__ __forceinline__ void pcgf_load_resident(const PcgArgs &a, int wg, int G, PcgBlk<W32> (&res)[RES > 0 ? RES : 1], int (&eres)[RES > 0 ? RES : 1]) {
+    if constexpr (RES > 0) {
+        constexpr int NW = TH / 64;
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int f_lo = (int)((long long)wg * a.F / G), f_hi = (int)((long long)(wg + 1) * a.F / G);
+#pragma unroll
+        for (int q = 0; q < RES; q++) {
+            const int f = f_lo + wave + (q == 2 ? NW : 0), off = q == 1 ? 64 : 0;
+            int e = -1;
+            PcgBlk<W32> b;
+#pragma unroll
+            for (int u = 0; u < (W32 ? 9 : 18); u++) b.v[u] = typename std::conditional<W32, float4, double2>::type{};
+            if (f < f_hi) {
+                const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
+                if (s0 + lane + off < s1) { e = a.fslot_ent[s0 + lane + off]; pcgf_load_blk<W32>(a, b, s0, s1, s0 + lane + off); }
+            }
+            res[q] = b;
+            eres[q] = e;
+        }
+    }
+}
+
+template <bool W32, int TH = PCG_THREADS, int RES = 0>
+__device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__restrict__ p, double *__restrict__ yacc, double *__restrict__ red, int wg, int G, int st_it,
+                                              const PcgBlk<W32> (&res)[RES > 0 ? RES : 1], const int (&eres)[RES > 0 ? RES : 1]) {
     constexpr int NW = TH / 64;
     const int n = 6 * a.A, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < n; i += TH) yacc[i] = 0.0;
@@ -755,37 +802,30 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
     // Frames: a CONTIGUOUS range per workgroup (F / G of them, to one), dealt round-robin to its wavefronts -- every workgroup takes the same number of rounds
     // (dealt wave-major over the whole grid, 5000 frames over 2048 wavefronts left 113 workgroups with three rounds and 143 with two)
     const int f_lo = (int)((long long)wg * a.F / G), f_hi = (int)((long long)(wg + 1) * a.F / G);
-    for (int f = f_lo + wave; f < f_hi; f += NW) {
+    typedef PcgBlk<W32> Blk;
+    // (second: the block's second use in a frame, behind the wavefront sums.  Its widened values are made again from the fp32 registers -- an empty asm keeps the
+    //  compiler from holding all 72 doubles of the first use alive across the sums, which is what filled the register file)
+    auto row = [&](const Blk &b, int i, double (&r)[6], bool second = false) {   // row i of the block as doubles
+        if constexpr (W32) {
+            const float *fp = reinterpret_cast<const float *>(b.v);
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                float f = fp[6 * i + j];
+                if (second) asm volatile("" : "+v"(f));
+                r[j] = (double)f;
+            }
+        } else {
+            r[0] = b.v[3 * i].x; r[1] = b.v[3 * i].y; r[2] = b.v[3 * i + 1].x; r[3] = b.v[3 * i + 1].y; r[4] = b.v[3 * i + 2].x; r[5] = b.v[3 * i + 2].y;
+        }
+    };
+    // one frame; R0 / R1: which resident block holds its first / second round (-1: fetched here)
+    auto frame = [&](int f, auto R0, auto R1) {
+        constexpr int r0 = decltype(R0)::value, r1 = decltype(R1)::value;
         const int s0 = a.fslot_start[f], s1 = a.fslot_start[f + 1];
         const double *Vi = a.Vinv + (size_t)f * 36;
-        // a W block in registers: 18 double2 (W32: 9 float4), row-major -- wv(b, q) = entry q of the block, widened on use
-        typedef typename std::conditional<W32, float4, double2>::type wreg;
-        constexpr int NR = W32 ? 9 : 18;
-        struct Blk { wreg v[NR]; };
-        Blk w0, w1;
+        Blk w0l, w1l;
         int e0 = -1, e1 = -1;
         double c[6] = {0, 0, 0, 0, 0, 0};
-        auto load = [&](Blk &b, int s) {
-            if constexpr (W32) {
-                const float4 *q = reinterpret_cast<const float4 *>(a.Wf + (size_t)s0 * 36) + (s - s0);
-                const int kf = s1 - s0;
-#pragma unroll
-                for (int u = 0; u < 9; u++) b.v[u] = q[(size_t)u * kf];
-            } else {
-                const double2 *q = reinterpret_cast<const double2 *>(a.W + (size_t)s * 36);
-#pragma unroll
-                for (int u = 0; u < 18; u++) b.v[u] = q[u];
-            }
-        };
-        auto row = [&](const Blk &b, int i, double (&r)[6]) {   // row i of the block as doubles
-            if constexpr (W32) {
-                const float *fp = reinterpret_cast<const float *>(b.v);
-#pragma unroll
-                for (int j = 0; j < 6; j++) r[j] = (double)fp[6 * i + j];
-            } else {
-                r[0] = b.v[3 * i].x; r[1] = b.v[3 * i].y; r[2] = b.v[3 * i + 1].x; r[3] = b.v[3 * i + 1].y; r[4] = b.v[3 * i + 2].x; r[5] = b.v[3 * i + 2].y;
-            }
-        };
         auto gather_c = [&](const Blk &b, int e) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
@@ -796,14 +836,18 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
                 for (int j = 0; j < 6; j++) c[j] = fma(r[j], pe, c[j]);
             }
         };
-        if (s0 + lane < s1) { e0 = a.fslot_ent[s0 + lane]; load(w0, s0 + lane); }
-        if (s0 + lane + 64 < s1) { e1 = a.fslot_ent[s0 + lane + 64]; load(w1, s0 + lane + 64); }
-        if (e0 >= 0) gather_c(w0, e0);
-        if (e1 >= 0) gather_c(w1, e1);
+        if constexpr (r0 >= 0) e0 = eres[r0 >= 0 ? r0 : 0];
+        else if (s0 + lane < s1) { e0 = a.fslot_ent[s0 + lane]; pcgf_load_blk<W32>(a, w0l, s0, s1, s0 + lane); }
+        if constexpr (r1 >= 0) e1 = eres[r1 >= 0 ? r1 : 0];
+        else if (s0 + lane + 64 < s1) { e1 = a.fslot_ent[s0 + lane + 64]; pcgf_load_blk<W32>(a, w1l, s0, s1, s0 + lane + 64); }
+        auto with0 = [&](auto fn) { if constexpr (r0 >= 0) fn(res[r0 >= 0 ? r0 : 0]); else fn(w0l); };
+        auto with1 = [&](auto fn) { if constexpr (r1 >= 0) fn(res[r1 >= 0 ? r1 : 0]); else fn(w1l); };
+        if (e0 >= 0) with0([&](const Blk &b) { gather_c(b, e0); });
+        if (e1 >= 0) with1([&](const Blk &b) { gather_c(b, e1); });
         for (int s = s0 + lane + 128; s < s1; s += 64) {
             const int e = a.fslot_ent[s];
             Blk wt;
-            load(wt, s);
+            pcgf_load_blk<W32>(a, wt, s0, s1, s);
             gather_c(wt, e);
         }
 #pragma unroll
@@ -821,28 +865,38 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 double r[6];
-                row(b, i, r);
+                row(b, i, r, true);
                 const double v = r[0] * t[0] + r[1] * t[1] + r[2] * t[2] + r[3] * t[3] + r[4] * t[4] + r[5] * t[5];
                 atomicAdd(yacc + 6 * e + i, -v);
             }
         };
-        if (e0 >= 0) scatter(w0, e0);
-        if (e1 >= 0) scatter(w1, e1);
+        if (e0 >= 0) with0([&](const Blk &b) { scatter(b, e0); });
+        if (e1 >= 0) with1([&](const Blk &b) { scatter(b, e1); });
         for (int s = s0 + lane + 128; s < s1; s += 64) {
             const int e = a.fslot_ent[s];
             Blk wt;
-            load(wt, s);
+            pcgf_load_blk<W32>(a, wt, s0, s1, s);
             scatter(wt, e);
         }
+    };
+    typedef std::integral_constant<int, -1> none_t;
+    int f = f_lo + wave;
+    if constexpr (RES >= 1) {
+        if (f < f_hi) { frame(f, std::integral_constant<int, 0>{}, std::integral_constant<int, RES >= 2 ? 1 : -1>{}); f += NW; }
     }
+    if constexpr (RES >= 3) {
+        if (f < f_hi) { frame(f, std::integral_constant<int, 2>{}, none_t{}); f += NW; }
+    }
+    for (; f < f_hi; f += NW) frame(f, none_t{}, none_t{});
     PCG_STAMP(st_it, 3 + (wave < 8 ? wave : 7));
     __syncthreads();
     if (wave == 0) PCG_STAMP(st_it, 11);
 }
 
 // (the fp32 operator needs 217 registers: two wavefronts per SIMD fit, and the frame pass is latency-bound -- 512 threads per workgroup there)
-template <bool W32>
+template <bool W32, int RES = 0>
 __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(const PcgArgs a, double *__restrict__ yg, double *__restrict__ sg) {
+    static_assert(RES == 0 || (RES <= 3 && W32), "resident blocks: fp32 storage only");
     constexpr int TH = W32 ? PCGF32_THREADS : PCG_THREADS;
     extern __shared__ __align__(16) double lds[];
     const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -871,7 +925,8 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     }
     const bool e_new = co && (a.e_refresh != 0 || ld_agent(a.eg + 144) == 0.0);   // (uniform over the grid: the mark is only ever written behind the hop below)
     if (e_new) {   // this workgroup's share of the coarse operator E = Z^T S Z, flushed with the rest
-        pcgf_setup_coarse<TH>(a, zd, Ews, wl, wg, G, false);   // (without the damping's part: that is added at today's mu below, so that kept sums do not carry an old one)
+        pcgf_setup_coarse<TH>(a, zd, Ews, wl, wg, G, false);
+   // (without the damping's part: that is added at today's mu below, so that kept sums do not carry an old one)
         for (int i = tid; i < 144; i += TH) { const double v = Ews[i]; if (v != 0.0) atomicAdd(a.eg + i, v); }
     }
     if (wave == 0) PCG_STAMP(31, 2);
@@ -962,13 +1017,16 @@ __global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(con
     if (wave == 0) PCG_STAMP(31, 5);
     int it_cg = 0;
     double rr = bb;
+    PcgBlk<W32> res[RES > 0 ? RES : 1];
+    int eres[RES > 0 ? RES : 1] = {};
+    pcgf_load_resident<W32, TH, RES>(a, wg, G, res, eres);   // (after the set-up: its registers are free)
     while (it_cg < a.max_it && (rr > a.eta2 * bb || rz > a.abs2) && bb > 0.0) {
         // y of this iteration: PCG_NYV partial vectors (workgroup wg adds into vector wg % PCG_NYV), summed by every reader.  Measured at config 5, k_pcg us per
         // solve: 1 vector 458, 2: 436, 4: 449, 8: 452, 16: 474 -- the flush's atomics are not what a hop waited for (that was the barrier's one counter)
         double *ygc = yg + (size_t)(it_cg % 3) * PCG_NYV * a.n_pad, *ygn = yg + (size_t)((it_cg + 1) % 3) * PCG_NYV * a.n_pad;
         for (int i = wg * TH + tid; i < PCG_NYV * a.n_pad; i += G * TH) st_agent(ygn + i, 0.0);
         if (wave == 0) PCG_STAMP(it_cg, 0);
-        pcgf_operator<W32, TH>(a, p, yacc, red, wg, G, it_cg);
+        pcgf_operator<W32, TH, RES>(a, p, yacc, red, wg, G, it_cg, res, eres);
         for (int i = tid; i < n; i += TH) {
             const double v = yacc[i];
             if (v != 0.0) atomicAdd(ygc + (size_t)(wg % PCG_NYV) * a.n_pad + i, v);
@@ -1508,7 +1566,7 @@ __global__ void __launch_bounds__(PCG_THREADS) k_pcgd_iter_f(const PcgDistArgs d
         return;
     }
     for (int i = wg * PCG_THREADS + tid; i < n; i += G * PCG_THREADS) bf.y_zero[i] = 0.0;   // the buffer of the NEXT launch (last read two launches ago)
-    pcgf_operator<W32>(a, p, yacc, red, wg, G);
+    { const PcgBlk<W32> nores[1] = {}; const int noe[1] = {-1}; pcgf_operator<W32, PCG_THREADS, 0>(a, p, yacc, red, wg, G, 0, nores, noe); }
     for (int i = tid; i < n; i += PCG_THREADS) {
         const double v = yacc[i];
         if (v != 0.0) atomicAdd(bf.y_wr + i, v);
@@ -1536,6 +1594,13 @@ int pcg_max_grid(int A, int cus) {
     int n1 = 0, n2 = 0, n3 = 0, n4 = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, k_pcgf<false>, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n3 = 1; }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, k_pcgf<true>, PCGF32_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n4 = 1; }
+    {
+        static size_t g5 = 48 * 1024;
+        int n5 = 0;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true, 1>), lds, g5);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n5, k_pcgf<true, 1>, PCGF32_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n5 = 1; }
+        n4 = std::min(n4, n5);
+    }
     n3 = std::min(n3, n4);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_pcg, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n1 = 1; }
     n1 = std::min(n1, n3);
@@ -1569,6 +1634,12 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
         // that rounding can show (ba_capi.hip, PCG_W32_MIN_ETA; AAR_PCG_W32=0: never): the allocation is the one place that decides
         if (b.Wf) {
             a.Wf = b.Wf;
+            static size_t granted_f32r = 48 * 1024;
+            if (P.pcg_resident) {
+                allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true, 1>), lds, granted_f32r);
+                hipLaunchKernelGGL((k_pcgf<true, 1>), dim3(P.pcg_grid), dim3(PCGF32_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NYV * P.n_pad);
+                return;
+            }
             allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true>), lds, granted_f32);
             hipLaunchKernelGGL(k_pcgf<true>, dim3(P.pcg_grid), dim3(PCGF32_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NYV * P.n_pad);
             return;
