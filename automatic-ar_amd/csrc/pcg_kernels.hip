@@ -722,7 +722,9 @@ __device__ __forceinline__ void pcgf_load_blk(const PcgArgs &a, PcgBlk<W32> &b, 
 // a fifth of a wavefront's 4.9 rounds at config 5); 2: + its second round; 3: + the first round of the second frame (61 %).  They are loaded after the set-up passes
 // (pcgf_load_resident), so the kernel's peak is the larger of the two phases, not their sum -- and still only RES = 1 fits: the CG loop holds ~220 registers of the
 // 256 a wavefront has at two per SIMD (hoisted addresses, the two streamed blocks of the generic frames), 2 / 3 spill 63 / 162 registers and LOSE
-// (profiles/r06_attempts.txt section 5; config 5: k_pcg 309 -> 296 us with one block, 336 / 387 with two / three).  Only RES = 0 and 1 are instantiated.
+// (profiles/r06_attempts.txt section 5; config 5: k_pcg 309 -> 296 us with one block, 336 / 387 with two / three; at ONE wavefront per SIMD -- THX = 256, 512 registers
+// per lane -- 4 / 6 / 7 blocks fit without spills, 114 - 231 of them AGPRs, and the kernel takes 360 / 350 / 346 us: what the frame pass gains the set-up passes and the
+// vector updates lose with half the wavefronts).  Only RES = 0 and 1 at the default thread counts are instantiated.
 // eres: the blocks' entities (-1: no such slot).
 template <bool W32, int TH, int RES>
 __device__ __forceinline__ void pcgf_load_resident(const PcgArgs &a, int wg, int G, PcgBlk<W32> (&res)[RES > 0 ? RES : 1], int (&eres)[RES > 0 ? RES : 1]) {
@@ -732,7 +734,7 @@ __device__ __forceinline__ void pcgf_load_resident(const PcgArgs &a, int wg, int
         const int f_lo = (int)((long long)wg * a.F / G), f_hi = (int)((long long)(wg + 1) * a.F / G);
 #pragma unroll
         for (int q = 0; q < RES; q++) {
-            const int f = f_lo + wave + (q == 2 ? NW : 0), off = q == 1 ? 64 : 0;
+            const int f = f_lo + wave + (q / 2) * NW, off = (q & 1) * 64;   // block q: round q % 2 of the wavefront's frame q / 2
             int e = -1;
             PcgBlk<W32> b;
 #pragma unroll
@@ -881,12 +883,14 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
     };
     typedef std::integral_constant<int, -1> none_t;
     int f = f_lo + wave;
-    if constexpr (RES >= 1) {
-        if (f < f_hi) { frame(f, std::integral_constant<int, 0>{}, std::integral_constant<int, RES >= 2 ? 1 : -1>{}); f += NW; }
-    }
-    if constexpr (RES >= 3) {
-        if (f < f_hi) { frame(f, std::integral_constant<int, 2>{}, none_t{}); f += NW; }
-    }
+    auto resident_frame = [&](auto K) {   // the wavefront's frame K: rounds 2 K and 2 K + 1 of the resident blocks, as far as they go
+        constexpr int k = decltype(K)::value;
+        if constexpr (2 * k < RES) {
+            if (f < f_hi) { frame(f, std::integral_constant<int, 2 * k>{}, std::integral_constant<int, (2 * k + 1 < RES) ? 2 * k + 1 : -1>{}); f += NW; }
+        }
+    };
+    resident_frame(std::integral_constant<int, 0>{}); resident_frame(std::integral_constant<int, 1>{});
+    resident_frame(std::integral_constant<int, 2>{}); resident_frame(std::integral_constant<int, 3>{});
     for (; f < f_hi; f += NW) frame(f, none_t{}, none_t{});
     PCG_STAMP(st_it, 3 + (wave < 8 ? wave : 7));
     __syncthreads();
@@ -894,10 +898,10 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
 }
 
 // (the fp32 operator needs 217 registers: two wavefronts per SIMD fit, and the frame pass is latency-bound -- 512 threads per workgroup there)
-template <bool W32, int RES = 0>
-__global__ void __launch_bounds__(W32 ? PCGF32_THREADS : PCG_THREADS) k_pcgf(const PcgArgs a, double *__restrict__ yg, double *__restrict__ sg) {
-    static_assert(RES == 0 || (RES <= 3 && W32), "resident blocks: fp32 storage only");
-    constexpr int TH = W32 ? PCGF32_THREADS : PCG_THREADS;
+template <bool W32, int RES = 0, int THX = 0>
+__global__ void __launch_bounds__(THX ? THX : (W32 ? PCGF32_THREADS : PCG_THREADS)) k_pcgf(const PcgArgs a, double *__restrict__ yg, double *__restrict__ sg) {
+    static_assert(RES == 0 || (RES <= 8 && W32), "resident blocks: fp32 storage only");
+    constexpr int TH = THX ? THX : (W32 ? PCGF32_THREADS : PCG_THREADS);
     extern __shared__ __align__(16) double lds[];
     const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
