@@ -36,17 +36,53 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 FP64_PEAK_TFLOPS = 78.6      # vector fp64
 
 
+_RESULT_STREAM = None
+
+
+def claim_stdout():
+    """The result line must be the ONLY thing on this process's standard output (the driver parses it).  Libraries loaded later write there behind Python's back
+    (librccl's banner through C stdio, flushed whenever libc likes -- at exit, behind the line): keep a private duplicate of descriptor 1 for the result and point
+    descriptor 1 itself at stderr for the rest of the process."""
+    global _RESULT_STREAM
+    if _RESULT_STREAM is None:
+        sys.stdout.flush()
+        stdout_to_stderr._flush_c_stdio()
+        _RESULT_STREAM = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit_result(line):
+    if _RESULT_STREAM is None:
+        print(line)
+        sys.stdout.flush()
+    else:
+        _RESULT_STREAM.write(line + "\n")
+        _RESULT_STREAM.flush()
+
+
 class stdout_to_stderr:
     """RCCL greets every new communicator with a version banner on the process's STDOUT (file descriptor 1, from inside librccl): the bench line must stay the only
     thing there, so the descriptor points at stderr while a communicator is made."""
+    @staticmethod
+    def _flush_c_stdio():
+        # librccl writes through C stdio, which buffers fully when stdout is a pipe or a file: without this its banner would sit in libc's buffer past the
+        # redirection and come out on descriptor 1 at process exit -- BEHIND the bench line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+
     def __enter__(self):
         sys.stdout.flush()
+        self._flush_c_stdio()
         self.saved = os.dup(1)
         os.dup2(2, 1)
         return self
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        self._flush_c_stdio()
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
@@ -620,9 +656,9 @@ def plumbing_only(args, world, rank, dist):
                 dist.all_gather_object(counts, mine)
             scaling[str(w)] = {"workload": WORKLOADS[w], "local_obs": counts, "marker_observations": int(dw.num_obs), "frames": [int(bw[r + 1] - bw[r]) for r in range(world)]}
     if rank == 0:
-        print(json.dumps({"metric": "LM iterations/sec", "value": None, "unit": "LM iterations/s", "n_gpus": world, "plumbing_only": True,
-                          "ranks_seen": world, "local_obs": per_rank, "max_rank_seconds": dt, "scaling_workloads": scaling,
-                          "config": {"workload": WORKLOADS[args.workload], "marker_observations": int(ds.num_obs)}}))
+        emit_result(json.dumps({"metric": "LM iterations/sec", "value": None, "unit": "LM iterations/s", "n_gpus": world, "plumbing_only": True,
+                                "ranks_seen": world, "local_obs": per_rank, "max_rank_seconds": dt, "scaling_workloads": scaling,
+                                "config": {"workload": WORKLOADS[args.workload], "marker_observations": int(ds.num_obs)}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -654,6 +690,10 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus, sys.argv[1:])      # before anything below can touch the GPU
+    claim_stdout()      # (a rank process: from here on only emit_result() reaches the real standard output)
+    if os.environ.get("AAR_BENCH_TEST_NOISE") == "1":   # (tests/test_bench_launcher.py: a library writing to standard output through C stdio, as librccl does)
+        import ctypes
+        ctypes.CDLL(None).puts(b"noise from a library on C stdout")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -882,7 +922,7 @@ def main():
             track["cpu_sample"] = "first %d frames, real SparseLevMarq::solve(z,f) with its own calcDerivates, 1 thread" % nf
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    emit_result(json.dumps(out))
     problem.close()
     if dist is not None:
         dist.destroy_process_group()

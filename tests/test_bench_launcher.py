@@ -48,6 +48,18 @@ def test_child_failure_propagates_and_prints_no_result():
     assert "child run failed" in out.stderr
 
 
+def test_a_librarys_c_stdio_output_never_reaches_the_result_stream():
+    # librccl greets a new communicator with a banner on the process's standard output through C stdio -- fully buffered on a pipe, so it used to come out at
+    # process exit, BEHIND the result line (found on the GPU box in round 6).  bench.py keeps a private duplicate of descriptor 1 for the line and points the
+    # descriptor itself at stderr: whatever a library writes there, and whenever libc flushes it, the driver reads exactly one line
+    for gpus in ("1", "2"):
+        out = run(["--gpus", gpus, "--plumbing-only", "--workload", "2"], {"AAR_BENCH_TEST_NOISE": "1", "AAR_BENCH_PLUMBING_FRAMES5": "200"})
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1 and json.loads(lines[0])["plumbing_only"] is True, out.stdout
+        assert "noise from a library" in out.stderr
+
+
 def test_single_rank_needs_no_launcher():
     out = run(["--gpus", "1", "--plumbing-only", "--workload", "2"])
     assert out.returncode == 0, out.stderr[-2000:]
