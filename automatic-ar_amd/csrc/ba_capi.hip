@@ -1264,6 +1264,9 @@ int aar_problem_create_ex(const aar_problem_desc *d, const aar_solver_options *o
         if (const char *t = getenv("AAR_SPCG_COARSE_FROM")) P.spcg_coarse_from = atoi(t);
         if (const char *t = getenv("AAR_PCG_COARSE")) P.pcg_coarse = atoi(t) != 0;
         if (const char *t = getenv("AAR_PCG_COARSE_FROM")) P.pcg_coarse_from = atoi(t);
+        // the coarse operator's pass costs like ~1.5 CG iterations and a kept operator ~0.1 - 0.7 more iterations per solve: keeping it pays on long sequences only
+        // (profiles/r06_attempts.txt section 3: +3.7 % at 160 entities x 4 000 frames, +1.4 % at config 5, -1 .. -3 % on 500-frame problems)
+        P.pcg_e_every = P.total_slots >= 300000 ? 3 : 1;
         if (const char *t = getenv("AAR_PCG_E_EVERY")) P.pcg_e_every = std::max(1, atoi(t));
         if (const char *t = getenv("AAR_PCG_RESIDENT")) P.pcg_resident = atoi(t) != 0;
         if (pcg_lds_bytes(A, true) > 150 * 1024) P.pcg_coarse = 0;   // (the coarse space's tables do not fit beside the vectors of this many entities: block-Jacobi only)
