@@ -123,7 +123,7 @@ struct DeviceProblem {
     mutable int want_w64 = 0;             // aar_eval_normal_equations: pass A writes the fp64 W blocks even where the solver only reads the fp32 copy (Blocks::Wf)
     int pcg_fused = 1;                    // AAR_PCG_FUSED=0: k_pcg (two passes over W and two hand-overs per iteration) instead of k_pcgf
     int pcg_rank0 = 1;                    // this rank adds the terms of the sharded PCG's set-up that must enter ONCE (the damping of the coarse operator)
-    int pcg_resident = 1;                 // AAR_PCG_RESIDENT=0: k_pcgf streams every fp32 W block once per CG iteration (1: the first round of every wavefront's first frame stays in registers for the solve)
+    int pcg_resident = 1;                 // AAR_PCG_RESIDENT=0: k_pcgf streams every W block once per CG iteration (1: the first round of every wavefront's first frame stays in registers for the solve -- fp32 blocks; both rounds with fp64 blocks, whose kernel has 512 registers per lane)
     int pcg_e_every = 1;                  // AAR_PCG_E_EVERY: k_pcgf forms the coarse operator's Z^T S Z every this-many solves of an LM run and keeps it in between (the damping's mu Z^T Z is always today's); 1: every solve; set by size at problem creation (3 from 300 000 (entity, frame) pairs)
     mutable int pcg_e_age = 0;            // solves since E was formed (0: the next one forms it; reset where an LM run starts)
     int pcg_coarse = 1, pcg_coarse_from = 8;   // AAR_PCG_COARSE=0 / AAR_PCG_COARSE_FROM: k_pcgf's coarse space (the groups' rigid-motion modes) joins when the previous solve of the LM run took this many iterations

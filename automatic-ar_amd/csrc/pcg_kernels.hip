@@ -722,9 +722,10 @@ __device__ __forceinline__ void pcgf_load_blk(const PcgArgs &a, PcgBlk<W32> &b, 
 // a fifth of a wavefront's 4.9 rounds at config 5); 2: + its second round; 3: + the first round of the second frame (61 %).  They are loaded after the set-up passes
 // (pcgf_load_resident), so the kernel's peak is the larger of the two phases, not their sum -- and still only RES = 1 fits: the CG loop holds ~220 registers of the
 // 256 a wavefront has at two per SIMD (hoisted addresses, the two streamed blocks of the generic frames), 2 / 3 spill 63 / 162 registers and LOSE
-// (profiles/r06_attempts.txt section 5; config 5: k_pcg 309 -> 296 us with one block, 336 / 387 with two / three; at ONE wavefront per SIMD -- THX = 256, 512 registers
+// (profiles/r06_attempts.txt section 5; config 5: k_pcg 309 -> 296 us with one block, 336 / 387 with two / three; the fp64-block kernel, one wavefront per SIMD, holds
+// TWO blocks of 18 double2: 455 -> 438 us; at ONE wavefront per SIMD -- THX = 256, 512 registers
 // per lane -- 4 / 6 / 7 blocks fit without spills, 114 - 231 of them AGPRs, and the kernel takes 360 / 350 / 346 us: what the frame pass gains the set-up passes and the
-// vector updates lose with half the wavefronts).  Only RES = 0 and 1 at the default thread counts are instantiated.
+// vector updates lose with half the wavefronts).  Instantiated: <true, 0 / 1>, <false, 0 / 2>.
 // eres: the blocks' entities (-1: no such slot).
 template <bool W32, int TH, int RES>
 __device__ __forceinline__ void pcgf_load_resident(const PcgArgs &a, int wg, int G, PcgBlk<W32> (&res)[RES > 0 ? RES : 1], int (&eres)[RES > 0 ? RES : 1]) {
@@ -900,7 +901,7 @@ __device__ __forceinline__ void pcgf_operator(const PcgArgs &a, const double *__
 // (the fp32 operator needs 217 registers: two wavefronts per SIMD fit, and the frame pass is latency-bound -- 512 threads per workgroup there)
 template <bool W32, int RES = 0, int THX = 0>
 __global__ void __launch_bounds__(THX ? THX : (W32 ? PCGF32_THREADS : PCG_THREADS)) k_pcgf(const PcgArgs a, double *__restrict__ yg, double *__restrict__ sg) {
-    static_assert(RES == 0 || (RES <= 8 && W32), "resident blocks: fp32 storage only");
+    static_assert(RES >= 0 && RES <= 8, "resident blocks");
     constexpr int TH = THX ? THX : (W32 ? PCGF32_THREADS : PCG_THREADS);
     extern __shared__ __align__(16) double lds[];
     const int n = 6 * a.A, G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -1597,6 +1598,13 @@ int pcg_max_grid(int A, int cus) {
     allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true>), lds, g4);
     int n1 = 0, n2 = 0, n3 = 0, n4 = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, k_pcgf<false>, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n3 = 1; }
+    {
+        static size_t g6 = 48 * 1024;
+        int n6 = 0;
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<false, 2>), lds, g6);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n6, k_pcgf<false, 2>, PCG_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n6 = 1; }
+        n3 = std::min(n3, n6);
+    }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, k_pcgf<true>, PCGF32_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n4 = 1; }
     {
         static size_t g5 = 48 * 1024;
@@ -1646,6 +1654,12 @@ void launch_pcg(const DeviceProblem &P, int which, double mu, hipStream_t st) {
             }
             allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<true>), lds, granted_f32);
             hipLaunchKernelGGL(k_pcgf<true>, dim3(P.pcg_grid), dim3(PCGF32_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NYV * P.n_pad);
+            return;
+        }
+        if (P.pcg_resident) {   // fp64 blocks, one wavefront per SIMD (512 registers per lane): both rounds of a wavefront's first frame stay in registers (2 x 18 double2 = 144: 256 + 210 in all)
+            static size_t granted_fr = 48 * 1024;
+            allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<false, 2>), lds, granted_fr);
+            hipLaunchKernelGGL((k_pcgf<false, 2>), dim3(P.pcg_grid), dim3(PCG_THREADS), lds, st, a, P.pcg_yg, P.pcg_yg + (size_t)3 * PCG_NYV * P.n_pad);
             return;
         }
         allow_dynamic_lds(reinterpret_cast<const void *>(k_pcgf<false>), lds, granted_f);
