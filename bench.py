@@ -192,6 +192,23 @@ def algorithmic_bytes(kernel, N, A, F, n_pad):
     return table.get(kernel, 0)
 
 
+def stage_timed_pass(problem, x0, params, n_steps):
+    """The library's stage timers over >= n_steps LM iterations (never fewer than 120 at the small workloads: the driver's own command asks for 20, and ONE stall of
+    this pool's boxes -- tens of milliseconds, seen in round 6 -- then is the whole average), solve by solve; returns ({stage: seconds per LM step, the MEDIAN over
+    the solves}, LM steps done).  Every solve of the pass has the same iteration count, so the per-solve figures are comparable."""
+    import statistics
+    problem.set_stage_timers(True)
+    per_solve, done = [], 0
+    while done < n_steps:
+        _, rep = problem.lm_solve(x0, params=params(max_iters=max(1, n_steps - done)), trace_cap=1)
+        it = max(1, rep["iterations"])
+        per_solve.append({k: v / it for k, v in problem.stage_times().items()})
+        done += it
+    problem.set_stage_timers(False)
+    keys = set().union(*[d.keys() for d in per_solve])
+    return {k: statistics.median([d.get(k, 0.0) for d in per_solve]) for k in keys}, done
+
+
 def amdahl_split(stage_times, steps, world):
     """Where a step's device time goes, from the library's stage timers (aar_get_stage_times; a separate, instrumented pass: every
     stage is bracketed by HIP events and waited for).  replicated = what EVERY rank does in full whatever the rank count (the dense
@@ -464,15 +481,8 @@ def single_rank_comm_leg(aar, ds, device, steps, warmup, params, one_gpu_it_per_
         dt = time.perf_counter() - t0
         c1 = comm.stats()
         st = pc.solver_stats()
-        pc.set_stage_timers(True)
-        acc, done_am = {}, 0
-        while done_am < n_t:
-            _, rep_am = pc.lm_solve(ds.x_full, params=params(max_iters=n_t - done_am), trace_cap=1)
-            for kk, vv in pc.stage_times().items():
-                acc[kk] = acc.get(kk, 0.0) + vv
-            done_am += rep_am["iterations"]
-        pc.set_stage_timers(False)
-    us = lambda k: 1e6 * acc.get(k, 0.0) / max(1, done_am)
+        acc, done_am = stage_timed_pass(pc, ds.x_full, params, max(n_t, 60))     # (per LM step, median over the solves)
+    us = lambda k: 1e6 * acc.get(k, 0.0)
     pcg = st["solver"] == "pcg"
     rep = us("control") + (0.0 if pcg else us("chol"))
     shard = us("jacobian_normal_eq") + us("schur") + us("backsub") + us("unpack") + us("residual") + (us("chol") if pcg else 0.0)
@@ -556,16 +566,9 @@ def scaling_workload(aar, w, world, rank, local_rank, comm, dist, steps, warmup)
     calls1 = comm.stats()["allreduce_calls"] if comm is not None else 0     # (before the instrumented pass below, which has collectives of its own)
     amdahl = None
     if st["solver"] != "pcg":
-        n_am = min(steps, 60)
-        problem.set_stage_timers(True)
-        acc, done_am = {}, 0
-        while done_am < n_am:
-            _, rep_am = problem.lm_solve(ds.x_full, params=params(max_iters=n_am - done_am), trace_cap=1)
-            for kk, vv in problem.stage_times().items():
-                acc[kk] = acc.get(kk, 0.0) + vv
-            done_am += rep_am["iterations"]
-        problem.set_stage_timers(False)
-        amdahl = amdahl_split(acc, done_am, world)
+        per_step, done_am = stage_timed_pass(problem, ds.x_full, params, max(60, min(steps, 120)))
+        amdahl = amdahl_split(per_step, 1, world)
+        amdahl["source"] = amdahl["source"].replace("over 1 instrumented steps", "per LM step, the median over the solves of %d instrumented steps" % done_am)
     per_rank = [int(problem.local_obs)]
     if dist is not None:
         per_rank = [None] * world
@@ -804,16 +807,9 @@ def main():
     # ---- where the step's time goes by how it scales with the rank count: a third, stage-timed pass ----
     amdahl = None
     if not args.no_amdahl and solver != "pcg":     # (the PCG solver has no replicated part to speak of: nothing for this split to say)
-        n_am = min(args.steps, 300)
-        problem.set_stage_timers(True)
-        acc, done_am = {}, 0
-        while done_am < n_am:
-            _, rep_am = problem.lm_solve(x0, params=params(max_iters=n_am - done_am), trace_cap=1)
-            for kk, vv in problem.stage_times().items():
-                acc[kk] = acc.get(kk, 0.0) + vv
-            done_am += rep_am["iterations"]
-        problem.set_stage_timers(False)
-        amdahl = amdahl_split(acc, done_am, world)
+        per_step, done_am = stage_timed_pass(problem, x0, params, max(120, min(args.steps, 300)))
+        amdahl = amdahl_split(per_step, 1, world)
+        amdahl["source"] = amdahl["source"].replace("over 1 instrumented steps", "per LM step, the median over the solves of %d instrumented steps" % done_am)
 
     # ---- next-row extra (not the headline metric): track(), every frame's own 6-DoF LM in one launch ----
     track = None
